@@ -1,0 +1,114 @@
+"""ORACLE (test infrastructure, not product code) -- greedy generation loop and logits processors.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Restates what the reference's patched `generate` does on the greedy/sample branch
+(reference model/patches/patch_hf.py:586-624) with the arguments the agent passes
+(reference agents/infinisst.py:307-332).  The processors and `_sample` themselves live in the un-vendored
+transformers==4.47.0 ("parity unpinned"): order RepetitionPenalty -> NoRepeatNGram -> EncoderNoRepeatNGram ->
+SuppressTokens, applied to the fp32 copy of the last position's logits; argmax; stop on EOS or max length.
+
+Greedy deviation: the reference asserts beam > 1 (agents/infinisst.py:86); the north star asks for greedy,
+which is this path with that assert waived.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import llm as ollm
+from . import speech_encoder as oenc
+
+
+def repetition_penalty_(scores: torch.Tensor, input_ids: Sequence[int], penalty: float) -> None:
+    """[3P] RepetitionPenaltyLogitsProcessor: gather, (<0 ? *p : /p), scatter.  scores (V,) fp32, in place."""
+    if penalty == 1.0 or len(input_ids) == 0:
+        return
+    idx = torch.tensor(sorted(set(int(t) for t in input_ids)), dtype=torch.long)
+    s = scores[idx]
+    scores[idx] = torch.where(s < 0, s * penalty, s / penalty)
+
+
+def banned_ngram_tokens(source_ids: Sequence[int], context_ids: Sequence[int], n: int) -> List[int]:
+    """Tokens t such that (last n-1 tokens of `context_ids`) + (t,) occurs as an n-gram in `source_ids`.
+    [3P] _get_ngrams + _get_generated_ngrams.  NoRepeatNGram: source == context == input_ids;
+    EncoderNoRepeatNGram: source == encoder_input_ids, context == input_ids."""
+    if n <= 0:
+        return []
+    cur_len = len(context_ids)
+    start = cur_len + 1 - n
+    if start < 0:  # fewer than n-1 context tokens: HF's negative slice yields a shorter key -> no match
+        return []
+    key = tuple(int(t) for t in context_ids[start:cur_len])
+    src = list(source_ids)
+    out = []
+    for j in range(len(src) - n + 1):
+        if tuple(src[j: j + n - 1]) == key:
+            out.append(int(src[j + n - 1]))
+    return out
+
+
+def process_logits(scores: torch.Tensor, input_ids: Sequence[int], encoder_input_ids: Sequence[int],
+                   repetition_penalty: float, no_repeat_ngram_size: int, encoder_no_repeat_ngram_size: int,
+                   suppress_tokens: Sequence[int]) -> torch.Tensor:
+    """scores (V,) fp32 raw logits of the last position -> processed copy."""
+    s = scores.clone()
+    repetition_penalty_(s, input_ids, repetition_penalty)
+    if no_repeat_ngram_size > 0 and len(input_ids) + 1 >= no_repeat_ngram_size:
+        for t in banned_ngram_tokens(input_ids, input_ids, no_repeat_ngram_size):
+            s[t] = float("-inf")
+    if encoder_no_repeat_ngram_size > 0:
+        for t in banned_ngram_tokens(encoder_input_ids, input_ids, encoder_no_repeat_ngram_size):
+            s[t] = float("-inf")
+    for t in suppress_tokens:
+        s[int(t)] = float("-inf")
+    return s
+
+
+@dataclass
+class GenerateOutput:
+    sequences: List[int]  # prompt + generated (the last generated token is never fed to the model)
+    step_logits: List[torch.Tensor]  # raw last-position logits per step, model dtype
+    step_scores: List[torch.Tensor]  # processed fp32 scores per step
+    speech_features: Optional[torch.Tensor] = None
+
+
+def generate(w: Dict[str, torch.Tensor], cfg, gen, input_ids: List[int], speech_batch: torch.Tensor, kv,
+             speech_cache, rope_llm, rope_enc, encoder_input_ids: Sequence[int],
+             forced_tokens: Optional[Sequence[int]] = None,
+             keep_logits: bool = True) -> GenerateOutput:
+    """One chunk: encoder (step 0) + prefill + greedy decode.  Mutates `kv` and `speech_cache`.
+
+    `forced_tokens` (teacher forcing, test aid): token j of the list is appended instead of the argmax at step j;
+    the loop then runs exactly len(forced_tokens) steps unless EOS/max length stops it first."""
+    m = gen.latency_multiplier
+    feats, _ = oenc.encode_speech(w, cfg, speech_batch, speech_cache, m, rope_enc)  # model/llm.py:69-81
+    feats = feats[0]
+    seq = list(input_ids)
+    max_length = len(seq) + gen.max_new_tokens
+    out = GenerateOutput(sequences=seq, step_logits=[], step_scores=[], speech_features=feats)
+    step = 0
+    while True:
+        if step == 0:
+            logits = ollm.model_forward(w, cfg, torch.tensor(seq), kv, rope_llm, speech=feats)
+        else:
+            logits = ollm.model_forward(w, cfg, torch.tensor(seq[-1:]), kv, rope_llm)
+        raw = logits.float()  # outputs.logits[:, -1, :].float()
+        scores = process_logits(raw, seq, encoder_input_ids, gen.repetition_penalty, gen.no_repeat_ngram_size,
+                                gen.no_repeat_ngram_size, gen.suppress_tokens)
+        if keep_logits:
+            out.step_logits.append(logits)
+            out.step_scores.append(scores)
+        if forced_tokens is not None and step < len(forced_tokens):
+            tok = int(forced_tokens[step])
+        else:
+            tok = int(torch.argmax(scores))
+        seq.append(tok)
+        step += 1
+        if tok in cfg.eos_ids or len(seq) >= max_length:
+            break
+        if forced_tokens is not None and step >= len(forced_tokens):
+            break
+    return out

@@ -1,0 +1,547 @@
+"""Generate golden input/output vectors by running the REFERENCE's own functions (this container only).
+
+    python tests/golden/gen_golden.py        # needs /root/reference ; writes tests/golden/*.npz
+
+The reference cannot be imported as a whole here (fairseq, simuleval, lightning, rotary_embedding_torch,
+wandb are absent; transformers is 5.15 instead of the pinned 4.47) -- SURVEY.md section 8(c) / Appendix A.
+This script registers stub modules for those packages in `sys.modules`, imports the reference modules from
+/root/reference unchanged, binds the reference's functions onto toy modules and records what they compute.
+Nothing from the reference is copied: the fixtures hold only tensors (inputs, weights, outputs) and scalars.
+
+Third-party behaviour that has to be *restated* by a stub (and is therefore NOT pinned by these fixtures):
+rotary_embedding_torch.RotaryEmbedding (stub below), fairseq's ConvFeatureExtractionModel (toy stand-in).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..", "..")))
+
+
+def _mod(name, **attrs):
+    import importlib.machinery
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+# ------------------------------------------------------------------ stubs: fairseq + rotary -----
+class _TransposeLast(nn.Module):
+    def forward(self, x):
+        return x.transpose(-2, -1)
+
+
+class _StubRotary(nn.Module):
+    """Stand-in for rotary_embedding_torch.RotaryEmbedding(dim, use_xpos=False): fp32 tables, interleaved pairs,
+    queries at offset K-Q.  (Restated third-party behaviour: NOT a pin of that package.)"""
+
+    def __init__(self, dim, use_xpos=False, theta=10000):
+        super().__init__()
+        self.dim = dim
+        self.register_buffer("freqs", 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim)),
+                             persistent=False)
+
+    def _rot(self, t, offset):
+        n = t.shape[-2]
+        pos = torch.arange(n, dtype=torch.float32) + offset
+        ang = (pos.unsqueeze(1) * self.freqs.float().unsqueeze(0)).repeat_interleave(2, dim=-1)
+        t2 = t.reshape(*t.shape[:-1], -1, 2)
+        rot = torch.stack((-t2[..., 1], t2[..., 0]), dim=-1).reshape(t.shape)
+        return (t.float() * ang.cos() + rot.float() * ang.sin()).to(t.dtype)
+
+    def rotate_queries_with_cached_keys(self, q, k):
+        return self._rot(q, k.shape[-2] - q.shape[-2]), self._rot(k, 0)
+
+
+def install_fairseq_stubs():
+    def pad_to_multiple(x, multiple, dim=-1, value=0):
+        if x is None:
+            return None, 0
+        tsz = x.size(dim)
+        m = tsz / multiple
+        remainder = int(np.ceil(m)) * multiple - tsz
+        if m == int(m):
+            return x, 0
+        pad_offset = (0,) * (-1 - dim) * 2
+        return F.pad(x, (*pad_offset, 0, remainder), value=value), remainder
+
+    class MultiheadAttention(nn.Module):
+        @staticmethod
+        def _append_prev_key_padding_mask(**kw):
+            return None
+
+        def reset_parameters(self):
+            pass
+
+        def apply_sparse_mask(self, attn_weights, tgt_len, src_len, bsz):
+            return attn_weights
+
+    class _Empty(nn.Module):
+        pass
+
+    utils = _mod("fairseq.utils", index_put=lambda t, m, v: t.masked_fill(m, v), is_xla_tensor=lambda t: False,
+                 softmax=lambda x, dim, onnx_trace=False: F.softmax(x.float(), dim=dim),
+                 eval_str_dict=lambda x, type=dict: None if x is None else eval(x))
+    fs = _mod("fairseq", utils=utils)
+    W2V = type("Wav2Vec2Model", (nn.Module,), {})
+    _mod("fairseq.models")
+    _mod("fairseq.models.wav2vec", TransformerEncoder=type("TransformerEncoder", (nn.Module,), {}),
+         TransformerSentenceEncoderLayer=type("TransformerSentenceEncoderLayer", (nn.Module,), {}),
+         Wav2Vec2Model=W2V, Wav2VecEncoder=type("Wav2VecEncoder", (nn.Module,), {}))
+    _mod("fairseq.models.wav2vec.wav2vec2", Wav2Vec2Model=W2V)
+    _mod("fairseq.models.wav2vec.utils", pad_to_multiple=pad_to_multiple)
+    _mod("fairseq.models.hubert")
+    _mod("fairseq.models.hubert.hubert", HubertModel=type("HubertModel", (nn.Module,), {}))
+    _mod("fairseq.models.speech_to_text", lengths_to_padding_mask=lambda l: None)
+    _mod("fairseq.modules", GradMultiply=None, TransposeLast=_TransposeLast)
+    _mod("fairseq.modules.multihead_attention", MultiheadAttention=MultiheadAttention)
+    _mod("fairseq.modules.fairseq_dropout", FairseqDropout=lambda p, module_name=None: nn.Identity())
+    _mod("fairseq.modules.quant_noise", quant_noise=lambda m, p, b: m)
+    _mod("rotary_embedding_torch", RotaryEmbedding=_StubRotary)
+    return fs
+
+
+def install_misc_stubs():
+    _mod("lightning", LightningModule=nn.Module)
+    _mod("wandb")
+    _mod("jieba")
+    tr = _mod("train")
+    tr.__path__ = []
+    # string constants of reference train/dataset.py:47-57 that the hot path reads (data values, supplied here
+    # because train/dataset.py itself needs fairseq's data stack to import)
+    _mod("train.dataset", SpeechSampler=object, DEFAULT_SPEECH_PATCH_TOKEN="<sp_patch>",
+         DEFAULT_SPEECH_START_TOKEN="<sp_start>", DEFAULT_SPEECH_END_TOKEN="<sp_end>",
+         DEFAULT_LATENCY_TOKEN="<latency_{}>", IGNORE_INDEX=-100)
+
+    class AgentStates:
+        def __init__(self):
+            self.reset()
+
+        def reset(self):
+            self.source, self.target = [], []
+            self.source_finished, self.target_finished = False, False
+            self.source_sample_rate = 0
+
+    class SpeechToTextAgent:
+        def __init__(self, args=None):
+            self.args = args
+
+    class WriteAction:
+        def __init__(self, content, finished):
+            self.content, self.finished = content, finished
+
+    class ReadAction:
+        pass
+
+    _mod("simuleval")
+    _mod("simuleval.agents", SpeechToTextAgent=SpeechToTextAgent)
+    _mod("simuleval.agents.states", AgentStates=AgentStates)
+    _mod("simuleval.agents.actions", WriteAction=WriteAction, ReadAction=ReadAction)
+    _mod("simuleval.utils", entrypoint=lambda c: c)
+    _mod("simuleval.data")
+    _mod("simuleval.data.segments", SpeechSegment=object)
+    _mod("model.patches.patch_hf", patch_hf=lambda: None)  # needs transformers.generation.beam_search (4.47 only)
+
+
+# ------------------------------------------------------------------ 1. masks ---------------------
+def gen_masks(pse):
+    out = {}
+    cases_t = [(48, 576, 48), (48, None, 48), (96, 576, 96), (50, 20, 16), (7, 3, 2), (33, 10, 12), (144, 100, 48)]
+    for n, (s, c, b) in enumerate(cases_t):
+        out[f"train_{n}_args"] = np.array([s, -1 if c is None else c, b])
+        out[f"train_{n}"] = pse.get_attn_mask_training(s, c, b, device="cpu").numpy()
+    cases_i = [(48, 48, 576, 48), (48, 576, 576, 48), (48, 624, 576, 48), (48, 1200, 576, 48), (96, 960, 576, 96),
+               (16, 40, 20, 16), (10, 7, 5, 4), (5, 33, 12, 3), (48, 100, 576, 48), (96, 48, 576, 48),
+               (24, 30, 20, 16)]
+    for n, (s, p, c, b) in enumerate(cases_i):
+        out[f"inf_{n}_args"] = np.array([s, p, c, b])
+        out[f"inf_{n}"] = pse.get_attn_mask_inference(s, p, c, b, device="cpu").numpy()
+    out["n_train"], out["n_inf"] = np.array(len(cases_t)), np.array(len(cases_i))
+    np.savez_compressed(os.path.join(OUT, "masks.npz"), **out)
+    print("masks.npz", len(out))
+
+
+# ------------------------------------------------------------------ 2. encoder stack -------------
+def build_ref_encoder(pse, cfg, w, dtype):
+    """Toy fairseq-shaped modules with the reference's patched methods bound (Appendix A)."""
+    from fairseq.models.wav2vec import TransformerEncoder, TransformerSentenceEncoderLayer, Wav2Vec2Model
+    from fairseq.modules.multihead_attention import MultiheadAttention
+    from oracle.speech_encoder import ENC
+
+    def lin(name, bias=True):
+        W = w[name + ".weight"]
+        m = nn.Linear(W.shape[1], W.shape[0], bias=bias)
+        m.weight.data = W.clone()
+        if bias:
+            m.bias.data = w[name + ".bias"].clone()
+        return m
+
+    def ln(name, dim):
+        m = nn.LayerNorm(dim)
+        m.weight.data = w[name + ".weight"].clone()
+        m.bias.data = w[name + ".bias"].clone()
+        return m
+
+    layers = []
+    for i in range(cfg.enc_layers):
+        p = f"{ENC}encoder.layers.{i}."
+        layer = TransformerSentenceEncoderLayer()
+        attn = MultiheadAttention(cfg.enc_dim, cfg.enc_heads, self_attention=True)  # patched __init__
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            setattr(attn, n, lin(p + "self_attn." + n))
+        layer.self_attn = attn
+        layer.self_attn_layer_norm = ln(p + "self_attn_layer_norm", cfg.enc_dim)
+        layer.final_layer_norm = ln(p + "final_layer_norm", cfg.enc_dim)
+        layer.fc1, layer.fc2 = lin(p + "fc1"), lin(p + "fc2")
+        layer.activation_fn = lambda x: F.gelu(x.float()).type_as(x)  # fairseq utils.get_activation_fn("gelu")
+        layer.dropout1 = layer.dropout2 = layer.dropout3 = nn.Identity()
+        layer.layer_norm_first = True
+        layers.append(layer)
+    enc = TransformerEncoder()
+    enc.layers = nn.ModuleList(layers)
+    enc.layer_norm = ln(ENC + "encoder.layer_norm", cfg.enc_dim)
+    enc.layer_norm_first, enc.required_seq_len_multiple, enc.dropout, enc.layerdrop = True, 1, 0.0, 0.0
+    enc.blocksize = cfg.block_size
+
+    class ToyExtractor(nn.Module):  # stand-in for fairseq ConvFeatureExtractionModel(mode=layer_norm)
+        def forward(self_, x):
+            from oracle.speech_encoder import conv_feature_extractor
+            return conv_feature_extractor(w, cfg, x)
+
+    m = Wav2Vec2Model()
+    m.feature_grad_mult, m.feature_extractor = 0.0, ToyExtractor()
+    m.layer_norm = ln(ENC + "layer_norm", cfg.conv_dim)
+    m.post_extract_proj = lin(ENC + "post_extract_proj")
+    m.dropout_input = m.dropout_features = nn.Identity()
+    m.input_quantizer, m.crop_seq_to_multiple, m.encoder, m.blocksize = None, 1, enc, cfg.block_size
+    m.to(dtype).eval()
+    return m
+
+
+def gen_encoder(pse, msp):
+    from infinisst_amd.config import toy_config
+    from infinisst_amd import synth
+    cfg = toy_config().replace(block_size=16, max_cache_size=40, enc_rope_mode="fp32")
+    pse.patch_w2v2(0, 1)
+    out = {"block_size": np.array(cfg.block_size), "max_cache_size": np.array(cfg.max_cache_size)}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        w = synth.random_weights(cfg, dtype=dtype, std=0.08, norm_jitter=0.1, seed=1234)
+        model = build_ref_encoder(pse, cfg, w, dtype)
+        cache = msp.W2V2RoPECache(max_steps=cfg.max_cache_size, layers=[msp.LayerCache() for _ in range(cfg.enc_layers)])
+        n_chunks = 6  # 16 frames each: window (40) saturates from chunk 3 on
+        audio = synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=3)
+        for c in range(n_chunks):
+            seg = torch.from_numpy(audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples])
+            if c == 0:
+                seg = torch.cat([torch.zeros(cfg.first_chunk_offset), seg])
+            with torch.no_grad():
+                res = model.forward(seg.unsqueeze(0).to(dtype), padding_mask=None, mask=False, features_only=True,
+                                    cache=cache)
+            out[f"{tag}_x_{c}"] = res["x"].float().numpy()
+            out[f"{tag}_k0_{c}"] = cache.layers[0].k.float().numpy()
+            out[f"{tag}_state_{c}"] = np.array([cache.src.size(1), cache.src_len, cache.n_steps])
+        # one-shot over the same audio with the training mask (streaming == one-shot invariant, fp32 only)
+        if tag == "fp32":
+            cache1 = msp.W2V2RoPECache(max_steps=cfg.max_cache_size,
+                                       layers=[msp.LayerCache() for _ in range(cfg.enc_layers)])
+            full = torch.cat([torch.zeros(cfg.first_chunk_offset), torch.from_numpy(audio)])
+            with torch.no_grad():
+                res = model.forward(full.unsqueeze(0), padding_mask=None, mask=False, features_only=True, cache=cache1)
+            out["fp32_oneshot"] = res["x"].numpy()
+    out["audio"] = audio
+    np.savez_compressed(os.path.join(OUT, "encoder.npz"), **out)
+    print("encoder.npz", len(out))
+
+
+# ------------------------------------------------------------------ 3. length shrink -------------
+def gen_shrink(msp):
+    torch.manual_seed(7)
+    m = msp.ConvFeatureExtractionModel([(32, 2, 2)] * 2, in_d=32)
+    for p in m.parameters():
+        p.data = p.data + 0.05 * torch.randn_like(p)
+    x = torch.randn(1, 32, 48)
+    with torch.no_grad():
+        y = m(x)
+    out = {"x": x.numpy(), "y": y.numpy()}
+    for i in range(2):
+        out[f"conv{i}"] = m.conv_layers[i][0].weight.data.numpy()
+        out[f"ln{i}_w"] = m.conv_layers[i][2][1].weight.data.numpy()
+        out[f"ln{i}_b"] = m.conv_layers[i][2][1].bias.data.numpy()
+    np.savez_compressed(os.path.join(OUT, "shrink.npz"), **out)
+    print("shrink.npz")
+
+
+# ------------------------------------------------------------------ 4. llama attention -----------
+def gen_llm_attention():
+    import transformers.models.llama.modeling_llama as ml
+    ml.LlamaFlashAttention2 = type("LlamaFlashAttention2", (), {})
+    ml.LlamaSdpaAttention = type("LlamaSdpaAttention", (nn.Module,), {})
+    import importlib
+    pl = importlib.import_module("model.patches.patch_llm")
+    from transformers import LlamaConfig
+    from infinisst_amd.config import toy_config
+    from infinisst_amd import synth
+    cfg = toy_config()
+    hcfg = LlamaConfig(hidden_size=cfg.llm_dim, num_attention_heads=cfg.llm_heads, num_key_value_heads=cfg.llm_kv_heads,
+                       head_dim=cfg.llm_head_dim, max_position_embeddings=131072,
+                       rope_parameters={"rope_type": "llama3", "rope_theta": cfg.rope_theta, "factor": cfg.rope_factor,
+                                        "low_freq_factor": cfg.rope_low_freq_factor,
+                                        "high_freq_factor": cfg.rope_high_freq_factor,
+                                        "original_max_position_embeddings": cfg.rope_original_max_pos})
+    rot = ml.LlamaRotaryEmbedding(hcfg)  # transformers 5.15 build: secondary stand-in for 4.47's class
+
+    class CatCache:
+        def __init__(self):
+            self.k, self.v = {}, {}
+
+        def update(self, k, v, layer_idx, kwargs=None):
+            if layer_idx in self.k:
+                self.k[layer_idx] = torch.cat([self.k[layer_idx], k], dim=-2)
+                self.v[layer_idx] = torch.cat([self.v[layer_idx], v], dim=-2)
+            else:
+                self.k[layer_idx], self.v[layer_idx] = k, v
+            return self.k[layer_idx], self.v[layer_idx]
+
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        w = synth.random_weights(cfg, dtype=dtype, std=0.05, seed=4321)
+        p = "model.layers.0.self_attn."
+
+        class Shim(nn.Module):
+            pass
+        shim = Shim()
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            W = w[p + n + ".weight"]
+            lin = nn.Linear(W.shape[1], W.shape[0], bias=False)
+            lin.weight.data = W.clone()
+            setattr(shim, n, lin)
+        shim.head_dim, shim.num_heads, shim.num_key_value_groups = cfg.llm_head_dim, cfg.llm_heads, cfg.llm_heads // cfg.llm_kv_heads
+        shim.attention_dropout, shim.layer_idx = 0.0, 0
+        shim.rotary_emb = lambda x, position_ids: rot(x, position_ids)
+        shim.eval()
+
+        def causal(q_len, total):  # HF 4-D additive mask, lower-right aligned (attention_mask=None, cache present)
+            past = total - q_len
+            m = torch.full((q_len, total), float("-inf"))
+            m = m.masked_fill(torch.arange(total).unsqueeze(0) <= (torch.arange(q_len).unsqueeze(1) + past), 0.0)
+            return m.to(dtype).unsqueeze(0).unsqueeze(0)
+
+        g = torch.Generator().manual_seed(99)
+        cache = CatCache()
+        seqs = [30, 1, 1, 22, 1]  # prefill, decode, decode, chunked prefill (q>1, past>0), decode
+        xs, ys = [], []
+        total = 0
+        for q_len in seqs:
+            x = (0.5 * torch.randn(1, q_len, cfg.llm_dim, generator=g)).to(dtype)
+            total += q_len
+            pos = torch.arange(total - q_len, total).unsqueeze(0)
+            pe = rot(x, pos)
+            mask = None if q_len == 1 else causal(q_len, total)
+            with torch.no_grad():
+                y, _, _ = pl.llama_sdpa_attention_new_forward(shim, hidden_states=x, attention_mask=mask,
+                                                              past_key_value=cache, position_embeddings=pe)
+            xs.append(x.float().numpy())
+            ys.append(y.float().numpy())
+        # eviction: keep first 5 (system) + last 20, then decode again -> positions re-index to 0..T-1
+        keep = torch.cat([torch.arange(5), torch.arange(total - 20, total)])
+        cache.k[0], cache.v[0] = cache.k[0][:, :, keep], cache.v[0][:, :, keep]
+        total = 25
+        for q_len in (1, 22):
+            x = (0.5 * torch.randn(1, q_len, cfg.llm_dim, generator=g)).to(dtype)
+            total += q_len
+            pe = rot(x, torch.arange(total - q_len, total).unsqueeze(0))
+            mask = None if q_len == 1 else causal(q_len, total)
+            with torch.no_grad():
+                y, _, _ = pl.llama_sdpa_attention_new_forward(shim, hidden_states=x, attention_mask=mask,
+                                                              past_key_value=cache, position_embeddings=pe)
+            xs.append(x.float().numpy())
+            ys.append(y.float().numpy())
+        for j, (x, y) in enumerate(zip(xs, ys)):
+            out[f"{tag}_x_{j}"], out[f"{tag}_y_{j}"] = x, y
+        out[f"{tag}_kcache"] = cache.k[0].float().numpy()  # UNROTATED keys
+        out["n_calls"] = np.array(len(xs))
+        out["evict_after"] = np.array(len(seqs))
+        out["evict_keep"] = keep.numpy()
+    cos, sin = rot(torch.zeros(1, 1, 1), torch.arange(64).unsqueeze(0))
+    out["rope_cos"], out["rope_sin"] = cos[0].numpy(), sin[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "llm_attention.npz"), **out)
+    print("llm_attention.npz", len(out))
+
+
+# ------------------------------------------------------------------ 5. agent policy ---------------
+def gen_agent():
+    import importlib
+    ag = importlib.import_module("agents.infinisst")
+
+    class FakeCache:  # stands in for transformers DynamicCache (key_cache/value_cache lists + iteration)
+        def __init__(self, n_layers, T):
+            self.key_cache = [torch.arange(T, dtype=torch.float32).view(1, 1, T, 1).repeat(1, 2, 1, 4) for _ in range(n_layers)]
+            self.value_cache = [k + 0.5 for k in self.key_cache]
+
+        def __iter__(self):
+            return iter(zip(self.key_cache, self.value_cache))
+
+        def __getitem__(self, i):
+            return self.key_cache[i], self.value_cache[i]
+
+    class FakeTok:
+        pad_token_id = 0
+
+        def decode(self, ids, skip_special_tokens=True):
+            return " ".join(f"t{i}" for i in ids)
+
+    SYS, CH = 40, 22
+    rng = np.random.default_rng(5)
+
+    class FakeModel:
+        device, dtype = torch.device("cpu"), torch.bfloat16
+        model = types.SimpleNamespace(speech_features_extracted=False)
+
+        def __init__(self):
+            self.calls = []
+
+        def generate(self, **kw):
+            st = kw["states"]
+            past = kw["past_key_values"]
+            T_past = 0 if past is None else past[0][0].size(2)
+            n_gen = int(rng.integers(2, 11))  # tokens sampled; the last one is not cached
+            ids = kw["input_ids"]
+            gen = torch.tensor(rng.integers(10, 900, size=(1, n_gen)))
+            self.calls.append(dict(speech=kw["speech_batch"].float().numpy().copy(), enc_ids=kw["encoder_input_ids"].numpy().copy(),
+                                   T_past=T_past, n_gen=n_gen, prompt_len=ids.size(1)))
+            st.speech_cache = object()
+            T_new = T_past + ids.size(1) + n_gen - 1
+            cache = FakeCache(2, T_new)
+            if past is not None:  # carry over the identity of surviving entries so eviction can be traced
+                for i in range(2):
+                    cache.key_cache[i][:, :, :T_past] = past.key_cache[i]
+                    cache.key_cache[i][:, :, T_past:] = 1000 * len(self.calls) + torch.arange(T_new - T_past).view(1, 1, -1, 1)
+                    cache.value_cache[i] = cache.key_cache[i] + 0.5
+            else:
+                for i in range(2):
+                    cache.key_cache[i] = (1000 * len(self.calls) + torch.arange(T_new).view(1, 1, -1, 1)).float().repeat(1, 2, 1, 4)
+                    cache.value_cache[i] = cache.key_cache[i] + 0.5
+            return types.SimpleNamespace(sequences=torch.cat([ids, gen], dim=1), past_key_values=[cache])
+
+    out = {}
+    for variant, (keep_sys, max_cache) in enumerate([(True, 150), (False, 150), (True, 90)]):
+        agent = object.__new__(ag.InfiniSST)
+        agent.args = types.SimpleNamespace(block_size=48)
+        agent.min_start_sec, agent.latency_multiplier, agent.beam = 0.0, 1, 4
+        agent.no_repeat_ngram_lookback, agent.no_repeat_ngram_size, agent.repetition_penalty = 100, 5, 1.2
+        agent.max_new_tokens, agent.do_sample, agent.top_p, agent.top_k, agent.epsilon_cutoff, agent.temperature = 10, False, 1.0, 0, 0.0, 1.0
+        agent.pseudo_batch_size, agent.max_llm_cache_size, agent.always_cache_system_prompt = 1, max_cache, keep_sys
+        agent.cache_checkpoints, agent.dpo_sampling, agent.bad_words_ids = [], False, []
+        agent.target_lang, agent.tokenizer, agent.model = "German", FakeTok(), FakeModel()
+        agent.system_prompt_size = SYS
+
+        def prep_inputs(states, _a=agent):
+            n = CH + (SYS if states.speech_cache is None else 0)
+            return torch.arange(n).unsqueeze(0)
+        agent._prepare_inputs = prep_inputs
+        st = ag.S2TAgentStates(src_len=0, speech_cache=None, past_key_values=None, target_ids=[], segment_idx=0,
+                               translations_list=[])
+        st.reset()
+        st.source_sample_rate = 16000
+        seg_lens = [15360, 15360, 15360, 15360, 15361, 15359, 30720, 1, 15360, 7000, 15360, 15360]
+        audio = (0.1 * rng.standard_normal(sum(seg_lens))).astype(np.float32)
+        pos, recs = 0, []
+        for c, n in enumerate(seg_lens):
+            st.source.extend(audio[pos:pos + n].tolist())
+            pos += n
+            st.source_finished = c == len(seg_lens) - 1
+            act = agent.policy(st)
+            kv0 = st.past_key_values.key_cache[0][0, 0, :, 0].numpy().copy()
+            out[f"v{variant}_kvtrace_{c}"] = kv0
+            out[f"v{variant}_ckpt_{c}"] = np.array(agent.cache_checkpoints)
+            out[f"v{variant}_speech_{c}"] = agent.model.calls[-1]["speech"]
+            out[f"v{variant}_encids_{c}"] = agent.model.calls[-1]["enc_ids"]
+            recs.append([agent.model.calls[-1]["n_gen"], agent.model.calls[-1]["prompt_len"], len(st.target_ids),
+                         int(isinstance(act, ag.WriteAction)), int(getattr(act, "finished", False))])
+        out[f"v{variant}_recs"] = np.array(recs)
+        out[f"v{variant}_target_ids"] = np.array(st.target_ids)
+        out[f"v{variant}_cfg"] = np.array([int(keep_sys), max_cache, SYS, CH])
+        out[f"v{variant}_seg_lens"] = np.array(seg_lens)
+        out[f"v{variant}_audio"] = audio
+    np.savez_compressed(os.path.join(OUT, "agent.npz"), **out)
+    print("agent.npz", len(out))
+
+
+# ------------------------------------------------------------------ 6. speech splice --------------
+def gen_splice():
+    import importlib
+    mllm = importlib.import_module("model.llm")
+    from transformers import LlamaModel
+    captured = {}
+
+    def fake_super_forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, **kw):
+        captured["embeds"] = inputs_embeds
+        return None
+    orig = LlamaModel.forward
+    LlamaModel.forward = fake_super_forward
+    try:
+        D, V = 16, 1100
+        cfg = mllm.SpeechLlamaConfig(hidden_size=D, intermediate_size=32, num_hidden_layers=1, num_attention_heads=2,
+                                     num_key_value_heads=1, vocab_size=V)
+        cfg.user_token_id, cfg.assist_token_id, cfg.start_header_id = 882, 781, 1006
+        model = mllm.SpeechLlamaModel(cfg)
+        model.inference = True
+        out = {"ids_cfg": np.array([882, 781, 1006, 1024])}
+        g = torch.Generator().manual_seed(3)
+        for case, n_sp in enumerate([12, 24, 12]):
+            feats = torch.randn(1, n_sp + (6 if case == 2 else 0), D, generator=g)  # case 2: surplus features dropped
+
+            class Enc:
+                def set_blocksize(self, m):
+                    pass
+
+                def encode_speech(self, sb, sl, cache=None):
+                    return feats, "CACHE"
+            model.speech_encoder = Enc()
+            model.speech_features_extracted = False
+            turn = [1006, 882, 1007, 271] + [1024] * n_sp + [1009, 1006, 781, 1007, 271]
+            ids = ([1000, 1006, 912, 1007, 271, 5, 6, 7, 882, 781, 1009] if case != 1 else [1009]) + turn
+            states = types.SimpleNamespace(speech_cache=None)
+            with torch.no_grad():
+                model.forward(input_ids=torch.tensor([ids]), speech_batch=torch.zeros(1, 10), states=states, multiplier=1)
+            out[f"ids_{case}"] = np.array(ids)
+            out[f"feats_{case}"] = feats[0].numpy()
+            out[f"table_{case}"] = model.embed_tokens.weight.data.numpy()
+            out[f"embeds_{case}"] = captured["embeds"][0].numpy()
+        np.savez_compressed(os.path.join(OUT, "splice.npz"), **out)
+        print("splice.npz")
+    finally:
+        LlamaModel.forward = orig
+
+
+def main():
+    torch.set_num_threads(4)
+    import transformers.models.llama.modeling_llama  # noqa: F401  (before the wandb stub: accelerate probes it)
+    install_fairseq_stubs()
+    install_misc_stubs()
+    import importlib
+    pse = importlib.import_module("model.patches.patch_speech_encoder")
+    msp = importlib.import_module("model.speech_encoder")
+    gen_masks(pse)
+    gen_encoder(pse, msp)
+    gen_shrink(msp)
+    gen_llm_attention()
+    gen_agent()
+    gen_splice()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+"""Pin the oracle against the golden vectors produced by the reference's own functions
+(tests/golden/gen_golden.py ran them in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from infinisst_amd import synth
+from infinisst_amd.config import GenConfig, toy_config
+from oracle import agent as oag
+from oracle import llm as ollm
+from oracle import speech_encoder as oenc
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_masks_match_reference(golden_dir):
+    g = load(golden_dir, "masks.npz")
+    for n in range(int(g["n_train"])):
+        s, c, b = (int(v) for v in g[f"train_{n}_args"])
+        m = oenc.attn_mask_training(s, None if c < 0 else c, b).numpy()
+        assert np.array_equal(m, g[f"train_{n}"]), f"training mask case {n}"
+    for n in range(int(g["n_inf"])):
+        s, p, c, b = (int(v) for v in g[f"inf_{n}_args"])
+        m = oenc.attn_mask_inference(s, p, c, b).numpy()
+        assert m.shape == g[f"inf_{n}"].shape
+        assert np.array_equal(m, g[f"inf_{n}"]), f"inference mask case {n}"
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("fp32", torch.float32, 2e-5), ("bf16", torch.bfloat16, 6e-2)])
+def test_encoder_streaming_matches_reference(golden_dir, tag, dtype, tol):
+    """uni_w2v2_forward / uni_transformer_encoder_* / uni_self_attn_forward / uni_mha_forward driven unchanged
+    (patch_speech_encoder.py:228-933) vs oracle.w2v2_forward, 6 chunks: first (training mask), growing window,
+    saturated window (K trimmed to max_cache_size)."""
+    g = load(golden_dir, "encoder.npz")
+    cfg = toy_config().replace(block_size=int(g["block_size"]), max_cache_size=int(g["max_cache_size"]),
+                               enc_rope_mode="fp32")
+    w = synth.random_weights(cfg, dtype=dtype, std=0.08, norm_jitter=0.1, seed=1234)
+    rope = oenc.make_rope(cfg)
+    cache = oenc.new_cache(cfg)
+    audio = g["audio"]
+    for c in range(6):
+        seg = torch.from_numpy(audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples])
+        if c == 0:
+            seg = torch.cat([torch.zeros(cfg.first_chunk_offset), seg])
+        x = oenc.w2v2_forward(w, cfg, seg.unsqueeze(0).to(dtype), cache, cfg.block_size, rope)
+        ref = g[f"{tag}_x_{c}"]
+        assert x.shape == ref.shape
+        err = np.abs(x.float().numpy() - ref).max()
+        assert err <= tol, f"chunk {c}: max|d|={err}"
+        kref = g[f"{tag}_k0_{c}"]
+        assert cache.layers[0].k.shape == kref.shape, f"chunk {c}: K cache shape"
+        assert np.abs(cache.layers[0].k.float().numpy() - kref).max() <= tol
+        assert [cache.src.size(1), cache.src_len, cache.n_steps] == [int(v) for v in g[f"{tag}_state_{c}"]]
+
+
+def test_encoder_streaming_equals_oneshot(golden_dir):
+    """Invariant recorded from the reference: chunked streaming == one-shot encoding."""
+    g = load(golden_dir, "encoder.npz")
+    stream = np.concatenate([g[f"fp32_x_{c}"] for c in range(6)], axis=1)
+    assert np.abs(stream - g["fp32_oneshot"]).max() < 5e-5
+
+
+def test_shrink_block_matches_reference(golden_dir):
+    """ConvFeatureExtractionModel (reference model/speech_encoder.py:18-78) vs oracle.shrink_block."""
+    g = load(golden_dir, "shrink.npz")
+    cfg = toy_config().replace(shrink_layers=[(32, 2, 2)] * 2)
+    w = {}
+    for i in range(2):
+        p = f"{oenc.SHR}conv_layers.{i}."
+        w[p + "0.weight"] = torch.from_numpy(g[f"conv{i}"])
+        w[p + "2.1.weight"] = torch.from_numpy(g[f"ln{i}_w"])
+        w[p + "2.1.bias"] = torch.from_numpy(g[f"ln{i}_b"])
+    y = oenc.shrink_block(w, cfg, torch.from_numpy(g["x"]).transpose(1, 2)).transpose(1, 2)
+    assert np.abs(y.numpy() - g["y"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("fp32", torch.float32, 2e-5), ("bf16", torch.bfloat16, 2e-2)])
+def test_llm_attention_matches_reference(golden_dir, tag, dtype, tol):
+    """llama_sdpa_attention_new_forward (reference model/patches/patch_llm.py:231-336) vs oracle.attention:
+    prefill, decode, chunked prefill with a non-empty cache, and decode/prefill after eviction
+    (positions re-index to 0..T-1 because the cache holds unrotated K)."""
+    g = load(golden_dir, "llm_attention.npz")
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=dtype, std=0.05, seed=4321)
+    rope = ollm.llm_rope_tables(cfg, 256, dtype)
+    kv = ollm.new_kv(cfg)
+    n, ev = int(g["n_calls"]), int(g["evict_after"])
+    for j in range(n):
+        if j == ev:
+            keep = torch.from_numpy(g["evict_keep"])
+            kv[0][0], kv[0][1] = kv[0][0][:, :, keep], kv[0][1][:, :, keep]
+        x = torch.from_numpy(g[f"{tag}_x_{j}"]).to(dtype)
+        y = ollm.attention(w, cfg, 0, x, kv, rope)
+        err = np.abs(y.float().numpy() - g[f"{tag}_y_{j}"]).max()
+        assert err <= tol, f"call {j}: max|d|={err}"
+    assert np.abs(kv[0][0].float().numpy() - g[f"{tag}_kcache"]).max() <= tol  # cache holds UNROTATED keys
+
+
+def test_llm_rope_table_matches_transformers(golden_dir):
+    """llama3 rotary table vs the transformers build in the container (secondary reference for the pinned 4.47)."""
+    g = load(golden_dir, "llm_attention.npz")
+    cos, sin = ollm.llm_rope_tables(toy_config(), 64, torch.float32)
+    assert np.abs(cos.numpy() - g["rope_cos"]).max() < 1e-6
+    assert np.abs(sin.numpy() - g["rope_sin"]).max() < 1e-6
+
+
+def test_splice_matches_reference(golden_dir):
+    """SpeechLlamaModel.forward (reference model/llm.py:86-113) vs oracle.splice_speech."""
+    g = load(golden_dir, "splice.npz")
+    user, assist, sh, sp = (int(v) for v in g["ids_cfg"])
+    cfg = toy_config().replace(user_id=user, assistant_id=assist, start_header_id=sh, sp_patch_id=sp)
+    for case in range(3):
+        ids = torch.from_numpy(g[f"ids_{case}"])
+        table = torch.from_numpy(g[f"table_{case}"])
+        emb = torch.nn.functional.embedding(ids, table)
+        out = ollm.splice_speech(cfg, ids, emb, torch.from_numpy(g[f"feats_{case}"]))
+        assert np.array_equal(out.numpy(), g[f"embeds_{case}"]), f"case {case}"
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_agent_policy_matches_reference(golden_dir, variant):
+    """InfiniSST.policy (reference agents/infinisst.py:270-395) run unchanged over a stub model vs the oracle's
+    prepare_speech / evict / output slicing: padded speech tensors, encoder_input_ids, cache checkpoints and
+    the surviving KV entries after every chunk, incl. ragged segment lengths."""
+    g = load(golden_dir, "agent.npz")
+    keep_sys, max_cache, SYS, CH = (int(v) for v in g[f"v{variant}_cfg"])
+    cfg = toy_config().replace(block_size=48)
+    st = oag.States(source_sample_rate=16000)
+    audio, seg_lens, recs = g[f"v{variant}_audio"], g[f"v{variant}_seg_lens"], g[f"v{variant}_recs"]
+    ckpts, trace, pos, first = [], np.zeros(0), 0, True
+    target_ids = []
+    for c, n in enumerate(seg_lens):
+        st.source.extend(audio[pos:pos + n].tolist())
+        pos += int(n)
+        speech = oag.prepare_speech(cfg, st, torch.bfloat16)
+        assert np.array_equal(speech.float().numpy(), g[f"v{variant}_speech_{c}"]), f"chunk {c} speech"
+        n_gen, prompt_len = int(recs[c][0]), int(recs[c][1])
+        assert prompt_len == CH + (SYS if first else 0)
+        enc_ids = target_ids[-100:]
+        assert list(g[f"v{variant}_encids_{c}"].reshape(-1).astype(int)) == enc_ids
+        # emulate the stub model's cache growth, then apply the oracle's eviction
+        new = 1000 * (c + 1) + np.arange(prompt_len + n_gen - 1)
+        trace = np.concatenate([trace, new]) if not first else new.astype(float)
+        cur = len(trace)
+        ckpts.append(cur)
+        ev = oag.evict(ckpts, cur, max_cache, bool(keep_sys), SYS)
+        if ev is not None:
+            ckpts, new_size = ev
+            tail = trace[-new_size:] if new_size > 0 else trace[:0]
+            trace = np.concatenate([trace[:SYS], tail]) if keep_sys else tail
+        assert list(g[f"v{variant}_ckpt_{c}"]) == ckpts, f"chunk {c} checkpoints"
+        assert np.array_equal(g[f"v{variant}_kvtrace_{c}"], trace), f"chunk {c} surviving KV entries"
+        target_ids = list(g[f"v{variant}_target_ids"][: int(recs[c][2])])
+        assert int(recs[c][2]) == sum(int(r[0]) - 1 for r in recs[: c + 1])  # sequences[0, T:-1] drops the last token
+        first = False
