@@ -1,0 +1,155 @@
+/* C ABI of libinfinisst_hip.so -- the MI355X (gfx950) drop-in for the per-chunk compute behind the reference's
+ * SimulEval agent (LeiLiLab/InfiniSST agents/infinisst.py policy()).
+ *
+ * The reference is pure Python and has no FFI; its lower boundary is the call
+ *     outputs = self.model.generate(input_ids, speech_batch, past_key_values, states, multiplier, ...)
+ * at agents/infinisst.py:307-332 plus the two state objects it mutates (states.speech_cache,
+ * states.past_key_values) and the agent-side KV eviction at agents/infinisst.py:340-361.  Every entry point
+ * below names the reference interface it replaces.  Plain C types only: pointers, sizes, int status codes
+ * (0 = ok, negative = error, text via isst_last_error).  All device work is enqueued on the caller's
+ * hipStream_t (passed as void*); functions that return host results synchronise that stream before returning.
+ */
+#ifndef INFINISST_HIP_H
+#define INFINISST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISST_OK 0
+#define ISST_ERR_ARG (-1)
+#define ISST_ERR_HIP (-2)
+#define ISST_ERR_STATE (-3)
+#define ISST_ERR_NOMEM (-4)
+#define ISST_ERR_NOTFOUND (-5)
+
+#define ISST_MAX_CONV 8
+#define ISST_MAX_SHRINK 4
+#define ISST_MAX_EOS 8
+
+typedef struct isst_handle isst_handle;
+
+/* Model + runtime geometry.  Replaces the constructor arguments the reference spreads over
+ * agents/infinisst.py:150-181 (load_model), agents/options.py:1-41 and model/speech_encoder.py:99-121. */
+typedef struct isst_config {
+    /* wav2vec2 conv feature extractor: (dim, kernel, stride) per layer, layer-norm mode */
+    int n_conv;
+    int conv_dim[ISST_MAX_CONV], conv_k[ISST_MAX_CONV], conv_stride[ISST_MAX_CONV];
+    int conv_bias;
+    /* streaming transformer encoder (head_dim must be 64) */
+    int enc_dim, enc_layers, enc_heads, enc_ffn;
+    float enc_ln_eps;
+    int block_size;          /* --block-size: frames per block at multiplier 1 */
+    int max_cache_size;      /* --max-cache-size: encoder KV sliding window (frames) */
+    int enc_rope_round_each; /* 1: rotary products rounded to bf16 one by one (module cast to bf16); 0: one rounding */
+    /* length shrink convs (no bias) + projector */
+    int n_shrink;
+    int shrink_dim[ISST_MAX_SHRINK], shrink_k[ISST_MAX_SHRINK], shrink_stride[ISST_MAX_SHRINK];
+    /* Llama decoder (head_dim must be 128) */
+    int llm_dim, llm_layers, llm_heads, llm_kv_heads, llm_ffn, vocab;
+    float rms_eps;
+    /* ids the speech splice looks for (reference model/llm.py:181-183) and EOS set */
+    int user_id, assistant_id, start_header_id;
+    int n_eos;
+    int eos_ids[ISST_MAX_EOS];
+    /* capacity */
+    int max_streams;         /* concurrent streams sharing the weights */
+    int max_multiplier;      /* largest latency multiplier (blocks per call) */
+    int max_prompt_len;      /* longest prompt of one call (first chunk incl. system prompt) */
+    int max_new_tokens;      /* upper bound of max_new_tokens */
+    int max_llm_cache_size;  /* --max-llm-cache-size (ring sized for this + one chunk) */
+    int max_system_prompt;   /* pinned system-prompt capacity (--always-cache-system-prompt) */
+    int debug_taps;          /* keep copies of intermediate activations for isst_debug_tap */
+} isst_config;
+
+/* generation arguments of one call; mirrors the keyword arguments at agents/infinisst.py:307-332 */
+typedef struct isst_gen_params {
+    int multiplier;                    /* multiplier= */
+    int max_new_tokens;                /* max_new_tokens= */
+    int no_repeat_ngram_size;          /* no_repeat_ngram_size= */
+    int encoder_no_repeat_ngram_size;  /* encoder_no_repeat_ngram_size= */
+    float repetition_penalty;          /* repetition_penalty= */
+    const int* suppress_tokens;        /* suppress_tokens= (bad_words_ids), may be NULL */
+    int n_suppress;
+    int system_prompt_size;            /* >0: pin this many leading positions of a FRESH stream (keep-system-prompt) */
+} isst_gen_params;
+
+typedef struct isst_stream_info {
+    int llm_cache_len;   /* = states.past_key_values[0][0].size(2) */
+    int llm_sys_len;     /* pinned prefix inside llm_cache_len */
+    int enc_n_steps;     /* = states.speech_cache.n_steps */
+    int enc_cache_len;   /* = states.speech_cache.layers[i].k.size(1) */
+    int chunks;
+} isst_stream_info;
+
+/* ---- lifetime (replaces InfiniSST.load_model, agents/infinisst.py:130-183) ---- */
+int isst_create(const isst_config* cfg, isst_handle** out);
+void isst_destroy(isst_handle* h);
+const char* isst_last_error(isst_handle* h); /* h may be NULL: last create error */
+
+/* One tensor of the reference checkpoint (`pytorch_model.bin` keys, agents/infinisst.py:179-180), bf16 bits,
+ * row-major, host or device pointer.  The library copies and re-lays it out (MFMA-fragment-major tiles). */
+int isst_load_weight(isst_handle* h, const char* name, const void* data, int ndim, const int64_t* shape, int on_device);
+/* Rotary tables computed by the host with the third-party semantics it wants to reproduce:
+ * encoder (rotary_embedding_torch, patch_speech_encoder.py:631,:824): fp32 cos/sin [enc_rows][32];
+ * LLM (HF LlamaRotaryEmbedding llama3, patch_llm.py:290-299): bf16 cos/sin [llm_rows][64] (first half of the dims). */
+int isst_set_rope_tables(isst_handle* h, const float* enc_cos, const float* enc_sin, int enc_rows, const uint16_t* llm_cos,
+                         const uint16_t* llm_sin, int llm_rows);
+int isst_finalize_weights(isst_handle* h); /* fails listing the first missing tensor */
+
+/* ---- per-utterance state (replaces S2TAgentStates.reset / build_states, agents/infinisst.py:50-67,115-123) ---- */
+int isst_stream_open(isst_handle* h, int* stream_id);
+int isst_stream_reset(isst_handle* h, int stream_id);
+int isst_stream_close(isst_handle* h, int stream_id);
+int isst_stream_info_get(isst_handle* h, int stream_id, isst_stream_info* out);
+
+/* ---- the hot path: model.generate(...) for n streams (agents/infinisst.py:307-332) ----
+ * pcm[i]: n_samples new fp32 samples of stream i as prepared by _prepare_speech (zero-padded to a multiple of
+ *   block_size/4*1280 samples; WITHOUT the 399-sample first-chunk offset: the library keeps that history itself);
+ *   n_samples is the same for all streams of a call.
+ * prompt_ids[i]/prompt_lens[i]: this chunk's prompt (agents/infinisst.py:225-268).
+ * prev_target_ids[i]/n_prev[i]: encoder_input_ids = last <=lookback target ids (:298-301).
+ * forced_tokens[i] (may be NULL): teacher forcing for tests -- token k replaces the argmax of step k.
+ * out_ids[i] receives the generated ids = outputs.sequences[0, len(prompt):] (up to max_new_tokens),
+ * out_lens[i] their count.  logits_out (may be NULL): raw fp32 last-position logits, [n][max_new_tokens][vocab]. */
+int isst_generate(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const float* const* pcm,
+                  int n_samples, const int* const* prompt_ids, const int* prompt_lens, const int* const* prev_target_ids,
+                  const int* n_prev, const int* const* forced_tokens, const int* n_forced, int* const* out_ids, int* out_lens,
+                  float* logits_out, void* hip_stream);
+
+/* LLM-KV eviction of one stream (agents/infinisst.py:354-361): keep the first keep_prefix entries and the last
+ * new_cache_size entries; the rest is dropped and the remaining keys re-index (positions 0..T-1). */
+int isst_kv_evict(isst_handle* h, int stream_id, int new_cache_size, int keep_prefix);
+
+/* Encoder only (speech_encoder.encode_speech, model/speech_encoder.py:219-236) for one stream: advances the
+ * stream's speech cache and returns the projected features [S][llm_dim] as bf16 bits.  Test aid. */
+int isst_encode_speech(isst_handle* h, int stream_id, const float* pcm, int n_samples, int multiplier, uint16_t* out_features,
+                       int* out_rows, void* hip_stream);
+
+/* copy of an intermediate activation of the last call (needs cfg.debug_taps): names "conv_out", "post_proj",
+ * "enc_layer_<i>", "enc_out", "shrink", "speech", "llm_embed", "llm_layer_<i>", "llm_final". bf16 bits. */
+int isst_debug_tap(isst_handle* h, const char* name, uint16_t* dst, int64_t max_elems, int64_t* got_elems);
+
+/* ---- per-kernel entry points (parity tests and micro-benchmarks); all pointers are DEVICE pointers ---- */
+/* W [n_rows][K] row-major bf16 (conv_k > 0: Conv1d weight [n_rows][K/conv_k][conv_k]) -> packed tiles */
+int isst_op_pack_weight(const uint16_t* w, uint16_t* packed, int n_rows, int K, int conv_k, void* hip_stream);
+int64_t isst_op_packed_elems(int n_rows, int K);
+/* out = epi(A @ W^T); epi: 0 none, 1 bias, 2 bias+gelu, 3 residual, 4 bias+residual, 5 swiglu (packed rows
+ * alternate gate/up tiles), 6 fp32 out.  Replaces torch F.linear / F.conv1d call sites (see gemm.hip). */
+int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, const uint16_t* res,
+                 int64_t ldres, void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, void* hip_stream);
+int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps,
+                      int gelu, void* hip_stream);
+int isst_op_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int rows, int D, float eps, void* hip_stream);
+int isst_op_conv0(const uint16_t* audio, const uint16_t* w, const uint16_t* bias, const uint16_t* ln_w, const uint16_t* ln_b,
+                  uint16_t* out, int T, int C, int k, int stride, void* hip_stream);
+/* logits [vocab] fp32 (modified in place) -> *out_token (device int) */
+int isst_op_sample(float* logits, int vocab, const int* ids, int n_ids, const int* enc_ids, int n_enc, const int* suppress,
+                   int n_suppress, float repetition_penalty, int ngram, int enc_ngram, int* out_token, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFINISST_HIP_H */

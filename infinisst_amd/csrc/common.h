@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the InfiniSST hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; arithmetic is always done in fp32
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+// round-to-nearest-even; hipcc emits v_cvt_pk_bf16_f32 (keeps NaN a NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+// value after one rounding to bf16 (the reference rounds after every torch op)
+__device__ __forceinline__ float bfr(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+__device__ __forceinline__ void unpack8(const u32x4_t& v, float* f) {
+    f[0] = lo_bf(v.x); f[1] = hi_bf(v.x); f[2] = lo_bf(v.y); f[3] = hi_bf(v.y);
+    f[4] = lo_bf(v.z); f[5] = hi_bf(v.z); f[6] = lo_bf(v.w); f[7] = hi_bf(v.w);
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+    u32x4_t v;
+    v.x = pack_bf(f[0], f[1]); v.y = pack_bf(f[2], f[3]); v.z = pack_bf(f[4], f[5]); v.w = pack_bf(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// ---- status codes of the C ABI (include/infinisst_hip.h) ----
+#define ISST_OK 0
+#define ISST_ERR_ARG (-1)
+#define ISST_ERR_HIP (-2)
+#define ISST_ERR_STATE (-3)
+#define ISST_ERR_NOMEM (-4)
+#define ISST_ERR_NOTFOUND (-5)
+
+// ---- epilogues of the packed-weight GEMM ----
+enum GemmEpi {
+    EPI_NONE = 0,       // out = bf16(acc)
+    EPI_BIAS = 1,       // out = bf16(acc + bias)
+    EPI_BIAS_GELU = 2,  // out = bf16(gelu(bf16(acc + bias)))
+    EPI_RES = 3,        // out = bf16(res + bf16(acc))
+    EPI_BIAS_RES = 4,   // out = bf16(res + bf16(acc + bias))
+    EPI_SWIGLU = 5,     // tile pairs (gate, up): out = bf16(bf16(silu(bf16 g)) * bf16 u)
+    EPI_F32 = 6,        // out(fp32) = bf16-rounded acc
+};
+
+// launchers (defined in the kernel .hip files; all asynchronous on `stream`)
+struct GemmArgs {
+    const bf16_t* A; long lda; long a_batch;      // A[batch][M][K] with row stride lda (elements)
+    const bf16_t* Wp;                              // packed weight [N/16][K/32][64][8]
+    const bf16_t* bias;                            // [N] or null
+    const bf16_t* res; long ldres; long res_batch; // residual, may alias out
+    void* out; long ldo; long out_batch;           // bf16 (or fp32 for EPI_F32)
+    int M, N, K, batch, epi;                       // N = number of packed rows (multiple of 16)
+    int n_valid;                                   // output columns actually stored (<= N, or N/2 for SWIGLU)
+};
+int launch_gemm(const GemmArgs& g, hipStream_t stream);
+int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,
+                       int tile_phase, int conv_k, hipStream_t stream);

@@ -1,0 +1,1018 @@
+// Host side of libinfinisst_hip.so: owns device weights (re-laid out for the MFMA GEMM), per-stream state
+// (audio history, encoder KV rings, LLM KV arenas) and runs one chunk of the InfiniSST hot path for n streams:
+//   conv feature extractor -> streaming encoder -> shrink + projector -> splice -> Llama prefill -> greedy decode.
+// It is the MI355X replacement of `self.model.generate(...)` at reference agents/infinisst.py:307-332 (which reaches
+// model/llm.py:51-126,192-270, model/speech_encoder.py:219-236, model/patches/patch_speech_encoder.py:228-933,
+// model/patches/patch_llm.py:231-336 and model/patches/patch_hf.py:586-624).  No CPU fallback exists: every compute
+// step is a HIP kernel launch on the caller's stream.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/infinisst_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct PackedLinear {
+    bf16_t* wp = nullptr;
+    bf16_t* bias = nullptr;
+    int N = 0;        // packed rows (multiple of 16)
+    int K = 0;
+    int n_valid = 0;  // real output columns
+};
+struct Norm {
+    bf16_t* w = nullptr;
+    bf16_t* b = nullptr;
+};
+struct ConvLayer {
+    PackedLinear lin;         // layers >= 1 (implicit GEMM)
+    bf16_t* w_raw = nullptr;  // layer 0: [C][k]
+    Norm ln;
+    int dim = 0, k = 0, stride = 0;
+};
+struct EncLayer {
+    Norm ln1, ln2;
+    PackedLinear qkv, out, fc1, fc2;
+};
+struct LlmLayer {
+    bf16_t* in_norm = nullptr;
+    bf16_t* post_norm = nullptr;
+    PackedLinear qkv, o, gateup, down;
+};
+struct StreamState {
+    bool open = false;
+    int chunks = 0;
+    int enc_start = 0, enc_len = 0, enc_steps = 0;
+    int llm_sys = 0, llm_ring_start = 0, llm_ring_len = 0;
+};
+struct Tap {
+    bf16_t* dev = nullptr;
+    int64_t cap = 0, elems = 0;
+};
+
+static std::string g_create_error;
+
+}  // namespace
+
+struct isst_handle {
+    isst_config cfg{};
+    std::string err;
+    std::vector<void*> allocs;
+    std::set<std::string> loaded;
+    std::vector<std::string> expected;
+    bool finalized = false, rope_set = false;
+
+    // geometry
+    int hist = 0;           // receptive field - 1 samples of audio history (399)
+    int samples_per_frame = 0, chunk_samples = 0, shrink_factor = 1;
+    int enc_cap = 0;        // encoder ring slots
+    int sys_cap = 0, ring_cap = 0;
+    int vocab_pad = 0;
+    int max_ids = 0;        // prompt + generated ids per stream and call
+    int max_enc_ids = 256;
+    int n_new_max = 0, enc_rows_max = 0, llm_rows_max = 0;
+    std::vector<int> conv_T;  // scratch
+
+    // weights
+    std::vector<ConvLayer> conv;
+    Norm enc_ln_in;
+    PackedLinear post_proj;
+    std::vector<EncLayer> enc;
+    Norm enc_ln_out;
+    std::vector<ConvLayer> shrink;
+    PackedLinear proj;
+    bf16_t* embed = nullptr;
+    std::vector<LlmLayer> llm;
+    bf16_t* final_norm = nullptr;
+    PackedLinear lm_head;
+    float *enc_cos = nullptr, *enc_sin = nullptr;
+    bf16_t *llm_cos = nullptr, *llm_sin = nullptr;
+    int enc_rope_rows = 0, llm_rope_rows = 0;
+    bf16_t* stage = nullptr;
+    size_t stage_bytes = 0;
+
+    // state pools
+    std::vector<StreamState> streams;
+    bf16_t* audio_hist = nullptr;               // [max_streams][hist]
+    bf16_t *enc_k = nullptr, *enc_v = nullptr;  // [max_streams][enc_layers][heads][enc_cap][64]
+    long enc_stream_stride = 0, enc_layer_stride = 0;
+    bf16_t *llm_k = nullptr, *llm_v = nullptr;  // [max_streams][llm_layers][kv_heads][sys_cap+ring_cap][128]
+    long llm_stream_stride = 0;
+    LlmAttnDims adims{};
+
+    // workspace
+    float* pcm_f32 = nullptr;
+    bf16_t *window = nullptr, *act_a = nullptr, *act_b = nullptr;
+    bf16_t *ex = nullptr, *exn = nullptr, *eqkv = nullptr, *eattn = nullptr, *effn = nullptr, *speech = nullptr;
+    bf16_t *lx = nullptr, *lxn = nullptr, *lqkv = nullptr, *lqrot = nullptr, *lattn = nullptr, *lact = nullptr, *llast = nullptr;
+    float *lpartial = nullptr, *logits = nullptr;
+    int* out_tok = nullptr;
+    unsigned char* meta_dev = nullptr;
+    unsigned char* meta_host = nullptr;  // pinned
+    size_t meta_bytes = 0;
+    int* tok_host = nullptr;  // pinned
+
+    std::map<std::string, Tap> taps;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    template <typename T>
+    T* dalloc(size_t count, bool zero = false) {
+        void* p = nullptr;
+        size_t bytes = count * sizeof(T);
+        if (bytes == 0) bytes = 16;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        if (zero) (void)hipMemset(p, 0, bytes);
+        allocs.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return h->fail(ISST_ERR_HIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(x)                                                                        \
+    do {                                                                              \
+        int r_ = (x);                                                                 \
+        if (r_ != ISST_OK) return h->fail(r_, "%s -> %d (%s:%d)", #x, r_, __FILE__, __LINE__); \
+    } while (0)
+#define NEED(p)                                                                  \
+    do {                                                                         \
+        if (!(p)) return h->fail(ISST_ERR_NOMEM, "device allocation failed: %s", #p); \
+    } while (0)
+
+namespace {
+
+const char* ENC = "model.speech_encoder.speech_encoder.";
+const char* SHR = "model.speech_encoder.length_shrink.";
+const char* PRJ = "model.speech_encoder.proj.";
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+bool alloc_linear(isst_handle* h, PackedLinear& L, int n_rows, int K, bool bias) {
+    L.N = round_up(n_rows, 16);
+    L.K = K;
+    L.n_valid = n_rows;
+    L.wp = h->dalloc<bf16_t>((size_t)L.N * K, true);
+    if (bias) L.bias = h->dalloc<bf16_t>(round_up(n_rows, 8), true);
+    return L.wp && (!bias || L.bias);
+}
+bool alloc_norm(isst_handle* h, Norm& n, int dim, bool bias = true) {
+    n.w = h->dalloc<bf16_t>(round_up(dim, 8), true);
+    if (bias) n.b = h->dalloc<bf16_t>(round_up(dim, 8), true);
+    return n.w && (!bias || n.b);
+}
+
+void expected_names(isst_handle* h) {
+    const isst_config& c = h->cfg;
+    auto& e = h->expected;
+    char b[256];
+    for (int i = 0; i < c.n_conv; ++i) {
+        snprintf(b, sizeof b, "%sfeature_extractor.conv_layers.%d.0.weight", ENC, i); e.push_back(b);
+        if (c.conv_bias) { snprintf(b, sizeof b, "%sfeature_extractor.conv_layers.%d.0.bias", ENC, i); e.push_back(b); }
+        snprintf(b, sizeof b, "%sfeature_extractor.conv_layers.%d.2.1.weight", ENC, i); e.push_back(b);
+        snprintf(b, sizeof b, "%sfeature_extractor.conv_layers.%d.2.1.bias", ENC, i); e.push_back(b);
+    }
+    for (const char* s : {"layer_norm.weight", "layer_norm.bias", "post_extract_proj.weight", "post_extract_proj.bias",
+                          "encoder.layer_norm.weight", "encoder.layer_norm.bias"}) {
+        snprintf(b, sizeof b, "%s%s", ENC, s); e.push_back(b);
+    }
+    for (int i = 0; i < c.enc_layers; ++i)
+        for (const char* s : {"self_attn.q_proj.weight", "self_attn.q_proj.bias", "self_attn.k_proj.weight", "self_attn.k_proj.bias",
+                              "self_attn.v_proj.weight", "self_attn.v_proj.bias", "self_attn.out_proj.weight", "self_attn.out_proj.bias",
+                              "self_attn_layer_norm.weight", "self_attn_layer_norm.bias", "fc1.weight", "fc1.bias", "fc2.weight",
+                              "fc2.bias", "final_layer_norm.weight", "final_layer_norm.bias"}) {
+            snprintf(b, sizeof b, "%sencoder.layers.%d.%s", ENC, i, s); e.push_back(b);
+        }
+    for (int i = 0; i < c.n_shrink; ++i)
+        for (const char* s : {"0.weight", "2.1.weight", "2.1.bias"}) {
+            snprintf(b, sizeof b, "%sconv_layers.%d.%s", SHR, i, s); e.push_back(b);
+        }
+    snprintf(b, sizeof b, "%sweight", PRJ); e.push_back(b);
+    snprintf(b, sizeof b, "%sbias", PRJ); e.push_back(b);
+    e.push_back("model.embed_tokens.weight");
+    for (int i = 0; i < c.llm_layers; ++i)
+        for (const char* s : {"input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                              "self_attn.o_proj.weight", "post_attention_layernorm.weight", "mlp.gate_proj.weight",
+                              "mlp.up_proj.weight", "mlp.down_proj.weight"}) {
+            snprintf(b, sizeof b, "model.layers.%d.%s", i, s); e.push_back(b);
+        }
+    e.push_back("model.norm.weight");
+    e.push_back("lm_head.weight");
+}
+
+int conv_out_len(int n, int k, int s) { return n < k ? 0 : (n - k) / s + 1; }
+
+int validate_config(const isst_config& c, std::string& why) {
+    auto bad = [&](const char* m) { why = m; return ISST_ERR_ARG; };
+    if (c.n_conv < 1 || c.n_conv > ISST_MAX_CONV || c.n_shrink < 0 || c.n_shrink > ISST_MAX_SHRINK) return bad("n_conv / n_shrink out of range");
+    if (c.enc_heads <= 0 || c.enc_dim != c.enc_heads * 64) return bad("encoder head_dim must be 64");
+    if (c.llm_heads <= 0 || c.llm_kv_heads <= 0 || c.llm_heads % c.llm_kv_heads) return bad("llm heads / kv heads");
+    { const int g = c.llm_heads / c.llm_kv_heads; if (g != 1 && g != 2 && g != 4) return bad("llm heads per kv head must be 1, 2 or 4"); }
+    if (c.llm_dim % 32 || c.llm_ffn % 32 || c.enc_dim % 32 || c.enc_ffn % 32) return bad("hidden sizes must be multiples of 32");
+    for (int i = 0; i < c.n_conv; ++i) {
+        if (c.conv_dim[i] % 32 || c.conv_dim[i] > 512 || c.conv_k[i] < 1 || c.conv_k[i] > 16 || c.conv_stride[i] < 1) return bad("conv layer geometry");
+    }
+    for (int i = 0; i < c.n_shrink; ++i)
+        if (c.shrink_dim[i] != c.enc_dim || c.shrink_k[i] < 1 || c.shrink_stride[i] != c.shrink_k[i]) return bad("shrink layers must keep enc_dim and have k == stride");
+    if (c.max_streams < 1 || c.max_multiplier < 1 || c.max_prompt_len < 8 || c.max_new_tokens < 1 || c.max_llm_cache_size < 1) return bad("capacity fields");
+    if (c.block_size % 4 || c.block_size < 4) return bad("block_size must be a multiple of 4");
+    if (c.n_eos < 0 || c.n_eos > ISST_MAX_EOS) return bad("n_eos");
+    if (c.vocab < 16) return bad("vocab");
+    return ISST_OK;
+}
+
+}  // namespace
+
+extern "C" const char* isst_last_error(isst_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void isst_destroy(isst_handle* h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& kv : h->taps) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->meta_host) (void)hipHostFree(h->meta_host);
+    if (h->tok_host) (void)hipHostFree(h->tok_host);
+    delete h;
+}
+
+extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return ISST_ERR_ARG; }
+    std::string why;
+    if (int r = validate_config(*cfg, why)) { g_create_error = why; return r; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device visible (this library has no CPU path)"; return ISST_ERR_HIP; }
+    isst_handle* h = new isst_handle();
+    h->cfg = *cfg;
+    const isst_config& c = h->cfg;
+    auto die = [&](int code) { g_create_error = h->err; isst_destroy(h); return code; };
+
+    // ---- geometry ----
+    int rf = 1, spf = 1;
+    for (int i = c.n_conv - 1; i >= 0; --i) rf = (rf - 1) * c.conv_stride[i] + c.conv_k[i];
+    for (int i = 0; i < c.n_conv; ++i) spf *= c.conv_stride[i];
+    h->hist = rf - 1;
+    h->samples_per_frame = spf;
+    h->chunk_samples = c.block_size / 4 * 1280;  // int(block_size // 4 * 0.08 * 16000), agents/infinisst.py:201
+    for (int i = 0; i < c.n_shrink; ++i) h->shrink_factor *= c.shrink_stride[i];
+    if (h->chunk_samples % spf || (h->chunk_samples / spf) != c.block_size) { h->fail(ISST_ERR_ARG, "block_size %d does not match %d samples per chunk / %d samples per frame", c.block_size, h->chunk_samples, spf); return die(ISST_ERR_ARG); }
+    if (c.block_size % h->shrink_factor) { h->fail(ISST_ERR_ARG, "block_size not divisible by the shrink factor"); return die(ISST_ERR_ARG); }
+    h->n_new_max = h->chunk_samples * c.max_multiplier;
+    h->enc_rows_max = c.max_streams * c.block_size * c.max_multiplier;
+    h->llm_rows_max = c.max_streams * c.max_prompt_len;
+    h->enc_cap = round_up(c.max_cache_size + c.block_size * c.max_multiplier, 64);
+    if (h->enc_cap > 768) { h->fail(ISST_ERR_ARG, "encoder window %d > 768 keys unsupported", h->enc_cap); return die(ISST_ERR_ARG); }
+    h->sys_cap = round_up(c.max_system_prompt, 8);
+    h->ring_cap = round_up(c.max_llm_cache_size + c.max_prompt_len + c.max_new_tokens + 8, 8);
+    h->vocab_pad = round_up(c.vocab, 16);
+    h->max_ids = c.max_prompt_len + c.max_new_tokens + 1;
+
+    // ---- weights ----
+    h->conv.resize(c.n_conv);
+    int cin = 1;
+    bool ok = true;
+    for (int i = 0; i < c.n_conv; ++i) {
+        ConvLayer& L = h->conv[i];
+        L.dim = c.conv_dim[i]; L.k = c.conv_k[i]; L.stride = c.conv_stride[i];
+        if (i == 0) {
+            L.w_raw = h->dalloc<bf16_t>((size_t)L.dim * L.k, true);
+            L.lin.bias = c.conv_bias ? h->dalloc<bf16_t>(L.dim, true) : nullptr;
+            ok = ok && L.w_raw && (!c.conv_bias || L.lin.bias);
+        } else {
+            ok = ok && alloc_linear(h, L.lin, L.dim, cin * L.k, c.conv_bias != 0);
+        }
+        ok = ok && alloc_norm(h, L.ln, L.dim);
+        cin = L.dim;
+    }
+    const int cdim = cin, D = c.enc_dim;
+    ok = ok && alloc_norm(h, h->enc_ln_in, cdim) && alloc_linear(h, h->post_proj, D, cdim, true);
+    h->enc.resize(c.enc_layers);
+    for (auto& L : h->enc)
+        ok = ok && alloc_norm(h, L.ln1, D) && alloc_norm(h, L.ln2, D) && alloc_linear(h, L.qkv, 3 * D, D, true) &&
+             alloc_linear(h, L.out, D, D, true) && alloc_linear(h, L.fc1, c.enc_ffn, D, true) && alloc_linear(h, L.fc2, D, c.enc_ffn, true);
+    ok = ok && alloc_norm(h, h->enc_ln_out, D);
+    h->shrink.resize(c.n_shrink);
+    for (int i = 0; i < c.n_shrink; ++i) {
+        ConvLayer& L = h->shrink[i];
+        L.dim = c.shrink_dim[i]; L.k = c.shrink_k[i]; L.stride = c.shrink_stride[i];
+        ok = ok && alloc_linear(h, L.lin, L.dim, D * L.k, false) && alloc_norm(h, L.ln, L.dim);
+    }
+    const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
+    ok = ok && alloc_linear(h, h->proj, DL, D, true);
+    h->embed = h->dalloc<bf16_t>((size_t)c.vocab * DL, true);
+    ok = ok && h->embed;
+    h->llm.resize(c.llm_layers);
+    for (auto& L : h->llm) {
+        L.in_norm = h->dalloc<bf16_t>(DL, true);
+        L.post_norm = h->dalloc<bf16_t>(DL, true);
+        ok = ok && L.in_norm && L.post_norm && alloc_linear(h, L.qkv, (H + 2 * KV) * 128, DL, false) && alloc_linear(h, L.o, DL, H * 128, false) &&
+             alloc_linear(h, L.gateup, 2 * c.llm_ffn, DL, false) && alloc_linear(h, L.down, DL, c.llm_ffn, false);
+        L.gateup.n_valid = c.llm_ffn;
+    }
+    h->final_norm = h->dalloc<bf16_t>(DL, true);
+    ok = ok && h->final_norm && alloc_linear(h, h->lm_head, c.vocab, DL, false);
+    if (!ok) { h->fail(ISST_ERR_NOMEM, "weight allocation failed"); return die(ISST_ERR_NOMEM); }
+    expected_names(h);
+
+    // ---- state pools ----
+    h->streams.resize(c.max_streams);
+    h->audio_hist = h->dalloc<bf16_t>((size_t)c.max_streams * round_up(h->hist, 8) + 8, true);
+    h->enc_layer_stride = (long)c.enc_heads * h->enc_cap * 64;
+    h->enc_stream_stride = h->enc_layer_stride * c.enc_layers;
+    h->enc_k = h->dalloc<bf16_t>((size_t)h->enc_stream_stride * c.max_streams, true);
+    h->enc_v = h->dalloc<bf16_t>((size_t)h->enc_stream_stride * c.max_streams, true);
+    h->adims.heads = H; h->adims.kv_heads = KV; h->adims.sys_cap = h->sys_cap; h->adims.ring_cap = h->ring_cap;
+    h->adims.layer_stride = (long)KV * (h->sys_cap + h->ring_cap) * 128;
+    h->llm_stream_stride = h->adims.layer_stride * c.llm_layers;
+    h->llm_k = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams, true);
+    h->llm_v = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams, true);
+    h->enc_rope_rows = h->enc_cap;
+    h->llm_rope_rows = h->sys_cap + h->ring_cap;
+    h->enc_cos = h->dalloc<float>((size_t)h->enc_rope_rows * 32, true);
+    h->enc_sin = h->dalloc<float>((size_t)h->enc_rope_rows * 32, true);
+    h->llm_cos = h->dalloc<bf16_t>((size_t)h->llm_rope_rows * 64, true);
+    h->llm_sin = h->dalloc<bf16_t>((size_t)h->llm_rope_rows * 64, true);
+
+    // ---- workspace ----
+    const int ns = c.max_streams;
+    const int win = h->hist + h->n_new_max;
+    const int T0 = conv_out_len(win, c.conv_k[0], c.conv_stride[0]);
+    int cmax = 0;
+    for (int i = 0; i < c.n_conv; ++i) cmax = c.conv_dim[i] > cmax ? c.conv_dim[i] : cmax;
+    const size_t ER = h->enc_rows_max, LR = h->llm_rows_max;
+    h->pcm_f32 = h->dalloc<float>((size_t)ns * h->n_new_max);
+    h->window = h->dalloc<bf16_t>((size_t)ns * round_up(win, 8));
+    h->act_a = h->dalloc<bf16_t>((size_t)ns * T0 * cmax);
+    h->act_b = h->dalloc<bf16_t>((size_t)ns * T0 * cmax);
+    h->ex = h->dalloc<bf16_t>(ER * D); h->exn = h->dalloc<bf16_t>(ER * D); h->eqkv = h->dalloc<bf16_t>(ER * 3 * D);
+    h->eattn = h->dalloc<bf16_t>(ER * D); h->effn = h->dalloc<bf16_t>(ER * c.enc_ffn);
+    h->speech = h->dalloc<bf16_t>(ER * DL);
+    h->lx = h->dalloc<bf16_t>(LR * DL); h->lxn = h->dalloc<bf16_t>(LR * DL); h->lqkv = h->dalloc<bf16_t>(LR * (H + 2 * KV) * 128);
+    h->lqrot = h->dalloc<bf16_t>(LR * H * 128); h->lattn = h->dalloc<bf16_t>(LR * H * 128); h->lact = h->dalloc<bf16_t>(LR * c.llm_ffn);
+    h->llast = h->dalloc<bf16_t>((size_t)ns * DL);
+    h->lpartial = h->dalloc<float>(LR * H * llm_attn_splits(h->llm_rope_rows) * 130);
+    h->logits = h->dalloc<float>((size_t)ns * h->vocab_pad);
+    h->out_tok = h->dalloc<int>(ns);
+    h->meta_bytes = (size_t)LR * 4 * sizeof(int) + (size_t)ns * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
+                    (size_t)ns * (h->max_ids + h->max_enc_ids) * sizeof(int) + 65536 * sizeof(int) + 4096;
+    h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
+    const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
+                          h->window, h->act_a, h->act_b, h->ex, h->exn, h->eqkv, h->eattn, h->effn, h->speech, h->lx, h->lxn, h->lqkv, h->lqrot,
+                          h->lattn, h->lact, h->llast, h->lpartial, h->logits, h->out_tok, h->meta_dev};
+    for (const void* p : must)
+        if (!p) { h->fail(ISST_ERR_NOMEM, "state/workspace allocation failed"); return die(ISST_ERR_NOMEM); }
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->meta_host), h->meta_bytes) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->tok_host), sizeof(int) * ns) != hipSuccess) {
+        h->fail(ISST_ERR_NOMEM, "pinned host allocation failed"); return die(ISST_ERR_NOMEM);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { h->fail(ISST_ERR_HIP, "device sync after allocation failed"); return die(ISST_ERR_HIP); }
+    *out = h;
+    return ISST_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// weights
+// --------------------------------------------------------------------------------------------
+namespace {
+
+bool shape_is(int ndim, const int64_t* s, std::initializer_list<int64_t> want) {
+    if (ndim != (int)want.size()) return false;
+    int i = 0;
+    for (int64_t w : want) if (s[i++] != w) return false;
+    return true;
+}
+
+int copy_vec(isst_handle* h, bf16_t* dst, const bf16_t* src, size_t n) {
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(bf16_t), hipMemcpyDeviceToDevice, 0));
+    return ISST_OK;
+}
+int pack_into(isst_handle* h, PackedLinear& L, const bf16_t* src, int n_rows, int row_offset_tiles, int tile_stride, int tile_phase, int conv_k) {
+    CHK(launch_pack_weight(src, L.wp, n_rows, L.K, row_offset_tiles, tile_stride, tile_phase, conv_k, 0));
+    return ISST_OK;
+}
+
+}  // namespace
+
+extern "C" int isst_load_weight(isst_handle* h, const char* name, const void* data, int ndim, const int64_t* shape, int on_device) {
+    if (!h || !name || !data || !shape || ndim < 1 || ndim > 3) return h ? h->fail(ISST_ERR_ARG, "isst_load_weight: bad argument") : ISST_ERR_ARG;
+    const isst_config& c = h->cfg;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(data);
+    if (!on_device) {
+        if (n * 2 > h->stage_bytes) {
+            HIPCHK(hipDeviceSynchronize());
+            if (h->stage) (void)hipFree(h->stage);
+            h->stage = nullptr; h->stage_bytes = 0;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->stage), n * 2));
+            h->stage_bytes = n * 2;
+        }
+        HIPCHK(hipDeviceSynchronize());  // previous pack kernel may still read the staging buffer
+        HIPCHK(hipMemcpy(h->stage, data, n * 2, hipMemcpyHostToDevice));
+        src = h->stage;
+    }
+    const std::string nm(name);
+    auto bad_shape = [&]() { return h->fail(ISST_ERR_ARG, "unexpected shape for %s", name); };
+    int li = -1;
+    char suf[128] = {0};
+    const int D = c.enc_dim, DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
+    const std::string enc(ENC), shr(SHR), prj(PRJ);
+    int rc = ISST_ERR_NOTFOUND;
+    if (nm.compare(0, enc.size(), enc) == 0) {
+        const char* rest = name + enc.size();
+        if (sscanf(rest, "feature_extractor.conv_layers.%d.%127s", &li, suf) == 2 && li >= 0 && li < c.n_conv) {
+            ConvLayer& L = h->conv[li];
+            const int cin = li == 0 ? 1 : h->conv[li - 1].dim;
+            if (!strcmp(suf, "0.weight")) {
+                if (!shape_is(ndim, shape, {L.dim, cin, L.k})) return bad_shape();
+                rc = li == 0 ? copy_vec(h, L.w_raw, src, n) : pack_into(h, L.lin, src, L.dim, 0, 1, 0, L.k);
+            } else if (!strcmp(suf, "0.bias")) {
+                if (!c.conv_bias || !shape_is(ndim, shape, {L.dim})) return bad_shape();
+                rc = copy_vec(h, L.lin.bias, src, n);
+            } else if (!strcmp(suf, "2.1.weight") || !strcmp(suf, "2.1.bias")) {
+                if (!shape_is(ndim, shape, {L.dim})) return bad_shape();
+                rc = copy_vec(h, suf[4] == 'w' ? L.ln.w : L.ln.b, src, n);
+            }
+        } else if (sscanf(rest, "encoder.layers.%d.%127s", &li, suf) == 2 && li >= 0 && li < c.enc_layers) {
+            EncLayer& L = h->enc[li];
+            struct { const char* n; int part; } qkv[] = {{"self_attn.q_proj", 0}, {"self_attn.k_proj", 1}, {"self_attn.v_proj", 2}};
+            for (auto& q : qkv) {
+                const std::string wn = std::string(q.n) + ".weight", bn = std::string(q.n) + ".bias";
+                if (wn == suf) { if (!shape_is(ndim, shape, {D, D})) return bad_shape(); rc = pack_into(h, L.qkv, src, D, q.part * D / 16, 1, 0, 0); }
+                if (bn == suf) { if (!shape_is(ndim, shape, {D})) return bad_shape(); rc = copy_vec(h, L.qkv.bias + (size_t)q.part * D, src, n); }
+            }
+            if (!strcmp(suf, "self_attn.out_proj.weight")) { if (!shape_is(ndim, shape, {D, D})) return bad_shape(); rc = pack_into(h, L.out, src, D, 0, 1, 0, 0); }
+            if (!strcmp(suf, "self_attn.out_proj.bias")) { if (!shape_is(ndim, shape, {D})) return bad_shape(); rc = copy_vec(h, L.out.bias, src, n); }
+            if (!strcmp(suf, "fc1.weight")) { if (!shape_is(ndim, shape, {c.enc_ffn, D})) return bad_shape(); rc = pack_into(h, L.fc1, src, c.enc_ffn, 0, 1, 0, 0); }
+            if (!strcmp(suf, "fc1.bias")) { if (!shape_is(ndim, shape, {c.enc_ffn})) return bad_shape(); rc = copy_vec(h, L.fc1.bias, src, n); }
+            if (!strcmp(suf, "fc2.weight")) { if (!shape_is(ndim, shape, {D, c.enc_ffn})) return bad_shape(); rc = pack_into(h, L.fc2, src, D, 0, 1, 0, 0); }
+            if (!strcmp(suf, "fc2.bias")) { if (!shape_is(ndim, shape, {D})) return bad_shape(); rc = copy_vec(h, L.fc2.bias, src, n); }
+            struct { const char* n; bf16_t* p; } norms[] = {{"self_attn_layer_norm.weight", L.ln1.w}, {"self_attn_layer_norm.bias", L.ln1.b},
+                                                            {"final_layer_norm.weight", L.ln2.w}, {"final_layer_norm.bias", L.ln2.b}};
+            for (auto& q : norms)
+                if (!strcmp(suf, q.n)) { if (!shape_is(ndim, shape, {D})) return bad_shape(); rc = copy_vec(h, q.p, src, n); }
+        } else {
+            const int cdim = h->conv.back().dim;
+            if (!strcmp(rest, "layer_norm.weight") || !strcmp(rest, "layer_norm.bias")) {
+                if (!shape_is(ndim, shape, {cdim})) return bad_shape();
+                rc = copy_vec(h, rest[11] == 'w' ? h->enc_ln_in.w : h->enc_ln_in.b, src, n);
+            } else if (!strcmp(rest, "post_extract_proj.weight")) {
+                if (!shape_is(ndim, shape, {D, cdim})) return bad_shape();
+                rc = pack_into(h, h->post_proj, src, D, 0, 1, 0, 0);
+            } else if (!strcmp(rest, "post_extract_proj.bias")) {
+                if (!shape_is(ndim, shape, {D})) return bad_shape();
+                rc = copy_vec(h, h->post_proj.bias, src, n);
+            } else if (!strcmp(rest, "encoder.layer_norm.weight") || !strcmp(rest, "encoder.layer_norm.bias")) {
+                if (!shape_is(ndim, shape, {D})) return bad_shape();
+                rc = copy_vec(h, rest[19] == 'w' ? h->enc_ln_out.w : h->enc_ln_out.b, src, n);
+            }
+        }
+    } else if (nm.compare(0, shr.size(), shr) == 0) {
+        if (sscanf(name + shr.size(), "conv_layers.%d.%127s", &li, suf) == 2 && li >= 0 && li < c.n_shrink) {
+            ConvLayer& L = h->shrink[li];
+            if (!strcmp(suf, "0.weight")) { if (!shape_is(ndim, shape, {L.dim, D, L.k})) return bad_shape(); rc = pack_into(h, L.lin, src, L.dim, 0, 1, 0, L.k); }
+            if (!strcmp(suf, "2.1.weight")) { if (!shape_is(ndim, shape, {L.dim})) return bad_shape(); rc = copy_vec(h, L.ln.w, src, n); }
+            if (!strcmp(suf, "2.1.bias")) { if (!shape_is(ndim, shape, {L.dim})) return bad_shape(); rc = copy_vec(h, L.ln.b, src, n); }
+        }
+    } else if (nm.compare(0, prj.size(), prj) == 0) {
+        if (nm == prj + "weight") { if (!shape_is(ndim, shape, {DL, D})) return bad_shape(); rc = pack_into(h, h->proj, src, DL, 0, 1, 0, 0); }
+        if (nm == prj + "bias") { if (!shape_is(ndim, shape, {DL})) return bad_shape(); rc = copy_vec(h, h->proj.bias, src, n); }
+    } else if (nm == "model.embed_tokens.weight") {
+        if (!shape_is(ndim, shape, {c.vocab, DL})) return bad_shape();
+        rc = copy_vec(h, h->embed, src, n);
+    } else if (nm == "model.norm.weight") {
+        if (!shape_is(ndim, shape, {DL})) return bad_shape();
+        rc = copy_vec(h, h->final_norm, src, n);
+    } else if (nm == "lm_head.weight") {
+        if (!shape_is(ndim, shape, {c.vocab, DL})) return bad_shape();
+        rc = pack_into(h, h->lm_head, src, c.vocab, 0, 1, 0, 0);
+    } else if (sscanf(name, "model.layers.%d.%127s", &li, suf) == 2 && li >= 0 && li < c.llm_layers) {
+        LlmLayer& L = h->llm[li];
+        if (!strcmp(suf, "input_layernorm.weight")) { if (!shape_is(ndim, shape, {DL})) return bad_shape(); rc = copy_vec(h, L.in_norm, src, n); }
+        if (!strcmp(suf, "post_attention_layernorm.weight")) { if (!shape_is(ndim, shape, {DL})) return bad_shape(); rc = copy_vec(h, L.post_norm, src, n); }
+        if (!strcmp(suf, "self_attn.q_proj.weight")) { if (!shape_is(ndim, shape, {H * 128, DL})) return bad_shape(); rc = pack_into(h, L.qkv, src, H * 128, 0, 1, 0, 0); }
+        if (!strcmp(suf, "self_attn.k_proj.weight")) { if (!shape_is(ndim, shape, {KV * 128, DL})) return bad_shape(); rc = pack_into(h, L.qkv, src, KV * 128, H * 8, 1, 0, 0); }
+        if (!strcmp(suf, "self_attn.v_proj.weight")) { if (!shape_is(ndim, shape, {KV * 128, DL})) return bad_shape(); rc = pack_into(h, L.qkv, src, KV * 128, (H + KV) * 8, 1, 0, 0); }
+        if (!strcmp(suf, "self_attn.o_proj.weight")) { if (!shape_is(ndim, shape, {DL, H * 128})) return bad_shape(); rc = pack_into(h, L.o, src, DL, 0, 1, 0, 0); }
+        if (!strcmp(suf, "mlp.gate_proj.weight")) { if (!shape_is(ndim, shape, {c.llm_ffn, DL})) return bad_shape(); rc = pack_into(h, L.gateup, src, c.llm_ffn, 0, 2, 0, 0); }
+        if (!strcmp(suf, "mlp.up_proj.weight")) { if (!shape_is(ndim, shape, {c.llm_ffn, DL})) return bad_shape(); rc = pack_into(h, L.gateup, src, c.llm_ffn, 0, 2, 1, 0); }
+        if (!strcmp(suf, "mlp.down_proj.weight")) { if (!shape_is(ndim, shape, {DL, c.llm_ffn})) return bad_shape(); rc = pack_into(h, L.down, src, DL, 0, 1, 0, 0); }
+    }
+    if (rc == ISST_ERR_NOTFOUND) return h->fail(rc, "tensor %s is not part of the hot path", name);
+    if (rc != ISST_OK) return rc;
+    h->loaded.insert(nm);
+    h->finalized = false;
+    return ISST_OK;
+}
+
+extern "C" int isst_set_rope_tables(isst_handle* h, const float* enc_cos, const float* enc_sin, int enc_rows, const uint16_t* llm_cos,
+                                    const uint16_t* llm_sin, int llm_rows) {
+    if (!h || !enc_cos || !enc_sin || !llm_cos || !llm_sin) return h ? h->fail(ISST_ERR_ARG, "null rope table") : ISST_ERR_ARG;
+    if (enc_rows < h->enc_rope_rows || llm_rows < h->llm_rope_rows)
+        return h->fail(ISST_ERR_ARG, "rope tables too short: need %d encoder rows and %d llm rows", h->enc_rope_rows, h->llm_rope_rows);
+    HIPCHK(hipMemcpy(h->enc_cos, enc_cos, (size_t)h->enc_rope_rows * 32 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->enc_sin, enc_sin, (size_t)h->enc_rope_rows * 32 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->llm_cos, llm_cos, (size_t)h->llm_rope_rows * 64 * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->llm_sin, llm_sin, (size_t)h->llm_rope_rows * 64 * 2, hipMemcpyHostToDevice));
+    h->rope_set = true;
+    return ISST_OK;
+}
+
+extern "C" int isst_finalize_weights(isst_handle* h) {
+    if (!h) return ISST_ERR_ARG;
+    for (const auto& n : h->expected)
+        if (!h->loaded.count(n)) return h->fail(ISST_ERR_STATE, "missing tensor %s", n.c_str());
+    if (!h->rope_set) return h->fail(ISST_ERR_STATE, "rotary tables not set (isst_set_rope_tables)");
+    HIPCHK(hipDeviceSynchronize());
+    if (h->stage) { (void)hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+    h->finalized = true;
+    return ISST_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// streams
+// --------------------------------------------------------------------------------------------
+extern "C" int isst_stream_open(isst_handle* h, int* stream_id) {
+    if (!h || !stream_id) return ISST_ERR_ARG;
+    for (size_t i = 0; i < h->streams.size(); ++i)
+        if (!h->streams[i].open) {
+            h->streams[i] = StreamState();
+            h->streams[i].open = true;
+            *stream_id = (int)i;
+            return isst_stream_reset(h, (int)i);
+        }
+    return h->fail(ISST_ERR_STATE, "all %d stream slots are open", (int)h->streams.size());
+}
+extern "C" int isst_stream_reset(isst_handle* h, int id) {
+    if (!h || id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h ? h->fail(ISST_ERR_ARG, "bad stream id %d", id) : ISST_ERR_ARG;
+    h->streams[id] = StreamState();
+    h->streams[id].open = true;
+    // first-chunk offset: 79 + 320 zeros in front of the first samples (agents/infinisst.py:216-218)
+    HIPCHK(hipMemsetAsync(h->audio_hist + (size_t)id * round_up(h->hist, 8), 0, (size_t)h->hist * 2, 0));
+    HIPCHK(hipStreamSynchronize(0));
+    return ISST_OK;
+}
+extern "C" int isst_stream_close(isst_handle* h, int id) {
+    if (!h || id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h ? h->fail(ISST_ERR_ARG, "bad stream id %d", id) : ISST_ERR_ARG;
+    h->streams[id].open = false;
+    return ISST_OK;
+}
+extern "C" int isst_stream_info_get(isst_handle* h, int id, isst_stream_info* out) {
+    if (!h || !out || id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h ? h->fail(ISST_ERR_ARG, "bad stream id %d", id) : ISST_ERR_ARG;
+    const StreamState& s = h->streams[id];
+    out->llm_cache_len = s.llm_sys + s.llm_ring_len;
+    out->llm_sys_len = s.llm_sys;
+    out->enc_n_steps = s.enc_steps;
+    out->enc_cache_len = s.enc_len;
+    out->chunks = s.chunks;
+    return ISST_OK;
+}
+
+extern "C" int isst_kv_evict(isst_handle* h, int id, int new_cache_size, int keep_prefix) {
+    if (!h || id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h ? h->fail(ISST_ERR_ARG, "bad stream id %d", id) : ISST_ERR_ARG;
+    StreamState& s = h->streams[id];
+    if (new_cache_size < 0 || keep_prefix < 0) return h->fail(ISST_ERR_ARG, "negative size");
+    if (keep_prefix != 0 && keep_prefix != s.llm_sys)
+        return h->fail(ISST_ERR_STATE, "keep_prefix %d differs from the pinned system prompt (%d entries); pin it with gen_params.system_prompt_size on the first chunk", keep_prefix, s.llm_sys);
+    if (new_cache_size > s.llm_ring_len)
+        return h->fail(ISST_ERR_STATE, "new_cache_size %d exceeds the %d evictable entries (overlap with the pinned prefix is undefined in the reference)", new_cache_size, s.llm_ring_len);
+    if (keep_prefix == 0) s.llm_sys = 0;  // nothing pinned any more: logical position 0 is the ring start
+    const int drop = s.llm_ring_len - new_cache_size;
+    s.llm_ring_start = (s.llm_ring_start + drop) % h->ring_cap;
+    s.llm_ring_len = new_cache_size;
+    return ISST_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// debug taps
+// --------------------------------------------------------------------------------------------
+namespace {
+int tap(isst_handle* h, const std::string& name, const bf16_t* src, int64_t elems, hipStream_t st) {
+    if (!h->cfg.debug_taps) return ISST_OK;
+    Tap& t = h->taps[name];
+    if (t.cap < elems) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (t.dev) (void)hipFree(t.dev);
+        t.dev = nullptr; t.cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&t.dev), (size_t)elems * 2));
+        t.cap = elems;
+    }
+    t.elems = elems;
+    HIPCHK(hipMemcpyAsync(t.dev, src, (size_t)elems * 2, hipMemcpyDeviceToDevice, st));
+    return ISST_OK;
+}
+
+int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int epi, const bf16_t* res, long ldres, void* out, long ldo,
+         int M, hipStream_t st, int batch = 1, long a_batch = 0, long out_batch = 0, long res_batch = 0) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.a_batch = a_batch;
+    g.Wp = L.wp; g.bias = L.bias;
+    g.res = res; g.ldres = ldres; g.res_batch = res_batch;
+    g.out = out; g.ldo = ldo; g.out_batch = out_batch;
+    g.M = M; g.N = L.N; g.K = L.K; g.batch = batch; g.epi = epi; g.n_valid = L.n_valid;
+    CHK(launch_gemm(g, st));
+    return ISST_OK;
+}
+
+// conv extractor + encoder + shrink + projector for n streams; result in h->speech [n*S][llm_dim]
+int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm, int n_samples, int multiplier, hipStream_t st, int* out_S) {
+    const isst_config& c = h->cfg;
+    const int hist = h->hist, win = hist + n_samples, winp = round_up(hist + h->n_new_max, 8);
+    const int histp = round_up(hist, 8);
+    // ---- audio: [history | new samples] per stream, bf16 (agents/infinisst.py:222) ----
+    for (int i = 0; i < n; ++i) {
+        HIPCHK(hipMemcpyAsync(h->pcm_f32 + (size_t)i * h->n_new_max, pcm[i], (size_t)n_samples * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->window + (size_t)i * winp, h->audio_hist + (size_t)sids[i] * histp, (size_t)hist * 2, hipMemcpyDeviceToDevice, st));
+        CHK(launch_cast_f32_bf16(h->pcm_f32 + (size_t)i * h->n_new_max, h->window + (size_t)i * winp + hist, n_samples, st));
+    }
+    // ---- conv stack ----
+    std::vector<int> T(c.n_conv);
+    int len = win;
+    for (int i = 0; i < c.n_conv; ++i) { len = conv_out_len(len, c.conv_k[i], c.conv_stride[i]); T[i] = len; }
+    const int Q = T.back();
+    if (Q != n_samples / h->samples_per_frame) return h->fail(ISST_ERR_STATE, "conv stack produced %d frames for %d samples", Q, n_samples);
+    bf16_t* cur = h->act_a;
+    bf16_t* nxt = h->act_b;
+    CHK(launch_conv0(h->window, winp, h->conv[0].w_raw, h->conv[0].lin.bias, h->conv[0].ln.w, h->conv[0].ln.b, cur, (long)T[0] * c.conv_dim[0],
+                     T[0], c.conv_dim[0], c.conv_k[0], c.conv_stride[0], n, st));
+    for (int i = 1; i < c.n_conv; ++i) {
+        const ConvLayer& L = h->conv[i];
+        const int cin = h->conv[i - 1].dim;
+        CHK(gemm(h, cur, (long)L.stride * cin, L.lin, c.conv_bias ? EPI_BIAS : EPI_NONE, nullptr, 0, nxt, L.dim, T[i], st, n, (long)T[i - 1] * cin,
+                 (long)T[i] * L.dim));
+        // LN + GELU in place; the last layer writes a dense [n*Q][C] block (out_batch == T*C)
+        CHK(launch_layernorm(nxt, L.dim, L.ln.w, L.ln.b, nxt, L.dim, n * T[i], L.dim, 1e-5f, 1, st));
+        std::swap(cur, nxt);
+    }
+    const int cdim = h->conv.back().dim, D = c.enc_dim, ER = n * Q;
+    CHK(tap(h, "conv_out", cur, (int64_t)ER * cdim, st));
+    // history for the next chunk: last `hist` samples of the window
+    for (int i = 0; i < n; ++i)
+        HIPCHK(hipMemcpyAsync(h->audio_hist + (size_t)sids[i] * histp, h->window + (size_t)i * winp + (win - hist), (size_t)hist * 2, hipMemcpyDeviceToDevice, st));
+    // ---- LayerNorm + post_extract_proj (patch_speech_encoder.py:268-269,:301) ----
+    CHK(launch_layernorm(cur, cdim, h->enc_ln_in.w, h->enc_ln_in.b, nxt, cdim, ER, cdim, 1e-5f, 0, st));
+    CHK(gemm(h, nxt, cdim, h->post_proj, EPI_BIAS, nullptr, 0, h->ex, D, ER, st));
+    CHK(tap(h, "post_proj", h->ex, (int64_t)ER * D, st));
+    // ---- per-stream ring views: trim to max_cache_size before the layer calls (:516-520) ----
+    EncStreamView* ev_host = reinterpret_cast<EncStreamView*>(h->meta_host);
+    for (int i = 0; i < n; ++i) {
+        StreamState& s = h->streams[sids[i]];
+        if (s.enc_len > c.max_cache_size) {
+            s.enc_start = (s.enc_start + s.enc_len - c.max_cache_size) % h->enc_cap;
+            s.enc_len = c.max_cache_size;
+        }
+        ev_host[i].start = s.enc_start;
+        ev_host[i].prefix = s.enc_steps;
+    }
+    EncStreamView* ev = reinterpret_cast<EncStreamView*>(h->meta_dev);
+    HIPCHK(hipMemcpyAsync(ev, ev_host, sizeof(EncStreamView) * n, hipMemcpyHostToDevice, st));
+    const int bs = c.block_size * multiplier;
+    // the n streams of a call must be laid out with ONE stream stride between ring bases: use per-stream pointers
+    // via a base + sid * stride scheme -> requires contiguous slots; general case: launch per stream
+    bool contiguous = true;
+    for (int i = 1; i < n; ++i) contiguous = contiguous && (sids[i] == sids[0] + i);
+    for (int l = 0; l < c.enc_layers; ++l) {
+        const EncLayer& L = h->enc[l];
+        CHK(launch_layernorm(h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+        CHK(gemm(h, h->exn, D, L.qkv, EPI_BIAS, nullptr, 0, h->eqkv, 3 * D, ER, st));
+        if (contiguous) {
+            bf16_t* kb = h->enc_k + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
+            bf16_t* vb = h->enc_v + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
+            CHK(launch_enc_kv_append(h->eqkv, kb, vb, h->enc_stream_stride, ev, n, Q, c.enc_heads, h->enc_cap, c.max_cache_size, st));
+            CHK(launch_enc_attention(h->eqkv, kb, vb, h->enc_stream_stride, ev, h->enc_cos, h->enc_sin, c.enc_rope_round_each, h->eattn, n, Q,
+                                     c.enc_heads, h->enc_cap, c.max_cache_size, bs, st));
+        } else {
+            for (int i = 0; i < n; ++i) {
+                bf16_t* kb = h->enc_k + (size_t)sids[i] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
+                bf16_t* vb = h->enc_v + (size_t)sids[i] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
+                CHK(launch_enc_kv_append(h->eqkv + (size_t)i * Q * 3 * D, kb, vb, 0, ev + i, 1, Q, c.enc_heads, h->enc_cap, c.max_cache_size, st));
+                CHK(launch_enc_attention(h->eqkv + (size_t)i * Q * 3 * D, kb, vb, 0, ev + i, h->enc_cos, h->enc_sin, c.enc_rope_round_each,
+                                         h->eattn + (size_t)i * Q * D, 1, Q, c.enc_heads, h->enc_cap, c.max_cache_size, bs, st));
+            }
+        }
+        CHK(gemm(h, h->eattn, D, L.out, EPI_BIAS_RES, h->ex, D, h->ex, D, ER, st));
+        CHK(launch_layernorm(h->ex, D, L.ln2.w, L.ln2.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+        CHK(gemm(h, h->exn, D, L.fc1, EPI_BIAS_GELU, nullptr, 0, h->effn, c.enc_ffn, ER, st));
+        CHK(gemm(h, h->effn, c.enc_ffn, L.fc2, EPI_BIAS_RES, h->ex, D, h->ex, D, ER, st));
+        if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l), h->ex, (int64_t)ER * D, st));
+    }
+    CHK(launch_layernorm(h->ex, D, h->enc_ln_out.w, h->enc_ln_out.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+    CHK(tap(h, "enc_out", h->exn, (int64_t)ER * D, st));
+    for (int i = 0; i < n; ++i) {
+        StreamState& s = h->streams[sids[i]];
+        s.enc_len += Q;
+        s.enc_steps += Q;
+    }
+    // ---- length shrink (k == stride: rows [k frames x D] are contiguous) + projector ----
+    bf16_t* a = h->exn;
+    bf16_t* b = h->eattn;
+    int rows = ER;
+    for (int i = 0; i < c.n_shrink; ++i) {
+        const ConvLayer& L = h->shrink[i];
+        rows /= L.k;
+        CHK(gemm(h, a, (long)L.k * D, L.lin, EPI_NONE, nullptr, 0, b, D, rows, st));
+        CHK(launch_layernorm(b, D, L.ln.w, L.ln.b, b, D, rows, D, 1e-5f, 1, st));
+        std::swap(a, b);
+        if (b == h->exn) b = h->eqkv;  // keep `a` (current) and `b` distinct scratch buffers
+    }
+    CHK(tap(h, "shrink", a, (int64_t)rows * D, st));
+    CHK(gemm(h, a, D, h->proj, EPI_BIAS, nullptr, 0, h->speech, c.llm_dim, rows, st));
+    CHK(tap(h, "speech", h->speech, (int64_t)rows * c.llm_dim, st));
+    *out_S = Q / h->shrink_factor;
+    return ISST_OK;
+}
+
+struct StepMeta {
+    int *row_stream, *row_pos, *ids, *speech_row, *last_rows;
+    LlmStreamView* views;
+    SampleStream* samp;
+    int *ids_pool, *enc_pool, *suppress;
+    size_t step_bytes;      // bytes from the block start up to (not including) the suppress list
+    size_t suppress_offset;
+};
+// carve the metadata block (same offsets on host and device)
+StepMeta carve(isst_handle* h, unsigned char* base) {
+    StepMeta m;
+    const size_t LR = h->llm_rows_max, ns = h->cfg.max_streams;
+    unsigned char* p = base + 4096;  // first 4 KiB: encoder views
+    auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 15) / 16 * 16; return r; };
+    m.row_stream = reinterpret_cast<int*>(take(LR * 4)); m.row_pos = reinterpret_cast<int*>(take(LR * 4));
+    m.ids = reinterpret_cast<int*>(take(LR * 4)); m.speech_row = reinterpret_cast<int*>(take(LR * 4));
+    m.last_rows = reinterpret_cast<int*>(take(ns * 4));
+    m.views = reinterpret_cast<LlmStreamView*>(take(ns * sizeof(LlmStreamView)));
+    m.samp = reinterpret_cast<SampleStream*>(take(ns * sizeof(SampleStream)));
+    m.ids_pool = reinterpret_cast<int*>(take(ns * h->max_ids * 4));
+    m.enc_pool = reinterpret_cast<int*>(take(ns * h->max_enc_ids * 4));
+    m.step_bytes = (size_t)(p - base);
+    m.suppress_offset = m.step_bytes;
+    m.suppress = reinterpret_cast<int*>(take(65536 * 4));
+    return m;
+}
+
+// one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
+int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int max_pos, bool splice, const char* tap_prefix, hipStream_t st) {
+    const isst_config& c = h->cfg;
+    const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
+    CHK(launch_embed_splice(d.ids, splice ? d.speech_row : nullptr, h->embed, h->speech, h->lx, rows, DL, st));
+    if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "embed", h->lx, (int64_t)rows * DL, st));
+    for (int l = 0; l < c.llm_layers; ++l) {
+        const LlmLayer& L = h->llm[l];
+        CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+        CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
+        CHK(launch_llm_qkv_post(h->lqkv, d.row_stream, d.row_pos, d.views, h->llm_cos, h->llm_sin, h->lqrot, h->llm_k, h->llm_v, h->adims, l, rows, st));
+        CHK(launch_llm_attention(h->lqrot, d.row_stream, d.row_pos, d.views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_v, h->lpartial, h->lattn,
+                                 h->adims, l, rows, max_pos, st));
+        CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
+        CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+        CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+        CHK(gemm(h, h->lact, c.llm_ffn, L.down, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
+        if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
+    }
+    CHK(launch_rmsnorm(h->lx, DL, d.last_rows, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
+    if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "final", h->llast, (int64_t)n_last * DL, st));
+    CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
+    return ISST_OK;
+}
+
+int check_ready(isst_handle* h) {
+    if (!h->finalized) return h->fail(ISST_ERR_STATE, "weights not finalized (isst_finalize_weights)");
+    return ISST_OK;
+}
+
+}  // namespace
+
+extern "C" int isst_encode_speech(isst_handle* h, int stream_id, const float* pcm, int n_samples, int multiplier, uint16_t* out_features,
+                                  int* out_rows, void* hip_stream) {
+    if (!h) return ISST_ERR_ARG;
+    CHK(check_ready(h));
+    if (stream_id < 0 || stream_id >= (int)h->streams.size() || !h->streams[stream_id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", stream_id);
+    if (!pcm || n_samples <= 0 || n_samples % h->chunk_samples || n_samples > h->n_new_max || multiplier < 1 || multiplier > h->cfg.max_multiplier)
+        return h->fail(ISST_ERR_ARG, "n_samples must be a positive multiple of %d and <= %d", h->chunk_samples, h->n_new_max);
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    int S = 0;
+    const float* pp[1] = {pcm};
+    CHK(run_encoder(h, 1, &stream_id, pp, n_samples, multiplier, st, &S));
+    h->streams[stream_id].chunks++;
+    if (out_features) HIPCHK(hipMemcpyAsync(out_features, h->speech, (size_t)S * h->cfg.llm_dim * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (out_rows) *out_rows = S;
+    return ISST_OK;
+}
+
+extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const float* const* pcm, int n_samples,
+                             const int* const* prompt_ids, const int* prompt_lens, const int* const* prev_target_ids, const int* n_prev,
+                             const int* const* forced_tokens, const int* n_forced, int* const* out_ids, int* out_lens, float* logits_out,
+                             void* hip_stream) {
+    if (!h) return ISST_ERR_ARG;
+    CHK(check_ready(h));
+    const isst_config& c = h->cfg;
+    if (!p || !stream_ids || !pcm || !prompt_ids || !prompt_lens || !out_ids || !out_lens) return h->fail(ISST_ERR_ARG, "null argument");
+    if (n < 1 || n > c.max_streams) return h->fail(ISST_ERR_ARG, "n = %d streams, capacity %d", n, c.max_streams);
+    if (n_samples <= 0 || n_samples % h->chunk_samples || n_samples > h->n_new_max)
+        return h->fail(ISST_ERR_ARG, "n_samples %d must be a positive multiple of %d and <= %d", n_samples, h->chunk_samples, h->n_new_max);
+    if (p->multiplier < 1 || p->multiplier > c.max_multiplier || p->max_new_tokens < 1 || p->max_new_tokens > c.max_new_tokens)
+        return h->fail(ISST_ERR_ARG, "multiplier / max_new_tokens out of configured range");
+    if (p->n_suppress < 0 || p->n_suppress > 65536 || (p->n_suppress && !p->suppress_tokens)) return h->fail(ISST_ERR_ARG, "suppress_tokens");
+    if (p->no_repeat_ngram_size < 0 || p->encoder_no_repeat_ngram_size < 0 || p->no_repeat_ngram_size > 64 || p->encoder_no_repeat_ngram_size > 64)
+        return h->fail(ISST_ERR_ARG, "ngram sizes");
+    for (int i = 0; i < n; ++i) {
+        const int id = stream_ids[i];
+        if (id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", id);
+        for (int j = 0; j < i; ++j) if (stream_ids[j] == id) return h->fail(ISST_ERR_ARG, "stream %d listed twice", id);
+        if (prompt_lens[i] < 1 || prompt_lens[i] > c.max_prompt_len) return h->fail(ISST_ERR_ARG, "prompt length %d (max %d)", prompt_lens[i], c.max_prompt_len);
+        if (n_prev && (n_prev[i] < 0 || n_prev[i] > h->max_enc_ids)) return h->fail(ISST_ERR_ARG, "too many previous target ids");
+        const StreamState& s = h->streams[id];
+        const int total = s.llm_sys + s.llm_ring_len;
+        int sys = s.llm_sys;
+        if (total == 0 && p->system_prompt_size > 0) {
+            if (p->system_prompt_size > h->sys_cap || p->system_prompt_size > prompt_lens[i]) return h->fail(ISST_ERR_ARG, "system_prompt_size %d (capacity %d, prompt %d)", p->system_prompt_size, h->sys_cap, prompt_lens[i]);
+            sys = p->system_prompt_size;
+        }
+        if (total - sys + prompt_lens[i] + p->max_new_tokens > h->ring_cap)
+            return h->fail(ISST_ERR_STATE, "stream %d: LLM cache of %d entries + this chunk exceeds the ring (%d); evict first", id, total, h->ring_cap);
+        for (int t = 0; t < prompt_lens[i]; ++t)
+            if (prompt_ids[i][t] < 0 || prompt_ids[i][t] >= c.vocab) return h->fail(ISST_ERR_ARG, "prompt token %d out of range", prompt_ids[i][t]);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+
+    // ---- 1. speech encoder (model/llm.py:69-81) ----
+    int S = 0;
+    CHK(run_encoder(h, n, stream_ids, pcm, n_samples, p->multiplier, st, &S));
+
+    // ---- 2. prefill rows, speech splice map (model/llm.py:86-113) ----
+    StepMeta mh = carve(h, h->meta_host), md = carve(h, h->meta_dev);
+    std::vector<int> total0(n), gen_count(n, 0), row0(n);
+    std::vector<char> done(n, 0);
+    int R = 0, max_pos = 0;
+    for (int i = 0; i < n; ++i) {
+        StreamState& s = h->streams[stream_ids[i]];
+        if (s.llm_sys + s.llm_ring_len == 0 && p->system_prompt_size > 0) s.llm_sys = p->system_prompt_size;
+        total0[i] = s.llm_sys + s.llm_ring_len;
+        mh.views[i].sys_len = s.llm_sys;
+        mh.views[i].ring_start = s.llm_ring_start;
+        mh.views[i].kv_offset = (long)stream_ids[i] * h->llm_stream_stride;
+        row0[i] = R;
+        const int len = prompt_lens[i];
+        const int* ids = prompt_ids[i];
+        for (int t = 0; t < len; ++t) {
+            mh.row_stream[R + t] = i;
+            mh.row_pos[R + t] = total0[i] + t;
+            mh.ids[R + t] = ids[t];
+            mh.speech_row[R + t] = -1;
+        }
+        // user / assistant header pairs
+        std::vector<int> users, assists;
+        for (int t = 1; t < len; ++t) {
+            if (ids[t - 1] != c.start_header_id) continue;
+            if (ids[t] == c.user_id) users.push_back(t);
+            if (ids[t] == c.assistant_id) assists.push_back(t);
+        }
+        int index = 0;
+        for (size_t q = 0; q < users.size() && q < assists.size(); ++q) {
+            const int u = users[q], a = assists[q], cnt = a - u - 5;
+            if (cnt < 0 || index + cnt > S) return h->fail(ISST_ERR_ARG, "stream %d: prompt has %d speech slots but the encoder produced %d features", stream_ids[i], index + cnt, S);
+            for (int k = 0; k < cnt; ++k) mh.speech_row[R + u + 3 + k] = i * S + index + k;
+            index += cnt;
+        }
+        mh.last_rows[i] = R + len - 1;
+        R += len;
+        max_pos = std::max(max_pos, total0[i] + len + p->max_new_tokens);
+        // sampling context
+        std::memcpy(mh.ids_pool + (size_t)i * h->max_ids, ids, (size_t)len * 4);
+        const int ne = n_prev ? n_prev[i] : 0;
+        if (ne) std::memcpy(mh.enc_pool + (size_t)i * h->max_enc_ids, prev_target_ids[i], (size_t)ne * 4);
+        mh.samp[i].n_ids = len; mh.samp[i].n_enc = ne;
+        mh.samp[i].ids_off = i * h->max_ids; mh.samp[i].enc_off = i * h->max_enc_ids; mh.samp[i].logits_row = i;
+    }
+    if (p->n_suppress) {
+        std::memcpy(mh.suppress, p->suppress_tokens, (size_t)p->n_suppress * 4);
+        HIPCHK(hipMemcpyAsync(h->meta_dev + mh.suppress_offset, h->meta_host + mh.suppress_offset, (size_t)p->n_suppress * 4, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+    CHK(llm_forward(h, md, R, n, max_pos, true, "llm_", st));
+
+    // ---- 3. greedy loop (patch_hf.py:606-624 -> HF _sample) ----
+    std::vector<int> active(n);
+    for (int i = 0; i < n; ++i) active[i] = i;
+    int step = 0;
+    while (true) {
+        const int na = (int)active.size();
+        if (logits_out)
+            for (int r = 0; r < na; ++r)
+                HIPCHK(hipMemcpyAsync(logits_out + ((size_t)active[r] * p->max_new_tokens + gen_count[active[r]]) * c.vocab,
+                                      h->logits + (size_t)r * h->vocab_pad, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToHost, st));
+        CHK(launch_sample(h->logits, h->vocab_pad, c.vocab, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
+                          p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->out_tok, na, st));
+        HIPCHK(hipMemcpyAsync(h->tok_host, h->out_tok, sizeof(int) * na, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<int> next_active;
+        for (int r = 0; r < na; ++r) {
+            const int i = active[r];
+            int tok = h->tok_host[r];
+            if (forced_tokens && forced_tokens[i] && n_forced && gen_count[i] < n_forced[i]) tok = forced_tokens[i][gen_count[i]];
+            if (tok < 0 || tok >= c.vocab) return h->fail(ISST_ERR_ARG, "token %d out of range", tok);
+            out_ids[i][gen_count[i]++] = tok;
+            bool stop = gen_count[i] >= p->max_new_tokens;
+            for (int e = 0; e < c.n_eos; ++e) stop = stop || tok == c.eos_ids[e];
+            if (forced_tokens && forced_tokens[i] && n_forced && gen_count[i] >= n_forced[i]) stop = true;
+            if (!stop) next_active.push_back(i);
+            else done[i] = 1;
+        }
+        active.swap(next_active);
+        if (active.empty()) break;
+        ++step;
+        // next decode step: one row per active stream, the token just sampled at the next position
+        const int nr = (int)active.size();
+        for (int r = 0; r < nr; ++r) {
+            const int i = active[r];
+            const int tok = out_ids[i][gen_count[i] - 1];
+            mh.row_stream[r] = i;
+            mh.row_pos[r] = total0[i] + prompt_lens[i] + gen_count[i] - 1;
+            mh.ids[r] = tok;
+            mh.last_rows[r] = r;
+            mh.ids_pool[(size_t)i * h->max_ids + prompt_lens[i] + gen_count[i] - 1] = tok;
+            mh.samp[r].n_ids = prompt_lens[i] + gen_count[i];
+            mh.samp[r].n_enc = n_prev ? n_prev[i] : 0;
+            mh.samp[r].ids_off = i * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
+        }
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+        CHK(llm_forward(h, md, nr, nr, max_pos, false, nullptr, st));
+    }
+    // ---- 4. state: the cache holds the prompt and every generated token except the last one ----
+    for (int i = 0; i < n; ++i) {
+        StreamState& s = h->streams[stream_ids[i]];
+        s.llm_ring_len = total0[i] + prompt_lens[i] + gen_count[i] - 1 - s.llm_sys;
+        s.chunks++;
+        out_lens[i] = gen_count[i];
+    }
+    return ISST_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// per-kernel entry points
+// --------------------------------------------------------------------------------------------
+extern "C" int64_t isst_op_packed_elems(int n_rows, int K) { return (int64_t)round_up(n_rows, 16) * K; }
+
+extern "C" int isst_op_pack_weight(const uint16_t* w, uint16_t* packed, int n_rows, int K, int conv_k, void* hip_stream) {
+    return launch_pack_weight(w, packed, n_rows, K, 0, 1, 0, conv_k, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, const uint16_t* res, int64_t ldres,
+                            void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, void* hip_stream) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.Wp = packed; g.bias = bias; g.res = res; g.ldres = ldres; g.out = out; g.ldo = ldo;
+    g.M = M; g.N = round_up(N, 16); g.K = K; g.batch = 1; g.epi = epi; g.n_valid = n_valid;
+    return launch_gemm(g, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps, int gelu,
+                                 void* hip_stream) {
+    return launch_layernorm(x, C, w, b, out, C, rows, C, eps, gelu, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int rows, int D, float eps, void* hip_stream) {
+    return launch_rmsnorm(x, D, nullptr, w, out, D, rows, D, eps, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_conv0(const uint16_t* audio, const uint16_t* w, const uint16_t* bias, const uint16_t* ln_w, const uint16_t* ln_b,
+                             uint16_t* out, int T, int C, int k, int stride, void* hip_stream) {
+    return launch_conv0(audio, 0, w, bias, ln_w, ln_b, out, 0, T, C, k, stride, 1, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_sample(float* logits, int vocab, const int* ids, int n_ids, const int* enc_ids, int n_enc, const int* suppress,
+                              int n_suppress, float repetition_penalty, int ngram, int enc_ngram, int* out_token, void* hip_stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    SampleStream ss{n_ids, n_enc, 0, 0, 0};
+    SampleStream* dss = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dss), sizeof ss) != hipSuccess) return ISST_ERR_NOMEM;
+    int rc = ISST_ERR_HIP;
+    if (hipMemcpyAsync(dss, &ss, sizeof ss, hipMemcpyHostToDevice, st) == hipSuccess)
+        rc = launch_sample(logits, vocab, vocab, dss, ids, enc_ids, suppress, n_suppress, repetition_penalty, ngram, enc_ngram, out_token, 1, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(dss);
+    return rc;
+}
+
+extern "C" int isst_debug_tap(isst_handle* h, const char* name, uint16_t* dst, int64_t max_elems, int64_t* got_elems) {
+    if (!h || !name || !got_elems) return ISST_ERR_ARG;
+    auto it = h->taps.find(name);
+    if (it == h->taps.end() || !it->second.dev) return h->fail(ISST_ERR_NOTFOUND, "no tap named %s (cfg.debug_taps set?)", name);
+    *got_elems = it->second.elems;
+    if (dst) {
+        const int64_t nel = it->second.elems < max_elems ? it->second.elems : max_elems;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(dst, it->second.dev, (size_t)nel * 2, hipMemcpyDeviceToHost));
+    }
+    return ISST_OK;
+}

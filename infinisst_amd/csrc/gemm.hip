@@ -1,0 +1,231 @@
+// Packed-weight skinny GEMM for gfx950:  out[M,N] = epi(A[M,K] @ W[N,K]^T).
+//
+// This is the kernel every Linear / Conv1d of the InfiniSST hot path runs through (reference call sites:
+// model/patches/patch_speech_encoder.py:741-743,923,586-589 (encoder q/k/v/out/fc1/fc2),
+// model/speech_encoder.py:233-234 (shrink convs as implicit GEMM, projector), patch_llm.py:260-262,334 and
+// HF LlamaMLP / lm_head (model/llm.py:237)).  With one stream per GPU every one of them is a weight-streaming
+// problem (M = 1..64 rows against a weight read exactly once), so the design is HBM-first:
+//
+//   * weights are re-laid out ONCE at load time into MFMA-fragment-major order
+//         Wp[n_tile][k_tile][lane 0..63][8 bf16]   (n_tile = 16 rows of W, k_tile = 32 columns)
+//     so that the B operand of v_mfma_f32_16x16x32_bf16 for (n_tile,k_tile) is one fully contiguous 1 KiB
+//     global_load_dwordx4 per wave -- no LDS round trip, no 64-byte row fragments;
+//   * a workgroup owns NTB n-tiles and all of K; its waves interleave k-tiles (wave w takes kt = w, w+W, ..),
+//     so the block streams one contiguous [NTB][K/32] KiB run; partial sums meet in LDS once at the end;
+//   * A (activations, L2-resident) goes straight to VGPRs in the A-operand layout; rows >= M are not loaded;
+//   * the epilogue applies bias / GELU / residual / SwiGLU with the reference's bf16 rounding points.
+//
+// Operand maps (cdna_hip_programming.md section 3): A lane l holds A[row l&15][k = 8(l>>4)+j], B lane l holds
+// B[k = 8(l>>4)+j][col l&15], C/D lane l reg r is (row 4(l>>4)+r, col l&15).
+#include "common.h"
+
+#define GEMM_UNROLL 4
+
+// ------------------------------------------------------------------------------------------------
+// weight packer: src row-major [n_rows][K] (or Conv1d [n_rows][Cin][conv_k]) -> fragment-major tiles
+// dst tile index of source row-tile rt is  row_offset_tiles + rt * tile_stride + tile_phase.
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int n_rows, int K,
+                                   int row_offset_tiles, int tile_stride, int tile_phase, int conv_k) {
+    const int KT = K >> 5;
+    const long tile = blockIdx.x;  // rt * KT + kt
+    const int rt = (int)(tile / KT), kt = (int)(tile % KT);
+    const int lane = threadIdx.x;
+    const int n = rt * 16 + (lane & 15);
+    const int k0 = kt * 32 + 8 * (lane >> 4);
+    bf16_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        bf16_t x = 0;
+        if (n < n_rows) {
+            if (conv_k > 0) {  // GEMM column k = kk * Cin + ci  <-  Conv1d weight [n][ci][kk]
+                const int cin = K / conv_k;
+                const int ci = k % cin, kk = k / cin;
+                x = src[(long)n * K + (long)ci * conv_k + kk];
+            } else {
+                x = src[(long)n * K + k];
+            }
+        }
+        v[j] = x;
+    }
+    const long dt = (long)row_offset_tiles + (long)rt * tile_stride + tile_phase;
+    bf16_t* d = dst + (dt * KT + kt) * 512 + lane * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = v[j];
+}
+
+int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,
+                       int tile_phase, int conv_k, hipStream_t stream) {
+    if (K % 32 != 0 || n_rows <= 0) return ISST_ERR_ARG;
+    const int RT = (n_rows + 15) / 16;
+    const long tiles = (long)RT * (K / 32);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, src, dst, n_rows, K,
+                       row_offset_tiles, tile_stride, tile_phase, conv_k);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool NT>
+__device__ __forceinline__ u32x4_t load_w(const u32x4_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+template <int MT, int NTB, int EPI, bool NT>
+__global__ void gemm_skinny_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [W][MT*NTB*4][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int W = blockDim.x >> 6;
+    const int KT = g.K >> 5;
+    const int NTILES = g.N >> 4;
+    const int nt0 = blockIdx.x * NTB;
+    const int m0 = blockIdx.y * (MT * 16);
+    const long b = blockIdx.z;
+    const bf16_t* A = g.A + b * g.a_batch;
+
+    f32x4_t acc[MT][NTB];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) acc[mt][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int arow = lane & 15;
+    const int kq = (lane >> 4) * 8;
+    const bf16_t* aptr[MT];
+    bool avalid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = m0 + mt * 16 + arow;
+        avalid[mt] = row < g.M;
+        aptr[mt] = A + (long)(avalid[mt] ? row : 0) * g.lda + kq;
+    }
+    const u32x4_t* wptr[NTB];
+    bool wvalid[NTB];
+#pragma unroll
+    for (int nb = 0; nb < NTB; ++nb) {
+        const int nt = nt0 + nb;
+        wvalid[nb] = nt < NTILES;
+        wptr[nb] = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(wvalid[nb] ? nt : 0) * KT) * 64 + lane;
+    }
+
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    for (int kt0 = wave; kt0 < KT; kt0 += W * GEMM_UNROLL) {
+        u32x4_t wf[GEMM_UNROLL][NTB];
+        u32x4_t af[GEMM_UNROLL][MT];
+#pragma unroll
+        for (int u = 0; u < GEMM_UNROLL; ++u) {
+            const int kt = kt0 + u * W;
+            const bool kv = kt < KT;
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb)
+                wf[u][nb] = (kv && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                af[u][mt] = (kv && avalid[mt]) ? *reinterpret_cast<const u32x4_t*>(aptr[mt] + (long)kt * 32) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < GEMM_UNROLL; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < NTB; ++nb)
+                    acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, af[u][mt]), __builtin_bit_cast(bf16x8_t, wf[u][nb]), acc[mt][nb], 0, 0, 0);
+    }
+
+    // ---- cross-wave reduction through LDS: red[wave][(mt*NTB+nb)*4 + r][lane] ----
+    constexpr int TILES = MT * NTB;
+    float* my = red + (long)wave * (TILES * 256);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) my[((mt * NTB + nb) * 4 + r) * 64 + lane] = acc[mt][nb][r];
+    __syncthreads();
+
+    const bf16_t* res = g.res ? g.res + b * g.res_batch : nullptr;
+    constexpr int OUT_TILES = (EPI == EPI_SWIGLU) ? TILES / 2 : TILES;
+    for (int e = threadIdx.x; e < OUT_TILES * 256; e += blockDim.x) {
+        const int ot = e >> 8;  // output tile index within the block
+        const int rl = e & 255;
+        const int r = rl >> 6, l = rl & 63;
+        int mt, nb;
+        if constexpr (EPI == EPI_SWIGLU) { mt = ot / (NTB / 2); nb = (ot % (NTB / 2)) * 2; }
+        else { mt = ot / NTB; nb = ot % NTB; }
+        float s = 0.f, s2 = 0.f;
+        for (int w = 0; w < W; ++w) {
+            const float* p = red + (long)w * (TILES * 256);
+            s += p[((mt * NTB + nb) * 4 + r) * 64 + l];
+            if constexpr (EPI == EPI_SWIGLU) s2 += p[((mt * NTB + nb + 1) * 4 + r) * 64 + l];
+        }
+        const int row = m0 + mt * 16 + (l >> 4) * 4 + r;
+        int col;
+        if constexpr (EPI == EPI_SWIGLU) col = ((nt0 + nb) >> 1) * 16 + (l & 15);
+        else col = (nt0 + nb) * 16 + (l & 15);
+        if (row >= g.M || col >= g.n_valid) continue;
+        if constexpr (EPI == EPI_F32) {
+            reinterpret_cast<float*>(g.out)[b * g.out_batch + (long)row * g.ldo + col] = bfr(s);
+        } else {
+            float v;
+            if constexpr (EPI == EPI_NONE) v = s;
+            else if constexpr (EPI == EPI_BIAS) v = s + bf2f(g.bias[col]);
+            else if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(bfr(s + bf2f(g.bias[col])));
+            else if constexpr (EPI == EPI_RES) v = bf2f(res[(long)row * g.ldres + col]) + bfr(s);
+            else if constexpr (EPI == EPI_BIAS_RES) v = bf2f(res[(long)row * g.ldres + col]) + bfr(s + bf2f(g.bias[col]));
+            else /* EPI_SWIGLU */ v = bfr(silu(bfr(s))) * bfr(s2);
+            reinterpret_cast<bf16_t*>(g.out)[b * g.out_batch + (long)row * g.ldo + col] = f2bf(v);
+        }
+    }
+}
+
+template <int MT, int EPI, bool NT>
+static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
+    const int KT = g.K / 32, NTILES = g.N / 16;
+    // NTB: n-tiles per block (SwiGLU needs the (gate, up) pair in one block)
+    const bool swiglu = EPI == EPI_SWIGLU;
+    int ntb = swiglu ? 2 : ((NTILES >= 2048) ? 2 : 1);
+    const int blocks_x = (NTILES + ntb - 1) / ntb;
+    const int blocks_y = (g.M + MT * 16 - 1) / (MT * 16);
+    // waves per block: enough waves chip-wide to cover HBM latency (>= ~2048), bounded by K-tiles and LDS
+    long blocks = (long)blocks_x * blocks_y * g.batch;
+    int W = 4;
+    while (W < 16 && blocks * W < 2048 && W * 2 * GEMM_UNROLL <= KT * 2) W *= 2;
+    while (W > 1 && W > KT) W /= 2;
+    while (W > 1 && (size_t)W * MT * ntb * 1024 > 64 * 1024) W /= 2;
+    const size_t lds = (size_t)W * MT * ntb * 1024;
+    dim3 grid(blocks_x, blocks_y, g.batch), block(W * 64);
+    if (ntb == 2)
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2, EPI, NT>), grid, block, lds, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_skinny_kernel<MT, (EPI == EPI_SWIGLU ? 2 : 1), EPI, NT>), grid, block, lds, stream, g);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+template <int EPI>
+static int launch_epi(const GemmArgs& g, hipStream_t stream) {
+    const bool single = g.M <= 64 && g.batch == 1;  // weight read exactly once -> non-temporal loads
+    if (!single) return launch_cfg<4, EPI, false>(g, stream);
+    if (g.M <= 16) return launch_cfg<1, EPI, true>(g, stream);
+    if (g.M <= 32) return launch_cfg<2, EPI, true>(g, stream);
+    if (g.M <= 48) return launch_cfg<3, EPI, true>(g, stream);
+    return launch_cfg<4, EPI, true>(g, stream);
+}
+
+int launch_gemm(const GemmArgs& g, hipStream_t stream) {
+    if (g.M <= 0 || g.batch <= 0) return ISST_OK;
+    if (g.K % 32 != 0 || g.N % 16 != 0 || g.lda % 8 != 0) return ISST_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.Wp) & 15)) return ISST_ERR_ARG;
+    switch (g.epi) {
+        case EPI_NONE: return launch_epi<EPI_NONE>(g, stream);
+        case EPI_BIAS: return g.bias ? launch_epi<EPI_BIAS>(g, stream) : ISST_ERR_ARG;
+        case EPI_BIAS_GELU: return g.bias ? launch_epi<EPI_BIAS_GELU>(g, stream) : ISST_ERR_ARG;
+        case EPI_RES: return g.res ? launch_epi<EPI_RES>(g, stream) : ISST_ERR_ARG;
+        case EPI_BIAS_RES: return (g.res && g.bias) ? launch_epi<EPI_BIAS_RES>(g, stream) : ISST_ERR_ARG;
+        case EPI_SWIGLU: return (g.N % 32 == 0) ? launch_epi<EPI_SWIGLU>(g, stream) : ISST_ERR_ARG;
+        case EPI_F32: return launch_epi<EPI_F32>(g, stream);
+    }
+    return ISST_ERR_ARG;
+}

@@ -1,0 +1,63 @@
+// Launchers of the non-GEMM kernels (all asynchronous on `stream`, return ISST_* codes).
+#pragma once
+#include "common.h"
+
+// per-stream view of the encoder KV ring for one chunk (same for all layers)
+struct EncStreamView {
+    int start;   // physical ring slot of logical key 0 (after trimming to max_cache_size)
+    int prefix;  // frames consumed before this chunk (cache.n_steps); cached keys = min(prefix, max_cache)
+};
+
+// per-stream view of the LLM KV arena: [sys region: sys_cap slots][ring: ring_cap slots]
+struct LlmStreamView {
+    int sys_len;     // pinned system-prompt entries (logical positions 0..sys_len-1 live in the sys region)
+    int ring_start;  // physical ring slot of logical position sys_len
+    long kv_offset;  // element offset of this stream's arena inside the K (and V) pool, per layer-0 head-0 base
+};
+
+int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
+int launch_conv0(const bf16_t* audio, long audio_batch, const bf16_t* w, const bf16_t* bias, const bf16_t* ln_w,
+                 const bf16_t* ln_b, bf16_t* out, long out_batch, int T, int C, int k, int stride, int batch, hipStream_t s);
+int launch_layernorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C,
+                     float eps, int gelu, hipStream_t s);
+int launch_rmsnorm(const bf16_t* x, long ldx, const int* rows_idx, const bf16_t* w, bf16_t* out, long ldo, int rows, int D,
+                   float eps, hipStream_t s);
+int launch_embed_splice(const int* ids, const int* speech_row, const bf16_t* table, const bf16_t* speech, bf16_t* out,
+                        int rows, int D, hipStream_t s);
+
+// ---- encoder attention (enc_attn.hip) ----
+// qkv: [n_streams*Q][3*D] (q | k | v).  K/V rings: per stream `stream_stride` elements, layout [heads][cap][64].
+int launch_enc_kv_append(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long stream_stride, const EncStreamView* sv,
+                         int n_streams, int Q, int heads, int cap, int max_cache, hipStream_t s);
+int launch_enc_attention(const bf16_t* qkv, const bf16_t* kring, const bf16_t* vring, long stream_stride,
+                         const EncStreamView* sv, const float* rope_cos, const float* rope_sin, int rope_round_each,
+                         bf16_t* out, int n_streams, int Q, int heads, int cap, int max_cache, int blocksize, hipStream_t s);
+
+// ---- LLM attention (llm_attn.hip) ----
+struct LlmAttnDims {
+    int heads, kv_heads;         // head_dim is 128
+    int sys_cap, ring_cap;       // arena geometry (slots); per (layer, kv head) the arena is [sys_cap + ring_cap][128]
+    long layer_stride;           // elements between layers inside one stream's arena = kv_heads*(sys_cap+ring_cap)*128
+};
+// rotate q (positions row_pos) into qrot, append unrotated k and v to the arena of row_stream[r].
+int launch_llm_qkv_post(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
+                        const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* qrot, bf16_t* kpool, bf16_t* vpool,
+                        LlmAttnDims d, int layer, int rows, hipStream_t s);
+// causal attention of every row over its stream's keys 0..row_pos; RoPE applied to K on read.
+int launch_llm_attention(const bf16_t* qrot, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
+                         const bf16_t* rope_cos, const bf16_t* rope_sin, const bf16_t* kpool, const bf16_t* vpool,
+                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, int max_pos, hipStream_t s);
+#define LLM_ATTN_SPLIT 128
+static inline int llm_attn_splits(int max_pos) { return (max_pos + LLM_ATTN_SPLIT) / LLM_ATTN_SPLIT; }
+
+// ---- sampling (sample.hip) ----
+struct SampleStream {
+    int n_ids;        // prompt + generated so far (this chunk)
+    int n_enc;        // previous target ids (<= lookback)
+    int ids_off;      // offsets into the ids / enc_ids pools
+    int enc_off;
+    int logits_row;   // row of the logits buffer
+};
+int launch_sample(float* logits, long ld_logits, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool,
+                  const int* suppress, int n_suppress, float rep_penalty, int ngram, int enc_ngram, int* out_tokens,
+                  int n_streams, hipStream_t s);

@@ -1,0 +1,223 @@
+// Row-wise HBM-bound kernels of the InfiniSST hot path (gfx950): first conv layer, LayerNorm(+GELU),
+// RMSNorm, embedding gather + speech splice, audio cast.  One wave (or block) per row, 16-byte accesses.
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// fp32 PCM -> bf16 (reference agents/infinisst.py:222 casts the waveform to the model dtype)
+// ------------------------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f2bf(src[i]);
+}
+int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s) {
+    if (n <= 0) return ISST_OK;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv layer 0: Conv1d(1 -> C, k, stride, bias) + LayerNorm over channels + GELU, fused.
+// [3P fairseq ConvFeatureExtractionModel(mode=layer_norm)], call site patch_speech_encoder.py:245-251.
+// One wave per output frame; the k input samples are wave-uniform, each lane owns channels lane, lane+64, ...
+// (C <= 64*CPL).  Rounding points: conv(+bias) -> bf16, LN -> bf16, GELU -> bf16.
+// ------------------------------------------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const bf16_t* __restrict__ audio, long audio_batch,
+                                                            const bf16_t* __restrict__ w /*[C][k]*/,
+                                                            const bf16_t* __restrict__ bias,
+                                                            const bf16_t* __restrict__ ln_w,
+                                                            const bf16_t* __restrict__ ln_b, bf16_t* __restrict__ out,
+                                                            long out_batch, int T, int C, int k, int stride) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const bf16_t* a = audio + (long)blockIdx.y * audio_batch + (long)t * stride;
+    float x[16];
+    for (int j = 0; j < k; ++j) x[j] = bf2f(a[j]);
+    float v[CPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        float acc = 0.f;
+        if (c < C) {
+            for (int j = 0; j < k; ++j) acc += x[j] * bf2f(w[c * k + j]);
+            if (bias) acc += bf2f(bias[c]);
+            acc = bfr(acc);
+            sum += acc;
+        }
+        v[i] = acc;
+    }
+    const float mean = wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+        if (lane + 64 * i < C) { const float d = v[i] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) / C + 1e-5f);
+    bf16_t* o = out + (long)blockIdx.y * out_batch + (long)t * C;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+            const float y = bfr((v[i] - mean) * rstd * bf2f(ln_w[c]) + bf2f(ln_b[c]));
+            o[c] = f2bf(gelu_erf(y));
+        }
+    }
+}
+
+int launch_conv0(const bf16_t* audio, long audio_batch, const bf16_t* w, const bf16_t* bias, const bf16_t* ln_w,
+                 const bf16_t* ln_b, bf16_t* out, long out_batch, int T, int C, int k, int stride, int batch,
+                 hipStream_t s) {
+    if (T <= 0) return ISST_OK;
+    if (k > 16 || C > 512) return ISST_ERR_ARG;
+    dim3 grid((T + 3) / 4, batch), block(256);
+    if (C <= 64)
+        hipLaunchKernelGGL(conv0_ln_gelu_kernel<1>, grid, block, 0, s, audio, audio_batch, w, bias, ln_w, ln_b, out, out_batch, T, C, k, stride);
+    else
+        hipLaunchKernelGGL(conv0_ln_gelu_kernel<8>, grid, block, 0, s, audio, audio_batch, w, bias, ln_w, ln_b, out, out_batch, T, C, k, stride);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (+ optional GELU), one wave per row, 8 bf16 per lane per step.
+// torch semantics: statistics and affine in fp32, one rounding to bf16; GELU of the bf16 value, rounded again.
+// ------------------------------------------------------------------------------------------------
+template <int STEPS>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, long ldx, const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ b, bf16_t* out, long ldo,
+                                                        int rows, int C, float eps, int gelu) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + row * ldx;
+    float v[STEPS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (lane + 64 * s) * 8;
+        if (c < C) {
+            unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[s][j];
+        }
+    }
+    const float mean = wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+        if ((lane + 64 * s) * 8 < C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[s][j] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / C + eps);
+    bf16_t* orow = out + row * ldo;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (lane + 64 * s) * 8;
+        if (c < C) {
+            float wv[8], bv[8], y[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(w + c), wv);
+            unpack8(*reinterpret_cast<const u32x4_t*>(b + c), bv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                y[j] = (v[s][j] - mean) * rstd * wv[j] + bv[j];
+                if (gelu) y[j] = gelu_erf(bfr(y[j]));
+            }
+            *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
+        }
+    }
+}
+
+int launch_layernorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C,
+                     float eps, int gelu, hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    if (C % 8 != 0 || C > 4096 || ldx % 8 != 0 || ldo % 8 != 0) return ISST_ERR_ARG;
+    dim3 grid((rows + 3) / 4), block(256);
+    if (C <= 512)
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu);
+    else if (C <= 1024)
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm [3P HF LlamaRMSNorm]: var = mean(x^2) in fp32; (x * rsqrt(var+eps)) -> bf16; * weight -> bf16.
+// One 256-thread block per row (D <= 256*8*STEPS); optional row gather (rows_idx) so that only the rows that
+// need the final norm (last prompt position of each stream) are touched.
+// ------------------------------------------------------------------------------------------------
+template <int STEPS>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, long ldx, const int* __restrict__ rows_idx,
+                                                      const bf16_t* __restrict__ w, bf16_t* __restrict__ out, long ldo, int D,
+                                                      float eps) {
+    __shared__ float part[4];
+    const long row = rows_idx ? rows_idx[blockIdx.x] : blockIdx.x;
+    const bf16_t* xr = x + row * ldx;
+    float v[STEPS][8];
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8;
+        if (c < D) {
+            unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sq += v[s][j] * v[s][j];
+        }
+    }
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    const float tot = part[0] + part[1] + part[2] + part[3];
+    const float r = rsqrtf(tot / D + eps);
+    bf16_t* orow = out + (long)blockIdx.x * ldo;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8;
+        if (c < D) {
+            float wv[8], y[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(w + c), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = wv[j] * bfr(v[s][j] * r);
+            *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
+        }
+    }
+}
+
+int launch_rmsnorm(const bf16_t* x, long ldx, const int* rows_idx, const bf16_t* w, bf16_t* out, long ldo, int rows, int D,
+                   float eps, hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    if (D % 8 != 0 || D > 8192 || ldx % 8 != 0 || ldo % 8 != 0) return ISST_ERR_ARG;
+    if (D <= 2048)
+        hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(rows), dim3(256), 0, s, x, ldx, rows_idx, w, out, ldo, D, eps);
+    else if (D <= 4096)
+        hipLaunchKernelGGL(rmsnorm_kernel<2>, dim3(rows), dim3(256), 0, s, x, ldx, rows_idx, w, out, ldo, D, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<4>, dim3(rows), dim3(256), 0, s, x, ldx, rows_idx, w, out, ldo, D, eps);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding gather + speech splice (reference model/llm.py:86-113): row r takes the speech feature row
+// src_row[r] >= 0, else the embedding of token ids[r].  One wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_splice_kernel(const int* __restrict__ ids, const int* __restrict__ speech_row,
+                                                           const bf16_t* __restrict__ table, const bf16_t* __restrict__ speech,
+                                                           bf16_t* __restrict__ out, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int sr = speech_row ? speech_row[r] : -1;
+    const bf16_t* src = sr >= 0 ? speech + (long)sr * D : table + (long)ids[r] * D;
+    bf16_t* o = out + (long)r * D;
+    for (int c = lane * 8; c < D; c += 512) *reinterpret_cast<u32x4_t*>(o + c) = *reinterpret_cast<const u32x4_t*>(src + c);
+}
+
+int launch_embed_splice(const int* ids, const int* speech_row, const bf16_t* table, const bf16_t* speech, bf16_t* out,
+                        int rows, int D, hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    if (D % 8 != 0) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(embed_splice_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, speech_row, table, speech, out, rows, D);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}

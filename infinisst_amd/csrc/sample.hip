@@ -1,0 +1,82 @@
+// Logits processors + greedy argmax on the device (gfx950), one 1024-thread block per stream.
+//
+// Reference: the processors the agent configures (agents/infinisst.py:319-329) as built by the patched generate
+// (model/patches/patch_hf.py:586-600) and applied by HF `_sample` [3P transformers 4.47.0] to the fp32 copy of the
+// last position's logits, in this order: RepetitionPenalty(over this chunk's input_ids) ->
+// NoRepeatNGram(n, same ids) -> EncoderNoRepeatNGram(n, last <=100 previous target ids) -> SuppressTokens -> argmax
+// (first index on ties).
+#include "common.h"
+#include "kernels.h"
+
+__global__ __launch_bounds__(1024) void sample_kernel(float* __restrict__ logits, long ld, int vocab,
+                                                      const SampleStream* __restrict__ ss, const int* __restrict__ ids_pool,
+                                                      const int* __restrict__ enc_pool, const int* __restrict__ suppress,
+                                                      int n_suppress, float pen, int ngram, int enc_ngram,
+                                                      int* __restrict__ out_tokens) {
+    __shared__ float sval[16];
+    __shared__ int sidx[16];
+    const SampleStream st = ss[blockIdx.x];
+    float* L = logits + (long)st.logits_row * ld;
+    const int* ids = ids_pool + st.ids_off;
+    const int* enc = enc_pool + st.enc_off;
+    const int n = st.n_ids, tid = threadIdx.x;
+
+    // 1. repetition penalty, once per distinct token
+    if (pen != 1.0f) {
+        for (int i = tid; i < n; i += blockDim.x) {
+            const int t = ids[i];
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && (ids[j] != t);
+            if (first) { const float v = L[t]; L[t] = v < 0.f ? v * pen : v / pen; }
+        }
+    }
+    __syncthreads();
+    // 2. n-gram bans: the last (n-1) ids followed by t already occurs in ids (resp. in enc)
+    if (ngram > 0 && n + 1 >= ngram) {
+        const int* key = ids + n - (ngram - 1);
+        for (int p = tid; p + ngram <= n; p += blockDim.x) {
+            bool eq = true;
+            for (int q = 0; q < ngram - 1; ++q) eq = eq && (ids[p + q] == key[q]);
+            if (eq) L[ids[p + ngram - 1]] = -INFINITY;
+        }
+    }
+    if (enc_ngram > 0 && n + 1 >= enc_ngram) {
+        const int* key = ids + n - (enc_ngram - 1);
+        for (int p = tid; p + enc_ngram <= st.n_enc; p += blockDim.x) {
+            bool eq = true;
+            for (int q = 0; q < enc_ngram - 1; ++q) eq = eq && (enc[p + q] == key[q]);
+            if (eq) L[enc[p + enc_ngram - 1]] = -INFINITY;
+        }
+    }
+    for (int i = tid; i < n_suppress; i += blockDim.x) L[suppress[i]] = -INFINITY;
+    __syncthreads();
+    // 3. argmax, smallest index on ties
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = tid; v < vocab; v += blockDim.x) {
+        const float x = L[v];
+        if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, WAVE);
+        const int oi = __shfl_xor(bi, o, WAVE);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sval[tid >> 6] = bv; sidx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (sval[w] > bv || (sval[w] == bv && sidx[w] < bi)) { bv = sval[w]; bi = sidx[w]; }
+        out_tokens[blockIdx.x] = bi;
+    }
+}
+
+int launch_sample(float* logits, long ld_logits, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool,
+                  const int* suppress, int n_suppress, float rep_penalty, int ngram, int enc_ngram, int* out_tokens,
+                  int n_streams, hipStream_t s) {
+    if (n_streams <= 0) return ISST_OK;
+    hipLaunchKernelGGL(sample_kernel, dim3(n_streams), dim3(1024), 0, s, logits, ld_logits, vocab, ss, ids_pool, enc_pool,
+                       suppress, n_suppress, rep_penalty, ngram, enc_ngram, out_tokens);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}

@@ -1,0 +1,358 @@
+"""ctypes binding of libinfinisst_hip.so (include/infinisst_hip.h) -- the only compute path of this package.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, construction fails loudly.
+PyTorch is used here for plumbing only (device tensors handed over as raw pointers, the current HIP stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import rope
+from .config import GenConfig, ModelConfig
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libinfinisst_hip.so")
+_lib = None
+
+ISST_MAX_CONV, ISST_MAX_SHRINK, ISST_MAX_EOS = 8, 4, 8
+
+EPI = {"none": 0, "bias": 1, "bias_gelu": 2, "res": 3, "bias_res": 4, "swiglu": 5, "f32": 6}
+
+
+class IsstError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [
+        ("n_conv", C.c_int), ("conv_dim", C.c_int * ISST_MAX_CONV), ("conv_k", C.c_int * ISST_MAX_CONV),
+        ("conv_stride", C.c_int * ISST_MAX_CONV), ("conv_bias", C.c_int),
+        ("enc_dim", C.c_int), ("enc_layers", C.c_int), ("enc_heads", C.c_int), ("enc_ffn", C.c_int),
+        ("enc_ln_eps", C.c_float), ("block_size", C.c_int), ("max_cache_size", C.c_int),
+        ("enc_rope_round_each", C.c_int),
+        ("n_shrink", C.c_int), ("shrink_dim", C.c_int * ISST_MAX_SHRINK), ("shrink_k", C.c_int * ISST_MAX_SHRINK),
+        ("shrink_stride", C.c_int * ISST_MAX_SHRINK),
+        ("llm_dim", C.c_int), ("llm_layers", C.c_int), ("llm_heads", C.c_int), ("llm_kv_heads", C.c_int),
+        ("llm_ffn", C.c_int), ("vocab", C.c_int), ("rms_eps", C.c_float),
+        ("user_id", C.c_int), ("assistant_id", C.c_int), ("start_header_id", C.c_int),
+        ("n_eos", C.c_int), ("eos_ids", C.c_int * ISST_MAX_EOS),
+        ("max_streams", C.c_int), ("max_multiplier", C.c_int), ("max_prompt_len", C.c_int),
+        ("max_new_tokens", C.c_int), ("max_llm_cache_size", C.c_int), ("max_system_prompt", C.c_int),
+        ("debug_taps", C.c_int),
+    ]
+
+
+class _GenParams(C.Structure):
+    _fields_ = [
+        ("multiplier", C.c_int), ("max_new_tokens", C.c_int), ("no_repeat_ngram_size", C.c_int),
+        ("encoder_no_repeat_ngram_size", C.c_int), ("repetition_penalty", C.c_float),
+        ("suppress_tokens", C.POINTER(C.c_int)), ("n_suppress", C.c_int), ("system_prompt_size", C.c_int),
+    ]
+
+
+class _StreamInfo(C.Structure):
+    _fields_ = [("llm_cache_len", C.c_int), ("llm_sys_len", C.c_int), ("enc_n_steps", C.c_int),
+                ("enc_cache_len", C.c_int), ("chunks", C.c_int)]
+
+
+# every symbol include/infinisst_hip.h declares
+EXPORTS = [
+    "isst_create", "isst_destroy", "isst_last_error", "isst_load_weight", "isst_set_rope_tables",
+    "isst_finalize_weights", "isst_stream_open", "isst_stream_reset", "isst_stream_close", "isst_stream_info_get",
+    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_op_pack_weight",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
+]
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the HIP library; raises if it has not been built (python __graft_entry__.py / make -C csrc)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise IsstError(f"{p} not found: build it with `make -C infinisst_amd/csrc` (no CPU fallback exists)")
+    lib = C.CDLL(p)
+    lib.isst_last_error.restype = C.c_char_p
+    lib.isst_last_error.argtypes = [C.c_void_p]
+    lib.isst_destroy.restype = None
+    lib.isst_destroy.argtypes = [C.c_void_p]
+    lib.isst_op_packed_elems.restype = C.c_int64
+    lib.isst_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+    lib.isst_load_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
+    lib.isst_set_rope_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.isst_finalize_weights.argtypes = [C.c_void_p]
+    lib.isst_stream_open.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.isst_stream_reset.argtypes = [C.c_void_p, C.c_int]
+    lib.isst_stream_close.argtypes = [C.c_void_p, C.c_int]
+    lib.isst_stream_info_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(_StreamInfo)]
+    lib.isst_kv_evict.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.isst_generate.argtypes = [C.c_void_p, C.POINTER(_GenParams), C.c_int, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+    lib.isst_encode_speech.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.POINTER(C.c_int), C.c_void_p]
+    lib.isst_debug_tap.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.isst_op_pack_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.isst_op_packed_elems.argtypes = [C.c_int, C.c_int]
+    lib.isst_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.isst_op_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                      C.c_int, C.c_void_p]
+    lib.isst_op_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    lib.isst_op_conv0.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.isst_op_sample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def make_c_config(cfg: ModelConfig, max_streams: int, max_multiplier: int, max_prompt_len: int, max_new_tokens: int,
+                  max_llm_cache_size: int, max_system_prompt: int, debug_taps: bool) -> _Config:
+    c = _Config()
+    c.n_conv = len(cfg.conv_layers)
+    for i, (d, k, s) in enumerate(cfg.conv_layers):
+        c.conv_dim[i], c.conv_k[i], c.conv_stride[i] = d, k, s
+    c.conv_bias = int(cfg.conv_bias)
+    c.enc_dim, c.enc_layers, c.enc_heads, c.enc_ffn = cfg.enc_dim, cfg.enc_layers, cfg.enc_heads, cfg.enc_ffn
+    c.enc_ln_eps, c.block_size, c.max_cache_size = cfg.enc_ln_eps, cfg.block_size, cfg.max_cache_size
+    c.enc_rope_round_each = int(cfg.enc_rope_mode == "bf16")
+    c.n_shrink = len(cfg.shrink_layers)
+    for i, (d, k, s) in enumerate(cfg.shrink_layers):
+        c.shrink_dim[i], c.shrink_k[i], c.shrink_stride[i] = d, k, s
+    if cfg.llm_head_dim != 128:
+        raise IsstError("llm_head_dim must be 128")
+    c.llm_dim, c.llm_layers, c.llm_heads, c.llm_kv_heads = cfg.llm_dim, cfg.llm_layers, cfg.llm_heads, cfg.llm_kv_heads
+    c.llm_ffn, c.vocab, c.rms_eps = cfg.llm_ffn, cfg.vocab, cfg.rms_eps
+    c.user_id, c.assistant_id, c.start_header_id = cfg.user_id, cfg.assistant_id, cfg.start_header_id
+    c.n_eos = len(cfg.eos_ids)
+    for i, e in enumerate(cfg.eos_ids):
+        c.eos_ids[i] = e
+    c.max_streams, c.max_multiplier, c.max_prompt_len = max_streams, max_multiplier, max_prompt_len
+    c.max_new_tokens, c.max_llm_cache_size, c.max_system_prompt = max_new_tokens, max_llm_cache_size, max_system_prompt
+    c.debug_taps = int(debug_taps)
+    return c
+
+
+class Engine:
+    """Owns one library handle: device weights + per-stream KV state on the current CUDA(HIP) device."""
+
+    def __init__(self, cfg: ModelConfig, max_streams: int = 1, max_multiplier: int = 1, max_prompt_len: int = 128,
+                 max_new_tokens: int = 40, max_llm_cache_size: int = 1000, max_system_prompt: int = 128,
+                 debug_taps: bool = False):
+        if not torch.cuda.is_available():
+            raise IsstError("no GPU visible: the InfiniSST hot path has no CPU implementation in this package")
+        self.lib = load_library()
+        self.cfg = cfg
+        self.c_cfg = make_c_config(cfg, max_streams, max_multiplier, max_prompt_len, max_new_tokens,
+                                   max_llm_cache_size, max_system_prompt, debug_taps)
+        self.max_new_tokens = max_new_tokens
+        self.h = C.c_void_p()
+        rc = self.lib.isst_create(C.byref(self.c_cfg), C.byref(self.h))
+        if rc != 0:
+            raise IsstError(f"isst_create failed ({rc}): {self.lib.isst_last_error(None).decode()}")
+
+    # ---------------------------------------------------------------- errors / lifetime
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise IsstError(f"{what} failed ({rc}): {self.lib.isst_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.isst_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- weights
+    def load_weights(self, weights: Dict[str, torch.Tensor], strict: bool = True):
+        """`weights`: reference checkpoint keys -> bf16 tensors (CPU or GPU).  Unknown keys raise if strict."""
+        for name, t in weights.items():
+            if t.dtype != torch.bfloat16:
+                raise IsstError(f"{name}: expected bfloat16, got {t.dtype}")
+            t = t.contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            rc = self.lib.isst_load_weight(self.h, name.encode(), C.c_void_p(t.data_ptr()), t.dim(), shape, int(t.is_cuda))
+            if rc == -5 and not strict:
+                continue
+            self._check(rc, f"isst_load_weight({name})")
+        rows_e, rows_l = 1024, 1 << 14
+        ec, es = rope.encoder_tables(self.cfg, rows_e)
+        lc, ls = rope.llm_tables(self.cfg, rows_l)
+        self._check(self.lib.isst_set_rope_tables(self.h, C.c_void_p(ec.data_ptr()), C.c_void_p(es.data_ptr()), rows_e,
+                                                  C.c_void_p(lc.data_ptr()), C.c_void_p(ls.data_ptr()), rows_l),
+                    "isst_set_rope_tables")
+        self._check(self.lib.isst_finalize_weights(self.h), "isst_finalize_weights")
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- streams
+    def open_stream(self) -> int:
+        sid = C.c_int(-1)
+        self._check(self.lib.isst_stream_open(self.h, C.byref(sid)), "isst_stream_open")
+        return sid.value
+
+    def reset_stream(self, sid: int):
+        self._check(self.lib.isst_stream_reset(self.h, sid), "isst_stream_reset")
+
+    def close_stream(self, sid: int):
+        self._check(self.lib.isst_stream_close(self.h, sid), "isst_stream_close")
+
+    def stream_info(self, sid: int) -> dict:
+        info = _StreamInfo()
+        self._check(self.lib.isst_stream_info_get(self.h, sid, C.byref(info)), "isst_stream_info_get")
+        return {k: getattr(info, k) for k, _ in _StreamInfo._fields_}
+
+    def kv_evict(self, sid: int, new_cache_size: int, keep_prefix: int):
+        self._check(self.lib.isst_kv_evict(self.h, sid, new_cache_size, keep_prefix), "isst_kv_evict")
+
+    # ---------------------------------------------------------------- hot path
+    def generate(self, gen: GenConfig, stream_ids: Sequence[int], pcm: Sequence[np.ndarray],
+                 prompt_ids: Sequence[Sequence[int]], prev_target_ids: Sequence[Sequence[int]],
+                 system_prompt_size: int = 0, forced_tokens: Optional[Sequence[Optional[Sequence[int]]]] = None,
+                 return_logits: bool = False):
+        """model.generate(...) of reference agents/infinisst.py:307-332 for len(stream_ids) streams.
+        Returns (list of generated id lists, logits or None)."""
+        n = len(stream_ids)
+        pcm = [np.ascontiguousarray(p, dtype=np.float32) for p in pcm]
+        n_samples = pcm[0].shape[0]
+        if any(p.shape != (n_samples,) for p in pcm):
+            raise IsstError("all streams of one call must bring the same number of samples")
+        p = _GenParams()
+        p.multiplier, p.max_new_tokens = gen.latency_multiplier, gen.max_new_tokens
+        p.no_repeat_ngram_size = p.encoder_no_repeat_ngram_size = gen.no_repeat_ngram_size
+        p.repetition_penalty = gen.repetition_penalty
+        sup = np.asarray(gen.suppress_tokens, dtype=np.int32)
+        p.suppress_tokens = sup.ctypes.data_as(C.POINTER(C.c_int)) if sup.size else None
+        p.n_suppress = int(sup.size)
+        p.system_prompt_size = system_prompt_size
+        sid_arr = (C.c_int * n)(*stream_ids)
+        prompts = [np.asarray(x, dtype=np.int32) for x in prompt_ids]
+        prevs = [np.asarray(x, dtype=np.int32) for x in prev_target_ids]
+        outs = [np.zeros(gen.max_new_tokens, dtype=np.int32) for _ in range(n)]
+        forced = [None] * n if forced_tokens is None else [
+            None if f is None else np.asarray(f, dtype=np.int32) for f in forced_tokens]
+
+        def vp(arrs):
+            return (C.c_void_p * n)(*[None if a is None or a.size == 0 else a.ctypes.data for a in arrs])
+
+        def lens(arrs):
+            return (C.c_int * n)(*[0 if a is None else int(a.size) for a in arrs])
+
+        out_lens = (C.c_int * n)()
+        logits = np.zeros((n, gen.max_new_tokens, self.cfg.vocab), dtype=np.float32) if return_logits else None
+        rc = self.lib.isst_generate(self.h, C.byref(p), n, sid_arr, vp(pcm), n_samples, vp(prompts), lens(prompts),
+                                    vp(prevs), lens(prevs), vp(forced), lens(forced),
+                                    (C.c_void_p * n)(*[o.ctypes.data for o in outs]), out_lens,
+                                    None if logits is None else logits.ctypes.data, _stream_ptr())
+        self._check(rc, "isst_generate")
+        return [outs[i][: out_lens[i]].tolist() for i in range(n)], logits
+
+    def encode_speech(self, sid: int, pcm: np.ndarray, multiplier: int = 1) -> torch.Tensor:
+        """speech_encoder.encode_speech for one stream -> (S, llm_dim) bf16 CPU tensor (test aid)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        S_max = pcm.shape[0] // (self.cfg.samples_per_frame * self.cfg.shrink_factor)
+        out = torch.empty((S_max, self.cfg.llm_dim), dtype=torch.bfloat16)
+        rows = C.c_int(0)
+        self._check(self.lib.isst_encode_speech(self.h, sid, pcm.ctypes.data, pcm.shape[0], multiplier, out.data_ptr(),
+                                                C.byref(rows), _stream_ptr()), "isst_encode_speech")
+        return out[: rows.value]
+
+    def debug_tap(self, name: str) -> torch.Tensor:
+        got = C.c_int64(0)
+        self._check(self.lib.isst_debug_tap(self.h, name.encode(), None, 0, C.byref(got)), f"isst_debug_tap({name})")
+        out = torch.empty(got.value, dtype=torch.bfloat16)
+        self._check(self.lib.isst_debug_tap(self.h, name.encode(), out.data_ptr(), got.value, C.byref(got)),
+                    "isst_debug_tap")
+        return out
+
+
+# -------------------------------------------------------------------- per-kernel wrappers (device tensors)
+def op_pack_weight(w: torch.Tensor, conv_k: int = 0) -> torch.Tensor:
+    lib = load_library()
+    n_rows = w.shape[0]
+    K = w.numel() // n_rows
+    out = torch.zeros(lib.isst_op_packed_elems(n_rows, K), dtype=torch.bfloat16, device=w.device)
+    rc = lib.isst_op_pack_weight(_ptr(w.contiguous()), _ptr(out), n_rows, K, conv_k, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_pack_weight -> {rc}")
+    return out
+
+
+def op_gemm(A: torch.Tensor, packed: torch.Tensor, N: int, epi: str = "none", bias=None, res=None, n_valid=None,
+            lda: Optional[int] = None, M: Optional[int] = None, K: Optional[int] = None) -> torch.Tensor:
+    lib = load_library()
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    lda = A.stride(0) if lda is None else lda
+    n_out = (N // 2 if epi == "swiglu" else N) if n_valid is None else n_valid
+    out = torch.zeros((M, n_out), dtype=torch.float32 if epi == "f32" else torch.bfloat16, device=A.device)
+    rc = lib.isst_op_gemm(_ptr(A), lda, _ptr(packed), _ptr(bias), _ptr(res), 0 if res is None else res.stride(0),
+                          _ptr(out), out.stride(0), M, N, K, n_out, EPI[epi], _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_gemm -> {rc}")
+    return out
+
+
+def op_layernorm(x, w, b, eps=1e-5, gelu=False):
+    lib = load_library()
+    out = torch.empty_like(x)
+    rc = lib.isst_op_layernorm(_ptr(x), _ptr(w), _ptr(b), _ptr(out), x.shape[0], x.shape[1], eps, int(gelu), _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_layernorm -> {rc}")
+    return out
+
+
+def op_rmsnorm(x, w, eps=1e-5):
+    lib = load_library()
+    out = torch.empty_like(x)
+    rc = lib.isst_op_rmsnorm(_ptr(x), _ptr(w), _ptr(out), x.shape[0], x.shape[1], eps, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_rmsnorm -> {rc}")
+    return out
+
+
+def op_conv0(audio, w, bias, ln_w, ln_b, k, stride):
+    lib = load_library()
+    Cc = w.shape[0]
+    T = (audio.shape[0] - k) // stride + 1
+    out = torch.empty((T, Cc), dtype=torch.bfloat16, device=audio.device)
+    rc = lib.isst_op_conv0(_ptr(audio), _ptr(w.contiguous()), _ptr(bias), _ptr(ln_w), _ptr(ln_b), _ptr(out), T, Cc, k,
+                           stride, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_conv0 -> {rc}")
+    return out
+
+
+def op_sample(logits: torch.Tensor, ids, enc_ids, suppress, penalty, ngram, enc_ngram) -> int:
+    lib = load_library()
+    dev = logits.device
+
+    def mk(x):
+        return torch.tensor(list(x) if len(x) else [0], dtype=torch.int32, device=dev)
+
+    ids_t, enc_t, sup_t = mk(ids), mk(enc_ids), mk(suppress)
+    out = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = lib.isst_op_sample(_ptr(logits), logits.numel(), _ptr(ids_t), len(ids), _ptr(enc_t), len(enc_ids), _ptr(sup_t),
+                            len(suppress), penalty, ngram, enc_ngram, _ptr(out), _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_sample -> {rc}")
+    return int(out.item())

@@ -1,0 +1,169 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header declares, the package
+fails loudly without a GPU, and the host-side logic (chunk padding, eviction policy, rope tables, prompts)
+agrees with the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from infinisst_amd import engine as E
+from infinisst_amd import rope, synth
+from infinisst_amd.agent import InfiniSST, S2TAgentStates, default_args
+from infinisst_amd.config import GenConfig, full_config, toy_config
+from oracle import agent as oag
+from oracle import llm as ollm
+from oracle import speech_encoder as oenc
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = E.load_library()
+    hdr = open(os.path.join(ROOT, "include", "infinisst_hip.h")).read()
+    declared = set(re.findall(r"\b(isst_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(E.EXPORTS)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} not exported"
+
+
+def test_c_config_struct_matches_header_field_order():
+    hdr = open(os.path.join(ROOT, "include", "infinisst_hip.h")).read()
+    start = hdr.index("typedef struct isst_config {") + len("typedef struct isst_config {")
+    body = hdr[start:hdr.index("} isst_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl or decl.startswith("typedef"):
+            continue
+        decl = re.sub(r"^(int|float)\s+", "", decl)
+        names += [re.sub(r"\[.*\]", "", n).strip() for n in decl.split(",")]
+    assert names == [f for f, _ in E._Config._fields_]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box without GPU")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    with pytest.raises(E.IsstError, match="no GPU"):
+        E.Engine(toy_config())
+
+
+def test_full_config_geometry():
+    c = full_config()
+    assert (c.chunk_samples, c.first_chunk_offset, c.samples_per_frame, c.receptive_field, c.shrink_factor) == (15360, 399, 320, 400, 4)
+    assert oenc.feat_extract_output_lengths(c, 399 + 15360) == 12
+    assert len(synth.chunk_prompt_ids(c)) == 22
+    n_params = sum(int(np.prod(s)) for s in synth.weight_shapes(c).values())
+    assert 8.3e9 < n_params < 8.4e9
+
+
+def test_rope_tables_match_oracle():
+    for mode in ("bf16", "fp32"):
+        cfg = toy_config().replace(enc_rope_mode=mode)
+        c, s = rope.encoder_tables(cfg, 700)
+        oc, os_, _ = oenc.make_rope(cfg, 700)
+        assert torch.equal(c, oc) and torch.equal(s, os_)
+    cfg = full_config()
+    c, s = rope.llm_tables(cfg, 1500)
+    oc, os_ = ollm.llm_rope_tables(cfg, 1500, torch.bfloat16)
+    assert torch.equal(c, oc[:, :64]) and torch.equal(s, os_[:, :64])
+    assert torch.equal(oc[:, :64], oc[:, 64:])  # halves are duplicates, so storing one is lossless
+
+
+class _FakeEngine:
+    """Records what the agent asks of the library; emulates cache growth so the eviction policy can be traced."""
+
+    def __init__(self, rng):
+        self.rng, self.len, self.sys, self.calls, self.evictions = rng, 0, 0, [], []
+
+    def open_stream(self):
+        return 0
+
+    def reset_stream(self, sid):
+        self.len = self.sys = 0
+
+    def generate(self, gen, sids, pcm, prompts, prevs, system_prompt_size=0, **kw):
+        n_gen = int(self.rng.integers(2, gen.max_new_tokens + 1))
+        self.calls.append(dict(n_samples=len(pcm[0]), pcm=pcm[0].copy(), prompt_len=len(prompts[0]), prev=list(prevs[0]), pin=system_prompt_size, n_gen=n_gen))
+        if self.len == 0:
+            self.sys = system_prompt_size
+        self.len += len(prompts[0]) + n_gen - 1
+        return [[int(x) for x in self.rng.integers(10, 900, size=n_gen)]], None
+
+    def stream_info(self, sid):
+        return {"llm_cache_len": self.len}
+
+    def kv_evict(self, sid, new_size, keep):
+        self.evictions.append((new_size, keep))
+        self.len = new_size + keep
+
+
+@pytest.mark.parametrize("keep_sys,max_cache", [(True, 150), (False, 150), (True, 90)])
+def test_agent_host_logic_matches_oracle(keep_sys, max_cache):
+    """Chunk padding, encoder_input_ids window, checkpoint list and eviction sizes of the product agent == oracle
+    (which is pinned to the reference's policy() by tests/golden/agent.npz)."""
+    cfg = toy_config().replace(block_size=48)
+    rng = np.random.default_rng(7)
+    eng = _FakeEngine(rng)
+    args = default_args(max_llm_cache_size=max_cache, always_cache_system_prompt=keep_sys, max_new_tokens=10)
+    agent = InfiniSST(args, engine=eng, model_cfg=cfg)
+    st = agent.build_states()
+    st.source_sample_rate = 16000
+    st_o = oag.States(source_sample_rate=16000)
+    seg_lens = [15360, 15360, 15361, 15359, 30720, 1, 15360, 7000, 15360, 15360, 15360, 15360]
+    audio = (0.1 * rng.standard_normal(sum(seg_lens))).astype(np.float32)
+    ckpts, pos, cur, first = [], 0, 0, True
+    for c, n in enumerate(seg_lens):
+        seg = audio[pos:pos + n].tolist()
+        pos += n
+        st.source.extend(seg)
+        st_o.source.extend(seg)
+        st.source_finished = c == len(seg_lens) - 1
+        agent.policy(st)
+        call = eng.calls[-1]
+        ref_speech = oag.prepare_speech(cfg, st_o, torch.float32)[0].numpy()
+        if first:
+            ref_speech = ref_speech[cfg.first_chunk_offset:]  # the library owns the 399-sample history
+        assert np.array_equal(call["pcm"], ref_speech), f"chunk {c}"
+        assert call["pin"] == (agent.system_prompt_size if (first and keep_sys) else 0)
+        cur += call["prompt_len"] + call["n_gen"] - 1
+        ckpts.append(cur)
+        ev = oag.evict(ckpts, cur, max_cache, keep_sys, agent.system_prompt_size)
+        if ev is not None:
+            ckpts, new_size = ev
+            assert eng.evictions[-1] == (new_size, agent.system_prompt_size if keep_sys else 0)
+            cur = new_size + (agent.system_prompt_size if keep_sys else 0)
+        assert agent.cache_checkpoints == ckpts
+        assert eng.len == cur
+        assert call["prev"] == st.target_ids[: len(st.target_ids) - (call["n_gen"] - 1)][-100:]
+        first = False
+
+
+def test_agent_flags_match_reference_names():
+    """Flag names/defaults of agents/options.py + agents/infinisst.py:185-198 (the config contract)."""
+    import argparse
+    p = argparse.ArgumentParser()
+    InfiniSST.add_args(p)
+    a = p.parse_args([])
+    expect = dict(block_size=12, max_cache_size=125, xpos=1, rope=1, beam=1, no_repeat_ngram_lookback=100, no_repeat_ngram_size=3,
+                  repetition_penalty=1.2, max_new_tokens=1000, min_start_sec=0.32, latency_multiplier=4, max_latency_multiplier=4,
+                  max_llm_cache_size=10000, always_cache_system_prompt=False, pseudo_batch_size=1, source_lang="English",
+                  target_lang="German", max_len_a=5, max_len_b=20, top_p=1.0, top_k=0, temperature=1.0)
+    for k, v in expect.items():
+        assert getattr(a, k) == v, k
+
+
+def test_policy_gating_without_compute():
+    cfg = toy_config()
+    eng = _FakeEngine(np.random.default_rng(1))
+    agent = InfiniSST(default_args(min_start_sec=0.32), engine=eng, model_cfg=cfg)
+    st = agent.build_states()
+    assert type(agent.policy(st)).__name__ == "ReadAction"  # sample rate unknown, nothing read
+    st.source_sample_rate = 16000
+    st.source = [0.0] * 1000
+    assert type(agent.policy(st)).__name__ == "ReadAction"  # < min_start_sec
+    st.source_finished = True
+    act = agent.policy(st)
+    assert type(act).__name__ == "WriteAction" and act.content == "" and act.finished  # < 0.32 s total
+    assert eng.calls == []

@@ -1,0 +1,166 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel entry point of the C ABI against the CPU oracle / the
+same torch op the reference calls, on seeded inputs.  bf16 outputs must agree within one bf16 rounding of the
+fp32 result (stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+from infinisst_amd import engine as E
+from infinisst_amd import synth
+from infinisst_amd.config import toy_config
+from oracle import generate as ogen
+from oracle import llm as ollm
+from oracle import speech_encoder as oenc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def close_bf16(got, ref, what, ulps=2.0, atol=1e-6):
+    """|got - ref| <= ulps * 2^-8 * |ref| + atol   (bf16 has 8 significant bits)."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    err = (got - ref).abs()
+    tol = ulps * (2.0 ** -8) * ref.abs() + atol
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, worst {float(err.max()):.5g} at {np.unravel_index(int(err.argmax()), err.shape)}"
+
+
+def ref_linear(A, W, epi, bias=None, res=None):
+    acc = A.float() @ W.float().t()
+    r = lambda t: t.to(torch.bfloat16).float()
+    if epi == "none":
+        return bf(acc)
+    if epi == "bias":
+        return bf(acc + bias.float())
+    if epi == "bias_gelu":
+        return bf(torch.nn.functional.gelu(r(acc + bias.float())))
+    if epi == "res":
+        return bf(res.float() + r(acc))
+    if epi == "bias_res":
+        return bf(res.float() + r(acc + bias.float()))
+    if epi == "f32":
+        return r(acc)
+    raise ValueError(epi)
+
+
+@pytest.mark.parametrize("M", [1, 5, 16, 22, 48, 64, 100, 200])
+@pytest.mark.parametrize("N,K", [(256, 128), (1040, 512), (64, 4096)])
+def test_gemm_plain_and_epilogues(M, N, K):
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf(torch.randn(N, generator=g))
+    res = bf(torch.randn(M, N, generator=g))
+    Wp = E.op_pack_weight(W.to(DEV))
+    for epi in ("none", "bias", "bias_gelu", "res", "bias_res", "f32"):
+        out = E.op_gemm(A.to(DEV), Wp, N, epi, bias=bias.to(DEV) if "bias" in epi else None,
+                        res=res.to(DEV) if "res" in epi else None)
+        torch.cuda.synchronize()
+        close_bf16(out, ref_linear(A, W, epi, bias, res), f"gemm {epi} M{M} N{N} K{K}", ulps=2.5, atol=2e-3)
+
+
+def test_gemm_asymmetric_identity():
+    """A = I against an asymmetric W catches swapped fragment maps (cdna_hip_programming.md section 3)."""
+    K = N = 64
+    W = bf(torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 100)
+    A = bf(torch.eye(K))[:48]
+    out = E.op_gemm(A.to(DEV), E.op_pack_weight(W.to(DEV)), N, "none")
+    assert torch.equal(out.float().cpu(), W.float().t()[:48])
+
+
+def test_gemm_odd_vocab_f32():
+    g = torch.Generator().manual_seed(5)
+    A, W = bf(torch.randn(3, 256, generator=g)), bf(torch.randn(1031, 256, generator=g) * 0.05)
+    out = E.op_gemm(A.to(DEV), E.op_pack_weight(W.to(DEV)), 1031, "f32")
+    assert out.shape == (3, 1031)
+    close_bf16(out, ref_linear(A, W, "f32"), "lm_head-like", ulps=2.5, atol=2e-3)
+
+
+@pytest.mark.parametrize("M", [1, 7, 33, 70])
+def test_gemm_swiglu(M):
+    g = torch.Generator().manual_seed(M)
+    I, K = 512, 256
+    A = bf(torch.randn(M, K, generator=g))
+    Wg, Wu = bf(torch.randn(I, K, generator=g) * 0.1), bf(torch.randn(I, K, generator=g) * 0.1)
+    # interleave gate/up 16-row tiles the way the engine packs them
+    inter = torch.stack([Wg.view(I // 16, 16, K), Wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K)
+    out = E.op_gemm(A.to(DEV), E.op_pack_weight(inter.to(DEV)), 2 * I, "swiglu")
+    gg, uu = bf(A.float() @ Wg.float().t()), bf(A.float() @ Wu.float().t())
+    ref = torch.nn.functional.silu(gg) * uu
+    close_bf16(out, ref, f"swiglu M{M}", ulps=3, atol=2e-3)
+
+
+@pytest.mark.parametrize("k,stride,T", [(3, 2, 157), (2, 2, 48)])
+def test_conv1d_as_gemm(k, stride, T):
+    """Conv1d (no padding) over time-major activations == GEMM with overlapping rows (lda = stride*C)."""
+    Cc = 64
+    g = torch.Generator().manual_seed(k * 10 + T)
+    x = bf(torch.randn(T, Cc, generator=g))
+    w = bf(torch.randn(Cc, Cc, k, generator=g) * 0.1)
+    bias = bf(torch.randn(Cc, generator=g))
+    To = (T - k) // stride + 1
+    out = E.op_gemm(x.to(DEV), E.op_pack_weight(w.to(DEV), conv_k=k), Cc, "bias", bias=bias.to(DEV), lda=stride * Cc, M=To,
+                    K=k * Cc)
+    ref = torch.nn.functional.conv1d(x.t().unsqueeze(0).float(), w.float(), bias.float(), stride=stride)[0].t()
+    close_bf16(out, bf(ref), f"conv k{k}", ulps=2.5, atol=2e-3)
+
+
+@pytest.mark.parametrize("C,gelu", [(64, True), (512, True), (512, False), (1024, False), (1024, True), (128, False)])
+def test_layernorm(C, gelu):
+    g = torch.Generator().manual_seed(C)
+    x = bf(torch.randn(37, C, generator=g) * 2 + 0.3)
+    w, b = bf(1 + 0.1 * torch.randn(C, generator=g)), bf(0.1 * torch.randn(C, generator=g))
+    out = E.op_layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, gelu)
+    ref = torch.nn.functional.layer_norm(x, (C,), w, b, 1e-5)
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    close_bf16(out, ref, f"layernorm C{C}", ulps=2.0, atol=1e-3)
+
+
+@pytest.mark.parametrize("D", [256, 4096])
+def test_rmsnorm(D):
+    g = torch.Generator().manual_seed(D)
+    x = bf(torch.randn(9, D, generator=g) * 3)
+    w = bf(1 + 0.1 * torch.randn(D, generator=g))
+    out = E.op_rmsnorm(x.to(DEV), w.to(DEV), 1e-5)
+    close_bf16(out, ollm.rmsnorm(x, w, 1e-5), f"rmsnorm D{D}", ulps=2.0, atol=1e-3)
+
+
+@pytest.mark.parametrize("C", [64, 512])
+def test_conv0_ln_gelu(C):
+    cfg = toy_config().replace(conv_layers=[(C, 10, 5)])
+    w = synth.random_weights(cfg.replace(enc_layers=0, llm_layers=0), dtype=torch.bfloat16, std=0.3, norm_jitter=0.1, seed=C)
+    audio = bf(torch.from_numpy(synth.synthetic_audio(399 + 5120)))
+    p = oenc.ENC + "feature_extractor.conv_layers.0."
+    out = E.op_conv0(audio.to(DEV), w[p + "0.weight"].to(DEV), w[p + "0.bias"].to(DEV), w[p + "2.1.weight"].to(DEV),
+                     w[p + "2.1.bias"].to(DEV), 10, 5)
+    ref = oenc.conv_feature_extractor(w, cfg, audio.unsqueeze(0))[0].t()
+    close_bf16(out, ref, f"conv0 C{C}", ulps=3.0, atol=4e-3)
+
+
+def test_sample_processors_and_argmax():
+    rng = np.random.default_rng(0)
+    V = 5000
+    for trial in range(20):
+        logits = torch.from_numpy(rng.standard_normal(V).astype(np.float32)).bfloat16().float()
+        n_ids = int(rng.integers(6, 40))
+        ids = rng.integers(0, 50, size=n_ids).tolist()  # small alphabet -> repeated n-grams
+        enc = rng.integers(0, 50, size=int(rng.integers(0, 60))).tolist()
+        sup = rng.integers(0, V, size=int(rng.integers(0, 5))).tolist()
+        n = int(rng.integers(2, 5))
+        if trial % 3 == 0:  # force a tie: lowest index must win
+            logits[100] = logits[4000] = 50.0
+        ref_scores = ogen.process_logits(logits.clone(), ids, enc, 1.2, n, n, sup)
+        ref_tok = int(torch.argmax(ref_scores))
+        dl = logits.clone().to(DEV)
+        tok = E.op_sample(dl, ids, enc, sup, 1.2, n, n)
+        assert tok == ref_tok, f"trial {trial}: {tok} vs {ref_tok}"
+        got = dl.cpu()
+        assert torch.equal(torch.isinf(got), torch.isinf(ref_scores))
+        fin = ~torch.isinf(ref_scores)
+        assert torch.allclose(got[fin], ref_scores[fin], rtol=1e-6, atol=1e-6)
