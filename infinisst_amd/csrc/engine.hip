@@ -49,7 +49,9 @@ struct StreamState {
     bool open = false;
     int chunks = 0;
     int enc_start = 0, enc_len = 0, enc_steps = 0;
-    int llm_sys = 0, llm_ring_start = 0, llm_ring_len = 0;
+    int llm_sys = 0;         // pinned boundary: logical positions < llm_sys live in the sys region
+    int llm_ring_start = 0;  // physical ring slot of logical position llm_sys
+    int llm_total = 0;       // cached entries (logical positions 0..llm_total-1)
 };
 struct Tap {
     bf16_t* dev = nullptr;
@@ -576,8 +578,8 @@ extern "C" int isst_stream_close(isst_handle* h, int id) {
 extern "C" int isst_stream_info_get(isst_handle* h, int id, isst_stream_info* out) {
     if (!h || !out || id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h ? h->fail(ISST_ERR_ARG, "bad stream id %d", id) : ISST_ERR_ARG;
     const StreamState& s = h->streams[id];
-    out->llm_cache_len = s.llm_sys + s.llm_ring_len;
-    out->llm_sys_len = s.llm_sys;
+    out->llm_cache_len = s.llm_total;
+    out->llm_sys_len = s.llm_sys < s.llm_total ? s.llm_sys : s.llm_total;
     out->enc_n_steps = s.enc_steps;
     out->enc_cache_len = s.enc_len;
     out->chunks = s.chunks;
@@ -590,12 +592,14 @@ extern "C" int isst_kv_evict(isst_handle* h, int id, int new_cache_size, int kee
     if (new_cache_size < 0 || keep_prefix < 0) return h->fail(ISST_ERR_ARG, "negative size");
     if (keep_prefix != 0 && keep_prefix != s.llm_sys)
         return h->fail(ISST_ERR_STATE, "keep_prefix %d differs from the pinned system prompt (%d entries); pin it with gen_params.system_prompt_size on the first chunk", keep_prefix, s.llm_sys);
-    if (new_cache_size > s.llm_ring_len)
-        return h->fail(ISST_ERR_STATE, "new_cache_size %d exceeds the %d evictable entries (overlap with the pinned prefix is undefined in the reference)", new_cache_size, s.llm_ring_len);
+    if (s.llm_total < s.llm_sys) return h->fail(ISST_ERR_STATE, "cache shorter than its pinned prefix");
+    const int ring_len = s.llm_total - s.llm_sys;
+    if (new_cache_size > ring_len)
+        return h->fail(ISST_ERR_STATE, "new_cache_size %d exceeds the %d evictable entries (overlap with the pinned prefix is undefined in the reference)", new_cache_size, ring_len);
     if (keep_prefix == 0) s.llm_sys = 0;  // nothing pinned any more: logical position 0 is the ring start
-    const int drop = s.llm_ring_len - new_cache_size;
+    const int drop = ring_len - new_cache_size;
     s.llm_ring_start = (s.llm_ring_start + drop) % h->ring_cap;
-    s.llm_ring_len = new_cache_size;
+    s.llm_total = s.llm_sys + new_cache_size;
     return ISST_OK;
 }
 
@@ -838,13 +842,13 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         if (prompt_lens[i] < 1 || prompt_lens[i] > c.max_prompt_len) return h->fail(ISST_ERR_ARG, "prompt length %d (max %d)", prompt_lens[i], c.max_prompt_len);
         if (n_prev && (n_prev[i] < 0 || n_prev[i] > h->max_enc_ids)) return h->fail(ISST_ERR_ARG, "too many previous target ids");
         const StreamState& s = h->streams[id];
-        const int total = s.llm_sys + s.llm_ring_len;
+        const int total = s.llm_total;
         int sys = s.llm_sys;
         if (total == 0 && p->system_prompt_size > 0) {
             if (p->system_prompt_size > h->sys_cap || p->system_prompt_size > prompt_lens[i]) return h->fail(ISST_ERR_ARG, "system_prompt_size %d (capacity %d, prompt %d)", p->system_prompt_size, h->sys_cap, prompt_lens[i]);
             sys = p->system_prompt_size;
         }
-        if (total - sys + prompt_lens[i] + p->max_new_tokens > h->ring_cap)
+        if (total + prompt_lens[i] + p->max_new_tokens - sys > h->ring_cap)
             return h->fail(ISST_ERR_STATE, "stream %d: LLM cache of %d entries + this chunk exceeds the ring (%d); evict first", id, total, h->ring_cap);
         for (int t = 0; t < prompt_lens[i]; ++t)
             if (prompt_ids[i][t] < 0 || prompt_ids[i][t] >= c.vocab) return h->fail(ISST_ERR_ARG, "prompt token %d out of range", prompt_ids[i][t]);
@@ -862,8 +866,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     int R = 0, max_pos = 0;
     for (int i = 0; i < n; ++i) {
         StreamState& s = h->streams[stream_ids[i]];
-        if (s.llm_sys + s.llm_ring_len == 0 && p->system_prompt_size > 0) s.llm_sys = p->system_prompt_size;
-        total0[i] = s.llm_sys + s.llm_ring_len;
+        if (s.llm_total == 0) s.llm_sys = p->system_prompt_size > 0 ? p->system_prompt_size : 0;
+        total0[i] = s.llm_total;
         mh.views[i].sys_len = s.llm_sys;
         mh.views[i].ring_start = s.llm_ring_start;
         mh.views[i].kv_offset = (long)stream_ids[i] * h->llm_stream_stride;
@@ -910,7 +914,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     // ---- 3. greedy loop (patch_hf.py:606-624 -> HF _sample) ----
     std::vector<int> active(n);
     for (int i = 0; i < n; ++i) active[i] = i;
-    int step = 0;
+
     while (true) {
         const int na = (int)active.size();
         if (logits_out)
@@ -936,7 +940,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         }
         active.swap(next_active);
         if (active.empty()) break;
-        ++step;
+
         // next decode step: one row per active stream, the token just sampled at the next position
         const int nr = (int)active.size();
         for (int r = 0; r < nr; ++r) {
@@ -957,7 +961,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     // ---- 4. state: the cache holds the prompt and every generated token except the last one ----
     for (int i = 0; i < n; ++i) {
         StreamState& s = h->streams[stream_ids[i]];
-        s.llm_ring_len = total0[i] + prompt_lens[i] + gen_count[i] - 1 - s.llm_sys;
+        s.llm_total = total0[i] + prompt_lens[i] + gen_count[i] - 1;
         s.chunks++;
         out_lens[i] = gen_count[i];
     }

@@ -61,7 +61,10 @@ def test_gemm_plain_and_epilogues(M, N, K):
         out = E.op_gemm(A.to(DEV), Wp, N, epi, bias=bias.to(DEV) if "bias" in epi else None,
                         res=res.to(DEV) if "res" in epi else None)
         torch.cuda.synchronize()
-        close_bf16(out, ref_linear(A, W, epi, bias, res), f"gemm {epi} M{M} N{N} K{K}", ulps=2.5, atol=2e-3)
+        # compound epilogues round twice (inner Linear output, then residual add / GELU): a one-ulp flip of the inner
+        # rounding moves the result by an ulp of the INNER magnitude, hence the absolute slack
+        atol = 2e-3 if epi in ("none", "bias", "f32") else 3.2e-2
+        close_bf16(out, ref_linear(A, W, epi, bias, res), f"gemm {epi} M{M} N{N} K{K}", ulps=2.5, atol=atol)
 
 
 def test_gemm_asymmetric_identity():
