@@ -137,9 +137,11 @@ int isst_debug_tap(isst_handle* h, const char* name, uint16_t* dst, int64_t max_
 int isst_op_pack_weight(const uint16_t* w, uint16_t* packed, int n_rows, int K, int conv_k, void* hip_stream);
 int64_t isst_op_packed_elems(int n_rows, int K);
 /* out = epi(A @ W^T); epi: 0 none, 1 bias, 2 bias+gelu, 3 residual, 4 bias+residual, 5 swiglu (packed rows
- * alternate gate/up tiles), 6 fp32 out.  Replaces torch F.linear / F.conv1d call sites (see gemm.hip). */
+ * alternate gate/up tiles), 6 fp32 out.  Replaces torch F.linear / F.conv1d call sites (see gemm.hip).
+ * norm_w != NULL (epi 0, 5, 6 only): LlamaRMSNorm(norm_w, norm_eps) is applied to the rows of A on load. */
 int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, const uint16_t* res,
-                 int64_t ldres, void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, void* hip_stream);
+                 int64_t ldres, void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, const uint16_t* norm_w,
+                 float norm_eps, void* hip_stream);
 int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps,
                       int gelu, void* hip_stream);
 int isst_op_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int rows, int D, float eps, void* hip_stream);

@@ -77,7 +77,10 @@ struct GemmArgs {
     void* out; long ldo; long out_batch;           // bf16 (or fp32 for EPI_F32)
     int M, N, K, batch, epi;                       // N = number of packed rows (multiple of 16)
     int n_valid;                                   // output columns actually stored (<= N, or N/2 for SWIGLU)
+    const bf16_t* norm_w;                          // non-null: A rows are RMS-normalised on load (HF LlamaRMSNorm) with this weight
+    float norm_eps;
 };
+#define GEMM_FUSED_NORM_MAX_M 8  // rows for which the GEMM stages (and optionally RMS-normalises) A in LDS
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,
                        int tile_phase, int conv_k, hipStream_t stream);

@@ -115,6 +115,8 @@ struct isst_handle {
     bf16_t *lx = nullptr, *lxn = nullptr, *lqkv = nullptr, *lqrot = nullptr, *lattn = nullptr, *lact = nullptr, *llast = nullptr;
     float *lpartial = nullptr, *logits = nullptr;
     int* out_tok = nullptr;
+    float* samp_val = nullptr;  // partial argmax scratch, 64 per stream
+    int* samp_idx = nullptr;
     unsigned char* meta_dev = nullptr;
     unsigned char* meta_host = nullptr;  // pinned
     size_t meta_bytes = 0;
@@ -279,7 +281,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->enc_rows_max = c.max_streams * c.block_size * c.max_multiplier;
     h->llm_rows_max = c.max_streams * c.max_prompt_len;
     h->enc_cap = round_up(c.max_cache_size + c.block_size * c.max_multiplier, 64);
-    if (h->enc_cap > 768) { h->fail(ISST_ERR_ARG, "encoder window %d > 768 keys unsupported", h->enc_cap); return die(ISST_ERR_ARG); }
+    if (h->enc_cap > 1024) { h->fail(ISST_ERR_ARG, "encoder window %d > 1024 keys unsupported", h->enc_cap); return die(ISST_ERR_ARG); }
     h->sys_cap = round_up(c.max_system_prompt, 8);
     h->ring_cap = round_up(c.max_llm_cache_size + c.max_prompt_len + c.max_new_tokens + 8, 8);
     h->vocab_pad = round_up(c.vocab, 16);
@@ -371,12 +373,14 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->lpartial = h->dalloc<float>(LR * H * llm_attn_splits(h->llm_rope_rows) * 130);
     h->logits = h->dalloc<float>((size_t)ns * h->vocab_pad);
     h->out_tok = h->dalloc<int>(ns);
+    h->samp_val = h->dalloc<float>((size_t)ns * 64);
+    h->samp_idx = h->dalloc<int>((size_t)ns * 64);
     h->meta_bytes = (size_t)LR * 4 * sizeof(int) + (size_t)ns * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
                     (size_t)ns * (h->max_ids + h->max_enc_ids) * sizeof(int) + 65536 * sizeof(int) + 4096;
     h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
     const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
                           h->window, h->act_a, h->act_b, h->ex, h->exn, h->eqkv, h->eattn, h->effn, h->speech, h->lx, h->lxn, h->lqkv, h->lqrot,
-                          h->lattn, h->lact, h->llast, h->lpartial, h->logits, h->out_tok, h->meta_dev};
+                          h->lattn, h->lact, h->llast, h->lpartial, h->logits, h->out_tok, h->samp_val, h->samp_idx, h->meta_dev};
     for (const void* p : must)
         if (!p) { h->fail(ISST_ERR_NOMEM, "state/workspace allocation failed"); return die(ISST_ERR_NOMEM); }
     if (hipHostMalloc(reinterpret_cast<void**>(&h->meta_host), h->meta_bytes) != hipSuccess ||
@@ -623,13 +627,15 @@ int tap(isst_handle* h, const std::string& name, const bf16_t* src, int64_t elem
 }
 
 int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int epi, const bf16_t* res, long ldres, void* out, long ldo,
-         int M, hipStream_t st, int batch = 1, long a_batch = 0, long out_batch = 0, long res_batch = 0) {
+         int M, hipStream_t st, int batch = 1, long a_batch = 0, long out_batch = 0, long res_batch = 0,
+         const bf16_t* norm_w = nullptr, float norm_eps = 0.f) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.a_batch = a_batch;
     g.Wp = L.wp; g.bias = L.bias;
     g.res = res; g.ldres = ldres; g.res_batch = res_batch;
     g.out = out; g.ldo = ldo; g.out_batch = out_batch;
     g.M = M; g.N = L.N; g.K = L.K; g.batch = batch; g.epi = epi; g.n_valid = L.n_valid;
+    g.norm_w = norm_w; g.norm_eps = norm_eps;
     CHK(launch_gemm(g, st));
     return ISST_OK;
 }
@@ -777,20 +783,37 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int max
     if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "embed", h->lx, (int64_t)rows * DL, st));
     for (int l = 0; l < c.llm_layers; ++l) {
         const LlmLayer& L = h->llm[l];
-        CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
-        CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
-        CHK(launch_llm_qkv_post(h->lqkv, d.row_stream, d.row_pos, d.views, h->llm_cos, h->llm_sin, h->lqrot, h->llm_k, h->llm_v, h->adims, l, rows, st));
-        CHK(launch_llm_attention(h->lqrot, d.row_stream, d.row_pos, d.views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_v, h->lpartial, h->lattn,
+        // decode shapes: RMSNorm is applied inside the projection's A-fragment load (gemm.hip NORM); larger row counts
+        // (prefill, many streams) run the norm kernel once instead of once per workgroup
+        const bool fuse = rows <= GEMM_FUSED_NORM_MAX_M;
+        if (fuse) {
+            CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps));
+        } else {
+            CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+            CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
+        }
+        CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_v, h->lpartial, h->lattn,
                                  h->adims, l, rows, max_pos, st));
         CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
-        CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
-        CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+        if (fuse) {
+            CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
+        } else {
+            CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+            CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+        }
         CHK(gemm(h, h->lact, c.llm_ffn, L.down, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
         if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
     }
-    CHK(launch_rmsnorm(h->lx, DL, d.last_rows, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
-    if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "final", h->llast, (int64_t)n_last * DL, st));
-    CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
+    if (splice) {  // prefill: the last prompt row of every stream is gathered and normalised
+        CHK(launch_rmsnorm(h->lx, DL, d.last_rows, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
+        if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "final", h->llast, (int64_t)n_last * DL, st));
+        CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
+    } else if (n_last <= GEMM_FUSED_NORM_MAX_M) {  // decode: rows == last rows, final norm fused into the lm_head projection
+        CHK(gemm(h, h->lx, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st, 1, 0, 0, 0, h->final_norm, c.rms_eps));
+    } else {
+        CHK(launch_rmsnorm(h->lx, DL, nullptr, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
+        CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
+    }
     return ISST_OK;
 }
 
@@ -871,6 +894,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         mh.views[i].sys_len = s.llm_sys;
         mh.views[i].ring_start = s.llm_ring_start;
         mh.views[i].kv_offset = (long)stream_ids[i] * h->llm_stream_stride;
+        mh.views[i].new_start = total0[i];
+        mh.views[i].row0 = R;
         row0[i] = R;
         const int len = prompt_lens[i];
         const int* ids = prompt_ids[i];
@@ -922,7 +947,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
                 HIPCHK(hipMemcpyAsync(logits_out + ((size_t)active[r] * p->max_new_tokens + gen_count[active[r]]) * c.vocab,
                                       h->logits + (size_t)r * h->vocab_pad, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToHost, st));
         CHK(launch_sample(h->logits, h->vocab_pad, c.vocab, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
-                          p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->out_tok, na, st));
+                          p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->out_tok, h->samp_val, h->samp_idx, na, st));
         HIPCHK(hipMemcpyAsync(h->tok_host, h->out_tok, sizeof(int) * na, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         std::vector<int> next_active;
@@ -948,6 +973,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             const int tok = out_ids[i][gen_count[i] - 1];
             mh.row_stream[r] = i;
             mh.row_pos[r] = total0[i] + prompt_lens[i] + gen_count[i] - 1;
+            mh.views[i].new_start = mh.row_pos[r];
+            mh.views[i].row0 = r;
             mh.ids[r] = tok;
             mh.last_rows[r] = r;
             mh.ids_pool[(size_t)i * h->max_ids + prompt_lens[i] + gen_count[i] - 1] = tok;
@@ -977,10 +1004,12 @@ extern "C" int isst_op_pack_weight(const uint16_t* w, uint16_t* packed, int n_ro
     return launch_pack_weight(w, packed, n_rows, K, 0, 1, 0, conv_k, reinterpret_cast<hipStream_t>(hip_stream));
 }
 extern "C" int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, const uint16_t* res, int64_t ldres,
-                            void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, void* hip_stream) {
+                            void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, const uint16_t* norm_w, float norm_eps,
+                            void* hip_stream) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.Wp = packed; g.bias = bias; g.res = res; g.ldres = ldres; g.out = out; g.ldo = ldo;
     g.M = M; g.N = round_up(N, 16); g.K = K; g.batch = 1; g.epi = epi; g.n_valid = n_valid;
+    g.norm_w = norm_w; g.norm_eps = norm_eps;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(hip_stream));
 }
 extern "C" int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps, int gelu,
@@ -998,13 +1027,15 @@ extern "C" int isst_op_sample(float* logits, int vocab, const int* ids, int n_id
                               int n_suppress, float repetition_penalty, int ngram, int enc_ngram, int* out_token, void* hip_stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     SampleStream ss{n_ids, n_enc, 0, 0, 0};
-    SampleStream* dss = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&dss), sizeof ss) != hipSuccess) return ISST_ERR_NOMEM;
+    unsigned char* scratch = nullptr;  // [SampleStream | 64 floats | 64 ints]
+    if (hipMalloc(reinterpret_cast<void**>(&scratch), 1024) != hipSuccess) return ISST_ERR_NOMEM;
+    SampleStream* dss = reinterpret_cast<SampleStream*>(scratch);
     int rc = ISST_ERR_HIP;
     if (hipMemcpyAsync(dss, &ss, sizeof ss, hipMemcpyHostToDevice, st) == hipSuccess)
-        rc = launch_sample(logits, vocab, vocab, dss, ids, enc_ids, suppress, n_suppress, repetition_penalty, ngram, enc_ngram, out_token, 1, st);
+        rc = launch_sample(logits, vocab, vocab, dss, ids, enc_ids, suppress, n_suppress, repetition_penalty, ngram, enc_ngram, out_token,
+                           reinterpret_cast<float*>(scratch + 256), reinterpret_cast<int*>(scratch + 512), 1, st);
     (void)hipStreamSynchronize(st);
-    (void)hipFree(dss);
+    (void)hipFree(scratch);
     return rc;
 }
 

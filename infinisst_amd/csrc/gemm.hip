@@ -72,9 +72,16 @@ __device__ __forceinline__ u32x4_t load_w(const u32x4_t* p) {
     return *p;
 }
 
-template <int MT, int NTB, int EPI, bool NT>
+// AMODE 0: A fragments come straight from global memory (any M).
+// AMODE 1: decode shapes (M <= 16 rows, M*K*2 <= 64 KiB): the workgroup stages its A rows ONCE in LDS while the first
+//          weight fragments are in flight; the k-loop then reads A with ds_read_b128 -- no global A load and no L2
+//          round trip inside the loop.
+// AMODE 2: as 1, and the staged rows are RMS-normalised in LDS ([3P] HF LlamaRMSNorm: var = mean(x^2) in fp32;
+//          bf16(x * rsqrt(var + eps)); bf16(weight * that)) -- removes the separate norm launch in front of the q/k/v,
+//          gate/up and lm_head projections (pure launch latency at M = 1).
+template <int MT, int NTB, int EPI, bool NT, int AMODE>
 __global__ void gemm_skinny_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [W][MT*NTB*4][64]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [W][MT*NTB*4][64], then the staged A rows (AMODE >= 1)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int W = blockDim.x >> 6;
@@ -109,21 +116,83 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
         wvalid[nb] = nt < NTILES;
         wptr[nb] = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(wvalid[nb] ? nt : 0) * KT) * 64 + lane;
     }
-
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+
+    // first batch of weight fragments goes in flight before anything else (also before the norm prologue)
+    u32x4_t wf[GEMM_UNROLL][NTB];
+#pragma unroll
+    for (int u = 0; u < GEMM_UNROLL; ++u) {
+        const int kt = wave + u * W;
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) wf[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
+    }
+
+    bf16_t* xs = reinterpret_cast<bf16_t*>(red + (long)W * (MT * NTB * 256));  // [M][K] staged rows (AMODE >= 1)
+    if constexpr (AMODE >= 1) {
+        float* part = reinterpret_cast<float*>(xs + (long)g.M * g.K);  // [W][16] partial sums, [16] rstd behind them
+        const int nthr = blockDim.x;
+        for (int rr = 0; rr < g.M; ++rr) {
+            const bf16_t* xr = A + (long)(m0 + rr) * g.lda;
+            float sq = 0.f;
+            for (int c = threadIdx.x * 8; c < g.K; c += nthr * 8) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(xr + c);
+                *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = v;
+                if constexpr (AMODE == 2) {
+                    float f[8];
+                    unpack8(v, f);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sq += f[q] * f[q];
+                }
+            }
+            if constexpr (AMODE == 2) {
+                sq = wave_sum(sq);
+                if (lane == 0) part[wave * 16 + rr] = sq;
+            }
+        }
+        __syncthreads();
+        if constexpr (AMODE == 2) {
+            if ((int)threadIdx.x < g.M) {
+                float t = 0.f;
+                for (int w2 = 0; w2 < W; ++w2) t += part[w2 * 16 + threadIdx.x];
+                part[W * 16 + threadIdx.x] = rsqrtf(t / g.K + g.norm_eps);
+            }
+            __syncthreads();
+            for (int rr = 0; rr < g.M; ++rr) {
+                const float rs = part[W * 16 + rr];
+                for (int c = threadIdx.x * 8; c < g.K; c += nthr * 8) {  // every thread rewrites the chunks it staged
+                    float f[8], nw[8];
+                    unpack8(*reinterpret_cast<const u32x4_t*>(xs + (long)rr * g.K + c), f);
+                    unpack8(*reinterpret_cast<const u32x4_t*>(g.norm_w + c), nw);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f[q] = nw[q] * bfr(f[q] * rs);
+                    *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = pack8(f);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
     for (int kt0 = wave; kt0 < KT; kt0 += W * GEMM_UNROLL) {
-        u32x4_t wf[GEMM_UNROLL][NTB];
         u32x4_t af[GEMM_UNROLL][MT];
 #pragma unroll
         for (int u = 0; u < GEMM_UNROLL; ++u) {
             const int kt = kt0 + u * W;
             const bool kv = kt < KT;
 #pragma unroll
-            for (int nb = 0; nb < NTB; ++nb)
-                wf[u][nb] = (kv && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (AMODE >= 1)
+                    af[u][mt] = (kv && avalid[mt]) ? *reinterpret_cast<const u32x4_t*>(xs + (long)arow * g.K + (long)kt * 32 + kq) : zero4;
+                else
+                    af[u][mt] = (kv && avalid[mt]) ? *reinterpret_cast<const u32x4_t*>(aptr[mt] + (long)kt * 32) : zero4;
+            }
+        }
+        // prefetch the next batch of weight fragments while this one is consumed
+        u32x4_t wn[GEMM_UNROLL][NTB];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                af[u][mt] = (kv && avalid[mt]) ? *reinterpret_cast<const u32x4_t*>(aptr[mt] + (long)kt * 32) : zero4;
+        for (int u = 0; u < GEMM_UNROLL; ++u) {
+            const int kt = kt0 + (GEMM_UNROLL + u) * W;
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) wn[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
         }
 #pragma unroll
         for (int u = 0; u < GEMM_UNROLL; ++u)
@@ -133,6 +202,10 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
                 for (int nb = 0; nb < NTB; ++nb)
                     acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, af[u][mt]), __builtin_bit_cast(bf16x8_t, wf[u][nb]), acc[mt][nb], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < GEMM_UNROLL; ++u)
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) wf[u][nb] = wn[u][nb];
     }
 
     // ---- cross-wave reduction through LDS: red[wave][(mt*NTB+nb)*4 + r][lane] ----
@@ -181,7 +254,11 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
     }
 }
 
-template <int MT, int EPI, bool NT>
+static inline bool gemm_can_stage(const GemmArgs& g) {
+    return g.batch == 1 && g.M <= 16 && (size_t)g.M * g.K * 2 <= 64 * 1024 && g.M <= GEMM_FUSED_NORM_MAX_M;
+}
+
+template <int MT, int EPI, bool NT, int AMODE>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     const int KT = g.K / 32, NTILES = g.N / 16;
     // NTB: n-tiles per block (SwiGLU needs the (gate, up) pair in one block)
@@ -195,23 +272,38 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     while (W < 16 && blocks * W < 2048 && W * 2 * GEMM_UNROLL <= KT * 2) W *= 2;
     while (W > 1 && W > KT) W /= 2;
     while (W > 1 && (size_t)W * MT * ntb * 1024 > 64 * 1024) W /= 2;
-    const size_t lds = (size_t)W * MT * ntb * 1024;
+    size_t lds = (size_t)W * MT * ntb * 1024;
+    if (AMODE >= 1) lds += (size_t)g.M * g.K * 2 + (W + 1) * 16 * sizeof(float);
     dim3 grid(blocks_x, blocks_y, g.batch), block(W * 64);
-    if (ntb == 2)
-        hipLaunchKernelGGL((gemm_skinny_kernel<MT, 2, EPI, NT>), grid, block, lds, stream, g);
-    else
-        hipLaunchKernelGGL((gemm_skinny_kernel<MT, (EPI == EPI_SWIGLU ? 2 : 1), EPI, NT>), grid, block, lds, stream, g);
+    if (ntb == 2) {
+        auto kern = gemm_skinny_kernel<MT, 2, EPI, NT, AMODE>;
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, g);
+    } else {
+        auto kern = gemm_skinny_kernel<MT, (EPI == EPI_SWIGLU ? 2 : 1), EPI, NT, AMODE>;
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, g);
+    }
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
 template <int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
+    if (g.norm_w) {
+        // fused norm: decode shapes only; every block re-normalises its rows, free at M <= 8 and wasteful beyond
+        // (callers run the norm kernel first for larger M)
+        if constexpr (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_F32) {
+            if (gemm_can_stage(g)) return launch_cfg<1, EPI, true, 2>(g, stream);
+        }
+        return ISST_ERR_ARG;
+    }
+    // (plain LDS staging without the norm, AMODE 1, measured 1.2 us slower per launch than direct A loads: not used)
     const bool single = g.M <= 64 && g.batch == 1;  // weight read exactly once -> non-temporal loads
-    if (!single) return launch_cfg<4, EPI, false>(g, stream);
-    if (g.M <= 16) return launch_cfg<1, EPI, true>(g, stream);
-    if (g.M <= 32) return launch_cfg<2, EPI, true>(g, stream);
-    if (g.M <= 48) return launch_cfg<3, EPI, true>(g, stream);
-    return launch_cfg<4, EPI, true>(g, stream);
+    if (!single) return launch_cfg<4, EPI, false, 0>(g, stream);
+    if (g.M <= 16) return launch_cfg<1, EPI, true, 0>(g, stream);
+    if (g.M <= 32) return launch_cfg<2, EPI, true, 0>(g, stream);
+    if (g.M <= 48) return launch_cfg<3, EPI, true, 0>(g, stream);
+    return launch_cfg<4, EPI, true, 0>(g, stream);
 }
 
 int launch_gemm(const GemmArgs& g, hipStream_t stream) {

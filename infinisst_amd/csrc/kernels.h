@@ -13,6 +13,8 @@ struct LlmStreamView {
     int sys_len;     // pinned system-prompt entries (logical positions 0..sys_len-1 live in the sys region)
     int ring_start;  // physical ring slot of logical position sys_len
     long kv_offset;  // element offset of this stream's arena inside the K (and V) pool, per layer-0 head-0 base
+    int new_start;   // first logical position written by THIS launch (keys >= new_start are read from the qkv rows)
+    int row0;        // row of this launch that holds position new_start
 };
 
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
@@ -39,15 +41,12 @@ struct LlmAttnDims {
     int sys_cap, ring_cap;       // arena geometry (slots); per (layer, kv head) the arena is [sys_cap + ring_cap][128]
     long layer_stride;           // elements between layers inside one stream's arena = kv_heads*(sys_cap+ring_cap)*128
 };
-// rotate q (positions row_pos) into qrot, append unrotated k and v to the arena of row_stream[r].
-int launch_llm_qkv_post(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
-                        const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* qrot, bf16_t* kpool, bf16_t* vpool,
-                        LlmAttnDims d, int layer, int rows, hipStream_t s);
-// causal attention of every row over its stream's keys 0..row_pos; RoPE applied to K on read.
-int launch_llm_attention(const bf16_t* qrot, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
-                         const bf16_t* rope_cos, const bf16_t* rope_sin, const bf16_t* kpool, const bf16_t* vpool,
+// causal attention of every row over its stream's keys 0..row_pos, fused with the q rotation and the append of
+// the row's own (unrotated) k, v to the arena; RoPE applied to K on read.  qkv: [rows][(H + 2 KV) * 128].
+int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
+                         const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, int max_pos, hipStream_t s);
-#define LLM_ATTN_SPLIT 128
+#define LLM_ATTN_SPLIT 64
 static inline int llm_attn_splits(int max_pos) { return (max_pos + LLM_ATTN_SPLIT) / LLM_ATTN_SPLIT; }
 
 // ---- sampling (sample.hip) ----
@@ -60,4 +59,4 @@ struct SampleStream {
 };
 int launch_sample(float* logits, long ld_logits, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool,
                   const int* suppress, int n_suppress, float rep_penalty, int ngram, int enc_ngram, int* out_tokens,
-                  int n_streams, hipStream_t s);
+                  float* scratch_val, int* scratch_idx /* 64 per stream each */, int n_streams, hipStream_t s);

@@ -44,63 +44,23 @@ __device__ __forceinline__ void rope_half(const float* x1, const float* x2, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// q rotation + KV append.  grid = rows, block = 256; item = (head of q|k|v, 16-lane slice j)
+// fused q-rotation + KV append + split-KV attention partials.
+// grid = (splits of 64 keys, kv_heads, rows), block = 256 = 16 groups of 16 lanes; every group owns 4 keys of the
+// split and issues all their loads (K, V, cos, sin: 24 x 8 B) before the first use, so a block pays ONE round of
+// memory latency.  Keys written by this launch (logical position >= new_start, i.e. the prompt rows of a prefill or
+// the row itself in a decode step) are read straight from the qkv rows; the group that meets key == row_pos stores
+// that row's unrotated k and v into the arena, so every new key is appended exactly once and nobody reads a slot
+// that another workgroup writes in the same launch.
+// partial layout: [row][head][split][2 + 128] fp32 (m, l, o).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void llm_qkv_post_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
-                                                           const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
-                                                           const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
-                                                           bf16_t* __restrict__ qrot, bf16_t* __restrict__ kpool,
-                                                           bf16_t* __restrict__ vpool, LlmAttnDims d, int layer) {
-    const int r = blockIdx.x;
-    const int H = d.heads, KV = d.kv_heads;
-    const LlmStreamView v = sv[row_stream[r]];
-    const int p = row_pos[r];
-    const long slots = (long)d.sys_cap + d.ring_cap;
-    const long slot = llm_slot(v, d, p);
-    const bf16_t* src_row = qkv + (long)r * (H + 2 * KV) * HD;
-    for (int item = threadIdx.x; item < (H + 2 * KV) * 16; item += blockDim.x) {
-        const int hh = item >> 4, j = item & 15;
-        float x1[4], x2[4];
-        load4(src_row + hh * HD + 4 * j, x1);
-        load4(src_row + hh * HD + 64 + 4 * j, x2);
-        if (hh < H) {
-            float c[4], s[4], r1[4], r2[4];
-            load4(rope_cos + (long)p * 64 + 4 * j, c);
-            load4(rope_sin + (long)p * 64 + 4 * j, s);
-            rope_half(x1, x2, c, s, r1, r2);
-            bf16_t* dst = qrot + (long)r * H * HD + hh * HD;
-            store4(dst + 4 * j, r1);
-            store4(dst + 64 + 4 * j, r2);
-        } else {
-            const bool isk = hh < H + KV;
-            const int kvh = isk ? hh - H : hh - H - KV;
-            bf16_t* dst = (isk ? kpool : vpool) + v.kv_offset + (long)layer * d.layer_stride + ((long)kvh * slots + slot) * HD;
-            store4(dst + 4 * j, x1);
-            store4(dst + 64 + 4 * j, x2);
-        }
-    }
-}
+#define KEYS_PER_GROUP (LLM_ATTN_SPLIT / 16)
 
-int launch_llm_qkv_post(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
-                        const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* qrot, bf16_t* kpool, bf16_t* vpool,
-                        LlmAttnDims d, int layer, int rows, hipStream_t s) {
-    if (rows <= 0) return ISST_OK;
-    hipLaunchKernelGGL(llm_qkv_post_kernel, dim3(rows), dim3(256), 0, s, qkv, row_stream, row_pos, sv, rope_cos, rope_sin, qrot,
-                       kpool, vpool, d, layer);
-    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
-}
-
-// ------------------------------------------------------------------------------------------------
-// split-KV attention partials: grid = (splits, kv_heads, rows), block = 256 (16 groups of 16 lanes, one key per
-// group per step).  Each group keeps an online softmax (m, l, o[128]) for the G query heads of the kv head.
-// partial layout: [row][head][split][2 + 128] fp32.
-// ------------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __restrict__ qrot, const int* __restrict__ row_stream,
+__global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
                                                                const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
                                                                const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
-                                                               const bf16_t* __restrict__ kpool, const bf16_t* __restrict__ vpool,
-                                                               float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits) {
+                                                               bf16_t* kpool, bf16_t* vpool, float* __restrict__ partial,
+                                                               LlmAttnDims d, int layer, int n_splits) {
     __shared__ float red[16][G][2 + HD];
     const int sp = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
     const int p = row_pos[r];
@@ -109,53 +69,97 @@ __global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __r
     if (k_lo >= k_hi) return;  // block-uniform
     const LlmStreamView v = sv[row_stream[r]];
     const int tid = threadIdx.x;
-    const int j = tid & 15, grp = tid >> 4;  // 16 groups per block
+    const int j = tid & 15, grp = tid >> 4;
+    const int H = d.heads, KV = d.kv_heads;
+    const long ldq = (long)(H + 2 * KV) * HD;
     const long slots = (long)d.sys_cap + d.ring_cap;
     const long base = v.kv_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
-    const bf16_t* kb = kpool + base;
-    const bf16_t* vb = vpool + base;
+    bf16_t* kb = kpool + base;
+    bf16_t* vb = vpool + base;
     const float scale = 0.08838834764831845f;  // 1/sqrt(128)
 
-    float q1[G][4], q2[G][4], m[G], l[G], a1[G][4], a2[G][4];
+    // ---- issue every load of this group's keys first ----
+    u32x2_t kx1[KEYS_PER_GROUP], kx2[KEYS_PER_GROUP], vx1[KEYS_PER_GROUP], vx2[KEYS_PER_GROUP], cx[KEYS_PER_GROUP], sx[KEYS_PER_GROUP];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const bf16_t* qh = qrot + ((long)r * d.heads + kvh * G + g) * HD;
-        load4(qh + 4 * j, q1[g]);
-        load4(qh + 64 + 4 * j, q2[g]);
-        m[g] = -INFINITY; l[g] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a1[g][i] = 0.f; a2[g][i] = 0.f; }
+    for (int u = 0; u < KEYS_PER_GROUP; ++u) {
+        const int key = k_lo + grp + 16 * u;
+        const int kk = key < k_hi ? key : k_lo;  // clamp: loads stay in bounds, result is discarded
+        const bf16_t* kp;
+        const bf16_t* vp;
+        if (kk >= v.new_start) {
+            const bf16_t* row = qkv + (long)(v.row0 + (kk - v.new_start)) * ldq;
+            kp = row + (long)(H + kvh) * HD;
+            vp = row + (long)(H + KV + kvh) * HD;
+        } else {
+            const long slot = llm_slot(v, d, kk);
+            kp = kb + slot * HD;
+            vp = vb + slot * HD;
+        }
+        kx1[u] = *reinterpret_cast<const u32x2_t*>(kp + 4 * j);
+        kx2[u] = *reinterpret_cast<const u32x2_t*>(kp + 64 + 4 * j);
+        vx1[u] = *reinterpret_cast<const u32x2_t*>(vp + 4 * j);
+        vx2[u] = *reinterpret_cast<const u32x2_t*>(vp + 64 + 4 * j);
+        cx[u] = *reinterpret_cast<const u32x2_t*>(rope_cos + (long)kk * 64 + 4 * j);
+        sx[u] = *reinterpret_cast<const u32x2_t*>(rope_sin + (long)kk * 64 + 4 * j);
     }
-    for (int key = k_lo + grp; key < k_hi; key += 16) {
-        const long slot = llm_slot(v, d, key);
-        float x1[4], x2[4], c[4], s[4], r1[4], r2[4], v1[4], v2[4];
-        load4(kb + slot * HD + 4 * j, x1);
-        load4(kb + slot * HD + 64 + 4 * j, x2);
-        load4(vb + slot * HD + 4 * j, v1);
-        load4(vb + slot * HD + 64 + 4 * j, v2);
-        load4(rope_cos + (long)key * 64 + 4 * j, c);
-        load4(rope_sin + (long)key * 64 + 4 * j, s);
-        rope_half(x1, x2, c, s, r1, r2);
+    // ---- rotated queries of the G heads sharing this kv head ----
+    float q1[G][4], q2[G][4], m[G], l[G], a1[G][4], a2[G][4];
+    {
+        float c[4], s[4];
+        load4(rope_cos + (long)p * 64 + 4 * j, c);
+        load4(rope_sin + (long)p * 64 + 4 * j, s);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float part = 0.f;
+            const bf16_t* qh = qkv + (long)r * ldq + (long)(kvh * G + g) * HD;
+            float x1[4], x2[4];
+            load4(qh + 4 * j, x1);
+            load4(qh + 64 + 4 * j, x2);
+            rope_half(x1, x2, c, s, q1[g], q2[g]);
+            m[g] = -INFINITY; l[g] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part += q1[g][i] * r1[i] + q2[g][i] * r2[i];
-            part += __shfl_xor(part, 8, WAVE);
-            part += __shfl_xor(part, 4, WAVE);
-            part += __shfl_xor(part, 2, WAVE);
-            part += __shfl_xor(part, 1, WAVE);
-            const float sc = part * scale;
-            const float mn = fmaxf(m[g], sc);
-            const float alpha = expf(m[g] - mn);  // exp(-inf) = 0 on the first key
-            const float pe = expf(sc - mn);
-            l[g] = l[g] * alpha + pe;
+            for (int i = 0; i < 4; ++i) { a1[g][i] = 0.f; a2[g][i] = 0.f; }
+        }
+    }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a1[g][i] = a1[g][i] * alpha + pe * v1[i];
-                a2[g][i] = a2[g][i] * alpha + pe * v2[i];
+    for (int u = 0; u < KEYS_PER_GROUP; ++u) {
+        const int key = k_lo + grp + 16 * u;
+        if (key < k_hi) {  // uniform within the 16-lane group
+            if (key == p) {  // this row's own key: append the unrotated k, v to the arena
+                const long slot = llm_slot(v, d, key);
+                *reinterpret_cast<u32x2_t*>(kb + slot * HD + 4 * j) = kx1[u];
+                *reinterpret_cast<u32x2_t*>(kb + slot * HD + 64 + 4 * j) = kx2[u];
+                *reinterpret_cast<u32x2_t*>(vb + slot * HD + 4 * j) = vx1[u];
+                *reinterpret_cast<u32x2_t*>(vb + slot * HD + 64 + 4 * j) = vx2[u];
             }
-            m[g] = mn;
+            const float x1[4] = {lo_bf(kx1[u].x), hi_bf(kx1[u].x), lo_bf(kx1[u].y), hi_bf(kx1[u].y)};
+            const float x2[4] = {lo_bf(kx2[u].x), hi_bf(kx2[u].x), lo_bf(kx2[u].y), hi_bf(kx2[u].y)};
+            const float v1[4] = {lo_bf(vx1[u].x), hi_bf(vx1[u].x), lo_bf(vx1[u].y), hi_bf(vx1[u].y)};
+            const float v2[4] = {lo_bf(vx2[u].x), hi_bf(vx2[u].x), lo_bf(vx2[u].y), hi_bf(vx2[u].y)};
+            const float c[4] = {lo_bf(cx[u].x), hi_bf(cx[u].x), lo_bf(cx[u].y), hi_bf(cx[u].y)};
+            const float s[4] = {lo_bf(sx[u].x), hi_bf(sx[u].x), lo_bf(sx[u].y), hi_bf(sx[u].y)};
+            float r1[4], r2[4];
+            rope_half(x1, x2, c, s, r1, r2);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part += q1[g][i] * r1[i] + q2[g][i] * r2[i];
+                part += __shfl_xor(part, 8, WAVE);
+                part += __shfl_xor(part, 4, WAVE);
+                part += __shfl_xor(part, 2, WAVE);
+                part += __shfl_xor(part, 1, WAVE);
+                const float sc = part * scale;
+                const float mn = fmaxf(m[g], sc);
+                const float alpha = expf(m[g] - mn);  // exp(-inf) = 0 on the first key
+                const float pe = expf(sc - mn);
+                l[g] = l[g] * alpha + pe;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a1[g][i] = a1[g][i] * alpha + pe * v1[i];
+                    a2[g][i] = a2[g][i] * alpha + pe * v2[i];
+                }
+                m[g] = mn;
+            }
         }
     }
 #pragma unroll
@@ -185,6 +189,10 @@ __global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __r
     }
 }
 
+// Combine of the split partials.  A separate launch on purpose: folding it into the partial kernel (last-arriver
+// ticket + agent-scope release/acquire, or write-through slabs + sc1 loads) measured 28-31 us per layer against
+// 12.7 + 7.0 us for two launches on MI355X (profiles/r01), because every split pays the ticket round trip and the
+// reducer serialises its slab loads.
 __global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __restrict__ partial, const int* __restrict__ row_pos,
                                                                bf16_t* __restrict__ out, int heads, int n_splits) {
     const int h = blockIdx.x, r = blockIdx.y, dd = threadIdx.x;
@@ -201,15 +209,15 @@ __global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __re
     out[((long)r * heads + h) * HD + dd] = f2bf(O / L);
 }
 
-int launch_llm_attention(const bf16_t* qrot, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
-                         const bf16_t* rope_cos, const bf16_t* rope_sin, const bf16_t* kpool, const bf16_t* vpool,
+int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
+                         const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, int max_pos, hipStream_t s) {
     if (rows <= 0) return ISST_OK;
     const int G = d.heads / d.kv_heads;
     const int n_splits = llm_attn_splits(max_pos);
     dim3 grid(n_splits, d.kv_heads, rows), block(256);
 #define LAUNCH_G(GG) \
-    hipLaunchKernelGGL(llm_attn_partial_kernel<GG>, grid, block, 0, s, qrot, row_stream, row_pos, sv, rope_cos, rope_sin, kpool, vpool, partial, d, layer, n_splits)
+    hipLaunchKernelGGL(llm_attn_partial_kernel<GG>, grid, block, 0, s, qkv, row_stream, row_pos, sv, rope_cos, rope_sin, kpool, vpool, partial, d, layer, n_splits)
     switch (G) {
         case 1: LAUNCH_G(1); break;
         case 2: LAUNCH_G(2); break;

@@ -8,19 +8,16 @@
 #include "common.h"
 #include "kernels.h"
 
-__global__ __launch_bounds__(1024) void sample_kernel(float* __restrict__ logits, long ld, int vocab,
-                                                      const SampleStream* __restrict__ ss, const int* __restrict__ ids_pool,
-                                                      const int* __restrict__ enc_pool, const int* __restrict__ suppress,
-                                                      int n_suppress, float pen, int ngram, int enc_ngram,
-                                                      int* __restrict__ out_tokens) {
-    __shared__ float sval[16];
-    __shared__ int sidx[16];
+// stage 1 (one 256-thread block per stream): processors, in place on the logits row
+__global__ __launch_bounds__(256) void sample_process_kernel(float* __restrict__ logits, long ld, const SampleStream* __restrict__ ss,
+                                                             const int* __restrict__ ids_pool, const int* __restrict__ enc_pool,
+                                                             const int* __restrict__ suppress, int n_suppress, float pen, int ngram,
+                                                             int enc_ngram) {
     const SampleStream st = ss[blockIdx.x];
     float* L = logits + (long)st.logits_row * ld;
     const int* ids = ids_pool + st.ids_off;
     const int* enc = enc_pool + st.enc_off;
     const int n = st.n_ids, tid = threadIdx.x;
-
     // 1. repetition penalty, once per distinct token
     if (pen != 1.0f) {
         for (int i = tid; i < n; i += blockDim.x) {
@@ -49,34 +46,53 @@ __global__ __launch_bounds__(1024) void sample_kernel(float* __restrict__ logits
         }
     }
     for (int i = tid; i < n_suppress; i += blockDim.x) L[suppress[i]] = -INFINITY;
-    __syncthreads();
-    // 3. argmax, smallest index on ties
+}
+
+__device__ __forceinline__ void argmax_merge(float& bv, int& bi, float ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
+// stage 2: grid (SAMPLE_PARTS, streams): partial argmax (first index on ties) of one slice of the row
+#define SAMPLE_PARTS 64
+__global__ __launch_bounds__(256) void sample_argmax_part_kernel(const float* __restrict__ logits, long ld, int vocab,
+                                                                 const SampleStream* __restrict__ ss, float* __restrict__ pval,
+                                                                 int* __restrict__ pidx) {
+    __shared__ float sval[4];
+    __shared__ int sidx[4];
+    const float* L = logits + (long)ss[blockIdx.y].logits_row * ld;
+    const int per = (vocab + SAMPLE_PARTS - 1) / SAMPLE_PARTS;
+    const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = tid; v < vocab; v += blockDim.x) {
-        const float x = L[v];
-        if (x > bv || (x == bv && v < bi)) { bv = x; bi = v; }
-    }
+    for (int v = lo + threadIdx.x; v < hi; v += blockDim.x) argmax_merge(bv, bi, L[v], v);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, WAVE);
-        const int oi = __shfl_xor(bi, o, WAVE);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
-    if ((tid & 63) == 0) { sval[tid >> 6] = bv; sidx[tid >> 6] = bi; }
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, WAVE), __shfl_xor(bi, o, WAVE));
+    if ((threadIdx.x & 63) == 0) { sval[threadIdx.x >> 6] = bv; sidx[threadIdx.x >> 6] = bi; }
     __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
-            if (sval[w] > bv || (sval[w] == bv && sidx[w] < bi)) { bv = sval[w]; bi = sidx[w]; }
-        out_tokens[blockIdx.x] = bi;
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) argmax_merge(bv, bi, sval[w], sidx[w]);
+        pval[blockIdx.y * SAMPLE_PARTS + blockIdx.x] = bv;
+        pidx[blockIdx.y * SAMPLE_PARTS + blockIdx.x] = bi;
     }
+}
+// stage 3: one wave per stream merges the SAMPLE_PARTS partial results
+__global__ __launch_bounds__(64) void sample_argmax_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
+                                                                 int* __restrict__ out_tokens) {
+    float bv = pval[blockIdx.x * SAMPLE_PARTS + threadIdx.x];
+    int bi = pidx[blockIdx.x * SAMPLE_PARTS + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, WAVE), __shfl_xor(bi, o, WAVE));
+    if (threadIdx.x == 0) out_tokens[blockIdx.x] = bi;
 }
 
 int launch_sample(float* logits, long ld_logits, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool,
                   const int* suppress, int n_suppress, float rep_penalty, int ngram, int enc_ngram, int* out_tokens,
-                  int n_streams, hipStream_t s) {
+                  float* scratch_val, int* scratch_idx, int n_streams, hipStream_t s) {
     if (n_streams <= 0) return ISST_OK;
-    hipLaunchKernelGGL(sample_kernel, dim3(n_streams), dim3(1024), 0, s, logits, ld_logits, vocab, ss, ids_pool, enc_pool,
-                       suppress, n_suppress, rep_penalty, ngram, enc_ngram, out_tokens);
+    hipLaunchKernelGGL(sample_process_kernel, dim3(n_streams), dim3(256), 0, s, logits, ld_logits, ss, ids_pool, enc_pool, suppress,
+                       n_suppress, rep_penalty, ngram, enc_ngram);
+    hipLaunchKernelGGL(sample_argmax_part_kernel, dim3(SAMPLE_PARTS, n_streams), dim3(256), 0, s, logits, ld_logits, vocab, ss,
+                       scratch_val, scratch_idx);
+    hipLaunchKernelGGL(sample_argmax_final_kernel, dim3(n_streams), dim3(64), 0, s, scratch_val, scratch_idx, out_tokens);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }

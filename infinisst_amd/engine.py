@@ -101,7 +101,7 @@ def load_library(path: Optional[str] = None):
     lib.isst_op_pack_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.isst_op_packed_elems.argtypes = [C.c_int, C.c_int]
     lib.isst_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
     lib.isst_op_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                       C.c_int, C.c_void_p]
     lib.isst_op_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
@@ -298,7 +298,8 @@ def op_pack_weight(w: torch.Tensor, conv_k: int = 0) -> torch.Tensor:
 
 
 def op_gemm(A: torch.Tensor, packed: torch.Tensor, N: int, epi: str = "none", bias=None, res=None, n_valid=None,
-            lda: Optional[int] = None, M: Optional[int] = None, K: Optional[int] = None) -> torch.Tensor:
+            lda: Optional[int] = None, M: Optional[int] = None, K: Optional[int] = None, norm_w=None,
+            norm_eps: float = 1e-5) -> torch.Tensor:
     lib = load_library()
     M = A.shape[0] if M is None else M
     K = A.shape[1] if K is None else K
@@ -306,7 +307,7 @@ def op_gemm(A: torch.Tensor, packed: torch.Tensor, N: int, epi: str = "none", bi
     n_out = (N // 2 if epi == "swiglu" else N) if n_valid is None else n_valid
     out = torch.zeros((M, n_out), dtype=torch.float32 if epi == "f32" else torch.bfloat16, device=A.device)
     rc = lib.isst_op_gemm(_ptr(A), lda, _ptr(packed), _ptr(bias), _ptr(res), 0 if res is None else res.stride(0),
-                          _ptr(out), out.stride(0), M, N, K, n_out, EPI[epi], _stream_ptr())
+                          _ptr(out), out.stride(0), M, N, K, n_out, EPI[epi], _ptr(norm_w), norm_eps, _stream_ptr())
     if rc:
         raise IsstError(f"isst_op_gemm -> {rc}")
     return out

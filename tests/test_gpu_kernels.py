@@ -48,7 +48,7 @@ def ref_linear(A, W, epi, bias=None, res=None):
     raise ValueError(epi)
 
 
-@pytest.mark.parametrize("M", [1, 5, 16, 22, 48, 64, 100, 200])
+@pytest.mark.parametrize("M", [1, 3, 5, 8, 9, 16, 22, 48, 64, 100, 200])
 @pytest.mark.parametrize("N,K", [(256, 128), (1040, 512), (64, 4096)])
 def test_gemm_plain_and_epilogues(M, N, K):
     g = torch.Generator().manual_seed(M * 1000 + N + K)
@@ -96,6 +96,25 @@ def test_gemm_swiglu(M):
     gg, uu = bf(A.float() @ Wg.float().t()), bf(A.float() @ Wu.float().t())
     ref = torch.nn.functional.silu(gg) * uu
     close_bf16(out, ref, f"swiglu M{M}", ulps=3, atol=2e-3)
+
+
+@pytest.mark.parametrize("M", [1, 2, 5, 8])
+@pytest.mark.parametrize("epi", ["none", "f32", "swiglu"])
+def test_gemm_fused_rmsnorm(M, epi):
+    """RMSNorm applied inside the A-fragment load == rmsnorm kernel / oracle followed by the plain projection."""
+    g = torch.Generator().manual_seed(M + len(epi))
+    K, N = 512, 256
+    x = bf(torch.randn(M, K, generator=g) * 2)
+    nw = bf(1 + 0.2 * torch.randn(K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    if epi == "swiglu":
+        W = torch.stack([W[: N // 2].view(N // 32, 16, K), W[N // 2:].view(N // 32, 16, K)], dim=1).reshape(N, K)
+    Wp = E.op_pack_weight(W.to(DEV))
+    fused = E.op_gemm(x.to(DEV), Wp, N, epi, norm_w=nw.to(DEV), norm_eps=1e-5)
+    xn = ollm.rmsnorm(x, nw, 1e-5)
+    two_step = E.op_gemm(xn.to(DEV), Wp, N, epi)
+    torch.cuda.synchronize()
+    close_bf16(fused, two_step, f"fused norm {epi} M{M}", ulps=2.5, atol=4e-3)
 
 
 @pytest.mark.parametrize("k,stride,T", [(3, 2, 157), (2, 2, 48)])
