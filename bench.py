@@ -138,20 +138,27 @@ def gemm_roofline(cfg, device, iters=40):
         packs.append(E.op_pack_weight(w))
         del w
     x = torch.randn(1, K, device=device, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(K, device=device, generator=g)).bfloat16()  # post_attention_layernorm weight (fused RMSNorm)
     for p in packs:
-        E.op_gemm(x, p, N, "swiglu")
+        E.op_gemm(x, p, N, "swiglu", norm_w=nw, norm_eps=cfg.rms_eps)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for i in range(iters):
-        E.op_gemm(x, packs[i % copies], N, "swiglu")
+        E.op_gemm(x, packs[i % copies], N, "swiglu", norm_w=nw, norm_eps=cfg.rms_eps)
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / iters
     algo_bytes = w_bytes + K * 2 + (N // 2) * 2  # weights once + activation row in + bf16 row out
     achieved = algo_bytes / (ms * 1e-3) / 1e9
+    traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 --pmc)
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath) and N == 28672 and K == 4096:
+        with open(tpath) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "gemm_skinny_kernel<1,2,SWIGLU,nt>",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": "gemm_skinny_kernel<1,2,EPI_SWIGLU,nt,AMODE=2> (gate/up GEMV with fused RMSNorm)",
             "launch_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": algo_bytes,
             "shape": f"M=1 N={N} K={K} (gate/up of one layer, one token)"}
 

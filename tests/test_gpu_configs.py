@@ -1,0 +1,126 @@
+"""The other BASELINE.json configurations as parity / property tests on the GPU (toy dimensions, same structure):
+latency multiplier 2, many concurrent streams with shared weights, and a long unbounded stream with rolling eviction."""
+import numpy as np
+import pytest
+import torch
+
+from infinisst_amd import synth
+from infinisst_amd.config import GenConfig, toy_config
+from infinisst_amd.engine import Engine
+from oracle import generate as ogen
+from oracle import llm as ollm
+from oracle import speech_encoder as oenc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_latency_multiplier_2_matches_oracle():
+    """m = 2: 96-frame blocks, 24 speech tokens per chunk, max_new_tokens = 20 (reference agents/infinisst.py:125-128,245;
+    model/speech_encoder.py:143-145)."""
+    cfg = toy_config()
+    gen = GenConfig(latency_multiplier=2, max_new_tokens=12, max_llm_cache_size=200)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=31)
+    eng = Engine(cfg, max_streams=1, max_multiplier=2, max_prompt_len=128, max_new_tokens=20, max_llm_cache_size=200,
+                 max_system_prompt=64)
+    eng.load_weights(w)
+    sid = eng.open_stream()
+    n = cfg.chunk_samples * 2
+    audio = synth.synthetic_audio(n * 3, stream_id=7)
+    kv, sc = ollm.new_kv(cfg), oenc.new_cache(cfg)
+    rope_l, rope_e = ollm.llm_rope_tables(cfg, 2048, torch.bfloat16), oenc.make_rope(cfg)
+    worst = 0.0
+    for c in range(3):
+        seg = audio[c * n:(c + 1) * n]
+        prompt = synth.chunk_prompt_ids(cfg, 2, first=(c == 0))
+        x = torch.from_numpy(seg)
+        if c == 0:
+            x = torch.cat([torch.zeros(cfg.first_chunk_offset), x])
+        ref = ogen.generate(w, cfg, gen, prompt, x.unsqueeze(0).bfloat16(), kv, sc, rope_l, rope_e, [])
+        forced = ref.sequences[len(prompt):]
+        outs, logits = eng.generate(gen, [sid], [seg], [prompt], [[]], forced_tokens=[forced], return_logits=True)
+        assert outs[0] == forced
+        for s, rl in enumerate(ref.step_logits):
+            worst = max(worst, float(np.abs(logits[0, s] - rl.float().numpy()).max()))
+        info = eng.stream_info(sid)
+        assert info["enc_n_steps"] == sc.n_steps == 96 * (c + 1)
+        assert info["llm_cache_len"] == ollm.kv_len(kv)
+    print(f"m=2: worst |logit diff| {worst:.4f}")
+    assert worst <= 0.15
+
+
+def test_64_concurrent_streams_shared_weights():
+    """BASELINE configs[2] in miniature: 64 streams stepped together, per-stream KV; every stream must produce the
+    logits it produces alone (stream 0, 17 and 63 are checked against single-stream engines)."""
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=4, max_llm_cache_size=150)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=32)
+    n_s = 64
+    eng = Engine(cfg, max_streams=n_s + 3, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=150, max_system_prompt=64)
+    eng.load_weights(w)
+    sids = [eng.open_stream() for _ in range(n_s)]
+    solo = {i: eng.open_stream() for i in (0, 17, 63)}
+    audio = [synth.synthetic_audio(cfg.chunk_samples * 3, stream_id=100 + i) for i in range(n_s)]
+    for c in range(3):
+        segs = [a[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples] for a in audio]
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        single = {}
+        for i, sid in solo.items():
+            o, l = eng.generate(gen, [sid], [segs[i]], [prompt], [[]], return_logits=True)
+            single[i] = (o[0], l[0])
+        forced = [single[i][0] if i in single else None for i in range(n_s)]
+        outs, logits = eng.generate(gen, sids, segs, [prompt] * n_s, [[] for _ in range(n_s)], forced_tokens=forced, return_logits=True)
+        for i in single:
+            n = len(single[i][0])
+            d = float(np.abs(logits[i][:n] - single[i][1][:n]).max())
+            assert d <= 0.07, f"chunk {c} stream {i}: {d}"
+        lens = {eng.stream_info(s)["llm_cache_len"] for s in sids}
+        assert all(l > 0 for l in lens)
+
+
+def test_long_stream_is_bounded_and_o1():
+    """BASELINE configs[4] in miniature: an unbounded stream (150 chunks) with rolling eviction: cache lengths stay
+    bounded, the encoder window saturates, outputs stay finite, and a late chunk equals the oracle run on the same
+    (evicted) state -- the ring wraps several times on the way."""
+    cfg = toy_config().replace(block_size=16, max_cache_size=40)
+    gen = GenConfig(max_new_tokens=4, max_llm_cache_size=90)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=33)
+    eng = Engine(cfg, max_streams=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=90, max_system_prompt=64)
+    eng.load_weights(w)
+    sid = eng.open_stream()
+    sys_n = len(synth.system_prompt_ids(cfg))
+    n_chunks = 150
+    audio = synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=9)
+    kv, sc = ollm.new_kv(cfg), oenc.new_cache(cfg)
+    rope_l, rope_e = ollm.llm_rope_tables(cfg, 2048, torch.bfloat16), oenc.make_rope(cfg)
+    ckpts = []
+    from oracle import agent as oag
+    worst = 0.0
+    for c in range(n_chunks):
+        seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        x = torch.from_numpy(seg)
+        if c == 0:
+            x = torch.cat([torch.zeros(cfg.first_chunk_offset), x])
+        ref = ogen.generate(w, cfg, gen, prompt, x.unsqueeze(0).bfloat16(), kv, sc, rope_l, rope_e, [], keep_logits=(c % 10 == 9))
+        forced = ref.sequences[len(prompt):]
+        outs, logits = eng.generate(gen, [sid], [seg], [prompt], [[]], system_prompt_size=sys_n if c == 0 else 0,
+                                    forced_tokens=[forced], return_logits=(c % 10 == 9))
+        if c % 10 == 9:
+            for s, rl in enumerate(ref.step_logits):
+                assert np.isfinite(logits[0, s]).all()
+                worst = max(worst, float(np.abs(logits[0, s] - rl.float().numpy()).max()))
+        cur = ollm.kv_len(kv)
+        info = eng.stream_info(sid)
+        assert info["llm_cache_len"] == cur
+        ckpts.append(cur)
+        ev = oag.evict(ckpts, cur, gen.max_llm_cache_size, True, sys_n)
+        if ev is not None:
+            ckpts, new_size = ev
+            for layer in kv:
+                for j in (0, 1):
+                    layer[j] = torch.cat([layer[j][:, :, :sys_n], layer[j][:, :, -new_size:]], dim=2)
+            eng.kv_evict(sid, new_size, sys_n)
+        assert eng.stream_info(sid)["llm_cache_len"] <= gen.max_llm_cache_size + sys_n
+        assert info["enc_cache_len"] <= cfg.max_cache_size + cfg.block_size
+    print(f"long stream: worst |logit diff| over sampled chunks {worst:.4f}")
+    assert worst <= 0.15
