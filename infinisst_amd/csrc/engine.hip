@@ -282,8 +282,8 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->llm_rows_max = c.max_streams * c.max_prompt_len;
     h->enc_cap = round_up(c.max_cache_size + c.block_size * c.max_multiplier, 64);
     if (h->enc_cap > 1024) { h->fail(ISST_ERR_ARG, "encoder window %d > 1024 keys unsupported", h->enc_cap); return die(ISST_ERR_ARG); }
-    h->sys_cap = round_up(c.max_system_prompt, 8);
-    h->ring_cap = round_up(c.max_llm_cache_size + c.max_prompt_len + c.max_new_tokens + 8, 8);
+    h->sys_cap = round_up(c.max_system_prompt, 64);  // the attention kernel walks 64-slot splits of [sys region | ring]
+    h->ring_cap = round_up(c.max_llm_cache_size + c.max_prompt_len + c.max_new_tokens + 8, 64);
     h->vocab_pad = round_up(c.vocab, 16);
     h->max_ids = c.max_prompt_len + c.max_new_tokens + 1;
 
@@ -370,12 +370,12 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->lx = h->dalloc<bf16_t>(LR * DL); h->lxn = h->dalloc<bf16_t>(LR * DL); h->lqkv = h->dalloc<bf16_t>(LR * (H + 2 * KV) * 128);
     h->lqrot = h->dalloc<bf16_t>(LR * H * 128); h->lattn = h->dalloc<bf16_t>(LR * H * 128); h->lact = h->dalloc<bf16_t>(LR * c.llm_ffn);
     h->llast = h->dalloc<bf16_t>((size_t)ns * DL);
-    h->lpartial = h->dalloc<float>(LR * H * llm_attn_splits(h->llm_rope_rows) * 130);
+    h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * 130);
     h->logits = h->dalloc<float>((size_t)ns * h->vocab_pad);
     h->out_tok = h->dalloc<int>(ns);
     h->samp_val = h->dalloc<float>((size_t)ns * 64);
     h->samp_idx = h->dalloc<int>((size_t)ns * 64);
-    h->meta_bytes = (size_t)LR * 4 * sizeof(int) + (size_t)ns * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
+    h->meta_bytes = (size_t)LR * 6 * sizeof(int) + (size_t)ns * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
                     (size_t)ns * (h->max_ids + h->max_enc_ids) * sizeof(int) + 65536 * sizeof(int) + 4096;
     h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
     const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
@@ -750,6 +750,7 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
 
 struct StepMeta {
     int *row_stream, *row_pos, *ids, *speech_row, *last_rows;
+    int2* groups;  // attention row groups of this launch
     LlmStreamView* views;
     SampleStream* samp;
     int *ids_pool, *enc_pool, *suppress;
@@ -765,6 +766,7 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
     m.row_stream = reinterpret_cast<int*>(take(LR * 4)); m.row_pos = reinterpret_cast<int*>(take(LR * 4));
     m.ids = reinterpret_cast<int*>(take(LR * 4)); m.speech_row = reinterpret_cast<int*>(take(LR * 4));
     m.last_rows = reinterpret_cast<int*>(take(ns * 4));
+    m.groups = reinterpret_cast<int2*>(take(LR * 8));
     m.views = reinterpret_cast<LlmStreamView*>(take(ns * sizeof(LlmStreamView)));
     m.samp = reinterpret_cast<SampleStream*>(take(ns * sizeof(SampleStream)));
     m.ids_pool = reinterpret_cast<int*>(take(ns * h->max_ids * 4));
@@ -776,7 +778,8 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
 }
 
 // one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
-int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int max_pos, bool splice, const char* tap_prefix, hipStream_t st) {
+int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_groups, int max_group_rows, bool splice, const char* tap_prefix,
+                hipStream_t st) {
     const isst_config& c = h->cfg;
     const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
     CHK(launch_embed_splice(d.ids, splice ? d.speech_row : nullptr, h->embed, h->speech, h->lx, rows, DL, st));
@@ -792,8 +795,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int max
             CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
         }
-        CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_v, h->lpartial, h->lattn,
-                                 h->adims, l, rows, max_pos, st));
+        CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
+                                 h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st));
         CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
         if (fuse) {
             CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
@@ -886,7 +889,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     StepMeta mh = carve(h, h->meta_host), md = carve(h, h->meta_dev);
     std::vector<int> total0(n), gen_count(n, 0), row0(n);
     std::vector<char> done(n, 0);
-    int R = 0, max_pos = 0;
+    int R = 0, n_groups = 0;
+    const int gmax = LLM_ATTN_GROUP_ROWS(c.llm_heads / c.llm_kv_heads);
     for (int i = 0; i < n; ++i) {
         StreamState& s = h->streams[stream_ids[i]];
         if (s.llm_total == 0) s.llm_sys = p->system_prompt_size > 0 ? p->system_prompt_size : 0;
@@ -920,8 +924,12 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             index += cnt;
         }
         mh.last_rows[i] = R + len - 1;
+        for (int t = 0; t < len; t += gmax) {  // attention row groups: consecutive rows of one stream
+            mh.groups[n_groups].x = R + t;
+            mh.groups[n_groups].y = std::min(gmax, len - t);
+            ++n_groups;
+        }
         R += len;
-        max_pos = std::max(max_pos, total0[i] + len + p->max_new_tokens);
         // sampling context
         std::memcpy(mh.ids_pool + (size_t)i * h->max_ids, ids, (size_t)len * 4);
         const int ne = n_prev ? n_prev[i] : 0;
@@ -934,7 +942,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         HIPCHK(hipMemcpyAsync(h->meta_dev + mh.suppress_offset, h->meta_host + mh.suppress_offset, (size_t)p->n_suppress * 4, hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-    CHK(llm_forward(h, md, R, n, max_pos, true, "llm_", st));
+    CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st));
 
     // ---- 3. greedy loop (patch_hf.py:606-624 -> HF _sample) ----
     std::vector<int> active(n);
@@ -975,6 +983,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             mh.row_pos[r] = total0[i] + prompt_lens[i] + gen_count[i] - 1;
             mh.views[i].new_start = mh.row_pos[r];
             mh.views[i].row0 = r;
+            mh.groups[r].x = r;
+            mh.groups[r].y = 1;
             mh.ids[r] = tok;
             mh.last_rows[r] = r;
             mh.ids_pool[(size_t)i * h->max_ids + prompt_lens[i] + gen_count[i] - 1] = tok;
@@ -983,7 +993,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             mh.samp[r].ids_off = i * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
         }
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-        CHK(llm_forward(h, md, nr, nr, max_pos, false, nullptr, st));
+        CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st));
     }
     // ---- 4. state: the cache holds the prompt and every generated token except the last one ----
     for (int i = 0; i < n; ++i) {

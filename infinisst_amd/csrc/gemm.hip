@@ -20,6 +20,8 @@
 #include "common.h"
 
 #define GEMM_UNROLL 4
+// k-tiles in flight per wave and batch: halved for the widest variants (MT*NTB >= 6) so that nothing spills
+constexpr int gemm_unroll(int MT, int NTB) { return (MT * NTB >= 6) ? 2 : GEMM_UNROLL; }
 
 // ------------------------------------------------------------------------------------------------
 // weight packer: src row-major [n_rows][K] (or Conv1d [n_rows][Cin][conv_k]) -> fragment-major tiles
@@ -81,6 +83,7 @@ __device__ __forceinline__ u32x4_t load_w(const u32x4_t* p) {
 //          gate/up and lm_head projections (pure launch latency at M = 1).
 template <int MT, int NTB, int EPI, bool NT, int AMODE>
 __global__ void gemm_skinny_kernel(GemmArgs g) {
+    constexpr int UNR = gemm_unroll(MT, NTB);
     extern __shared__ __attribute__((aligned(16))) float red[];  // [W][MT*NTB*4][64], then the staged A rows (AMODE >= 1)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -119,9 +122,9 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
 
     // first batch of weight fragments goes in flight before anything else (also before the norm prologue)
-    u32x4_t wf[GEMM_UNROLL][NTB];
+    u32x4_t wf[UNR][NTB];
 #pragma unroll
-    for (int u = 0; u < GEMM_UNROLL; ++u) {
+    for (int u = 0; u < UNR; ++u) {
         const int kt = wave + u * W;
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) wf[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
@@ -172,10 +175,10 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
         }
     }
 
-    for (int kt0 = wave; kt0 < KT; kt0 += W * GEMM_UNROLL) {
-        u32x4_t af[GEMM_UNROLL][MT];
+    for (int kt0 = wave; kt0 < KT; kt0 += W * UNR) {
+        u32x4_t af[UNR][MT];
 #pragma unroll
-        for (int u = 0; u < GEMM_UNROLL; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             const int kt = kt0 + u * W;
             const bool kv = kt < KT;
 #pragma unroll
@@ -187,15 +190,15 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
             }
         }
         // prefetch the next batch of weight fragments while this one is consumed
-        u32x4_t wn[GEMM_UNROLL][NTB];
+        u32x4_t wn[UNR][NTB];
 #pragma unroll
-        for (int u = 0; u < GEMM_UNROLL; ++u) {
-            const int kt = kt0 + (GEMM_UNROLL + u) * W;
+        for (int u = 0; u < UNR; ++u) {
+            const int kt = kt0 + (UNR + u) * W;
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) wn[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
         }
 #pragma unroll
-        for (int u = 0; u < GEMM_UNROLL; ++u)
+        for (int u = 0; u < UNR; ++u)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -203,7 +206,7 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
                     acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, af[u][mt]), __builtin_bit_cast(bf16x8_t, wf[u][nb]), acc[mt][nb], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < GEMM_UNROLL; ++u)
+        for (int u = 0; u < UNR; ++u)
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) wf[u][nb] = wn[u][nb];
     }

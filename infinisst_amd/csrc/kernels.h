@@ -43,11 +43,13 @@ struct LlmAttnDims {
 };
 // causal attention of every row over its stream's keys 0..row_pos, fused with the q rotation and the append of
 // the row's own (unrotated) k, v to the arena; RoPE applied to K on read.  qkv: [rows][(H + 2 KV) * 128].
-int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
-                         const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vpool,
-                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, int max_pos, hipStream_t s);
-#define LLM_ATTN_SPLIT 64
-static inline int llm_attn_splits(int max_pos) { return (max_pos + LLM_ATTN_SPLIT) / LLM_ATTN_SPLIT; }
+// kpool: K [slots][128] per (stream, layer, kv head); vtpool: V transposed [128][slots].  groups[z] = (first row,
+// row count): runs of consecutive rows of ONE stream, at most LLM_ATTN_GROUP_ROWS(G) rows each.
+// partial: [rows][heads][slots/64][2 + 128] fp32.
+#define LLM_ATTN_GROUP_ROWS(G) (16 / (G))
+int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
+                         int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
+                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s);
 
 // ---- sampling (sample.hip) ----
 struct SampleStream {

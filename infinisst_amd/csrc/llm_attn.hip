@@ -1,4 +1,4 @@
-// Llama attention over an UNROTATED KV arena with RoPE applied on read (gfx950).
+// Llama attention over an UNROTATED KV arena with RoPE applied on read (gfx950, both products on MFMA).
 //
 // Reference: llama_sdpa_attention_new_forward (model/patches/patch_llm.py:231-336): cache.update(unrotated K, V)
 // (:280-284); q rotated at positions past..total-1 and the ENTIRE K cache at 0..total-1 (:286-299); repeat_kv
@@ -7,225 +7,308 @@
 // [pinned system prompt][ring] and eviction is a ring-start advance: a key's rotation angle is its LOGICAL index
 // at read time, so nothing is copied and nothing is re-rotated in memory.
 //
-// Layout in HBM: per stream, layer, kv head: [sys_cap + ring_cap][128] bf16 for K and the same for V.
-// Logical position p -> slot p (p < sys_len) or sys_cap + (ring_start + p - sys_len) mod ring_cap.
+// Layout in HBM, per stream, layer and kv head:  K [slots][128] bf16 (row per key, unrotated) and V TRANSPOSED
+// [128][slots] (row per dim), slots = sys_cap + ring_cap (multiples of 64).  Logical position p lives in slot p
+// (p < sys_len) or sys_cap + (ring_start + p - sys_len) mod ring_cap.  Attention is a sum over keys, so the kernel
+// walks PHYSICAL 16-slot tiles and derives each slot's logical index (rotation angle, causal mask); dead slots
+// get probability 0.
 //
-// RoPE [3P HF apply_rotary_pos_emb, half-split]: out = bf16(bf16(x*cos) + bf16(rotate_half(x)*sin)) with the
-// bf16 cos/sin table (cos[d+64] == cos[d]); each lane owns dims {4j..4j+3} U {64+4j..64+4j+3}, so the rotation
-// partner is lane-local and a 16-lane group covers one 128-dim row with two 128-byte segments.
+// RoPE [3P HF apply_rotary_pos_emb, half-split]: out = bf16(bf16(x*cos) + bf16(rotate_half(x)*sin)) with the bf16
+// cos/sin table (cos[d+64] == cos[d]).  An MFMA k-step covers 32 dims, so the partner of dim d (d +- 64) sits two
+// k-steps away IN THE SAME LANE: the rotation needs no cross-lane traffic.
+//
+// One wave per 16-key tile, 4 waves (64 slots) per workgroup, grid = (slot splits, kv heads, row groups).  A row
+// group is a run of consecutive query rows of one stream (1 row in a decode step, up to 16/G rows of a prefill);
+// its columns c = (row, head of the kv group) fill the N dimension:
+//   S^T[key][c]  = K_rot[key][:] . Q_rot[c][:]        v_mfma_f32_16x16x32_bf16, A = K tile, B = Q^T
+//   P = exp(S^T - max_c)                              C layout: lane holds 4 keys of ONE column -> max/sum are
+//                                                     in-lane + 2 cross-row shuffles per tile (not per key)
+//   O[c][dim]   += P[c][key] V[key][dim]              v_mfma_f32_16x16x16_bf16: its A layout (4 consecutive k per
+//                                                     lane) IS the C layout of S^T, so P never leaves registers;
+//                                                     B = V^T, 8 bytes per lane
+// Keys written by this launch (logical position >= new_start: the prompt rows of a prefill, the row itself in a
+// decode step) are read from the qkv rows; the wave that meets a row's own key appends it (K row + V^T column) to
+// the arena, so every new key is stored exactly once and nobody reads a slot another workgroup writes.
+// The 4 waves' partials meet in LDS; one (m, l, o[128]) slab per (row, head, split) goes to global and a small
+// second kernel combines the splits (a fused last-arriver combine measured slower, see profiles/r01).
 #include "common.h"
 #include "kernels.h"
 
 #define HD 128
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
-__device__ __forceinline__ long llm_slot(const LlmStreamView& v, const LlmAttnDims& d, int p) {
-    if (p < v.sys_len) return p;
-    int x = v.ring_start + (p - v.sys_len);
-    x %= d.ring_cap;
-    return (long)d.sys_cap + x;
+// logical position of physical slot t (or -1 for a slot that holds nothing visible)
+__device__ __forceinline__ int llm_logical(const LlmStreamView& v, const LlmAttnDims& d, int t, int total) {
+    int j;
+    if (t < d.sys_cap) {
+        j = t < v.sys_len ? t : -1;
+    } else {
+        int x = t - d.sys_cap - v.ring_start;
+        if (x < 0) x += d.ring_cap;
+        j = v.sys_len + x;
+    }
+    return (j >= 0 && j < total) ? j : -1;
 }
 
-__device__ __forceinline__ void load4(const bf16_t* p, float* f) {
-    const u32x2_t v = *reinterpret_cast<const u32x2_t*>(p);
-    f[0] = lo_bf(v.x); f[1] = hi_bf(v.x); f[2] = lo_bf(v.y); f[3] = hi_bf(v.y);
-}
-__device__ __forceinline__ void store4(bf16_t* p, const float* f) {
-    u32x2_t v;
-    v.x = pack_bf(f[0], f[1]); v.y = pack_bf(f[2], f[3]);
-    *reinterpret_cast<u32x2_t*>(p) = v;
-}
-// x1 = dims 4j.., x2 = dims 64+4j..; c,s = cos/sin of dims 4j..
-__device__ __forceinline__ void rope_half(const float* x1, const float* x2, const float* c, const float* s, float* r1, float* r2) {
+// rotate the four 8-dim chunks a lane holds of one 128-dim row (dims 8fq + 32s, s = 0..3) at position pos
+__device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int fq, const bf16_t* __restrict__ rope_cos,
+                                                const bf16_t* __restrict__ rope_sin, u32x4_t* out) {
+    float x[4][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        r1[i] = bfr(bfr(x1[i] * c[i]) - bfr(x2[i] * s[i]));
-        r2[i] = bfr(bfr(x2[i] * c[i]) + bfr(x1[i] * s[i]));
+    for (int s = 0; s < 4; ++s) unpack8(raw[s], x[s]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // chunk pairs (s = h, s = h + 2): dims d and d + 64
+        float c[8], sn[8], r1[8], r2[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(rope_cos + (long)pos * 64 + 32 * h + 8 * fq), c);
+        unpack8(*reinterpret_cast<const u32x4_t*>(rope_sin + (long)pos * 64 + 32 * h + 8 * fq), sn);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            r1[i] = bfr(bfr(x[h][i] * c[i]) - bfr(x[h + 2][i] * sn[i]));
+            r2[i] = bfr(bfr(x[h + 2][i] * c[i]) + bfr(x[h][i] * sn[i]));
+        }
+        out[h] = pack8(r1);
+        out[h + 2] = pack8(r2);
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// fused q-rotation + KV append + split-KV attention partials.
-// grid = (splits of 64 keys, kv_heads, rows), block = 256 = 16 groups of 16 lanes; every group owns 4 keys of the
-// split and issues all their loads (K, V, cos, sin: 24 x 8 B) before the first use, so a block pays ONE round of
-// memory latency.  Keys written by this launch (logical position >= new_start, i.e. the prompt rows of a prefill or
-// the row itself in a decode step) are read straight from the qkv rows; the group that meets key == row_pos stores
-// that row's unrotated k and v into the arena, so every new key is appended exactly once and nobody reads a slot
-// that another workgroup writes in the same launch.
-// partial layout: [row][head][split][2 + 128] fp32 (m, l, o).
-// ------------------------------------------------------------------------------------------------
-#define KEYS_PER_GROUP (LLM_ATTN_SPLIT / 16)
-
-template <int G>
+template <int G, int CT>  // G q-heads per kv head, CT column tiles (16 columns each) per workgroup
 __global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
                                                                const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
-                                                               const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
-                                                               bf16_t* kpool, bf16_t* vpool, float* __restrict__ partial,
-                                                               LlmAttnDims d, int layer, int n_splits) {
-    __shared__ float red[16][G][2 + HD];
-    const int sp = blockIdx.x, kvh = blockIdx.y, r = blockIdx.z;
-    const int p = row_pos[r];
-    const int k_lo = sp * LLM_ATTN_SPLIT;
-    const int k_hi = min(k_lo + LLM_ATTN_SPLIT, p + 1);
-    if (k_lo >= k_hi) return;  // block-uniform
-    const LlmStreamView v = sv[row_stream[r]];
-    const int tid = threadIdx.x;
-    const int j = tid & 15, grp = tid >> 4;
+                                                               const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
+                                                               const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* vtpool,
+                                                               float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits) {
+    __shared__ float mS[4][CT * 16], lS[4][CT * 16];
+    __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
+    const int sp = blockIdx.x, kvh = blockIdx.y;
+    const int2 grp = groups[blockIdx.z];
+    const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
+    const LlmStreamView v = sv[row_stream[r0]];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
     const int H = d.heads, KV = d.kv_heads;
     const long ldq = (long)(H + 2 * KV) * HD;
-    const long slots = (long)d.sys_cap + d.ring_cap;
+    const int slots = d.sys_cap + d.ring_cap;
     const long base = v.kv_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
-    bf16_t* kb = kpool + base;
-    bf16_t* vb = vpool + base;
-    const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+    bf16_t* kb = kpool + base;    // [slots][128]
+    bf16_t* vt = vtpool + base;   // [128][slots]
+    const int total = row_pos[r0 + nrows - 1] + 1;  // keys visible to the last row of the group
+    const int t0 = sp * 64 + wave * 16;             // first physical slot of this wave's tile
+    const float scale = 0.08838834764831845f;       // 1/sqrt(128)
 
-    // ---- issue every load of this group's keys first ----
-    u32x2_t kx1[KEYS_PER_GROUP], kx2[KEYS_PER_GROUP], vx1[KEYS_PER_GROUP], vx2[KEYS_PER_GROUP], cx[KEYS_PER_GROUP], sx[KEYS_PER_GROUP];
+    // ---- this lane's key as an A-operand row: slot t0 + fr ----
+    const int jk = llm_logical(v, d, t0 + fr, total);
+    const bool k_new = jk >= 0 && jk >= v.new_start;
+    const bf16_t* k_src = k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD
+                                : kb + (long)(t0 + fr) * HD;
+    u32x4_t kraw[4];
 #pragma unroll
-    for (int u = 0; u < KEYS_PER_GROUP; ++u) {
-        const int key = k_lo + grp + 16 * u;
-        const int kk = key < k_hi ? key : k_lo;  // clamp: loads stay in bounds, result is discarded
-        const bf16_t* kp;
-        const bf16_t* vp;
-        if (kk >= v.new_start) {
-            const bf16_t* row = qkv + (long)(v.row0 + (kk - v.new_start)) * ldq;
-            kp = row + (long)(H + kvh) * HD;
-            vp = row + (long)(H + KV + kvh) * HD;
-        } else {
-            const long slot = llm_slot(v, d, kk);
-            kp = kb + slot * HD;
-            vp = vb + slot * HD;
-        }
-        kx1[u] = *reinterpret_cast<const u32x2_t*>(kp + 4 * j);
-        kx2[u] = *reinterpret_cast<const u32x2_t*>(kp + 64 + 4 * j);
-        vx1[u] = *reinterpret_cast<const u32x2_t*>(vp + 4 * j);
-        vx2[u] = *reinterpret_cast<const u32x2_t*>(vp + 64 + 4 * j);
-        cx[u] = *reinterpret_cast<const u32x2_t*>(rope_cos + (long)kk * 64 + 4 * j);
-        sx[u] = *reinterpret_cast<const u32x2_t*>(rope_sin + (long)kk * 64 + 4 * j);
-    }
-    // ---- rotated queries of the G heads sharing this kv head ----
-    float q1[G][4], q2[G][4], m[G], l[G], a1[G][4], a2[G][4];
-    {
-        float c[4], s[4];
-        load4(rope_cos + (long)p * 64 + 4 * j, c);
-        load4(rope_sin + (long)p * 64 + 4 * j, s);
+    for (int s = 0; s < 4; ++s) kraw[s] = *reinterpret_cast<const u32x4_t*>(k_src + 32 * s + 8 * fq);
+    // ---- the 4 keys this lane holds in the C layout: slots t0 + 4 fq + r ----
+    int jc[4];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const bf16_t* qh = qkv + (long)r * ldq + (long)(kvh * G + g) * HD;
-            float x1[4], x2[4];
-            load4(qh + 4 * j, x1);
-            load4(qh + 64 + 4 * j, x2);
-            rope_half(x1, x2, c, s, q1[g], q2[g]);
-            m[g] = -INFINITY; l[g] = 0.f;
+    for (int r = 0; r < 4; ++r) jc[r] = llm_logical(v, d, t0 + 4 * fq + r, total);
+    const bool tile_live = __any(jk >= 0);
+    const bool tile_has_new = __any(k_new);
+
+    // ---- V^T fragments: B[k = key 4fq + j][n = dim 16 nt + fr] ----
+    u32x2_t vf[8];
+    if (tile_live) {
+        if (!tile_has_new) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a1[g][i] = 0.f; a2[g][i] = 0.f; }
-        }
-    }
+            for (int nt = 0; nt < 8; ++nt) vf[nt] = *reinterpret_cast<const u32x2_t*>(vt + (long)(16 * nt + fr) * slots + t0 + 4 * fq);
+        } else {  // mixed tile: some keys still live only in the qkv rows -> scalar gather
 #pragma unroll
-    for (int u = 0; u < KEYS_PER_GROUP; ++u) {
-        const int key = k_lo + grp + 16 * u;
-        if (key < k_hi) {  // uniform within the 16-lane group
-            if (key == p) {  // this row's own key: append the unrotated k, v to the arena
-                const long slot = llm_slot(v, d, key);
-                *reinterpret_cast<u32x2_t*>(kb + slot * HD + 4 * j) = kx1[u];
-                *reinterpret_cast<u32x2_t*>(kb + slot * HD + 64 + 4 * j) = kx2[u];
-                *reinterpret_cast<u32x2_t*>(vb + slot * HD + 4 * j) = vx1[u];
-                *reinterpret_cast<u32x2_t*>(vb + slot * HD + 64 + 4 * j) = vx2[u];
-            }
-            const float x1[4] = {lo_bf(kx1[u].x), hi_bf(kx1[u].x), lo_bf(kx1[u].y), hi_bf(kx1[u].y)};
-            const float x2[4] = {lo_bf(kx2[u].x), hi_bf(kx2[u].x), lo_bf(kx2[u].y), hi_bf(kx2[u].y)};
-            const float v1[4] = {lo_bf(vx1[u].x), hi_bf(vx1[u].x), lo_bf(vx1[u].y), hi_bf(vx1[u].y)};
-            const float v2[4] = {lo_bf(vx2[u].x), hi_bf(vx2[u].x), lo_bf(vx2[u].y), hi_bf(vx2[u].y)};
-            const float c[4] = {lo_bf(cx[u].x), hi_bf(cx[u].x), lo_bf(cx[u].y), hi_bf(cx[u].y)};
-            const float s[4] = {lo_bf(sx[u].x), hi_bf(sx[u].x), lo_bf(sx[u].y), hi_bf(sx[u].y)};
-            float r1[4], r2[4];
-            rope_half(x1, x2, c, s, r1, r2);
+            for (int nt = 0; nt < 8; ++nt) {
+                bf16_t e[4];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float part = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) part += q1[g][i] * r1[i] + q2[g][i] * r2[i];
-                part += __shfl_xor(part, 8, WAVE);
-                part += __shfl_xor(part, 4, WAVE);
-                part += __shfl_xor(part, 2, WAVE);
-                part += __shfl_xor(part, 1, WAVE);
-                const float sc = part * scale;
-                const float mn = fmaxf(m[g], sc);
-                const float alpha = expf(m[g] - mn);  // exp(-inf) = 0 on the first key
-                const float pe = expf(sc - mn);
-                l[g] = l[g] * alpha + pe;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a1[g][i] = a1[g][i] * alpha + pe * v1[i];
-                    a2[g][i] = a2[g][i] * alpha + pe * v2[i];
+                for (int j = 0; j < 4; ++j) {
+                    const int jj = jc[j];
+                    const int dim = 16 * nt + fr;
+                    if (jj >= 0 && jj >= v.new_start)
+                        e[j] = qkv[(long)(v.row0 + (jj - v.new_start)) * ldq + (long)(H + KV + kvh) * HD + dim];
+                    else
+                        e[j] = vt[(long)dim * slots + t0 + 4 * fq + j];
                 }
-                m[g] = mn;
+                vf[nt].x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+                vf[nt].y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
             }
         }
     }
+
+    // ---- rotated query fragments: B[k = dim][n = column c], c = ct*16 + fr -> (row r0 + c / G, head kvh*G + c % G) ----
+    u32x4_t qf[CT][4];
+    int cpos[CT];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (j == 0) { red[grp][g][0] = m[g]; red[grp][g][1] = l[g]; }
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 16 + fr;
+        const bool cv = c < ncols;
+        const int row = r0 + (cv ? c / G : 0);
+        cpos[ct] = cv ? row_pos[row] : -1;
+        const bf16_t* qh = qkv + (long)row * ldq + (long)(kvh * G + (cv ? c % G : 0)) * HD;
+        u32x4_t qraw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            red[grp][g][2 + 4 * j + i] = a1[g][i];
-            red[grp][g][2 + 64 + 4 * j + i] = a2[g][i];
+        for (int s = 0; s < 4; ++s) qraw[s] = *reinterpret_cast<const u32x4_t*>(qh + 32 * s + 8 * fq);
+        rope_row_chunks(qraw, cv ? cpos[ct] : 0, fq, rope_cos, rope_sin, qf[ct]);
+    }
+
+    float m_col[CT], l_col[CT];
+    f32x4_t o[CT][8];
+    if (tile_live) {
+        // ---- append this group's own new keys (unrotated K row, V^T column) ----
+        if (k_new) {
+            const int krow = v.row0 + (jk - v.new_start);
+            if (krow >= r0 && krow < r0 + nrows) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kraw[s];
+                const bf16_t* vrow = qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(vrow + 32 * s + 8 * fq);
+                    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        vt[(long)(32 * s + 8 * fq + e) * slots + t0 + fr] = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffff));
+                }
+            }
         }
+        u32x4_t kf[4];
+        rope_row_chunks(kraw, jk >= 0 ? jk : 0, fq, rope_cos, rope_sin, kf);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x4_t st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[s]), __builtin_bit_cast(bf16x8_t, qf[ct][s]), st, 0, 0, 0);
+            // lane holds S^T[key 4fq + r][column fr]: causal mask against the column's own position
+            float sc[4], mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = jc[r] >= 0 && jc[r] <= cpos[ct];
+                sc[r] = ok ? st[r] * scale : -INFINITY;
+                mx = fmaxf(mx, sc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            float p[4], ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = (sc[r] == -INFINITY) ? 0.f : expf(sc[r] - mx);
+                ls += p[r];
+            }
+            ls += __shfl_xor(ls, 16, WAVE);
+            ls += __shfl_xor(ls, 32, WAVE);
+            m_col[ct] = mx;
+            l_col[ct] = ls;
+            // P (bf16) in the C layout == A operand of the 16x16x16 product: A[row = column fr][k = key 4fq + j]
+            u32x2_t pp;
+            pp.x = pack_bf(p[0], p[1]);
+            pp.y = pack_bf(p[2], p[3]);
+            const s16x4_t pa = __builtin_bit_cast(s16x4_t, pp);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+                o[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf[nt]), (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            m_col[ct] = -INFINITY;
+            l_col[ct] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) o[ct][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // ---- the 4 waves' partials meet in LDS.  o[ct][nt][r] is O[column ct*16 + 4fq + r][dim 16nt + fr] ----
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        if (fq == 0) { mS[wave][ct * 16 + fr] = m_col[ct]; lS[wave][ct * 16 + fr] = l_col[ct]; }
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oS[wave][ct * 16 + 4 * fq + r][16 * nt + fr] = o[ct][nt][r];
     }
     __syncthreads();
-    for (int e = tid; e < G * HD; e += 256) {
-        const int g = e / HD, dd = e % HD;
+    for (int e = tid; e < ncols * HD; e += 256) {
+        const int c = e / HD, dd = e % HD;
         float M = -INFINITY;
-        for (int q = 0; q < 16; ++q) M = fmaxf(M, red[q][g][0]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, mS[w][c]);
         float L = 0.f, O = 0.f;
-        for (int q = 0; q < 16; ++q) {
-            const float mq = red[q][g][0];
-            const float w = (mq == -INFINITY) ? 0.f : expf(mq - M);
-            L += red[q][g][1] * w;
-            O += red[q][g][2 + dd] * w;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = mS[w][c];
+            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+            L += lS[w][c] * f;
+            O += oS[w][c][dd] * f;
         }
-        float* dst = partial + (((long)r * d.heads + kvh * G + g) * n_splits + sp) * (2 + HD);
+        const int row = r0 + c / G, head = kvh * G + c % G;
+        float* dst = partial + (((long)row * H + head) * n_splits + sp) * (2 + HD);
         if (dd == 0) { dst[0] = M; dst[1] = L; }
         dst[2 + dd] = O;
     }
 }
 
-// Combine of the split partials.  A separate launch on purpose: folding it into the partial kernel (last-arriver
-// ticket + agent-scope release/acquire, or write-through slabs + sc1 loads) measured 28-31 us per layer against
-// 12.7 + 7.0 us for two launches on MI355X (profiles/r01), because every split pays the ticket round trip and the
-// reducer serialises its slab loads.
-__global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __restrict__ partial, const int* __restrict__ row_pos,
-                                                               bf16_t* __restrict__ out, int heads, int n_splits) {
+// Combine of the split partials (a separate launch on purpose, see the header).  All split loads are issued before
+// the first use (fully unrolled, predicated): two memory round trips instead of one per split.
+#define COMBINE_MAX_SPLITS 32
+__global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int heads,
+                                                               int n_splits) {
     const int h = blockIdx.x, r = blockIdx.y, dd = threadIdx.x;
-    const int ns = row_pos[r] / LLM_ATTN_SPLIT + 1;  // splits that hold at least one key
     const float* src = partial + ((long)r * heads + h) * n_splits * (2 + HD);
-    float M = -INFINITY;
-    for (int s = 0; s < ns; ++s) M = fmaxf(M, src[s * (2 + HD)]);
-    float L = 0.f, O = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        const float w = expf(src[s * (2 + HD)] - M);
-        L += src[s * (2 + HD) + 1] * w;
-        O += src[s * (2 + HD) + 2 + dd] * w;
+    float M = -INFINITY, L = 0.f, O = 0.f;
+    for (int s0 = 0; s0 < n_splits; s0 += COMBINE_MAX_SPLITS) {  // one trip for <= 32 splits (2048 slots)
+        float ms[COMBINE_MAX_SPLITS], ls[COMBINE_MAX_SPLITS], os[COMBINE_MAX_SPLITS];
+#pragma unroll
+        for (int s = 0; s < COMBINE_MAX_SPLITS; ++s) {
+            const bool ok = s0 + s < n_splits;
+            const float* p = src + (long)(ok ? s0 + s : 0) * (2 + HD);
+            ms[s] = ok ? p[0] : -INFINITY;
+            ls[s] = p[1];
+            os[s] = p[2 + dd];
+        }
+        float Mn = M;
+#pragma unroll
+        for (int s = 0; s < COMBINE_MAX_SPLITS; ++s) Mn = fmaxf(Mn, ms[s]);
+        const float f0 = (M == -INFINITY) ? 0.f : expf(M - Mn);
+        L *= f0;
+        O *= f0;
+#pragma unroll
+        for (int s = 0; s < COMBINE_MAX_SPLITS; ++s) {
+            const float w = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - Mn);  // -inf: split without a live key for this row
+            L += ls[s] * w;
+            O += os[s] * w;
+        }
+        M = Mn;
     }
     out[((long)r * heads + h) * HD + dd] = f2bf(O / L);
 }
 
-int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv,
-                         const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vpool,
-                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, int max_pos, hipStream_t s) {
-    if (rows <= 0) return ISST_OK;
+template <int G>
+static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
+                    int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
+                    float* partial, LlmAttnDims d, int layer, int n_splits, hipStream_t s) {
+    dim3 grid(n_splits, d.kv_heads, n_groups), block(256);
+    if (max_group_rows * G > 16) return ISST_ERR_ARG;  // one 16-column tile per workgroup (LLM_ATTN_GROUP_ROWS(G) rows)
+    hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
+                       vtpool, partial, d, layer, n_splits);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
+                         int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
+                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s) {
+    if (rows <= 0 || n_groups <= 0) return ISST_OK;
+    const int slots = d.sys_cap + d.ring_cap;
+    if (slots % 64 != 0 || d.sys_cap % 16 != 0) return ISST_ERR_ARG;
     const int G = d.heads / d.kv_heads;
-    const int n_splits = llm_attn_splits(max_pos);
-    dim3 grid(n_splits, d.kv_heads, rows), block(256);
-#define LAUNCH_G(GG) \
-    hipLaunchKernelGGL(llm_attn_partial_kernel<GG>, grid, block, 0, s, qkv, row_stream, row_pos, sv, rope_cos, rope_sin, kpool, vpool, partial, d, layer, n_splits)
+    const int n_splits = slots / 64;
+    int rc;
     switch (G) {
-        case 1: LAUNCH_G(1); break;
-        case 2: LAUNCH_G(2); break;
-        case 4: LAUNCH_G(4); break;
+        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, s); break;
+        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, s); break;
+        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, s); break;
         default: return ISST_ERR_ARG;
     }
-#undef LAUNCH_G
-    if (hipGetLastError() != hipSuccess) return ISST_ERR_HIP;
-    hipLaunchKernelGGL(llm_attn_combine_kernel, dim3(d.heads, rows), dim3(HD), 0, s, partial, row_pos, out, d.heads, n_splits);
+    if (rc != ISST_OK) return rc;
+    hipLaunchKernelGGL(llm_attn_combine_kernel, dim3(d.heads, rows), dim3(HD), 0, s, partial, out, d.heads, n_splits);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
