@@ -142,6 +142,8 @@ int64_t isst_op_packed_elems(int n_rows, int K);
 int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, const uint16_t* res,
                  int64_t ldres, void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, const uint16_t* norm_w,
                  float norm_eps, void* hip_stream);
+/* profiling aid: override the GEMM launch heuristic (waves per workgroup, 16-row n-tiles per workgroup); 0 = automatic */
+int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block);
 int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps,
                       int gelu, void* hip_stream);
 int isst_op_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int rows, int D, float eps, void* hip_stream);

@@ -1022,6 +1022,10 @@ extern "C" int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* pack
     g.norm_w = norm_w; g.norm_eps = norm_eps;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(hip_stream));
 }
+extern "C" int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block) {
+    gemm_set_tuning(waves_per_block, ntiles_per_block);
+    return ISST_OK;
+}
 extern "C" int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps, int gelu,
                                  void* hip_stream) {
     return launch_layernorm(x, C, w, b, out, C, rows, C, eps, gelu, reinterpret_cast<hipStream_t>(hip_stream));

@@ -257,6 +257,10 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
     }
 }
 
+// tuning overrides for profiles/gemv_sweep.py (0 = heuristic)
+static int g_tune_w = 0, g_tune_ntb = 0;
+void gemm_set_tuning(int w, int ntb) { g_tune_w = w; g_tune_ntb = ntb; }
+
 static inline bool gemm_can_stage(const GemmArgs& g) {
     return g.batch == 1 && g.M <= 16 && (size_t)g.M * g.K * 2 <= 64 * 1024 && g.M <= GEMM_FUSED_NORM_MAX_M;
 }
@@ -266,18 +270,28 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     const int KT = g.K / 32, NTILES = g.N / 16;
     // NTB: n-tiles per block (SwiGLU needs the (gate, up) pair in one block)
     const bool swiglu = EPI == EPI_SWIGLU;
-    int ntb = swiglu ? 2 : ((NTILES >= 2048) ? 2 : 1);
+    int ntb = swiglu ? 2 : 1;  // measured (profiles/gemv_sweep.py): one n-tile per workgroup wins for every plain shape, lm_head included
+    if (g_tune_ntb && MT == 1 && (!swiglu || g_tune_ntb % 2 == 0)) ntb = g_tune_ntb;
     const int blocks_x = (NTILES + ntb - 1) / ntb;
     const int blocks_y = (g.M + MT * 16 - 1) / (MT * 16);
     // waves per block: enough waves chip-wide to cover HBM latency (>= ~2048), bounded by K-tiles and LDS
     long blocks = (long)blocks_x * blocks_y * g.batch;
     int W = 4;
     while (W < 16 && blocks * W < 2048 && W * 2 * GEMM_UNROLL <= KT * 2) W *= 2;
+    if (g_tune_w) W = g_tune_w;
     while (W > 1 && W > KT) W /= 2;
     while (W > 1 && (size_t)W * MT * ntb * 1024 > 64 * 1024) W /= 2;
     size_t lds = (size_t)W * MT * ntb * 1024;
     if (AMODE >= 1) lds += (size_t)g.M * g.K * 2 + (W + 1) * 16 * sizeof(float);
     dim3 grid(blocks_x, blocks_y, g.batch), block(W * 64);
+    if constexpr (MT == 1) {
+        if (ntb == 4) {
+            auto kern = gemm_skinny_kernel<1, 4, EPI, NT, AMODE>;
+            if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, g);
+            return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+        }
+    }
     if (ntb == 2) {
         auto kern = gemm_skinny_kernel<MT, 2, EPI, NT, AMODE>;
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
