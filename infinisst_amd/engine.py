@@ -185,7 +185,14 @@ class Engine:
             pass
 
     # ---------------------------------------------------------------- weights
-    def load_weights(self, weights: Dict[str, torch.Tensor], strict: bool = True):
+    def load_checkpoint(self, path: str):
+        """Reference `pytorch_model.bin` (agents/infinisst.py:179-180) -> device weights; returns the skipped keys."""
+        from .checkpoint import load_checkpoint
+        weights, inv_freq, skipped = load_checkpoint(self.cfg, path)
+        self.load_weights(weights, enc_inv_freq=inv_freq)
+        return skipped
+
+    def load_weights(self, weights: Dict[str, torch.Tensor], strict: bool = True, enc_inv_freq=None):
         """`weights`: reference checkpoint keys -> bf16 tensors (CPU or GPU).  Unknown keys raise if strict."""
         for name, t in weights.items():
             if t.dtype != torch.bfloat16:
@@ -197,7 +204,7 @@ class Engine:
                 continue
             self._check(rc, f"isst_load_weight({name})")
         rows_e, rows_l = 1024, 1 << 14
-        ec, es = rope.encoder_tables(self.cfg, rows_e)
+        ec, es = rope.encoder_tables(self.cfg, rows_e, enc_inv_freq)
         lc, ls = rope.llm_tables(self.cfg, rows_l)
         self._check(self.lib.isst_set_rope_tables(self.h, C.c_void_p(ec.data_ptr()), C.c_void_p(es.data_ptr()), rows_e,
                                                   C.c_void_p(lc.data_ptr()), C.c_void_p(ls.data_ptr()), rows_l),

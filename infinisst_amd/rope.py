@@ -18,10 +18,15 @@ import torch
 from .config import ModelConfig
 
 
-def encoder_tables(cfg: ModelConfig, rows: int):
-    """fp32 cos, sin of shape (rows, head_dim // 2)."""
+def encoder_tables(cfg: ModelConfig, rows: int, inv_freq=None):
+    """fp32 cos, sin of shape (rows, head_dim // 2).  `inv_freq`: the `rotary_emb.freqs` parameter of a checkpoint
+    (strict load_state_dict overwrites the module's initial value with it), default: the module's initial value."""
     hd = cfg.enc_head_dim
     inv = 1.0 / (cfg.enc_rope_theta ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd))
+    if inv_freq is not None:
+        if tuple(inv_freq.shape) != tuple(inv.shape):
+            raise ValueError(f"rotary freqs shape {tuple(inv_freq.shape)} != {tuple(inv.shape)}")
+        inv = inv_freq.float()
     pos = torch.arange(rows, dtype=torch.float32)
     if cfg.enc_rope_mode == "bf16":
         ang = pos.bfloat16().unsqueeze(1) * inv.bfloat16().unsqueeze(0)

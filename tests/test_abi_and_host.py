@@ -167,3 +167,35 @@ def test_policy_gating_without_compute():
     act = agent.policy(st)
     assert type(act).__name__ == "WriteAction" and act.content == "" and act.finished  # < 0.32 s total
     assert eng.calls == []
+
+
+def test_checkpoint_split_matches_reference_key_layout(tmp_path):
+    """A synthetic `pytorch_model.bin` with the reference's key names plus tensors real checkpoints carry but the hot path
+    never reads (pos_conv, rotary freqs, pre-training heads): hot-path tensors come back as bf16, the rest is skipped,
+    a missing or mis-shaped tensor is an error (strict load, reference agents/infinisst.py:179-180)."""
+    from infinisst_amd import checkpoint
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.float32, seed=5)
+    state = dict(w)
+    enc = "model.speech_encoder.speech_encoder."
+    state[enc + "encoder.pos_conv.0.weight_g"] = torch.zeros(1, 1, 8)
+    state[enc + "mask_emb"] = torch.zeros(cfg.enc_dim)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)) * 1.01
+    for i in range(cfg.enc_layers):
+        state[f"{enc}encoder.layers.{i}.self_attn.rotary_emb.freqs"] = freqs
+    path = tmp_path / "pytorch_model.bin"
+    torch.save(state, path)
+    out, inv, skipped = checkpoint.load_checkpoint(cfg, str(path))
+    assert set(out) == set(w) and all(t.dtype == torch.bfloat16 for t in out.values())
+    assert torch.equal(inv, freqs) and len(skipped) == 2 + cfg.enc_layers
+    c, s = rope.encoder_tables(cfg, 16, inv)
+    c0, _ = rope.encoder_tables(cfg, 16)
+    assert not torch.equal(c, c0)
+    bad = dict(state)
+    del bad["lm_head.weight"]
+    with pytest.raises(KeyError, match="lm_head"):
+        checkpoint.split_state_dict(cfg, bad)
+    bad = dict(state)
+    bad["model.norm.weight"] = torch.zeros(3)
+    with pytest.raises(ValueError, match="model.norm.weight"):
+        checkpoint.split_state_dict(cfg, bad)
