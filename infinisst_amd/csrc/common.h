@@ -83,5 +83,7 @@ struct GemmArgs {
 #define GEMM_FUSED_NORM_MAX_M 8  // rows for which the GEMM stages (and optionally RMS-normalises) A in LDS
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 void gemm_set_tuning(int waves_per_block, int ntiles_per_block);  // 0 = heuristic; profiling aid
+bool gemm_tiled_supported(const GemmArgs& g);                      // gemm_tiled.hip: dense shapes (M > 64 or batched)
+int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream);
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,
                        int tile_phase, int conv_k, hipStream_t stream);

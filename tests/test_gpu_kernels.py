@@ -186,3 +186,37 @@ def test_sample_processors_and_argmax():
         assert torch.equal(torch.isinf(got), torch.isinf(ref_scores))
         fin = ~torch.isinf(ref_scores)
         assert torch.allclose(got[fin], ref_scores[fin], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 256, 128), (1574, 512, 1536), (700, 1040, 512), (257, 96, 192)])
+def test_gemm_tiled_dense_shapes(M, N, K):
+    """The LDS-tiled kernel (M > 64): every epilogue, ragged M/N edges, against the fp32 reference."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias, res = bf(torch.randn(N, generator=g)), bf(torch.randn(M, N, generator=g))
+    Wp = E.op_pack_weight(W.to(DEV))
+    for epi in ("none", "bias", "bias_gelu", "res", "bias_res", "f32"):
+        out = E.op_gemm(A.to(DEV), Wp, N, epi, bias=bias.to(DEV) if "bias" in epi else None, res=res.to(DEV) if "res" in epi else None)
+        atol = 2e-3 if epi in ("none", "bias", "f32") else 3.2e-2
+        close_bf16(out, ref_linear(A, W, epi, bias, res), f"tiled gemm {epi} M{M} N{N} K{K}", ulps=2.5, atol=atol)
+    # the skinny kernel on the same problem must agree with the tiled one to fp32 summation order
+    lib = E.load_library()
+    tiled = E.op_gemm(A.to(DEV), Wp, N, "none")
+    lib.isst_op_set_gemm_tuning(-1, 0)
+    try:
+        skinny = E.op_gemm(A.to(DEV), Wp, N, "none")
+    finally:
+        lib.isst_op_set_gemm_tuning(0, 0)
+    close_bf16(tiled, skinny, "tiled vs skinny", ulps=2.5, atol=4e-3)  # one bf16 rounding flip from the different fp32 summation order
+
+
+def test_gemm_tiled_swiglu():
+    g = torch.Generator().manual_seed(77)
+    M, I, K = 300, 512, 256
+    A = bf(torch.randn(M, K, generator=g))
+    Wg, Wu = bf(torch.randn(I, K, generator=g) * 0.1), bf(torch.randn(I, K, generator=g) * 0.1)
+    inter = torch.stack([Wg.view(I // 16, 16, K), Wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K)
+    out = E.op_gemm(A.to(DEV), E.op_pack_weight(inter.to(DEV)), 2 * I, "swiglu")
+    gg, uu = bf(A.float() @ Wg.float().t()), bf(A.float() @ Wu.float().t())
+    close_bf16(out, torch.nn.functional.silu(gg) * uu, "tiled swiglu", ulps=3, atol=2e-3)
