@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
-    ap.add_argument("--cpu-layers", type=int, default=16, help="Llama layers actually run by the CPU baseline (time is scaled to all layers)")
+    ap.add_argument("--cpu-layers", type=int, default=32, help="Llama layers actually run by the CPU baseline (time is scaled to all layers)")
     return ap.parse_args()
 
 
