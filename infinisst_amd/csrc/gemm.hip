@@ -121,13 +121,19 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
     }
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
 
-    // first batch of weight fragments goes in flight before anything else (also before the norm prologue)
-    u32x4_t wf[UNR][NTB];
+    // the first TWO batches of weight fragments go in flight before anything else (also before the norm prologue)
+    u32x4_t wf[UNR][NTB], wn[UNR][NTB];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
         const int kt = wave + u * W;
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) wf[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int kt = wave + (UNR + u) * W;
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) wn[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
     }
 
     bf16_t* xs = reinterpret_cast<bf16_t*>(red + (long)W * (MT * NTB * 256));  // [M][K] staged rows (AMODE >= 1)
@@ -189,14 +195,6 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
                     af[u][mt] = (kv && avalid[mt]) ? *reinterpret_cast<const u32x4_t*>(aptr[mt] + (long)kt * 32) : zero4;
             }
         }
-        // prefetch the next batch of weight fragments while this one is consumed
-        u32x4_t wn[UNR][NTB];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int kt = kt0 + (UNR + u) * W;
-#pragma unroll
-            for (int nb = 0; nb < NTB; ++nb) wn[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
-        }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
@@ -205,10 +203,16 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
                 for (int nb = 0; nb < NTB; ++nb)
                     acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8_t, af[u][mt]), __builtin_bit_cast(bf16x8_t, wf[u][nb]), acc[mt][nb], 0, 0, 0);
+        // rotate: the batch requested one iteration ago becomes current, and the batch after it is requested now
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
+        for (int u = 0; u < UNR; ++u) {
+            const int kt = kt0 + (2 * UNR + u) * W;
 #pragma unroll
-            for (int nb = 0; nb < NTB; ++nb) wf[u][nb] = wn[u][nb];
+            for (int nb = 0; nb < NTB; ++nb) {
+                wf[u][nb] = wn[u][nb];
+                wn[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
+            }
+        }
     }
 
     // ---- cross-wave reduction through LDS: red[wave][(mt*NTB+nb)*4 + r][lane] ----
