@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (configs[1] = 1)")
     ap.add_argument("--gen-tokens", type=int, default=10, help="max_new_tokens per chunk (production: 10 x multiplier)")
+    ap.add_argument("--beam", type=int, default=1, help="num_beams (1 = greedy, the north-star mode; 4 = the reference's production setting)")
     ap.add_argument("--toy", action="store_true", help="toy dimensions (plumbing check, not a valid benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -65,11 +66,11 @@ def parse():
     return ap.parse_args()
 
 
-def build_engine(cfg, n_streams, gen_tokens, device):
+def build_engine(cfg, n_streams, gen_tokens, device, beams=1):
     from infinisst_amd.engine import Engine
     sys_n = len(synth.system_prompt_ids(cfg))
     eng = Engine(cfg, max_streams=n_streams, max_multiplier=1, max_prompt_len=sys_n + 32, max_new_tokens=max(gen_tokens, 10),
-                 max_llm_cache_size=1000, max_system_prompt=sys_n)
+                 max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=beams)
     log("engine created")
     w = synth.random_weights_device(cfg, device)
     torch.cuda.synchronize()
@@ -255,8 +256,8 @@ def main():
 
     cfg = (toy_config() if args.toy else full_config()).replace(eos_ids=())  # fixed G: EOS never stops a chunk early
     gen = GenConfig(latency_multiplier=1, max_new_tokens=args.gen_tokens, no_repeat_ngram_size=5, no_repeat_ngram_lookback=100,
-                    repetition_penalty=1.2, max_llm_cache_size=1000, always_cache_system_prompt=True)
-    eng, weights, sys_n = build_engine(cfg, args.streams, args.gen_tokens, device)
+                    repetition_penalty=1.2, max_llm_cache_size=1000, always_cache_system_prompt=True, beam=args.beam)
+    eng, weights, sys_n = build_engine(cfg, args.streams, args.gen_tokens, device, args.beam)
     loop = ChunkLoop(eng, cfg, gen, args.streams, sys_n, rank)
 
     def sync_all():
@@ -319,7 +320,7 @@ def main():
             "config": {"workload": "toy dims (plumbing only)" if args.toy else
                        "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 1 stream per MI355X (BASELINE.json configs[1])",
                        "streams_per_gpu": args.streams, "chunk_ms": 960, "prompt_tokens": 22, "forward_passes_per_chunk": args.gen_tokens,
-                       "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "greedy": True,
+                       "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "greedy": args.beam == 1, "num_beams": args.beam,
                        "parallelism": f"stream-parallel replicas x{world}, no collective", "evictions_per_stream": loop.evictions // max(1, args.streams)},
             "p50_chunk_latency_ms": round(1e3 * float(np.percentile(all_lat, 50)), 3),
             "p95_chunk_latency_ms": round(1e3 * float(np.percentile(all_lat, 95)), 3),

@@ -62,6 +62,7 @@ typedef struct isst_config {
     int max_llm_cache_size;  /* --max-llm-cache-size (ring sized for this + one chunk) */
     int max_system_prompt;   /* pinned system-prompt capacity (--always-cache-system-prompt) */
     int debug_taps;          /* keep copies of intermediate activations for isst_debug_tap */
+    int max_beams;           /* largest num_beams of a generate call (1 = greedy only); KV arenas are allocated per beam */
 } isst_config;
 
 /* generation arguments of one call; mirrors the keyword arguments at agents/infinisst.py:307-332 */
@@ -74,6 +75,8 @@ typedef struct isst_gen_params {
     const int* suppress_tokens;        /* suppress_tokens= (bad_words_ids), may be NULL */
     int n_suppress;
     int system_prompt_size;            /* >0: pin this many leading positions of a FRESH stream (keep-system-prompt) */
+    int num_beams;                     /* num_beams= ; 0 or 1: greedy; >1: beam search (model/patches/patch_hf.py:687-967) */
+    float length_penalty;              /* BeamSearchScorer length_penalty (HF default 1.0; 0 is read as 1.0) */
 } isst_gen_params;
 
 typedef struct isst_stream_info {
@@ -131,6 +134,10 @@ int isst_encode_speech(isst_handle* h, int stream_id, const float* pcm, int n_sa
 /* copy of an intermediate activation of the last call (needs cfg.debug_taps): names "conv_out", "post_proj",
  * "enc_layer_<i>", "enc_out", "shrink", "speech", "llm_embed", "llm_layer_<i>", "llm_final". bf16 bits. */
 int isst_debug_tap(isst_handle* h, const char* name, uint16_t* dst, int64_t max_elems, int64_t* got_elems);
+
+/* unrotated K and V (128 bf16 each) of logical position `pos`, kv head `kv_head`, layer `layer` in the arena of beam
+ * `beam` of a stream (beam 0 for greedy streams).  Test aid for the KV ring / beam bookkeeping. */
+int isst_debug_read_kv(isst_handle* h, int stream_id, int beam, int layer, int kv_head, int pos, uint16_t* k_out, uint16_t* v_out);
 
 /* ---- per-kernel entry points (parity tests and micro-benchmarks); all pointers are DEVICE pointers ---- */
 /* W [n_rows][K] row-major bf16 (conv_k > 0: Conv1d weight [n_rows][K/conv_k][conv_k]) -> packed tiles */

@@ -122,9 +122,9 @@ class InfiniSST(_AgentBase):
         self.source_segment_size = getattr(args, "source_segment_size", 960 * args.latency_multiplier)
         self.max_latency_multiplier = args.max_latency_multiplier
         self.source_lang, self.target_lang = args.source_lang, args.target_lang
-        self.beam = args.beam
-        if self.beam != 1:
-            raise NotImplementedError("beam search is the next scope row (SURVEY.md section 8(f)); use --beam 1")
+        self.beam = args.beam  # 1: greedy (the reference asserts beam > 1, agents/infinisst.py:86); >1: beam search
+        if self.beam < 1:
+            raise ValueError("--beam must be >= 1")
         self.no_repeat_ngram_lookback = args.no_repeat_ngram_lookback
         self.no_repeat_ngram_size = args.no_repeat_ngram_size
         self.repetition_penalty = args.repetition_penalty
@@ -144,7 +144,8 @@ class InfiniSST(_AgentBase):
             engine = Engine(self.cfg, max_streams=1, max_multiplier=self.max_latency_multiplier,
                             max_prompt_len=self.system_prompt_size + 16 + 12 * self.max_latency_multiplier * 1,
                             max_new_tokens=max(self.max_new_tokens, 10 * self.max_latency_multiplier),
-                            max_llm_cache_size=self.max_llm_cache_size, max_system_prompt=self.system_prompt_size)
+                            max_llm_cache_size=self.max_llm_cache_size, max_system_prompt=self.system_prompt_size,
+                            max_beams=self.beam)
             if weights is None:
                 raise ValueError("either an engine with loaded weights or a weight dict is required")
             engine.load_weights(weights)
@@ -189,7 +190,7 @@ class InfiniSST(_AgentBase):
         return source
 
     def _gen_config(self) -> GenConfig:
-        return GenConfig(latency_multiplier=self.latency_multiplier, max_new_tokens=self.max_new_tokens, beam=1,
+        return GenConfig(latency_multiplier=self.latency_multiplier, max_new_tokens=self.max_new_tokens, beam=self.beam,
                          no_repeat_ngram_size=self.no_repeat_ngram_size,
                          no_repeat_ngram_lookback=self.no_repeat_ngram_lookback,
                          repetition_penalty=self.repetition_penalty, max_llm_cache_size=self.max_llm_cache_size,

@@ -1,0 +1,166 @@
+// Device pieces of beam search (reference model/patches/patch_hf.py:687-967, the production decoding mode):
+//   * the beams of a stream are B lock-stepped KV arenas that differ only in the positions written during the current
+//     chunk; "reordering the cache" (:910-913, a full index_select per step in the reference) and the per-hypothesis KV
+//     copies (:113-120, :193-200) become copies of a few POSITIONS between arenas and small buffers;
+//   * log_softmax over the vocabulary in fp32 (:833-837), then the logits processors act on log-probs (:839);
+//   * top-k over beams x vocab (:878): per-row top-k on the device, the host merges the B rows.
+#include "common.h"
+#include "kernels.h"
+
+#define HD 128
+
+// ---- copy `count` logical positions starting at p0 between an arena (K [slots][128], V^T [128][slots]) and a buffer
+//      (K [layers][kv][tcap][128], V [layers][kv][tcap][128], both row-major).  grid = (count, kv_heads, layers * n_ops)
+__global__ __launch_bounds__(128) void kv_positions_copy_kernel(bf16_t* kpool, bf16_t* vtpool, bf16_t* kbuf, bf16_t* vbuf,
+                                                               const KvCopyOp* __restrict__ ops, LlmAttnDims d, int layers, int tcap) {
+    const int t = blockIdx.x, kvh = blockIdx.y;
+    const int layer = blockIdx.z % layers;
+    const KvCopyOp op = ops[blockIdx.z / layers];
+    if (t >= op.count) return;
+    const int dd = threadIdx.x;
+    const int slots = d.sys_cap + d.ring_cap;
+    const int p = op.p0 + t;
+    long slot;
+    if (p < op.sys_len) slot = p;
+    else { int x = op.ring_start + (p - op.sys_len); x %= d.ring_cap; slot = (long)d.sys_cap + x; }
+    const long abase = op.arena_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
+    const long bidx = op.buf_offset + (((long)layer * d.kv_heads + kvh) * tcap + t) * HD + dd;
+    if (op.to_arena) {
+        kpool[abase + slot * HD + dd] = kbuf[bidx];
+        vtpool[abase + (long)dd * slots + slot] = vbuf[bidx];
+    } else {
+        kbuf[bidx] = kpool[abase + slot * HD + dd];
+        vbuf[bidx] = vtpool[abase + (long)dd * slots + slot];
+    }
+}
+
+int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* kbuf, bf16_t* vbuf, const KvCopyOp* ops, int n_ops, int max_count,
+                             LlmAttnDims d, int layers, int tcap, hipStream_t s) {
+    if (n_ops <= 0 || max_count <= 0) return ISST_OK;
+    hipLaunchKernelGGL(kv_positions_copy_kernel, dim3(max_count, d.kv_heads, layers * n_ops), dim3(HD), 0, s, kpool, vtpool, kbuf, vbuf, ops,
+                       d, layers, tcap);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+// ---- log_softmax, stage 1: per (part, row) running max and sum of exp ----
+#define LSE_PARTS 64
+__global__ __launch_bounds__(256) void lse_part_kernel(const float* __restrict__ logits, long ld, int vocab, float* __restrict__ pmax,
+                                                       float* __restrict__ psum) {
+    __shared__ float sm[4], ss[4];
+    const float* L = logits + (long)blockIdx.y * ld;
+    const int per = (vocab + LSE_PARTS - 1) / LSE_PARTS;
+    const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
+    float m = -INFINITY;
+    for (int v = lo + threadIdx.x; v < hi; v += blockDim.x) m = fmaxf(m, L[v]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float s = 0.f;
+    if (m > -INFINITY)
+        for (int v = lo + threadIdx.x; v < hi; v += blockDim.x) s += expf(L[v] - m);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pmax[blockIdx.y * LSE_PARTS + blockIdx.x] = m;
+        psum[blockIdx.y * LSE_PARTS + blockIdx.x] = ss[0] + ss[1] + ss[2] + ss[3];
+    }
+}
+// ---- stage 2: logits <- logits - logZ (in place) ----
+__global__ __launch_bounds__(256) void lse_apply_kernel(float* __restrict__ logits, long ld, int vocab, const float* __restrict__ pmax,
+                                                        const float* __restrict__ psum) {
+    __shared__ float logz;
+    if (threadIdx.x < 64) {
+        const float m = pmax[blockIdx.y * LSE_PARTS + threadIdx.x];
+        const float M = wave_max(m);
+        const float s = (m == -INFINITY) ? 0.f : psum[blockIdx.y * LSE_PARTS + threadIdx.x] * expf(m - M);
+        const float S = wave_sum(s);
+        if (threadIdx.x == 0) logz = M + logf(S);
+    }
+    __syncthreads();
+    float* L = logits + (long)blockIdx.y * ld;
+    const int per = (vocab + LSE_PARTS - 1) / LSE_PARTS;
+    const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
+    for (int v = lo + threadIdx.x; v < hi; v += blockDim.x) L[v] -= logz;
+}
+
+// ---- top-k (k <= BEAM_TOPK), ties -> lowest index.  Stage 1: the slice of a (part, row) is copied to LDS and the
+//      block argmax is taken k times; stage 2: the same over the LSE_PARTS * k survivors of a row. ----
+__device__ __forceinline__ void amax_merge(float& bv, int& bi, float ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+__device__ void block_topk(float* vals, const int* idx, int n, int k, float* out_val, int* out_idx) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    for (int it = 0; it < k; ++it) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff, bpos = -1;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const float x = vals[e];
+            const int id = idx ? idx[e] : e;
+            if (x > bv || (x == bv && id < bi)) { bv = x; bi = id; bpos = e; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, WAVE);
+            const int oi = __shfl_xor(bi, o, WAVE), op = __shfl_xor(bpos, o, WAVE);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bpos = op; }
+        }
+        __shared__ int sp[4];
+        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; sp[threadIdx.x >> 6] = bpos; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; bpos = sp[w]; }
+            out_val[it] = bv;
+            out_idx[it] = bi;
+            if (bpos >= 0) vals[bpos] = -INFINITY;  // NaN-free inputs: -inf entries simply never win again
+            sp[0] = bpos;
+        }
+        __syncthreads();
+    }
+}
+#define TOPK_SLICE 2048
+__global__ __launch_bounds__(256) void topk_part_kernel(const float* __restrict__ scores, long ld, int vocab, int k,
+                                                        float* __restrict__ cval, int* __restrict__ cidx) {
+    __shared__ float vals[TOPK_SLICE];
+    __shared__ int ids[TOPK_SLICE];
+    const float* L = scores + (long)blockIdx.y * ld;
+    const int per = (vocab + LSE_PARTS - 1) / LSE_PARTS;  // <= TOPK_SLICE (checked by the launcher)
+    const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
+    const int n = max(hi - lo, 0);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) { vals[e] = L[lo + e]; ids[e] = lo + e; }
+    __syncthreads();
+    block_topk(vals, ids, n, k, cval + ((long)blockIdx.y * LSE_PARTS + blockIdx.x) * BEAM_TOPK,
+               cidx + ((long)blockIdx.y * LSE_PARTS + blockIdx.x) * BEAM_TOPK);
+}
+__global__ __launch_bounds__(256) void topk_final_kernel(const float* __restrict__ cval, const int* __restrict__ cidx, int k,
+                                                         float* __restrict__ out_val, int* __restrict__ out_idx) {
+    __shared__ float vals[LSE_PARTS * BEAM_TOPK];
+    __shared__ int ids[LSE_PARTS * BEAM_TOPK];
+    int n = 0;
+    for (int e = threadIdx.x; e < LSE_PARTS * k; e += blockDim.x) {
+        const int part = e / k, j = e % k;
+        vals[e] = cval[((long)blockIdx.x * LSE_PARTS + part) * BEAM_TOPK + j];
+        ids[e] = cidx[((long)blockIdx.x * LSE_PARTS + part) * BEAM_TOPK + j];
+    }
+    n = LSE_PARTS * k;
+    __syncthreads();
+    block_topk(vals, ids, n, k, out_val + (long)blockIdx.x * BEAM_TOPK, out_idx + (long)blockIdx.x * BEAM_TOPK);
+}
+
+int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* psum, int rows, hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    hipLaunchKernelGGL(lse_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, logits, ld, vocab, pmax, psum);
+    hipLaunchKernelGGL(lse_apply_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, logits, ld, vocab, pmax, psum);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
+                     hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    if (k < 1 || k > BEAM_TOPK || (vocab + LSE_PARTS - 1) / LSE_PARTS > TOPK_SLICE) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(topk_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, scores, ld, vocab, k, cval, cidx);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, out_val, out_idx);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}

@@ -5,6 +5,8 @@
 // model/llm.py:51-126,192-270, model/speech_encoder.py:219-236, model/patches/patch_speech_encoder.py:228-933,
 // model/patches/patch_llm.py:231-336 and model/patches/patch_hf.py:586-624).  No CPU fallback exists: every compute
 // step is a HIP kernel launch on the caller's stream.
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -52,6 +54,7 @@ struct StreamState {
     int llm_sys = 0;         // pinned boundary: logical positions < llm_sys live in the sys region
     int llm_ring_start = 0;  // physical ring slot of logical position llm_sys
     int llm_total = 0;       // cached entries (logical positions 0..llm_total-1)
+    int beams = 0;           // 0: not decided yet, 1: greedy, >1: beam search (all arenas of the stream stay in sync)
 };
 struct Tap {
     bf16_t* dev = nullptr;
@@ -122,7 +125,17 @@ struct isst_handle {
     size_t meta_bytes = 0;
     int* tok_host = nullptr;  // pinned
 
+    // beam search (max_beams > 1): one KV arena per (stream, beam), tail buffers, scoring scratch
+    int max_beams = 1, tcap = 0, nbuf = 0;
+    bf16_t *tbuf_k = nullptr, *tbuf_v = nullptr;  // [max_streams][nbuf][layers][kv][tcap][128]
+    long tbuf_stride = 0;
+    float *lse_max = nullptr, *lse_sum = nullptr, *cand_val = nullptr, *top_val = nullptr;
+    int *cand_idx = nullptr, *top_idx = nullptr;
+    float* top_val_host = nullptr;
+    int* top_idx_host = nullptr;
+
     std::map<std::string, Tap> taps;
+    long arena_off(int sid, int beam) const { return ((long)sid * max_beams + beam) * llm_stream_stride; }
 
     int fail(int code, const char* fmt, ...) {
         char buf[1024];
@@ -238,6 +251,7 @@ int validate_config(const isst_config& c, std::string& why) {
     if (c.block_size % 4 || c.block_size < 4) return bad("block_size must be a multiple of 4");
     if (c.n_eos < 0 || c.n_eos > ISST_MAX_EOS) return bad("n_eos");
     if (c.vocab < 16) return bad("vocab");
+    if (c.max_beams < 0 || c.max_beams > 8) return bad("max_beams must be 0..8");
     return ISST_OK;
 }
 
@@ -253,6 +267,8 @@ extern "C" void isst_destroy(isst_handle* h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->meta_host) (void)hipHostFree(h->meta_host);
     if (h->tok_host) (void)hipHostFree(h->tok_host);
+    if (h->top_val_host) (void)hipHostFree(h->top_val_host);
+    if (h->top_idx_host) (void)hipHostFree(h->top_idx_host);
     delete h;
 }
 
@@ -279,13 +295,15 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (c.block_size % h->shrink_factor) { h->fail(ISST_ERR_ARG, "block_size not divisible by the shrink factor"); return die(ISST_ERR_ARG); }
     h->n_new_max = h->chunk_samples * c.max_multiplier;
     h->enc_rows_max = c.max_streams * c.block_size * c.max_multiplier;
-    h->llm_rows_max = c.max_streams * c.max_prompt_len;
+    h->llm_rows_max = c.max_streams * (c.max_prompt_len > 8 ? c.max_prompt_len : 8);
     h->enc_cap = round_up(c.max_cache_size + c.block_size * c.max_multiplier, 64);
     if (h->enc_cap > 1024) { h->fail(ISST_ERR_ARG, "encoder window %d > 1024 keys unsupported", h->enc_cap); return die(ISST_ERR_ARG); }
     h->sys_cap = round_up(c.max_system_prompt, 64);  // the attention kernel walks 64-slot splits of [sys region | ring]
     h->ring_cap = round_up(c.max_llm_cache_size + c.max_prompt_len + c.max_new_tokens + 8, 64);
     h->vocab_pad = round_up(c.vocab, 16);
     h->max_ids = c.max_prompt_len + c.max_new_tokens + 1;
+    h->max_beams = c.max_beams < 1 ? 1 : c.max_beams;
+    h->cfg.max_beams = h->max_beams;
 
     // ---- weights ----
     h->conv.resize(c.n_conv);
@@ -344,8 +362,8 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->adims.heads = H; h->adims.kv_heads = KV; h->adims.sys_cap = h->sys_cap; h->adims.ring_cap = h->ring_cap;
     h->adims.layer_stride = (long)KV * (h->sys_cap + h->ring_cap) * 128;
     h->llm_stream_stride = h->adims.layer_stride * c.llm_layers;
-    h->llm_k = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams, true);
-    h->llm_v = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams, true);
+    h->llm_k = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams * h->max_beams, true);
+    h->llm_v = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams * h->max_beams, true);
     h->enc_rope_rows = h->enc_cap;
     h->llm_rope_rows = h->sys_cap + h->ring_cap;
     h->enc_cos = h->dalloc<float>((size_t)h->enc_rope_rows * 32, true);
@@ -369,14 +387,31 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->speech = h->dalloc<bf16_t>(ER * DL);
     h->lx = h->dalloc<bf16_t>(LR * DL); h->lxn = h->dalloc<bf16_t>(LR * DL); h->lqkv = h->dalloc<bf16_t>(LR * (H + 2 * KV) * 128);
     h->lqrot = h->dalloc<bf16_t>(LR * H * 128); h->lattn = h->dalloc<bf16_t>(LR * H * 128); h->lact = h->dalloc<bf16_t>(LR * c.llm_ffn);
-    h->llast = h->dalloc<bf16_t>((size_t)ns * DL);
+    h->llast = h->dalloc<bf16_t>((size_t)ns * h->max_beams * DL);
     h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * 130);
-    h->logits = h->dalloc<float>((size_t)ns * h->vocab_pad);
-    h->out_tok = h->dalloc<int>(ns);
-    h->samp_val = h->dalloc<float>((size_t)ns * 64);
-    h->samp_idx = h->dalloc<int>((size_t)ns * 64);
-    h->meta_bytes = (size_t)LR * 6 * sizeof(int) + (size_t)ns * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
-                    (size_t)ns * (h->max_ids + h->max_enc_ids) * sizeof(int) + 65536 * sizeof(int) + 4096;
+    const size_t NB = (size_t)ns * h->max_beams;  // decode rows of a beam step
+    h->logits = h->dalloc<float>(NB * h->vocab_pad);
+    h->out_tok = h->dalloc<int>(NB);
+    h->samp_val = h->dalloc<float>(NB * 64);
+    h->samp_idx = h->dalloc<int>(NB * 64);
+    if (h->max_beams > 1) {
+        h->tcap = c.max_prompt_len > c.max_new_tokens ? c.max_prompt_len : c.max_new_tokens;
+        h->nbuf = 2 * h->max_beams + 1;
+        h->tbuf_stride = (long)c.llm_layers * KV * h->tcap * 128;
+        h->tbuf_k = h->dalloc<bf16_t>((size_t)h->tbuf_stride * h->nbuf * ns);
+        h->tbuf_v = h->dalloc<bf16_t>((size_t)h->tbuf_stride * h->nbuf * ns);
+        h->lse_max = h->dalloc<float>(NB * 64);
+        h->lse_sum = h->dalloc<float>(NB * 64);
+        h->cand_val = h->dalloc<float>(NB * 64 * BEAM_TOPK);
+        h->cand_idx = h->dalloc<int>(NB * 64 * BEAM_TOPK);
+        h->top_val = h->dalloc<float>(NB * BEAM_TOPK);
+        h->top_idx = h->dalloc<int>(NB * BEAM_TOPK);
+        if (!h->tbuf_k || !h->tbuf_v || !h->lse_max || !h->lse_sum || !h->cand_val || !h->cand_idx || !h->top_val || !h->top_idx) {
+            h->fail(ISST_ERR_NOMEM, "beam search allocation failed"); return die(ISST_ERR_NOMEM);
+        }
+    }
+    h->meta_bytes = (size_t)LR * 6 * sizeof(int) + NB * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
+                    NB * (h->max_ids + h->max_enc_ids) * sizeof(int) + NB * 4 * sizeof(KvCopyOp) + 65536 * sizeof(int) + 8192;
     h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
     const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
                           h->window, h->act_a, h->act_b, h->ex, h->exn, h->eqkv, h->eattn, h->effn, h->speech, h->lx, h->lxn, h->lqkv, h->lqrot,
@@ -384,7 +419,9 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     for (const void* p : must)
         if (!p) { h->fail(ISST_ERR_NOMEM, "state/workspace allocation failed"); return die(ISST_ERR_NOMEM); }
     if (hipHostMalloc(reinterpret_cast<void**>(&h->meta_host), h->meta_bytes) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&h->tok_host), sizeof(int) * ns) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void**>(&h->tok_host), sizeof(int) * NB) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->top_val_host), sizeof(float) * NB * BEAM_TOPK) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->top_idx_host), sizeof(int) * NB * BEAM_TOPK) != hipSuccess) {
         h->fail(ISST_ERR_NOMEM, "pinned host allocation failed"); return die(ISST_ERR_NOMEM);
     }
     if (hipDeviceSynchronize() != hipSuccess) { h->fail(ISST_ERR_HIP, "device sync after allocation failed"); return die(ISST_ERR_HIP); }
@@ -754,13 +791,14 @@ struct StepMeta {
     LlmStreamView* views;
     SampleStream* samp;
     int *ids_pool, *enc_pool, *suppress;
+    KvCopyOp* ops;  // position copies of a beam step
     size_t step_bytes;      // bytes from the block start up to (not including) the suppress list
     size_t suppress_offset;
 };
 // carve the metadata block (same offsets on host and device)
 StepMeta carve(isst_handle* h, unsigned char* base) {
     StepMeta m;
-    const size_t LR = h->llm_rows_max, ns = h->cfg.max_streams;
+    const size_t LR = h->llm_rows_max, ns = (size_t)h->cfg.max_streams * h->max_beams;
     unsigned char* p = base + 4096;  // first 4 KiB: encoder views
     auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 15) / 16 * 16; return r; };
     m.row_stream = reinterpret_cast<int*>(take(LR * 4)); m.row_pos = reinterpret_cast<int*>(take(LR * 4));
@@ -771,6 +809,7 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
     m.samp = reinterpret_cast<SampleStream*>(take(ns * sizeof(SampleStream)));
     m.ids_pool = reinterpret_cast<int*>(take(ns * h->max_ids * 4));
     m.enc_pool = reinterpret_cast<int*>(take(ns * h->max_enc_ids * 4));
+    m.ops = reinterpret_cast<KvCopyOp*>(take(ns * 4 * sizeof(KvCopyOp)));
     m.step_bytes = (size_t)(p - base);
     m.suppress_offset = m.step_bytes;
     m.suppress = reinterpret_cast<int*>(take(65536 * 4));
@@ -827,6 +866,283 @@ int check_ready(isst_handle* h) {
 
 }  // namespace
 
+
+// --------------------------------------------------------------------------------------------
+// beam search (reference model/patches/patch_hf.py:43-302, 687-967; production decoding mode, beam = 4)
+// --------------------------------------------------------------------------------------------
+namespace {
+
+struct BeamHyp {
+    double score;
+    std::vector<int> tokens;  // prompt + generated, without the EOS that closed it
+    int fed;                  // generated tokens whose KV exists (positions P0 .. P0 + fed - 1)
+    int buf;                  // tail buffer slot holding that KV, or -1 - beam when it still sits in arena `beam`
+};
+struct BeamHyps {  // BeamHypotheses, patch_hf.py:278-302 + [3P] is_done (early_stopping = False)
+    int num_beams;
+    double length_penalty;
+    std::vector<BeamHyp> beams;
+    double worst = 1e9;
+    // returns the buffer slot freed by an evicted (or rejected) hypothesis, or -1
+    int add(BeamHyp hyp, double sum_logprobs, int generated_len) {
+        hyp.score = sum_logprobs / std::pow((double)generated_len, length_penalty);
+        if ((int)beams.size() < num_beams || hyp.score > worst) {
+            beams.push_back(std::move(hyp));
+            if ((int)beams.size() > num_beams) {
+                std::vector<std::pair<double, int>> ranked;
+                for (size_t i = 0; i < beams.size(); ++i) ranked.push_back({beams[i].score, (int)i});
+                std::sort(ranked.begin(), ranked.end());
+                const int freed = beams[ranked[0].second].buf;
+                beams.erase(beams.begin() + ranked[0].second);
+                worst = ranked[1].first;
+                return freed >= 0 ? freed : -1;
+            }
+            worst = std::min(hyp.score, worst);
+            return -1;
+        }
+        return hyp.buf >= 0 ? hyp.buf : -1;
+    }
+    bool is_done(double best_sum_logprobs, int cur_len, int prompt_len) const {
+        if ((int)beams.size() < num_beams) return false;
+        const double highest = best_sum_logprobs / std::pow((double)(cur_len - prompt_len), length_penalty);
+        return worst >= highest;
+    }
+};
+
+struct BeamStream {  // host state of one stream during a beam call
+    std::vector<std::vector<int>> seq;  // per beam: prompt + generated
+    std::vector<float> score;
+    BeamHyps hyps;
+    bool done = false;
+    std::vector<int> free_bufs;
+};
+
+void push_copy(isst_handle* h, std::vector<KvCopyOp>& ops, int sid, int beam, int buf, int p0, int count, bool to_arena) {
+    if (count <= 0) return;
+    const StreamState& s = h->streams[sid];
+    KvCopyOp op{};
+    op.arena_offset = h->arena_off(sid, beam);
+    op.buf_offset = ((long)sid * h->nbuf + buf) * h->tbuf_stride;
+    op.p0 = p0; op.count = count;
+    op.sys_len = s.llm_sys; op.ring_start = s.llm_ring_start;
+    op.to_arena = to_arena ? 1 : 0;
+    ops.push_back(op);
+}
+// enqueue `ops` (all of them are independent of each other) and clear the list
+int flush_copies(isst_handle* h, std::vector<KvCopyOp>& ops, const StepMeta& mh, const StepMeta& md, hipStream_t st) {
+    if (ops.empty()) return ISST_OK;
+    const size_t cap = (size_t)h->cfg.max_streams * h->max_beams * 4;
+    for (size_t o = 0; o < ops.size(); o += cap) {
+        const int n = (int)std::min(cap, ops.size() - o);
+        int max_count = 0;
+        for (int i = 0; i < n; ++i) max_count = std::max(max_count, ops[o + i].count);
+        HIPCHK(hipStreamSynchronize(st));  // the pinned op list may still be read by the previous batch
+        std::memcpy(mh.ops, ops.data() + o, sizeof(KvCopyOp) * n);
+        HIPCHK(hipMemcpyAsync(md.ops, mh.ops, sizeof(KvCopyOp) * n, hipMemcpyHostToDevice, st));
+        CHK(launch_kv_positions_copy(h->llm_k, h->llm_v, h->tbuf_k, h->tbuf_v, md.ops, n, max_count, h->adims, h->cfg.llm_layers, h->tcap, st));
+    }
+    ops.clear();
+    return ISST_OK;
+}
+
+// decode phase of a beam call; the prefill (on arena 0 of every stream) has already produced h->logits rows 0..n-1
+int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const int* const* prompt_ids, const int* prompt_lens,
+                const int* const* prev_target_ids, const int* n_prev, const std::vector<int>& total0, int* const* out_ids, int* out_lens,
+                StepMeta& mh, StepMeta& md, hipStream_t st) {
+    const isst_config& c = h->cfg;
+    const int B = p->num_beams, V = c.vocab;
+    const int n_keep = std::max(2, 1 + c.n_eos) * B;
+    if (n_keep > BEAM_TOPK) return h->fail(ISST_ERR_ARG, "beam search keeps %d candidates per step, at most %d are supported", n_keep, BEAM_TOPK);
+    const double lp = p->length_penalty == 0.f ? 1.0 : (double)p->length_penalty;
+    std::vector<BeamStream> bs(n);
+    std::vector<KvCopyOp> ops;
+    for (int i = 0; i < n; ++i) {
+        bs[i].seq.assign(B, std::vector<int>(prompt_ids[i], prompt_ids[i] + prompt_lens[i]));
+        bs[i].score.assign(B, -1e9f);
+        bs[i].score[0] = 0.f;
+        bs[i].hyps.num_beams = B;
+        bs[i].hyps.length_penalty = lp;
+        for (int b = B; b < h->nbuf; ++b) bs[i].free_bufs.push_back(b);  // slots 0..B-1 are reorder temporaries
+        // the prompt's KV was written to arena 0: replicate it into the other beams' arenas (they are identical before it)
+        push_copy(h, ops, stream_ids[i], 0, 0, total0[i], prompt_lens[i], false);
+    }
+    CHK(flush_copies(h, ops, mh, md, st));
+    for (int i = 0; i < n; ++i)
+        for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], prompt_lens[i], true);
+    CHK(flush_copies(h, ops, mh, md, st));
+
+    int step = 0;  // tokens already chosen per beam
+    while (true) {
+        const int rows_per = step == 0 ? 1 : B;  // step 0: only beam 0 carries a finite score (:767-771)
+        const int rows = n * rows_per;
+        // ---- log_softmax -> processors (on log-probs) -> per-row top-k ----
+        for (int i = 0; i < n; ++i)
+            for (int b = 0; b < rows_per; ++b) {
+                const int r = i * rows_per + b;
+                const std::vector<int>& sq = bs[i].seq[b];
+                std::memcpy(mh.ids_pool + (size_t)r * h->max_ids, sq.data(), sq.size() * 4);
+                const int ne = n_prev ? n_prev[i] : 0;
+                if (b == 0 && ne) std::memcpy(mh.enc_pool + (size_t)i * h->max_enc_ids, prev_target_ids[i], (size_t)ne * 4);
+                mh.samp[r].n_ids = (int)sq.size(); mh.samp[r].n_enc = ne;
+                mh.samp[r].ids_off = r * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
+            }
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+        CHK(launch_log_softmax(h->logits, h->vocab_pad, V, h->lse_max, h->lse_sum, rows, st));
+        CHK(launch_sample_process(h->logits, h->vocab_pad, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
+                                  p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, rows, st));
+        CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val, h->top_idx, rows, st));
+        HIPCHK(hipMemcpyAsync(h->top_val_host, h->top_val, sizeof(float) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h->top_idx_host, h->top_idx, sizeof(int) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+
+        // ---- scorer (beam_search_process, :43-157) ----
+        bool all_done = true;
+        std::vector<std::vector<int>> parents(n), next_tok(n);
+        for (int i = 0; i < n; ++i) {
+            BeamStream& S = bs[i];
+            const int prompt_len = prompt_lens[i];
+            const int P0 = total0[i] + prompt_len;  // first position written by the decode phase
+            struct Cand { float val; long flat; };
+            std::vector<Cand> cands;
+            for (int b = 0; b < rows_per; ++b)
+                for (int j = 0; j < n_keep; ++j) {
+                    const int r = i * rows_per + b;
+                    const int idx = h->top_idx_host[r * BEAM_TOPK + j];
+                    if (idx < 0 || idx >= V) continue;
+                    cands.push_back({h->top_val_host[r * BEAM_TOPK + j] + S.score[b], (long)b * V + idx});
+                }
+            std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b2) { return a.val > b2.val || (a.val == b2.val && a.flat < b2.flat); });
+            if ((int)cands.size() > n_keep) cands.resize(n_keep);
+            const int cur_len = (int)S.seq[0].size() + 1;
+            std::vector<float> nscore;
+            std::vector<int>& ntok = next_tok[i];
+            std::vector<int>& npar = parents[i];
+            for (size_t rank = 0; rank < cands.size(); ++rank) {
+                const int b = (int)(cands[rank].flat / V), tok = (int)(cands[rank].flat % V);
+                bool is_eos = false;
+                for (int e = 0; e < c.n_eos; ++e) is_eos = is_eos || tok == c.eos_ids[e];
+                if (is_eos) {
+                    if ((int)rank >= B) continue;
+                    BeamHyp hyp;
+                    hyp.tokens = S.seq[b];
+                    hyp.fed = step;
+                    hyp.buf = -1;
+                    if (step > 0) {  // keep a copy of that beam's tail (the reference clones the whole KV cache, :113-120)
+                        if (S.free_bufs.empty()) return h->fail(ISST_ERR_STATE, "beam search ran out of hypothesis buffers");
+                        hyp.buf = S.free_bufs.back();
+                        S.free_bufs.pop_back();
+                        push_copy(h, ops, stream_ids[i], b, hyp.buf, P0, step, false);
+                    } else {
+                        hyp.buf = -1 - 0;  // empty tail: nothing to keep
+                    }
+                    const int freed = S.hyps.add(std::move(hyp), (double)cands[rank].val, cur_len - prompt_len);
+                    if (freed >= B) S.free_bufs.push_back(freed);
+                } else {
+                    nscore.push_back(cands[rank].val);
+                    ntok.push_back(tok);
+                    npar.push_back(b);
+                }
+                if ((int)ntok.size() == B) break;
+            }
+            if ((int)ntok.size() < B) return h->fail(ISST_ERR_STATE, "beam search: fewer than %d non-EOS candidates", B);
+            if (!cands.empty()) S.done = S.done || S.hyps.is_done((double)cands[0].val, cur_len, prompt_len);
+            // input_ids = cat(input_ids[beam_idx], tokens)  (:899)
+            std::vector<std::vector<int>> nseq(B);
+            for (int b = 0; b < B; ++b) { nseq[b] = S.seq[npar[b]]; nseq[b].push_back(ntok[b]); }
+            S.seq.swap(nseq);
+            S.score = nscore;
+            all_done = all_done && S.done;
+        }
+        CHK(flush_copies(h, ops, mh, md, st));  // hypothesis tails first: the reorder below overwrites arenas
+        ++step;
+        // ---- reorder the tails (:910-913): new beam b continues parent npar[b].  Like the reference this happens BEFORE
+        //      the stop test, so that finalize sees arena b == beam b ----
+        if (step - 1 > 0) {
+            for (int i = 0; i < n; ++i) {
+                const int P0 = total0[i] + prompt_lens[i];
+                std::set<int> needed;
+                for (int b = 0; b < B; ++b) if (parents[i][b] != b) needed.insert(parents[i][b]);
+                for (int src : needed) push_copy(h, ops, stream_ids[i], src, src, P0, step - 1, false);
+            }
+            CHK(flush_copies(h, ops, mh, md, st));
+            for (int i = 0; i < n; ++i) {
+                const int P0 = total0[i] + prompt_lens[i];
+                for (int b = 0; b < B; ++b) if (parents[i][b] != b) push_copy(h, ops, stream_ids[i], b, parents[i][b], P0, step - 1, true);
+            }
+            CHK(flush_copies(h, ops, mh, md, st));
+        }
+        if (all_done || step >= p->max_new_tokens) break;  // :920
+        // ---- next forward pass: one row per (stream, beam) ----
+        const int nr = n * B;
+        for (int i = 0; i < n; ++i) {
+            const StreamState& ss = h->streams[stream_ids[i]];
+            for (int b = 0; b < B; ++b) {
+                const int r = i * B + b;
+                mh.row_stream[r] = r;  // view index
+                mh.row_pos[r] = total0[i] + prompt_lens[i] + step - 1;
+                mh.ids[r] = bs[i].seq[b].back();
+                mh.last_rows[r] = r;
+                mh.views[r].sys_len = ss.llm_sys;
+                mh.views[r].ring_start = ss.llm_ring_start;
+                mh.views[r].kv_offset = h->arena_off(stream_ids[i], b);
+                mh.views[r].new_start = mh.row_pos[r];
+                mh.views[r].row0 = r;
+                mh.groups[r].x = r;
+                mh.groups[r].y = 1;
+            }
+        }
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+        CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st));
+    }
+
+    // ---- finalize (:159-275): open beams become hypotheses, the best one wins ----
+    for (int i = 0; i < n; ++i) {
+        BeamStream& S = bs[i];
+        const int prompt_len = prompt_lens[i];
+        const int P0 = total0[i] + prompt_len;
+        if (!S.done)
+            for (int b = 0; b < B; ++b) {
+                BeamHyp hyp;
+                hyp.tokens = S.seq[b];
+                hyp.fed = (int)S.seq[b].size() - prompt_len - 1;  // the last chosen token was never fed
+                hyp.buf = -1 - b;
+                const int freed = S.hyps.add(std::move(hyp), (double)S.score[b], (int)S.seq[b].size() - prompt_len);
+                if (freed >= B) S.free_bufs.push_back(freed);
+            }
+        if (S.hyps.beams.empty()) return h->fail(ISST_ERR_STATE, "beam search produced no hypothesis");
+        size_t best = 0;
+        for (size_t q = 1; q < S.hyps.beams.size(); ++q)
+            if (S.hyps.beams[q].score >= S.hyps.beams[best].score) best = q;  // sorted(...).pop(): the last of equal scores
+        const BeamHyp& win = S.hyps.beams[best];
+        // make every arena of the stream hold the winner's tail
+        if (win.fed > 0) {
+            int src_buf = win.buf;
+            int skip_beam = -1;
+            if (win.buf < 0) {  // still in an arena: stage it through temporary 0
+                skip_beam = -1 - win.buf;
+                push_copy(h, ops, stream_ids[i], skip_beam, 0, P0, win.fed, false);
+                CHK(flush_copies(h, ops, mh, md, st));
+                src_buf = 0;
+            }
+            for (int b = 0; b < B; ++b)
+                if (b != skip_beam) push_copy(h, ops, stream_ids[i], b, src_buf, P0, win.fed, true);
+            CHK(flush_copies(h, ops, mh, md, st));
+        }
+        StreamState& ss = h->streams[stream_ids[i]];
+        ss.llm_total = P0 + win.fed;
+        ss.chunks++;
+        const int max_length = prompt_len + p->max_new_tokens;
+        std::vector<int> outv(win.tokens.begin() + prompt_len, win.tokens.end());
+        if ((int)win.tokens.size() < std::min((int)win.tokens.size() + 1, max_length)) outv.push_back(c.n_eos ? c.eos_ids[0] : 0);
+        for (size_t q = 0; q < outv.size(); ++q) out_ids[i][q] = outv[q];
+        out_lens[i] = (int)outv.size();
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return ISST_OK;
+}
+
+}  // namespace
+
 extern "C" int isst_encode_speech(isst_handle* h, int stream_id, const float* pcm, int n_samples, int multiplier, uint16_t* out_features,
                                   int* out_rows, void* hip_stream) {
     if (!h) return ISST_ERR_ARG;
@@ -861,6 +1177,12 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     if (p->n_suppress < 0 || p->n_suppress > 65536 || (p->n_suppress && !p->suppress_tokens)) return h->fail(ISST_ERR_ARG, "suppress_tokens");
     if (p->no_repeat_ngram_size < 0 || p->encoder_no_repeat_ngram_size < 0 || p->no_repeat_ngram_size > 64 || p->encoder_no_repeat_ngram_size > 64)
         return h->fail(ISST_ERR_ARG, "ngram sizes");
+    const int B = p->num_beams > 1 ? p->num_beams : 1;
+    if (B > h->max_beams) return h->fail(ISST_ERR_ARG, "num_beams %d exceeds the configured max_beams %d", B, h->max_beams);
+    bool any_forced = false;
+    if (forced_tokens && n_forced)
+        for (int i = 0; i < n; ++i) any_forced = any_forced || (forced_tokens[i] != nullptr && n_forced[i] > 0);
+    if (B > 1 && (any_forced || logits_out)) return h->fail(ISST_ERR_ARG, "forced_tokens / logits_out are greedy-only test aids");
     for (int i = 0; i < n; ++i) {
         const int id = stream_ids[i];
         if (id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", id);
@@ -868,6 +1190,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         if (prompt_lens[i] < 1 || prompt_lens[i] > c.max_prompt_len) return h->fail(ISST_ERR_ARG, "prompt length %d (max %d)", prompt_lens[i], c.max_prompt_len);
         if (n_prev && (n_prev[i] < 0 || n_prev[i] > h->max_enc_ids)) return h->fail(ISST_ERR_ARG, "too many previous target ids");
         const StreamState& s = h->streams[id];
+        if (s.beams != 0 && s.beams != B && s.llm_total > 0)
+            return h->fail(ISST_ERR_STATE, "stream %d was started with num_beams %d; reset it before switching to %d", id, s.beams, B);
         const int total = s.llm_total;
         int sys = s.llm_sys;
         if (total == 0 && p->system_prompt_size > 0) {
@@ -894,10 +1218,11 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     for (int i = 0; i < n; ++i) {
         StreamState& s = h->streams[stream_ids[i]];
         if (s.llm_total == 0) s.llm_sys = p->system_prompt_size > 0 ? p->system_prompt_size : 0;
+        s.beams = B;
         total0[i] = s.llm_total;
         mh.views[i].sys_len = s.llm_sys;
         mh.views[i].ring_start = s.llm_ring_start;
-        mh.views[i].kv_offset = (long)stream_ids[i] * h->llm_stream_stride;
+        mh.views[i].kv_offset = h->arena_off(stream_ids[i], 0);
         mh.views[i].new_start = total0[i];
         mh.views[i].row0 = R;
         row0[i] = R;
@@ -943,6 +1268,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     }
     HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
     CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st));
+    if (B > 1)
+        return beam_decode(h, p, n, stream_ids, prompt_ids, prompt_lens, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);
 
     // ---- 3. greedy loop (patch_hf.py:606-624 -> HF _sample) ----
     std::vector<int> active(n);
@@ -1051,6 +1378,23 @@ extern "C" int isst_op_sample(float* logits, int vocab, const int* ids, int n_id
     (void)hipStreamSynchronize(st);
     (void)hipFree(scratch);
     return rc;
+}
+
+extern "C" int isst_debug_read_kv(isst_handle* h, int id, int beam, int layer, int kv_head, int pos, uint16_t* k_out, uint16_t* v_out) {
+    if (!h || !k_out || !v_out) return ISST_ERR_ARG;
+    if (id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", id);
+    const StreamState& s = h->streams[id];
+    if (beam < 0 || beam >= h->max_beams || layer < 0 || layer >= h->cfg.llm_layers || kv_head < 0 || kv_head >= h->cfg.llm_kv_heads || pos < 0 ||
+        pos >= s.llm_total)
+        return h->fail(ISST_ERR_ARG, "isst_debug_read_kv: index out of range");
+    const int slots = h->sys_cap + h->ring_cap;
+    long slot = pos;
+    if (pos >= s.llm_sys) slot = (long)h->sys_cap + (s.llm_ring_start + (pos - s.llm_sys)) % h->ring_cap;
+    const long base = h->arena_off(id, beam) + (long)layer * h->adims.layer_stride + (long)kv_head * slots * 128;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(k_out, h->llm_k + base + slot * 128, 256, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy2D(v_out, 2, h->llm_v + base + slot, (size_t)slots * 2, 2, 128, hipMemcpyDeviceToHost));  // V^T column
+    return ISST_OK;
 }
 
 extern "C" int isst_debug_tap(isst_handle* h, const char* name, uint16_t* dst, int64_t max_elems, int64_t* got_elems) {

@@ -62,3 +62,22 @@ struct SampleStream {
 int launch_sample(float* logits, long ld_logits, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool,
                   const int* suppress, int n_suppress, float rep_penalty, int ngram, int enc_ngram, int* out_tokens,
                   float* scratch_val, int* scratch_idx /* 64 per stream each */, int n_streams, hipStream_t s);
+
+// ---- beam search pieces (beam.hip) ----
+#define BEAM_TOPK 32
+struct KvCopyOp {
+    long arena_offset;  // element offset of the arena (stream, beam) inside the K / V^T pools
+    long buf_offset;    // element offset of the buffer inside kbuf / vbuf
+    int p0, count;      // logical positions p0 .. p0+count-1
+    int sys_len, ring_start;
+    int to_arena;       // 0: arena -> buffer, 1: buffer -> arena
+    int pad;
+};
+int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* kbuf, bf16_t* vbuf, const KvCopyOp* ops, int n_ops, int max_count,
+                             LlmAttnDims d, int layers, int tcap, hipStream_t s);
+int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* psum, int rows, hipStream_t s);
+int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
+                     hipStream_t s);
+// processors only (stage 1 of launch_sample), in place on the rows named by ss[]
+int launch_sample_process(float* logits, long ld_logits, const SampleStream* ss, const int* ids_pool, const int* enc_pool, const int* suppress,
+                          int n_suppress, float rep_penalty, int ngram, int enc_ngram, int n_rows, hipStream_t s);

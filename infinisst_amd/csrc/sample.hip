@@ -96,3 +96,11 @@ int launch_sample(float* logits, long ld_logits, int vocab, const SampleStream* 
     hipLaunchKernelGGL(sample_argmax_final_kernel, dim3(n_streams), dim3(64), 0, s, scratch_val, scratch_idx, out_tokens);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
+
+int launch_sample_process(float* logits, long ld_logits, const SampleStream* ss, const int* ids_pool, const int* enc_pool, const int* suppress,
+                          int n_suppress, float rep_penalty, int ngram, int enc_ngram, int n_rows, hipStream_t s) {
+    if (n_rows <= 0) return ISST_OK;
+    hipLaunchKernelGGL(sample_process_kernel, dim3(n_rows), dim3(256), 0, s, logits, ld_logits, ss, ids_pool, enc_pool, suppress, n_suppress,
+                       rep_penalty, ngram, enc_ngram);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}

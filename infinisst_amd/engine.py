@@ -42,7 +42,7 @@ class _Config(C.Structure):
         ("n_eos", C.c_int), ("eos_ids", C.c_int * ISST_MAX_EOS),
         ("max_streams", C.c_int), ("max_multiplier", C.c_int), ("max_prompt_len", C.c_int),
         ("max_new_tokens", C.c_int), ("max_llm_cache_size", C.c_int), ("max_system_prompt", C.c_int),
-        ("debug_taps", C.c_int),
+        ("debug_taps", C.c_int), ("max_beams", C.c_int),
     ]
 
 
@@ -51,6 +51,7 @@ class _GenParams(C.Structure):
         ("multiplier", C.c_int), ("max_new_tokens", C.c_int), ("no_repeat_ngram_size", C.c_int),
         ("encoder_no_repeat_ngram_size", C.c_int), ("repetition_penalty", C.c_float),
         ("suppress_tokens", C.POINTER(C.c_int)), ("n_suppress", C.c_int), ("system_prompt_size", C.c_int),
+        ("num_beams", C.c_int), ("length_penalty", C.c_float),
     ]
 
 
@@ -63,7 +64,7 @@ class _StreamInfo(C.Structure):
 EXPORTS = [
     "isst_create", "isst_destroy", "isst_last_error", "isst_load_weight", "isst_set_rope_tables",
     "isst_finalize_weights", "isst_stream_open", "isst_stream_reset", "isst_stream_close", "isst_stream_info_get",
-    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_op_pack_weight",
+    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_op_pack_weight",
     "isst_op_packed_elems", "isst_op_gemm", "isst_op_set_gemm_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
 ]
 
@@ -98,6 +99,7 @@ def load_library(path: Optional[str] = None):
     lib.isst_encode_speech.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                        C.POINTER(C.c_int), C.c_void_p]
     lib.isst_debug_tap.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    lib.isst_debug_read_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.isst_op_pack_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.isst_op_packed_elems.argtypes = [C.c_int, C.c_int]
     lib.isst_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -124,7 +126,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def make_c_config(cfg: ModelConfig, max_streams: int, max_multiplier: int, max_prompt_len: int, max_new_tokens: int,
-                  max_llm_cache_size: int, max_system_prompt: int, debug_taps: bool) -> _Config:
+                  max_llm_cache_size: int, max_system_prompt: int, debug_taps: bool, max_beams: int = 1) -> _Config:
     c = _Config()
     c.n_conv = len(cfg.conv_layers)
     for i, (d, k, s) in enumerate(cfg.conv_layers):
@@ -147,6 +149,7 @@ def make_c_config(cfg: ModelConfig, max_streams: int, max_multiplier: int, max_p
     c.max_streams, c.max_multiplier, c.max_prompt_len = max_streams, max_multiplier, max_prompt_len
     c.max_new_tokens, c.max_llm_cache_size, c.max_system_prompt = max_new_tokens, max_llm_cache_size, max_system_prompt
     c.debug_taps = int(debug_taps)
+    c.max_beams = max_beams
     return c
 
 
@@ -155,13 +158,13 @@ class Engine:
 
     def __init__(self, cfg: ModelConfig, max_streams: int = 1, max_multiplier: int = 1, max_prompt_len: int = 128,
                  max_new_tokens: int = 40, max_llm_cache_size: int = 1000, max_system_prompt: int = 128,
-                 debug_taps: bool = False):
+                 debug_taps: bool = False, max_beams: int = 1):
         if not torch.cuda.is_available():
             raise IsstError("no GPU visible: the InfiniSST hot path has no CPU implementation in this package")
         self.lib = load_library()
         self.cfg = cfg
         self.c_cfg = make_c_config(cfg, max_streams, max_multiplier, max_prompt_len, max_new_tokens,
-                                   max_llm_cache_size, max_system_prompt, debug_taps)
+                                   max_llm_cache_size, max_system_prompt, debug_taps, max_beams)
         self.max_new_tokens = max_new_tokens
         self.h = C.c_void_p()
         rc = self.lib.isst_create(C.byref(self.c_cfg), C.byref(self.h))
@@ -252,6 +255,8 @@ class Engine:
         p.suppress_tokens = sup.ctypes.data_as(C.POINTER(C.c_int)) if sup.size else None
         p.n_suppress = int(sup.size)
         p.system_prompt_size = system_prompt_size
+        p.num_beams = gen.beam
+        p.length_penalty = 1.0
         sid_arr = (C.c_int * n)(*stream_ids)
         prompts = [np.asarray(x, dtype=np.int32) for x in prompt_ids]
         prevs = [np.asarray(x, dtype=np.int32) for x in prev_target_ids]
@@ -283,6 +288,13 @@ class Engine:
         self._check(self.lib.isst_encode_speech(self.h, sid, pcm.ctypes.data, pcm.shape[0], multiplier, out.data_ptr(),
                                                 C.byref(rows), _stream_ptr()), "isst_encode_speech")
         return out[: rows.value]
+
+    def read_kv(self, sid: int, pos: int, layer: int = 0, kv_head: int = 0, beam: int = 0):
+        """(K, V) rows (128 bf16 each, unrotated) of one cached position (test aid)."""
+        k = torch.empty(128, dtype=torch.bfloat16)
+        v = torch.empty(128, dtype=torch.bfloat16)
+        self._check(self.lib.isst_debug_read_kv(self.h, sid, beam, layer, kv_head, pos, k.data_ptr(), v.data_ptr()), "isst_debug_read_kv")
+        return k, v
 
     def debug_tap(self, name: str) -> torch.Tensor:
         got = C.c_int64(0)

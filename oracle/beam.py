@@ -1,0 +1,163 @@
+"""ORACLE (test infrastructure, not product code) -- beam search with per-hypothesis KV caches.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Restates the reference's patched HF beam search (the production decoding mode, beam=4):
+  generation_mixin_beam_search   model/patches/patch_hf.py:687-967   (loop: log_softmax -> processors -> + beam scores ->
+                                                                     top-k over beams*vocab -> scorer -> reorder KV)
+  beam_search_process            :43-157    (EOS candidates inside the top `num_beams` ranks become hypotheses and take
+                                             a COPY of that beam's KV cache; the others fill the next beams)
+  beam_search_finalize           :159-275   (open beams become hypotheses; best one wins; EOS appended if it fits)
+  beam_hypotheses_add            :278-302   (score = sum_logprobs / generated_len ** length_penalty, keep the best n)
+  _expand_inputs_for_generation  :305-342   (inputs and KV cache repeated num_beams times)
+transformers 4.47.0 cannot be imported here, so `BeamHypotheses.is_done` (early_stopping=False heuristic) and
+`n_tokens_to_keep = max(2, 1 + n_eos) * num_beams` are restated from that release's published code: parity unpinned.
+
+The model is the batch-1 oracle; every beam carries its own KV list (what `_temporary_reorder_cache` + index_select
+achieve in the reference).
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import generate as ogen
+from . import llm as ollm
+from . import speech_encoder as oenc
+
+
+def clone_kv(kv):
+    return [[None if t is None else t.clone() for t in layer] for layer in kv]
+
+
+@dataclass
+class BeamHypotheses:
+    num_beams: int
+    length_penalty: float = 1.0
+    early_stopping: bool = False
+    beams: list = field(default_factory=list)  # (score, tokens, kv)
+    worst_score: float = 1e9
+
+    def __len__(self):
+        return len(self.beams)
+
+    def add(self, hyp: List[int], sum_logprobs: float, generated_len: int, kv):
+        """patch_hf.py:278-302."""
+        score = sum_logprobs / (generated_len ** self.length_penalty)
+        if len(self) < self.num_beams or score > self.worst_score:
+            self.beams.append((score, list(hyp), kv))
+            if len(self) > self.num_beams:
+                ranked = sorted((s, idx) for idx, (s, _, _) in enumerate(self.beams))
+                del self.beams[ranked[0][1]]
+                self.worst_score = ranked[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float, cur_len: int, decoder_prompt_len: int) -> bool:
+        """[3P transformers 4.47 BeamHypotheses.is_done], early_stopping=False branch."""
+        if len(self) < self.num_beams:
+            return False
+        if self.early_stopping is True:
+            return True
+        highest_attainable = best_sum_logprobs / (cur_len - decoder_prompt_len) ** self.length_penalty
+        return self.worst_score >= highest_attainable
+
+
+@dataclass
+class BeamStepRecord:
+    scores: List[torch.Tensor]  # per beam: processed log-probs + beam score (fp32, V)
+    cand_scores: List[float]
+    cand_tokens: List[int]
+    cand_beams: List[int]
+    next_tokens: List[int]
+    next_parents: List[int]
+    next_scores: List[float]
+
+
+@dataclass
+class BeamOutput:
+    sequences: List[int]  # prompt + best hypothesis (+ EOS if it fits under max_length)
+    kv: list  # KV cache of the best hypothesis
+    steps: List[BeamStepRecord]
+    speech_features: Optional[torch.Tensor] = None
+
+
+def scorer_process(hyps: BeamHypotheses, done: bool, input_ids: List[List[int]], cand_scores, cand_tokens, cand_beams, kvs,
+                   eos_ids: Sequence[int], num_beams: int, decoder_prompt_len: int):
+    """beam_search_process for batch size 1 (patch_hf.py:43-157).  Returns (next_scores, next_tokens, next_parents, done)."""
+    cur_len = len(input_ids[0]) + 1
+    next_scores, next_tokens, next_parents = [], [], []
+    for rank, (tok, sc, b) in enumerate(zip(cand_tokens, cand_scores, cand_beams)):
+        if tok in eos_ids:
+            if rank >= num_beams:
+                continue
+            hyps.add(input_ids[b], sc, cur_len - decoder_prompt_len, clone_kv(kvs[b]))
+        else:
+            next_scores.append(sc)
+            next_tokens.append(tok)
+            next_parents.append(b)
+        if len(next_tokens) == num_beams:
+            break
+    if len(next_tokens) < num_beams:
+        raise ValueError("not enough non-EOS candidates")
+    done = done or hyps.is_done(max(cand_scores), cur_len, decoder_prompt_len)
+    return next_scores, next_tokens, next_parents, done
+
+
+def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batch: torch.Tensor, kv, speech_cache, rope_llm,
+                  rope_enc, encoder_input_ids: Sequence[int], length_penalty: float = 1.0) -> BeamOutput:
+    """One chunk with beam search.  `kv` (the stream's cache before this chunk) is not modified; the winning
+    hypothesis' cache is returned (reference agents/infinisst.py:334-336: past_key_values[0])."""
+    m = gen.latency_multiplier
+    feats, _ = oenc.encode_speech(w, cfg, speech_batch, speech_cache, m, rope_enc)
+    feats = feats[0]
+    prompt_len = len(input_ids)
+    max_length = prompt_len + gen.max_new_tokens
+    n_keep = max(2, 1 + len(cfg.eos_ids)) * num_beams
+    seqs = [list(input_ids) for _ in range(num_beams)]
+    kvs = [clone_kv(kv) for _ in range(num_beams)]  # _expand_inputs_for_generation
+    beam_scores = [0.0] + [-1e9] * (num_beams - 1)
+    hyps = BeamHypotheses(num_beams, length_penalty)
+    done = False
+    steps: List[BeamStepRecord] = []
+    step = 0
+    V = None
+    while True:
+        rows = []
+        for b in range(num_beams):
+            if step == 0:
+                logits = ollm.model_forward(w, cfg, torch.tensor(seqs[b]), kvs[b], rope_llm, speech=feats)
+            else:
+                logits = ollm.model_forward(w, cfg, torch.tensor(seqs[b][-1:]), kvs[b], rope_llm)
+            lp = torch.log_softmax(logits.float(), dim=-1)  # :833-837
+            sc = ogen.process_logits(lp, seqs[b], encoder_input_ids, gen.repetition_penalty, gen.no_repeat_ngram_size,
+                                     gen.no_repeat_ngram_size, gen.suppress_tokens)  # :839, on log-probs
+            rows.append(sc + beam_scores[b])
+        V = rows[0].numel()
+        flat = torch.cat(rows)
+        top = torch.topk(flat, n_keep, largest=True, sorted=True)  # :878
+        cand_scores = [float(x) for x in top.values]
+        cand_beams = [int(i) // V for i in top.indices]
+        cand_tokens = [int(i) % V for i in top.indices]
+        ns, nt, npar, done = scorer_process(hyps, done, seqs, cand_scores, cand_tokens, cand_beams, kvs, cfg.eos_ids, num_beams, prompt_len)
+        steps.append(BeamStepRecord(rows, cand_scores, cand_tokens, cand_beams, nt, npar, ns))
+        seqs = [seqs[p] + [t] for p, t in zip(npar, nt)]  # input_ids[beam_idx] + token
+        kvs = [clone_kv(kvs[p]) for p in npar]  # _temporary_reorder_cache
+        beam_scores = ns
+        step += 1
+        if done or len(seqs[0]) >= max_length:  # :920
+            break
+    # finalize (:159-275)
+    if not done:
+        for b in range(num_beams):
+            hyps.add(seqs[b], beam_scores[b], len(seqs[b]) - prompt_len, kvs[b])
+    best = sorted(hyps.beams, key=lambda x: x[0])[-1]
+    hyp_tokens, best_kv = best[1], best[2]
+    sent_max_len = min(len(hyp_tokens) + 1, max_length)
+    out = list(hyp_tokens)
+    if len(hyp_tokens) < sent_max_len:
+        out.append(cfg.eos_ids[0])  # "inserting only the first eos_token_id"
+    return BeamOutput(sequences=out, kv=best_kv, steps=steps, speech_features=feats)

