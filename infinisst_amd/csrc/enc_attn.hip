@@ -13,44 +13,22 @@
 // PHYSICAL slots (aligned 16/32-slot tiles) and derives each slot's logical index for RoPE and masking; slots
 // outside the window get probability 0.
 //
-// One workgroup (4 waves) per (head, block of QB query rows, stream):
-//   1. S = (q/8) K^T: q fragments (rotated, bf16) stay in registers; every wave takes key tiles nt = w, w+4, ..; the
+// The chunk's own keys (logical index >= cached length) are read from the qkv rows and appended to the rings by the
+// workgroup of query block 0, so no separate append launch is needed.
+// One workgroup (8 waves) per (head, block of QB query rows, stream):
+//   1. S = (q/8) K^T: q fragments (rotated, bf16) stay in registers; every wave takes key tiles nt = w, w+8, ..; the
 //      K fragment of a lane is 8 consecutive dims of ONE key row, so the interleaved-pair rotation is lane-local.
 //      Scores are rounded to bf16, masked, and written to LDS  S[QB][cap] (bf16).
 //   2. row softmax in fp32 over the LDS row, probabilities rounded to bf16 in place.
-//   3. O = P V: wave w owns output dims 16w..16w+15; A = P from LDS, B = V^T straight from global.
+//   3. O = P V: wave w owns output dims 16(w&3)..+15 and half of the key steps (w>>2); A = P from LDS, B = V^T straight
+//      from global; the two halves meet in LDS.
 // The mask needs no tensor: row i may see logical columns [lo_i, hi_i) (closed form of :30-77).
 #include "common.h"
 #include "kernels.h"
 
 #define ENC_HD 64
 #define ENC_SPAD 8  // bf16 elements of padding per S row (keeps rows 16-byte aligned, shifts banks by 4 per row)
-
-__global__ void enc_kv_append_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kring, bf16_t* __restrict__ vring,
-                                     long stream_stride, const EncStreamView* __restrict__ sv, int Q, int heads, int cap,
-                                     int max_cache) {
-    const int i = blockIdx.x, s = blockIdx.y;
-    const int h = threadIdx.x >> 3, c8 = threadIdx.x & 7;
-    const int D = heads * ENC_HD;
-    const int len = min(sv[s].prefix, max_cache);
-    int phys = sv[s].start + len + i;
-    phys %= cap;
-    const bf16_t* row = qkv + ((long)s * Q + i) * 3 * D;
-    const long base = (long)s * stream_stride + (long)h * cap * ENC_HD;
-    *reinterpret_cast<u32x4_t*>(kring + base + (long)phys * ENC_HD + c8 * 8) =
-        *reinterpret_cast<const u32x4_t*>(row + D + h * ENC_HD + c8 * 8);
-    const bf16_t* v = row + 2 * D + h * ENC_HD + c8 * 8;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) vring[base + (long)(c8 * 8 + d) * cap + phys] = v[d];  // transposed: [dim][slot]
-}
-
-int launch_enc_kv_append(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long stream_stride, const EncStreamView* sv,
-                         int n_streams, int Q, int heads, int cap, int max_cache, hipStream_t s) {
-    if (heads * 8 > 1024) return ISST_ERR_ARG;
-    hipLaunchKernelGGL(enc_kv_append_kernel, dim3(Q, n_streams), dim3(heads * 8), 0, s, qkv, kring, vring, stream_stride, sv,
-                       Q, heads, cap, max_cache);
-    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
-}
+#define ENC_WAVES 8
 
 // interleaved-pair rotation of 8 consecutive dims (4 pairs) [3P rotary_embedding_torch semantics, see oracle]
 __device__ __forceinline__ void rot8(const float* x, const float* c, const float* sn, int round_each, float* y) {
@@ -79,8 +57,7 @@ __device__ __forceinline__ u32x4_t rot_frag(const bf16_t* p, int pos, int dim0, 
 }
 
 template <int QT>  // m-tiles of 16 query rows per workgroup
-__global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kring,
-                                                            const bf16_t* __restrict__ vring, long stream_stride,
+__global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                                                             const EncStreamView* __restrict__ sv,
                                                             const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                                             int round_each, bf16_t* __restrict__ out, int Q, int heads, int cap,
@@ -88,6 +65,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* S = reinterpret_cast<bf16_t*>(smem);  // [QT*16][cap + ENC_SPAD]
     const int ldS = cap + ENC_SPAD;
+    float* Ohalf = reinterpret_cast<float*>(smem + (size_t)QT * 16 * ldS * 2);  // [QT*16][64] partial O of the upper key half
     const int h = blockIdx.x, qb = blockIdx.y, s = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = sv[s].prefix, start = sv[s].start;
@@ -96,8 +74,10 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
     const int off = max(0, P - C);
     const int D = heads * ENC_HD;
     const int q0 = qb * (QT * 16);
-    const bf16_t* kr = kring + (long)s * stream_stride + (long)h * cap * ENC_HD;
-    const bf16_t* vt = vring + (long)s * stream_stride + (long)h * cap * ENC_HD;  // [64][cap]
+    bf16_t* kr = kring + (long)s * stream_stride + (long)h * cap * ENC_HD;
+    bf16_t* vt = vring + (long)s * stream_stride + (long)h * cap * ENC_HD;  // [64][cap]
+    const bf16_t* knew = qkv + (long)s * Q * 3 * D + D + h * ENC_HD;      // K of new frame i at knew + i*3D
+    const bf16_t* vnew = qkv + (long)s * Q * 3 * D + 2 * D + h * ENC_HD;  // V of new frame i at vnew + i*3D
     const int fr = lane & 15, fq = lane >> 4;
 
     // ---- rotated query fragments: A[row = fr][k = 8 fq + j] for both 32-dim k-steps ----
@@ -124,13 +104,19 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
 
     // ---- 1. scores ----
     const int n_tiles = cap >> 4;
-    for (int nt = wave; nt < n_tiles; nt += 4) {
+    for (int nt = wave; nt < n_tiles; nt += ENC_WAVES) {
         const int cphys = nt * 16 + fr;       // physical slot of this lane's key
         int j = cphys - start;                // logical index
         if (j < 0) j += cap;
         const bool live = j < K;
         const int jpos = live ? j : 0;
-        const bf16_t* krow = kr + (long)cphys * ENC_HD;
+        const bool is_new = live && j >= len;  // written by this chunk: still only in the qkv rows
+        const bf16_t* krow = is_new ? knew + (long)(j - len) * 3 * D : kr + (long)cphys * ENC_HD;
+        if (is_new && qb == 0) {  // append the unrotated key to the ring (query block 0 owns the append)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                *reinterpret_cast<u32x4_t*>(kr + (long)cphys * ENC_HD + ks * 32 + fq * 8) = *reinterpret_cast<const u32x4_t*>(krow + ks * 32 + fq * 8);
+        }
         u32x4_t kf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[ks] = rot_frag(krow + ks * 32 + fq * 8, jpos, ks * 32 + fq * 8, rope_cos, rope_sin, round_each);
@@ -153,7 +139,7 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
     __syncthreads();
 
     // ---- 2. softmax per row (fp32), probabilities rounded to bf16 in place ----
-    for (int row = wave; row < QT * 16; row += 4) {
+    for (int row = wave; row < QT * 16; row += ENC_WAVES) {
         bf16_t* srow = S + (long)row * ldS;
         float v[2][8];
         float mx = -INFINITY;
@@ -192,22 +178,46 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
     }
     __syncthreads();
 
-    // ---- 3. O = P V : wave w owns dims 16w .. 16w+15 ----
+    // ---- 3. O = P V : wave w owns dims 16(w&3) .. +15 and the key steps of half (w>>2) ----
+    const int dt = wave & 3, half = wave >> 2;
     f32x4_t o[QT];
 #pragma unroll
     for (int mt = 0; mt < QT; ++mt) o[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* vrow = vt + (long)(wave * 16 + fr) * cap + fq * 8;  // B[k = 8 fq + j][col = fr] = V^T[dim][slot]
-    const int k_steps = cap >> 5;  // cap is a multiple of 64 -> even
-    for (int ks0 = 0; ks0 < k_steps; ks0 += 4) {
+    const int dim = dt * 16 + fr;
+    const bf16_t* vrow = vt + (long)dim * cap + fq * 8;  // B[k = 8 fq + j][col = fr] = V^T[dim][slot]
+    const int k_steps = cap >> 5, k_half = (k_steps + 1) >> 1;
+    const int ks_lo = half * k_half, ks_hi = min(ks_lo + k_half, k_steps);
+    // physical slot range of the new keys: [nlo, nlo + Q) mod cap
+    int nlo = start + len;
+    if (nlo >= cap) nlo -= cap;
+    for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += 4) {
         u32x4_t vf[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {  // four V^T fragments in flight before the first use
-            const int ks = ks0 + u < k_steps ? ks0 + u : k_steps - 1;
-            vf[u] = *reinterpret_cast<const u32x4_t*>(vrow + ks * 32);
+            const int ks = ks0 + u < ks_hi ? ks0 + u : ks_hi - 1;
+            const int t0 = ks * 32 + fq * 8;  // first of this lane's 8 slots
+            int rel = t0 - nlo;
+            if (rel < 0) rel += cap;
+            const bool any_new = rel < Q || rel + 7 >= cap;  // the 8 slots touch [nlo, nlo+Q) (possibly wrapping)
+            if (!any_new) {
+                vf[u] = *reinterpret_cast<const u32x4_t*>(vrow + ks * 32);
+            } else {  // mixed fragment: new keys come from the qkv rows
+                bf16_t e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    int r2 = t0 + q - nlo;
+                    if (r2 < 0) r2 += cap;
+                    e[q] = (r2 < Q) ? vnew[(long)r2 * 3 * D + dim] : vt[(long)dim * cap + t0 + q];
+                }
+                vf[u].x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+                vf[u].y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+                vf[u].z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
+                vf[u].w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (ks0 + u < k_steps) {
+            if (ks0 + u < ks_hi) {
 #pragma unroll
                 for (int mt = 0; mt < QT; ++mt) {
                     const u32x4_t pf = *reinterpret_cast<const u32x4_t*>(S + (long)(mt * 16 + fr) * ldS + (ks0 + u) * 32 + fq * 8);
@@ -216,23 +226,41 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const bf16_t* __rest
             }
         }
     }
+    if (half == 1) {
 #pragma unroll
-    for (int mt = 0; mt < QT; ++mt)
+        for (int mt = 0; mt < QT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + mt * 16 + fq * 4 + r;
-            out[((long)s * Q + qi) * D + h * ENC_HD + wave * 16 + fr] = f2bf(o[mt][r]);
+            for (int r = 0; r < 4; ++r) Ohalf[(mt * 16 + fq * 4 + r) * ENC_HD + dim] = o[mt][r];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int mt = 0; mt < QT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = q0 + mt * 16 + fq * 4 + r;
+                out[((long)s * Q + qi) * D + h * ENC_HD + dim] = f2bf(o[mt][r] + Ohalf[(mt * 16 + fq * 4 + r) * ENC_HD + dim]);
+            }
+    }
+    // ---- append V^T of the chunk's own keys (query block 0): [dim][slot] <- V[new frame][dim] ----
+    if (qb == 0) {
+        for (int e = tid; e < Q * ENC_HD; e += ENC_WAVES * 64) {
+            const int i = e / ENC_HD, dd = e % ENC_HD;
+            int slot = nlo + i;
+            if (slot >= cap) slot -= cap;
+            vt[(long)dd * cap + slot] = vnew[(long)i * 3 * D + dd];
         }
+    }
 }
 
-int launch_enc_attention(const bf16_t* qkv, const bf16_t* kring, const bf16_t* vring, long stream_stride,
+int launch_enc_attention(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                          const EncStreamView* sv, const float* rope_cos, const float* rope_sin, int rope_round_each,
                          bf16_t* out, int n_streams, int Q, int heads, int cap, int max_cache, int blocksize, hipStream_t s) {
     if (Q <= 0 || n_streams <= 0) return ISST_OK;
     if (Q % 16 != 0 || cap % 64 != 0 || cap > 1024 || max_cache + Q > cap) return ISST_ERR_ARG;
     const int QT = (Q % 48 == 0) ? 3 : 1;
-    const size_t lds = (size_t)QT * 16 * (cap + ENC_SPAD) * 2;
-    dim3 grid(heads, Q / (QT * 16), n_streams), block(256);
+    const size_t lds = (size_t)QT * 16 * (cap + ENC_SPAD) * 2 + (size_t)QT * 16 * ENC_HD * sizeof(float);
+    dim3 grid(heads, Q / (QT * 16), n_streams), block(ENC_WAVES * 64);
     static size_t lds_set[2] = {0, 0};
     if (QT == 3) {
         if (lds > 64 * 1024 && lds > lds_set[0]) {
@@ -242,6 +270,10 @@ int launch_enc_attention(const bf16_t* qkv, const bf16_t* kring, const bf16_t* v
         hipLaunchKernelGGL(enc_attention_kernel<3>, grid, block, lds, s, qkv, kring, vring, stream_stride, sv, rope_cos, rope_sin,
                            rope_round_each, out, Q, heads, cap, max_cache, blocksize);
     } else {
+        if (lds > 64 * 1024 && lds > lds_set[1]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attention_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+            lds_set[1] = lds;
+        }
         hipLaunchKernelGGL(enc_attention_kernel<1>, grid, block, lds, s, qkv, kring, vring, stream_stride, sv, rope_cos, rope_sin,
                            rope_round_each, out, Q, heads, cap, max_cache, blocksize);
     }

@@ -29,9 +29,8 @@ int launch_embed_splice(const int* ids, const int* speech_row, const bf16_t* tab
 
 // ---- encoder attention (enc_attn.hip) ----
 // qkv: [n_streams*Q][3*D] (q | k | v).  K/V rings: per stream `stream_stride` elements, layout [heads][cap][64].
-int launch_enc_kv_append(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long stream_stride, const EncStreamView* sv,
-                         int n_streams, int Q, int heads, int cap, int max_cache, hipStream_t s);
-int launch_enc_attention(const bf16_t* qkv, const bf16_t* kring, const bf16_t* vring, long stream_stride,
+// also appends the chunk's own k / v (from the qkv rows) to the rings: no separate append launch is needed
+int launch_enc_attention(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                          const EncStreamView* sv, const float* rope_cos, const float* rope_sin, int rope_round_each,
                          bf16_t* out, int n_streams, int Q, int heads, int cap, int max_cache, int blocksize, hipStream_t s);
 
