@@ -149,6 +149,11 @@ int64_t isst_op_packed_elems(int n_rows, int K);
 int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, const uint16_t* res,
                  int64_t ldres, void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, const uint16_t* norm_w,
                  float norm_eps, void* hip_stream);
+/* the pair the decoder runs at 17..64 rows for o_proj / down_proj (HF LlamaDecoderLayer: residual + mlp/attn output, then the
+ * next RMSNorm): slabs[ksplit][M][N] (fp32, caller scratch) = A @ W^T per K slice; x[M][N] = bf16(x + bf16(sum of slabs)) in place;
+ * norm_w != NULL: out = LlamaRMSNorm(norm_w, norm_eps)(x).  K % (128 * ksplit) == 0, N % 16 == 0, 16 < M <= 64. */
+int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, const uint16_t* norm_w,
+                                uint16_t* out, float* slabs, int M, int N, int K, int ksplit, float norm_eps, void* hip_stream);
 /* profiling aid: override the GEMM launch heuristic (waves per workgroup, 16-row n-tiles per workgroup); 0 = automatic */
 int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block);
 int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps,

@@ -66,6 +66,7 @@ enum GemmEpi {
     EPI_BIAS_RES = 4,   // out = bf16(res + bf16(acc + bias))
     EPI_SWIGLU = 5,     // tile pairs (gate, up): out = bf16(bf16(silu(bf16 g)) * bf16 u)
     EPI_F32 = 6,        // out(fp32) = bf16-rounded acc
+    EPI_PARTIAL = 7,    // split-K slab: out(fp32)[slice][M][N] = raw partial sum (gemm_mid.hip; reduced by rmsnorm_reduce)
 };
 
 // launchers (defined in the kernel .hip files; all asynchronous on `stream`)
@@ -79,11 +80,15 @@ struct GemmArgs {
     int n_valid;                                   // output columns actually stored (<= N, or N/2 for SWIGLU)
     const bf16_t* norm_w;                          // non-null: A rows are RMS-normalised on load (HF LlamaRMSNorm) with this weight
     float norm_eps;
+    int ksplit;                                    // EPI_PARTIAL: K slices over workgroups (slab stride = out_batch elements)
 };
 #define GEMM_FUSED_NORM_MAX_M 8  // rows for which the GEMM stages (and optionally RMS-normalises) A in LDS
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 void gemm_set_tuning(int waves_per_block, int ntiles_per_block);  // 0 = heuristic; profiling aid
 bool gemm_tiled_supported(const GemmArgs& g);                      // gemm_tiled.hip: dense shapes (M > 64 or batched)
 int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream);
+bool gemm_mid_supported(const GemmArgs& g);                        // gemm_mid.hip: 17..64 rows, A staged through LDS
+int launch_gemm_mid(const GemmArgs& g, hipStream_t stream);
+void gemm_mid_set_tuning(int wn);
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,
                        int tile_phase, int conv_k, hipStream_t stream);

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "kernels.h"
 
+#define LLM_KSPLIT_MAX 4
 namespace {
 
 struct PackedLinear {
@@ -117,6 +118,7 @@ struct isst_handle {
     bf16_t *ex = nullptr, *exn = nullptr, *eqkv = nullptr, *eattn = nullptr, *effn = nullptr, *speech = nullptr;
     bf16_t *lx = nullptr, *lxn = nullptr, *lqkv = nullptr, *lqrot = nullptr, *lattn = nullptr, *lact = nullptr, *llast = nullptr;
     float *lpartial = nullptr, *logits = nullptr;
+    float* lslab = nullptr;  // split-K slabs of o_proj / down_proj at 17..64 rows: [LLM_KSPLIT_MAX][64][llm_dim] fp32
     int* out_tok = nullptr;
     float* samp_val = nullptr;  // partial argmax scratch, 64 per stream
     int* samp_idx = nullptr;
@@ -389,6 +391,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->lqrot = h->dalloc<bf16_t>(LR * H * 128); h->lattn = h->dalloc<bf16_t>(LR * H * 128); h->lact = h->dalloc<bf16_t>(LR * c.llm_ffn);
     h->llast = h->dalloc<bf16_t>((size_t)ns * h->max_beams * DL);
     h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * 130);
+    h->lslab = h->dalloc<float>((size_t)LLM_KSPLIT_MAX * 64 * DL);
     const size_t NB = (size_t)ns * h->max_beams;  // decode rows of a beam step
     h->logits = h->dalloc<float>(NB * h->vocab_pad);
     h->out_tok = h->dalloc<int>(NB);
@@ -415,7 +418,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
     const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
                           h->window, h->act_a, h->act_b, h->ex, h->exn, h->eqkv, h->eattn, h->effn, h->speech, h->lx, h->lxn, h->lqkv, h->lqrot,
-                          h->lattn, h->lact, h->llast, h->lpartial, h->logits, h->out_tok, h->samp_val, h->samp_idx, h->meta_dev};
+                          h->lattn, h->lact, h->llast, h->lpartial, h->lslab, h->logits, h->out_tok, h->samp_val, h->samp_idx, h->meta_dev};
     for (const void* p : must)
         if (!p) { h->fail(ISST_ERR_NOMEM, "state/workspace allocation failed"); return die(ISST_ERR_NOMEM); }
     if (hipHostMalloc(reinterpret_cast<void**>(&h->meta_host), h->meta_bytes) != hipSuccess ||
@@ -677,6 +680,24 @@ int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int e
     return ISST_OK;
 }
 
+// K slices over workgroups for a narrow-N projection at 17..64 rows (measured, profiles/r01/mid_probe.txt: 2 slices for
+// K = 4096, 4 for K = 14336; more slices only add slab traffic)
+int pick_ksplit(int K, int N) {
+    (void)N;
+    for (int s = K >= 8192 ? 4 : 2; s > 1; s >>= 1)
+        if (K % (128 * s) == 0 && K / (128 * s) >= 4) return s;
+    return 1;
+}
+// slabs[ksplit][M][N] (fp32) = A @ W^T per K slice; reduced by launch_rmsnorm_reduce
+int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, float* slabs, int M, int ksplit, hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.Wp = L.wp;
+    g.out = slabs; g.ldo = L.n_valid; g.out_batch = (long)M * L.n_valid;
+    g.M = M; g.N = L.N; g.K = L.K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = L.n_valid; g.ksplit = ksplit;
+    CHK(launch_gemm(g, st));
+    return ISST_OK;
+}
+
 // conv extractor + encoder + shrink + projector for n streams; result in h->speech [n*S][llm_dim]
 int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm, int n_samples, int multiplier, hipStream_t st, int* out_S) {
     const isst_config& c = h->cfg;
@@ -821,6 +842,13 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
     CHK(launch_embed_splice(d.ids, splice ? d.speech_row : nullptr, h->embed, h->speech, h->lx, rows, DL, st));
     if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "embed", h->lx, (int64_t)rows * DL, st));
+    // 17..64 rows (one stream's prefill, a 64-stream decode pass): o_proj and down_proj split K over workgroups and the
+    // residual + RMSNorm kernel that follows reduces the slabs (gemm_mid.hip); `pending`: lx still lacks the previous
+    // layer's down_proj slabs
+    const bool split_rows = rows > 16 && rows <= 64;
+    const int so = split_rows ? pick_ksplit(H * 128, DL) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL) : 1;
+    const long slab = (long)rows * DL;
+    bool pending = false;
     for (int l = 0; l < c.llm_layers; ++l) {
         const LlmLayer& L = h->llm[l];
         // decode shapes: RMSNorm is applied inside the projection's A-fragment load (gemm.hip NORM); larger row counts
@@ -829,20 +857,37 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         if (fuse) {
             CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps));
         } else {
-            CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+            if (pending) {
+                CHK(launch_rmsnorm_reduce(h->lslab, slab, sd, h->lx, DL, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+                if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
+                pending = false;
+            } else {
+                CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+            }
             CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
         }
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st));
-        CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
-        if (fuse) {
-            CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
-        } else {
-            CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+        if (so > 1) {
+            CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
+            CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+        } else {
+            CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
+            if (fuse) {
+                CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
+            } else {
+                CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+                CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+            }
         }
-        CHK(gemm(h, h->lact, c.llm_ffn, L.down, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
-        if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
+        if (sd > 1 && l + 1 < c.llm_layers) {
+            CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st));
+            pending = true;
+        } else {
+            CHK(gemm(h, h->lact, c.llm_ffn, L.down, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
+            if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
+        }
     }
     if (splice) {  // prefill: the last prompt row of every stream is gathered and normalised
         CHK(launch_rmsnorm(h->lx, DL, d.last_rows, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
@@ -1346,6 +1391,18 @@ extern "C" int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* pack
     g.M = M; g.N = round_up(N, 16); g.K = K; g.batch = 1; g.epi = epi; g.n_valid = n_valid;
     g.norm_w = norm_w; g.norm_eps = norm_eps;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, const uint16_t* norm_w, uint16_t* out,
+                                           float* slabs, int M, int N, int K, int ksplit, float norm_eps, void* hip_stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    if (N % 16 != 0) return ISST_ERR_ARG;
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.Wp = packed; g.out = slabs; g.ldo = N; g.out_batch = (long)M * N;
+    g.M = M; g.N = N; g.K = K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = N; g.ksplit = ksplit;
+    if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
+    const int rc = launch_gemm(g, st);
+    if (rc != ISST_OK) return rc;
+    return launch_rmsnorm_reduce(slabs, (long)M * N, ksplit, x, N, norm_w, out, N, M, N, norm_eps, st);
 }
 extern "C" int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block) {
     gemm_set_tuning(waves_per_block, ntiles_per_block);

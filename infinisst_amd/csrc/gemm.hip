@@ -263,7 +263,7 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
 
 // tuning overrides for profiles/gemv_sweep.py (0 = heuristic)
 static int g_tune_w = 0, g_tune_ntb = 0, g_force_skinny = 0;
-void gemm_set_tuning(int w, int ntb) { g_tune_w = w < 0 ? 0 : w; g_tune_ntb = ntb; g_force_skinny = w < 0; }  // w < 0: never use the tiled kernel
+void gemm_set_tuning(int w, int ntb) { g_tune_w = w < 0 ? 0 : w; g_tune_ntb = ntb; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }  // w < 0: never use the tiled kernel
 
 static inline bool gemm_can_stage(const GemmArgs& g) {
     return g.batch == 1 && g.M <= 16 && (size_t)g.M * g.K * 2 <= 64 * 1024 && g.M <= GEMM_FUSED_NORM_MAX_M;
@@ -335,6 +335,10 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
         const bool ok = (g.epi != EPI_BIAS && g.epi != EPI_BIAS_GELU && g.epi != EPI_BIAS_RES) || g.bias;
         if (!ok || ((g.epi == EPI_RES || g.epi == EPI_BIAS_RES) && !g.res) || (g.epi == EPI_SWIGLU && g.N % 32)) return ISST_ERR_ARG;
         return launch_gemm_tiled(g, stream);
+    }
+    if (gemm_mid_supported(g) && !g_force_skinny) {
+        if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return ISST_ERR_ARG;
+        return launch_gemm_mid(g, stream);
     }
     switch (g.epi) {
         case EPI_NONE: return launch_epi<EPI_NONE>(g, stream);

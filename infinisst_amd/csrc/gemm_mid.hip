@@ -1,0 +1,231 @@
+// Packed-weight GEMM for 17..64 rows on gfx950:  out[M,N] = epi(A[M,K] @ W[N,K]^T), weights read exactly once.
+//
+// Where it runs: the LLM prefill of one stream (22-66 prompt rows, reference model/llm.py:86-113 -> LlamaDecoderLayer) and
+// every decode pass of a 64-stream batch (64 rows, one per stream).  These are still weight-streaming problems (HBM-bound),
+// but unlike the 1..16-row case (gemm.hip) the ACTIVATIONS dominate the on-chip traffic: with 16-column workgroups every
+// workgroup re-reads all of A through L2 in fragment-shaped 64-byte pieces, 4x the weight bytes at 64 rows (measured: the
+// skinny kernel's time tracks A + W bytes at ~8 TB/s of L2->CU traffic, not W bytes at HBM rate).  So here
+//   * a workgroup (4 or 8 waves) owns 2 or 4 n-tiles (32 or 64 columns) and ALL rows: A is staged through LDS in full 128-byte lines
+//     (8 rows x 128 B per wave-load, cdna_hip_programming.md section 4 "x operand through LDS in full lines"), written as
+//     ready-made MFMA A fragments ([k-step][m-tile][lane] x 16 B: conflict-free ds_write_b128 and ds_read_b128), double
+//     buffered, one barrier per 128-deep K chunk; every wave reads the same staged fragments;
+//   * a wave owns one PAIR of n-tiles and one of the chunk's four k-steps, so each A fragment it reads from LDS feeds two
+//     MFMAs (LDS bandwidth, not HBM, bounds the skeleton of this kernel: measured with emptied descriptors); the weight
+//     fragments stream straight from the fragment-major packed layout into VGPRs through bounds-checked buffer loads, a
+//     ring of 4 chunks in flight, non-temporal (read once);
+//   * the K halves meet in LDS (fixed order: deterministic) and the epilogue applies bias / GELU / residual / SwiGLU with
+//     the reference's bf16 rounding points, exactly as gemm.hip;
+//   * narrow outputs (o_proj, down_proj: N = 4096 -> 64-128 workgroups) additionally split K over workgroups
+//     (EPI_PARTIAL): fp32 slabs [slice][M][N], reduced -- in fixed order -- by the residual + RMSNorm kernel that follows
+//     anyway (rowops.hip rmsnorm_reduce_kernel), so the split costs no extra launch.
+#include "common.h"
+
+#define MID_CK 128     // K elements per staged chunk (4 k-steps of 32)
+#define MID_RING 4     // chunks in flight per wave: weight fragments and staged A pieces
+
+// NP: n-tile pairs per workgroup (1 or 2) -> 32 or 64 columns, 4 * NP waves.  Wave (np, wk) owns the two n-tiles of pair np
+// (for SwiGLU exactly one (gate, up) pair) and k-step wk of every chunk: per chunk it reads its MT A fragments from LDS
+// once and feeds 2 * MT MFMAs on independent accumulators from them.
+template <int MT, int NP, int EPI>
+__global__ __launch_bounds__(NP * 256) void gemm_mid_kernel(GemmArgs g, int k_chunks, int dbg) {
+    constexpr int NW = NP * 4;                     // waves per workgroup
+    constexpr int WN = NP * 2;                     // n-tiles per workgroup
+    constexpr int AU = (MT * 4 + NW - 1) / NW;     // staging units (8 rows x 128 B) per wave and chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x [4 k-steps][MT][64 lanes][16 B]; later the K-reduction buffer [4][MT*WN][256] fp32
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the buffer descriptors below are built from it
+    const int np = wave % NP, wk = wave / NP;
+    const int KT = g.K >> 5, NTILES = g.N >> 4;
+    const int nt = blockIdx.x * WN + np * 2;       // first n-tile of the pair
+    const int chunk0 = blockIdx.y * k_chunks;
+    const int m0 = blockIdx.z * (MT * 16);
+
+    f32x4_t acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[mt][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // weight fragments of (chunk c, k-step wk) for the two n-tiles; ring slot = c % 4, reloaded 4 chunks ahead right after use.
+    // Loads go through buffer descriptors that cover exactly this slice of each n-tile: prefetches past the end (and tiles
+    // past N) return zeros without memory traffic and without a branch (a conditional load makes hipcc drain vmcnt(0)).
+    __amdgpu_buffer_rsrc_t wrsrc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const bool wvalid = nt + nb < NTILES && !(dbg & 2);
+        wrsrc[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + ((long)(wvalid ? nt + nb : 0) * KT + (long)chunk0 * 4) * 512, 0,
+                                                      wvalid ? k_chunks * 4096 : 0, 0x00020000);
+    }
+    const int woff = (wk * 64 + lane) * 16;
+    auto load_b = [&](int c, int nb) -> u32x4_t {
+        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc[nb], woff + c * 4096, 0, 2 /* nt: read once */);
+    };
+    u32x4_t wf[MID_RING][2];
+#pragma unroll
+    for (int u = 0; u < MID_RING; ++u)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) wf[u][nb] = load_b(u, nb);
+
+    // ---- A staging: unit = 8 rows x 128 B (two k-steps); lane -> (row rlo = lane & 7, 16-byte piece p = lane >> 3) ----
+    // register ring of 4 chunks: chunk c+3 is requested while chunk c is computed and written to LDS two barriers later, so an
+    // L2 round trip under full streaming load (1.8-3.3 us, cdna_hip_programming.md section 4) is off the critical path
+    const int rlo = lane & 7, p = lane >> 3;
+    // rows >= M re-read row M-1 (their products land in output rows >= M, which are never stored); chunks past the slice
+    // read on inside the row or, past the last row, hit the descriptor's bound
+    const __amdgpu_buffer_rsrc_t arsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, (dbg & 1) ? 0 : (int)((((long)g.M - 1) * g.lda + g.K) * 2), 0x00020000);
+    int aoff[AU];     // byte offset of this lane's piece of chunk 0
+    int adst[AU];     // byte offset inside one LDS buffer, -1: this wave has no such unit
+#pragma unroll
+    for (int a = 0; a < AU; ++a) {
+        const int unit = wave + a * NW;
+        const int kp = unit & 1, rg = unit >> 1;
+        const int row = rg * 8 + rlo;  // 0 .. MT*16-1
+        const int grow = min(m0 + row, g.M - 1);
+        aoff[a] = (int)(((long)grow * g.lda + (long)chunk0 * MID_CK + kp * 64 + p * 8) * 2);
+        const int ks = kp * 2 + (p >> 2), q = p & 3;
+        adst[a] = (((ks * MT + (row >> 4)) * 64) + q * 16 + (row & 15)) * 16;
+        if (unit >= MT * 4) adst[a] = -1;
+    }
+    constexpr int BUF = 4 * MT * 1024;
+    auto load_a = [&](int c, int a) -> u32x4_t { return __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[a] + c * (MID_CK * 2), 0, 0); };
+    u32x4_t areg[MID_RING][AU];  // slot c % 4 holds chunk c
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int a = 0; a < AU; ++a) areg[u][a] = load_a(u, a);
+#pragma unroll
+    for (int a = 0; a < AU; ++a)
+        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(smem + adst[a]) = areg[0][a];
+    __syncthreads();
+
+    for (int c0 = 0; c0 < k_chunks; c0 += MID_RING) {
+#pragma unroll
+        for (int u = 0; u < MID_RING; ++u) {
+            const int c = c0 + u;
+            if (c < k_chunks) {  // uniform over the workgroup
+#pragma unroll
+                for (int a = 0; a < AU; ++a) areg[(u + 3) % MID_RING][a] = load_a(c + 3, a);
+                const unsigned char* buf = smem + (c & 1) * BUF + ((wk * MT) * 64 + lane) * 16;
+                u32x4_t af[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4_t*>(buf + mt * 1024);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mt]), __builtin_bit_cast(bf16x8_t, wf[u][nb]), acc[mt][nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) wf[u][nb] = load_b(c + MID_RING, nb);
+                if (c + 1 < k_chunks) {
+                    unsigned char* nbuf = smem + ((c + 1) & 1) * BUF;
+#pragma unroll
+                    for (int a = 0; a < AU; ++a)
+                        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(nbuf + adst[a]) = areg[(u + 1) % MID_RING][a];
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- K reduction across the 4 k-step waves through LDS: red[wk][(mt*WN + n)*4 + r][lane], n = 2 np + nb ----
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int TILES = MT * WN;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(long)wk * (TILES * 256) + ((mt * WN + np * 2 + nb) * 4 + r) * 64 + lane] = acc[mt][nb][r];
+    __syncthreads();
+
+    const int nt0 = blockIdx.x * WN;
+    constexpr int OUT_TILES = (EPI == EPI_SWIGLU) ? TILES / 2 : TILES;
+    for (int e = tid; e < OUT_TILES * 256; e += NW * 64) {
+        const int ot = e >> 8, rl = e & 255;
+        const int r = rl >> 6, l = rl & 63;
+        int mt, nb;
+        if constexpr (EPI == EPI_SWIGLU) { mt = ot / (WN / 2); nb = (ot % (WN / 2)) * 2; }
+        else { mt = ot / WN; nb = ot % WN; }
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* pr = red + (long)w * (TILES * 256);
+            s += pr[((mt * WN + nb) * 4 + r) * 64 + l];
+            if constexpr (EPI == EPI_SWIGLU) s2 += pr[((mt * WN + nb + 1) * 4 + r) * 64 + l];
+        }
+        const int row = m0 + mt * 16 + (l >> 4) * 4 + r;
+        int col;
+        if constexpr (EPI == EPI_SWIGLU) col = ((nt0 + nb) >> 1) * 16 + (l & 15);
+        else col = (nt0 + nb) * 16 + (l & 15);
+        if (row >= g.M || col >= g.n_valid) continue;
+        if constexpr (EPI == EPI_PARTIAL) {
+            reinterpret_cast<float*>(g.out)[(long)blockIdx.y * g.out_batch + (long)row * g.ldo + col] = s;
+        } else if constexpr (EPI == EPI_F32) {
+            reinterpret_cast<float*>(g.out)[(long)row * g.ldo + col] = bfr(s);
+        } else {
+            float v;
+            if constexpr (EPI == EPI_NONE) v = s;
+            else if constexpr (EPI == EPI_BIAS) v = s + bf2f(g.bias[col]);
+            else if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(bfr(s + bf2f(g.bias[col])));
+            else if constexpr (EPI == EPI_RES) v = bf2f(g.res[(long)row * g.ldres + col]) + bfr(s);
+            else if constexpr (EPI == EPI_BIAS_RES) v = bf2f(g.res[(long)row * g.ldres + col]) + bfr(s + bf2f(g.bias[col]));
+            else /* EPI_SWIGLU */ v = bfr(silu(bfr(s))) * bfr(s2);
+            reinterpret_cast<bf16_t*>(g.out)[(long)row * g.ldo + col] = f2bf(v);
+        }
+    }
+}
+
+static int g_mid_wn = 0, g_mid_dbg = 0;  // tuning override (profiles/mid_probe.py): 0 = heuristic; bits 4-5: timing-only builds (A / W descriptor emptied)
+void gemm_mid_set_tuning(int wn) { g_mid_wn = wn & 15; g_mid_dbg = (wn >> 4) & 3; }
+
+bool gemm_mid_supported(const GemmArgs& g) {
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    return g.batch == 1 && g.M > 16 && g.M <= 64 && g.K % (MID_CK * ks) == 0 && g.N % 16 == 0 && g.lda % 8 == 0 && !g.norm_w;
+}
+
+template <int MT, int NP, int EPI>
+static int launch_mid_cfg(const GemmArgs& g, hipStream_t stream) {
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    const int NTILES = g.N / 16, WN = NP * 2;
+    dim3 grid((NTILES + WN - 1) / WN, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(NP * 256);
+    const size_t lds = (size_t)(NP == 2 ? 16 : 8) * MT * 1024;  // max(A double buffer 8 MT KiB, K-reduction buffer 4 * MT * WN KiB)
+    hipLaunchKernelGGL((gemm_mid_kernel<MT, NP, EPI>), grid, block, lds, stream, g, g.K / MID_CK / ks, g_mid_dbg);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+template <int MT, int EPI>
+static int launch_mid_wn(const GemmArgs& g, hipStream_t stream) {
+    // columns per workgroup (profiles/mid_probe.py, r01/mid_probe.txt): 64 when that still gives most CUs a workgroup, else 32
+    // (A is then staged twice as often); up to 32 rows the 4-wave / 32-column form wins except for the widest projection
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    int wn;
+    if (g.M <= 32) wn = g.N >= 16384 ? 4 : 2;
+    else wn = ((long)(g.N / 64) * ks >= 192) ? 4 : 2;
+    if (g_mid_wn == 2 || g_mid_wn == 4) wn = g_mid_wn;
+    if (wn == 4) return launch_mid_cfg<MT, 2, EPI>(g, stream);
+    return launch_mid_cfg<MT, 1, EPI>(g, stream);
+}
+
+template <int EPI>
+static int launch_mid_mt(const GemmArgs& g, hipStream_t stream) {
+    if (g.M <= 32) return launch_mid_wn<2, EPI>(g, stream);
+    if (g.M <= 48) return launch_mid_wn<3, EPI>(g, stream);
+    return launch_mid_wn<4, EPI>(g, stream);
+}
+
+int launch_gemm_mid(const GemmArgs& g, hipStream_t stream) {
+    if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
+    if (g.ksplit > 1 && g.epi != EPI_PARTIAL) return ISST_ERR_ARG;
+    switch (g.epi) {
+        case EPI_NONE: return launch_mid_mt<EPI_NONE>(g, stream);
+        case EPI_BIAS: return g.bias ? launch_mid_mt<EPI_BIAS>(g, stream) : ISST_ERR_ARG;
+        case EPI_BIAS_GELU: return g.bias ? launch_mid_mt<EPI_BIAS_GELU>(g, stream) : ISST_ERR_ARG;
+        case EPI_RES: return g.res ? launch_mid_mt<EPI_RES>(g, stream) : ISST_ERR_ARG;
+        case EPI_BIAS_RES: return (g.res && g.bias) ? launch_mid_mt<EPI_BIAS_RES>(g, stream) : ISST_ERR_ARG;
+        case EPI_SWIGLU: return (g.N % 32 == 0) ? launch_mid_mt<EPI_SWIGLU>(g, stream) : ISST_ERR_ARG;
+        case EPI_F32: return launch_mid_mt<EPI_F32>(g, stream);
+        case EPI_PARTIAL: return launch_mid_mt<EPI_PARTIAL>(g, stream);
+    }
+    return ISST_ERR_ARG;
+}

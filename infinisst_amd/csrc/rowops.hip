@@ -198,6 +198,70 @@ int launch_rmsnorm(const bf16_t* x, long ldx, const int* rows_idx, const bf16_t*
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
+// split-K epilogue + RMSNorm in one pass (rows > GEMM_FUSED_NORM_MAX_M): x = bf16(x + bf16(sum_s slab[s])) is written
+// back (the residual stream), then normalised as above.  The slab sum runs in slice order: deterministic.
+template <int STEPS>
+__global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int n_slabs, bf16_t* x,
+                                                             long ldx, const bf16_t* __restrict__ w, bf16_t* __restrict__ out, long ldo,
+                                                             int D, float eps) {
+    __shared__ float part[4];
+    const long row = blockIdx.x;
+    bf16_t* xr = x + row * ldx;
+    float v[STEPS][8];
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8;
+        if (c < D) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < n_slabs; ++k) {
+                const float* sp = slabs + (long)k * slab_stride + row * D + c;
+                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), b = *reinterpret_cast<const f32x4_t*>(sp + 4);
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+            }
+            unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + bfr(acc[j]));
+            *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sq += v[s][j] * v[s][j];
+        }
+    }
+    if (!w) return;
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    const float tot = part[0] + part[1] + part[2] + part[3];
+    const float r = rsqrtf(tot / D + eps);
+    bf16_t* orow = out + row * ldo;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8;
+        if (c < D) {
+            float wv[8], y[8];
+            unpack8(*reinterpret_cast<const u32x4_t*>(w + c), wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = wv[j] * bfr(v[s][j] * r);
+            *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
+        }
+    }
+}
+
+// slabs: fp32 [n_slabs][rows][D] (dense rows); x: residual stream, updated in place; w == null: no norm output
+int launch_rmsnorm_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* x, long ldx, const bf16_t* w, bf16_t* out, long ldo,
+                          int rows, int D, float eps, hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    if (D % 8 != 0 || D > 8192 || ldx % 8 != 0 || ldo % 8 != 0 || n_slabs < 1) return ISST_ERR_ARG;
+    if (D <= 2048)
+        hipLaunchKernelGGL(rmsnorm_reduce_kernel<1>, dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);
+    else if (D <= 4096)
+        hipLaunchKernelGGL(rmsnorm_reduce_kernel<2>, dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_reduce_kernel<4>, dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------
 // embedding gather + speech splice (reference model/llm.py:86-113): row r takes the speech feature row
 // src_row[r] >= 0, else the embedding of token ids[r].  One wave per row.

@@ -65,7 +65,7 @@ EXPORTS = [
     "isst_create", "isst_destroy", "isst_last_error", "isst_load_weight", "isst_set_rope_tables",
     "isst_finalize_weights", "isst_stream_open", "isst_stream_reset", "isst_stream_close", "isst_stream_info_get",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_op_pack_weight",
-    "isst_op_packed_elems", "isst_op_gemm", "isst_op_set_gemm_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_set_gemm_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
 ]
 
 
@@ -104,6 +104,8 @@ def load_library(path: Optional[str] = None):
     lib.isst_op_packed_elems.argtypes = [C.c_int, C.c_int]
     lib.isst_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
+    lib.isst_op_gemm_splitk_rmsnorm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
     lib.isst_op_set_gemm_tuning.argtypes = [C.c_int, C.c_int]
     lib.isst_op_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                       C.c_int, C.c_void_p]
@@ -331,6 +333,21 @@ def op_gemm(A: torch.Tensor, packed: torch.Tensor, N: int, epi: str = "none", bi
     if rc:
         raise IsstError(f"isst_op_gemm -> {rc}")
     return out
+
+
+def op_gemm_splitk_rmsnorm(A: torch.Tensor, packed: torch.Tensor, x: torch.Tensor, ksplit: int, norm_w=None, norm_eps: float = 1e-5):
+    """x <- bf16(x + bf16(A @ W^T)) through `ksplit` fp32 K-slabs; returns (x_new, RMSNorm(x_new) or None).  17..64 rows."""
+    lib = load_library()
+    M, K = A.shape
+    N = x.shape[1]
+    x = x.clone()
+    out = torch.empty_like(x) if norm_w is not None else None
+    slabs = torch.empty((ksplit, M, N), dtype=torch.float32, device=A.device)
+    rc = lib.isst_op_gemm_splitk_rmsnorm(_ptr(A), A.stride(0), _ptr(packed), _ptr(x), _ptr(norm_w), _ptr(out), _ptr(slabs), M, N, K,
+                                         ksplit, norm_eps, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_gemm_splitk_rmsnorm -> {rc}")
+    return x, out
 
 
 def op_layernorm(x, w, b, eps=1e-5, gelu=False):

@@ -220,3 +220,61 @@ def test_gemm_tiled_swiglu():
     out = E.op_gemm(A.to(DEV), E.op_pack_weight(inter.to(DEV)), 2 * I, "swiglu")
     gg, uu = bf(A.float() @ Wg.float().t()), bf(A.float() @ Wu.float().t())
     close_bf16(out, torch.nn.functional.silu(gg) * uu, "tiled swiglu", ulps=3, atol=2e-3)
+
+
+@pytest.mark.parametrize("M", [17, 22, 40, 64])
+@pytest.mark.parametrize("wn", [2, 4])
+def test_gemm_mid_rows_both_widths(M, wn):
+    """17..64 rows go through gemm_mid.hip (A staged in LDS); both workgroup widths, every epilogue, ragged N; and the
+    result must agree with the 1..16-row kernel's arithmetic (same products, different fp32 summation order)."""
+    lib = E.load_library()
+    g = torch.Generator().manual_seed(M * 10 + wn)
+    try:
+        for N, K in ((1040, 512), (256, 1024), (48, 128)):
+            A = bf(torch.randn(M, K, generator=g))
+            W = bf(torch.randn(N, K, generator=g) * 0.05)
+            bias = bf(torch.randn(N, generator=g))
+            res = bf(torch.randn(M, N, generator=g))
+            Wp = E.op_pack_weight(W.to(DEV))
+            for epi in ("none", "bias", "bias_gelu", "res", "bias_res", "f32"):
+                kw = dict(bias=bias.to(DEV) if "bias" in epi else None, res=res.to(DEV) if "res" in epi else None)
+                lib.isst_op_set_gemm_tuning(0, wn)
+                out = E.op_gemm(A.to(DEV), Wp, N, epi, **kw)
+                lib.isst_op_set_gemm_tuning(-1, 0)
+                skinny = E.op_gemm(A.to(DEV), Wp, N, epi, **kw)
+                torch.cuda.synchronize()
+                atol = 2e-3 if epi in ("none", "bias", "f32") else 3.2e-2
+                close_bf16(out, ref_linear(A, W, epi, bias, res), f"mid {epi} M{M} N{N} K{K} wn{wn}", ulps=2.5, atol=atol)
+                close_bf16(out, skinny, f"mid vs skinny {epi} M{M} N{N} K{K}", ulps=2.5, atol=atol)
+        # SwiGLU pairs
+        I, K = 512, 256
+        A = bf(torch.randn(M, K, generator=g))
+        Wg, Wu = bf(torch.randn(I, K, generator=g) * 0.1), bf(torch.randn(I, K, generator=g) * 0.1)
+        inter = torch.stack([Wg.view(I // 16, 16, K), Wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K)
+        lib.isst_op_set_gemm_tuning(0, wn)
+        out = E.op_gemm(A.to(DEV), E.op_pack_weight(inter.to(DEV)), 2 * I, "swiglu")
+        ref = torch.nn.functional.silu(bf(A.float() @ Wg.float().t())) * bf(A.float() @ Wu.float().t())
+        close_bf16(out, ref, f"mid swiglu M{M} wn{wn}", ulps=3, atol=2e-3)
+    finally:
+        lib.isst_op_set_gemm_tuning(0, 0)
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(22, 256, 1024, 2), (64, 512, 2048, 4), (33, 256, 4096, 8), (17, 4096, 1024, 1)])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_gemm_splitk_rmsnorm(M, N, K, ks, with_norm):
+    """o_proj / down_proj at 17..64 rows: K split over workgroups into fp32 slabs, reduced by the residual + RMSNorm kernel.
+    Reference = HF LlamaDecoderLayer: hidden = residual + Linear(x) (bf16 each), then LlamaRMSNorm."""
+    g = torch.Generator().manual_seed(M + N + K + ks)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    x = bf(torch.randn(M, N, generator=g))
+    nw = bf(1 + 0.2 * torch.randn(N, generator=g))
+    x_new, normed = E.op_gemm_splitk_rmsnorm(A.to(DEV), E.op_pack_weight(W.to(DEV)), x.to(DEV), ks, nw.to(DEV) if with_norm else None, 1e-5)
+    torch.cuda.synchronize()
+    ref_x = ref_linear(A, W, "res", res=x)
+    close_bf16(x_new, ref_x, f"splitk x M{M} N{N} K{K} S{ks}", ulps=2.5, atol=3.2e-2)
+    if with_norm:
+        # the norm is checked on the kernel's own x (a 1-ulp difference in x is amplified by nothing, but keep it exact)
+        close_bf16(normed, ollm.rmsnorm(x_new.cpu(), nw, 1e-5), f"splitk norm M{M}", ulps=2.0, atol=1e-3)
+    else:
+        assert normed is None
