@@ -318,7 +318,10 @@ def main():
             "dtype": "bf16",
             "data": "synthetic 16 kHz audio clip(0.1*N(0,1)), random-init weights N(0,0.02^2), synthetic prompt ids",
             "config": {"workload": "toy dims (plumbing only)" if args.toy else
-                       "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 1 stream per MI355X (BASELINE.json configs[1])",
+                       ("InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 1 stream per MI355X (BASELINE.json configs[1])"
+                        if args.streams == 1 else
+                        f"InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, {args.streams} streams per MI355X "
+                        "(BASELINE.json configs[2] shape)"),
                        "streams_per_gpu": args.streams, "chunk_ms": 960, "prompt_tokens": 22, "forward_passes_per_chunk": args.gen_tokens,
                        "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "greedy": args.beam == 1, "num_beams": args.beam,
                        "parallelism": f"stream-parallel replicas x{world}, no collective", "evictions_per_stream": loop.evictions // max(1, args.streams)},

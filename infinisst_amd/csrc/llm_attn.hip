@@ -17,7 +17,8 @@
 // cos/sin table (cos[d+64] == cos[d]).  An MFMA k-step covers 32 dims, so the partner of dim d (d +- 64) sits two
 // k-steps away IN THE SAME LANE: the rotation needs no cross-lane traffic.
 //
-// One wave per 16-key tile, 4 waves (64 slots) per workgroup, grid = (slot splits, kv heads, row groups).  A row
+// 4 waves per workgroup, grid = (slot splits, kv heads, row groups); a wave takes every 4th 16-key tile of the workgroup's
+// slot span (one tile at one stream, several with a flash-style running softmax at many streams).  A row
 // group is a run of consecutive query rows of one stream (1 row in a decode step, up to 16/G rows of a prefill);
 // its columns c = (row, head of the kv group) fill the N dimension:
 //   S^T[key][c]  = K_rot[key][:] . Q_rot[c][:]        v_mfma_f32_16x16x32_bf16, A = K tile, B = Q^T
@@ -35,6 +36,7 @@
 #include "kernels.h"
 
 #define HD 128
+#define LLM_ATTN_TARGET_WGS 1536  // workgroups wanted chip-wide before slot spans grow beyond 64
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 // logical position of physical slot t (or -1 for a slot that holds nothing visible)
@@ -71,12 +73,15 @@ __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int
     }
 }
 
-template <int G, int CT>  // G q-heads per kv head, CT column tiles (16 columns each) per workgroup
-__global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
+// MULTI: a wave may take several tiles (running softmax, next tile's keys prefetched); false: exactly one tile per wave,
+// the lean one-stream form (fewer registers, 3 waves per SIMD)
+template <int G, int CT, bool MULTI>  // G q-heads per kv head, CT column tiles (16 columns each) per workgroup
+__global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
                                                                const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
                                                                const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
                                                                const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* vtpool,
-                                                               float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits) {
+                                                               float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
+                                                               int tiles_per_split) {
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
     __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
     const int sp = blockIdx.x, kvh = blockIdx.y;
@@ -92,48 +97,9 @@ __global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __r
     bf16_t* kb = kpool + base;    // [slots][128]
     bf16_t* vt = vtpool + base;   // [128][slots]
     const int total = row_pos[r0 + nrows - 1] + 1;  // keys visible to the last row of the group
-    const int t0 = sp * 64 + wave * 16;             // first physical slot of this wave's tile
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
-
-    // ---- this lane's key as an A-operand row: slot t0 + fr ----
-    const int jk = llm_logical(v, d, t0 + fr, total);
-    const bool k_new = jk >= 0 && jk >= v.new_start;
-    const bf16_t* k_src = k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD
-                                : kb + (long)(t0 + fr) * HD;
-    u32x4_t kraw[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kraw[s] = *reinterpret_cast<const u32x4_t*>(k_src + 32 * s + 8 * fq);
-    // ---- the 4 keys this lane holds in the C layout: slots t0 + 4 fq + r ----
-    int jc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) jc[r] = llm_logical(v, d, t0 + 4 * fq + r, total);
-    const bool tile_live = __any(jk >= 0);
-    const bool tile_has_new = __any(k_new);
-
-    // ---- V^T fragments: B[k = key 4fq + j][n = dim 16 nt + fr] ----
-    u32x2_t vf[8];
-    if (tile_live) {
-        if (!tile_has_new) {
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) vf[nt] = *reinterpret_cast<const u32x2_t*>(vt + (long)(16 * nt + fr) * slots + t0 + 4 * fq);
-        } else {  // mixed tile: some keys still live only in the qkv rows -> scalar gather
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                bf16_t e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int jj = jc[j];
-                    const int dim = 16 * nt + fr;
-                    if (jj >= 0 && jj >= v.new_start)
-                        e[j] = qkv[(long)(v.row0 + (jj - v.new_start)) * ldq + (long)(H + KV + kvh) * HD + dim];
-                    else
-                        e[j] = vt[(long)dim * slots + t0 + 4 * fq + j];
-                }
-                vf[nt].x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
-                vf[nt].y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-            }
-        }
-    }
+    // this wave's 16-slot tiles: tile_begin + wave, + 4, ... below tile_end
+    const int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, slots >> 4);
 
     // ---- rotated query fragments: B[k = dim][n = column c], c = ct*16 + fr -> (row r0 + c / G, head kvh*G + c % G) ----
     u32x4_t qf[CT][4];
@@ -151,13 +117,86 @@ __global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __r
         rope_row_chunks(qraw, cv ? cpos[ct] : 0, fq, rope_cos, rope_sin, qf[ct]);
     }
 
-    float m_col[CT], l_col[CT];
+    // running softmax state of this wave (flash-style, fp32): per column fr its max and sum; O in the C layout
+    float m_run[CT], l_run[CT];
     f32x4_t o[CT][8];
-    if (tile_live) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        m_run[ct] = -INFINITY;
+        l_run[ct] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) o[ct][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // this lane's key of tile t as an A-operand row (slot 16 t + fr): source row (arena, or the qkv rows for keys written by
+    // this launch) and logical position
+    auto key_src = [&](int t, int& jk, bool& k_new) -> const bf16_t* {
+        jk = llm_logical(v, d, t * 16 + fr, total);
+        k_new = jk >= 0 && jk >= v.new_start;
+        return k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : kb + (long)(t * 16 + fr) * HD;
+    };
+    int t = tile_begin + wave;
+    int jk_n = -1;
+    bool knew_n = false;
+    u32x4_t kraw_n[4];
+    auto load_vt = [&](int tt, u32x2_t* dst) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) dst[nt] = *reinterpret_cast<const u32x2_t*>(vt + (long)(16 * nt + fr) * slots + tt * 16 + 4 * fq);
+    };
+    if (t < tile_end) {
+        const bf16_t* src = key_src(t, jk_n, knew_n);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+    }
+    auto tile_body = [&]() {
+        const int t0 = t * 16;
+        const int jk = jk_n;
+        const bool k_new = knew_n;
+        u32x4_t kraw[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kraw[s] = kraw_n[s];
+        u32x2_t vf[8];
+        if (MULTI && t + 4 < tile_end) {  // next tile's keys go in flight before this tile's arithmetic
+            const bf16_t* src = key_src(t + 4, jk_n, knew_n);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+        }
+        const bool tile_live = __any(jk >= 0);
+        if (!tile_live) return;
+        const bool tile_has_new = __any(k_new);
+        // ---- the 4 keys this lane holds in the C layout: slots t0 + 4 fq + r ----
+        int jc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) jc[r] = llm_logical(v, d, t0 + 4 * fq + r, total);
+
+        // ---- V^T fragments: B[k = key 4fq + j][n = dim 16 nt + fr] ----
+        if (!tile_has_new) {
+            load_vt(t, vf);
+        } else {  // mixed tile: some keys still live only in the qkv rows -> scalar gather
+            int slots_o = slots;  // opaque: keeps this rare path's address arithmetic out of the loop preheader (registers)
+            asm volatile("" : "+s"(slots_o));
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                bf16_t e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jj = jc[j];
+                    const int dim = 16 * nt + fr;
+                    if (jj >= 0 && jj >= v.new_start)
+                        e[j] = qkv[(long)(v.row0 + (jj - v.new_start)) * ldq + (long)(H + KV + kvh) * HD + dim];
+                    else
+                        e[j] = vt[(long)dim * slots_o + t0 + 4 * fq + j];
+                }
+                vf[nt].x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+                vf[nt].y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+            }
+        }
         // ---- append this group's own new keys (unrotated K row, V^T column) ----
         if (k_new) {
             const int krow = v.row0 + (jk - v.new_start);
             if (krow >= r0 && krow < r0 + nrows) {
+                int slots_o = slots;
+                asm volatile("" : "+s"(slots_o));
 #pragma unroll
                 for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kraw[s];
                 const bf16_t* vrow = qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD;
@@ -167,7 +206,7 @@ __global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __r
                     const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        vt[(long)(32 * s + 8 * fq + e) * slots + t0 + fr] = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffff));
+                        vt[(long)(32 * s + 8 * fq + e) * slots_o + t0 + fr] = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffff));
                 }
             }
         }
@@ -189,38 +228,48 @@ __global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __r
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
             mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            const float m_new = fmaxf(m_run[ct], mx);
+            // rescale of what this wave has accumulated so far for column fr (1 when the max did not move)
+            const float resc = (m_run[ct] == -INFINITY) ? 0.f : expf(m_run[ct] - m_new);
             float p[4], ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[r] = (sc[r] == -INFINITY) ? 0.f : expf(sc[r] - mx);
+                p[r] = (sc[r] == -INFINITY) ? 0.f : expf(sc[r] - m_new);
                 ls += p[r];
             }
             ls += __shfl_xor(ls, 16, WAVE);
             ls += __shfl_xor(ls, 32, WAVE);
-            m_col[ct] = mx;
-            l_col[ct] = ls;
+            l_run[ct] = l_run[ct] * resc + ls;
+            m_run[ct] = m_new;
+            // O rows are columns 4 fq + r: fetch their factors from the lanes that hold those columns' statistics
+            float rs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs[r] = __shfl(resc, 4 * fq + r, WAVE);
             // P (bf16) in the C layout == A operand of the 16x16x16 product: A[row = column fr][k = key 4fq + j]
             u32x2_t pp;
             pp.x = pack_bf(p[0], p[1]);
             pp.y = pack_bf(p[2], p[3]);
             const s16x4_t pa = __builtin_bit_cast(s16x4_t, pp);
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
-                o[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf[nt]), (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int nt = 0; nt < 8; ++nt) {
+                f32x4_t acc = o[ct][nt];
+                if constexpr (MULTI) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] *= rs[r];
+                }
+                o[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf[nt]), acc, 0, 0, 0);
+            }
         }
+    };
+    if constexpr (MULTI) {
+        for (; t < tile_end; t += 4) tile_body();
     } else {
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            m_col[ct] = -INFINITY;
-            l_col[ct] = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) o[ct][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        }
+        if (t < tile_end) tile_body();
     }
     // ---- the 4 waves' partials meet in LDS.  o[ct][nt][r] is O[column ct*16 + 4fq + r][dim 16nt + fr] ----
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        if (fq == 0) { mS[wave][ct * 16 + fr] = m_col[ct]; lS[wave][ct * 16 + fr] = l_col[ct]; }
+        if (fq == 0) { mS[wave][ct * 16 + fr] = m_run[ct]; lS[wave][ct * 16 + fr] = l_run[ct]; }
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -249,13 +298,13 @@ __global__ __launch_bounds__(256) void llm_attn_partial_kernel(const bf16_t* __r
 
 // Combine of the split partials (a separate launch on purpose, see the header).  All split loads are issued before
 // the first use (fully unrolled, predicated): two memory round trips instead of one per split.
-#define COMBINE_MAX_SPLITS 32
+template <int COMBINE_MAX_SPLITS>  // splits read per trip: 4 (many streams, long spans) or 32 (one stream, 64-slot spans)
 __global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int heads,
                                                                int n_splits) {
     const int h = blockIdx.x, r = blockIdx.y, dd = threadIdx.x;
     const float* src = partial + ((long)r * heads + h) * n_splits * (2 + HD);
     float M = -INFINITY, L = 0.f, O = 0.f;
-    for (int s0 = 0; s0 < n_splits; s0 += COMBINE_MAX_SPLITS) {  // one trip for <= 32 splits (2048 slots)
+    for (int s0 = 0; s0 < n_splits; s0 += COMBINE_MAX_SPLITS) {  // one trip in either configuration (<= 2048 slots)
         float ms[COMBINE_MAX_SPLITS], ls[COMBINE_MAX_SPLITS], os[COMBINE_MAX_SPLITS];
 #pragma unroll
         for (int s = 0; s < COMBINE_MAX_SPLITS; ++s) {
@@ -285,11 +334,15 @@ __global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __re
 template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                     int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
-                    float* partial, LlmAttnDims d, int layer, int n_splits, hipStream_t s) {
+                    float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s) {
     dim3 grid(n_splits, d.kv_heads, n_groups), block(256);
     if (max_group_rows * G > 16) return ISST_ERR_ARG;  // one 16-column tile per workgroup (LLM_ATTN_GROUP_ROWS(G) rows)
-    hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                       vtpool, partial, d, layer, n_splits);
+    if (tiles_per_split > 4)
+        hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, true>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
+                           vtpool, partial, d, layer, n_splits, tiles_per_split);
+    else
+        hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, false>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
+                           vtpool, partial, d, layer, n_splits, tiles_per_split);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
@@ -300,15 +353,25 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     const int slots = d.sys_cap + d.ring_cap;
     if (slots % 64 != 0 || d.sys_cap % 16 != 0) return ISST_ERR_ARG;
     const int G = d.heads / d.kv_heads;
-    const int n_splits = slots / 64;
+    // slot splits: one 64-slot span per workgroup while that fills the chip (one stream: latency), longer spans -- each wave
+    // then loops over several tiles with a running softmax -- once (kv heads x row groups) alone provide the workgroups
+    // (many streams: the per-workgroup prologue, LDS merge and slab traffic are amortised over more keys)
+    const int total_tiles = slots / 16;
+    int n_splits = (LLM_ATTN_TARGET_WGS + d.kv_heads * n_groups - 1) / (d.kv_heads * n_groups);
+    n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
+    const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
+    n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
     int rc;
     switch (G) {
-        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, s); break;
-        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, s); break;
-        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, s); break;
+        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s); break;
+        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s); break;
+        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s); break;
         default: return ISST_ERR_ARG;
     }
     if (rc != ISST_OK) return rc;
-    hipLaunchKernelGGL(llm_attn_combine_kernel, dim3(d.heads, rows), dim3(HD), 0, s, partial, out, d.heads, n_splits);
+    if (n_splits <= 4)
+        hipLaunchKernelGGL(llm_attn_combine_kernel<4>, dim3(d.heads, rows), dim3(HD), 0, s, partial, out, d.heads, n_splits);
+    else
+        hipLaunchKernelGGL(llm_attn_combine_kernel<32>, dim3(d.heads, rows), dim3(HD), 0, s, partial, out, d.heads, n_splits);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
