@@ -14,24 +14,25 @@ from oracle import speech_encoder as oenc
 pytestmark = pytest.mark.gpu
 
 
-def test_latency_multiplier_2_matches_oracle():
-    """m = 2: 96-frame blocks, 24 speech tokens per chunk, max_new_tokens = 20 (reference agents/infinisst.py:125-128,245;
-    model/speech_encoder.py:143-145)."""
+@pytest.mark.parametrize("m", [2, 3, 4])
+def test_latency_multiplier_matches_oracle(m):
+    """m = 2..4: 48 m-frame blocks, 12 m speech tokens per chunk, max_new_tokens = 10 m (reference agents/infinisst.py:125-128,245;
+    model/speech_encoder.py:143-145; the quality-latency curve of infer/infinisst.sh:42-47)."""
     cfg = toy_config()
-    gen = GenConfig(latency_multiplier=2, max_new_tokens=12, max_llm_cache_size=200)
+    gen = GenConfig(latency_multiplier=m, max_new_tokens=12, max_llm_cache_size=400)
     w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=31)
-    eng = Engine(cfg, max_streams=1, max_multiplier=2, max_prompt_len=128, max_new_tokens=20, max_llm_cache_size=200,
+    eng = Engine(cfg, max_streams=1, max_multiplier=m, max_prompt_len=160, max_new_tokens=20, max_llm_cache_size=400,
                  max_system_prompt=64)
     eng.load_weights(w)
     sid = eng.open_stream()
-    n = cfg.chunk_samples * 2
+    n = cfg.chunk_samples * m
     audio = synth.synthetic_audio(n * 3, stream_id=7)
     kv, sc = ollm.new_kv(cfg), oenc.new_cache(cfg)
     rope_l, rope_e = ollm.llm_rope_tables(cfg, 2048, torch.bfloat16), oenc.make_rope(cfg)
     worst = 0.0
     for c in range(3):
         seg = audio[c * n:(c + 1) * n]
-        prompt = synth.chunk_prompt_ids(cfg, 2, first=(c == 0))
+        prompt = synth.chunk_prompt_ids(cfg, m, first=(c == 0))
         x = torch.from_numpy(seg)
         if c == 0:
             x = torch.cat([torch.zeros(cfg.first_chunk_offset), x])
@@ -42,9 +43,9 @@ def test_latency_multiplier_2_matches_oracle():
         for s, rl in enumerate(ref.step_logits):
             worst = max(worst, float(np.abs(logits[0, s] - rl.float().numpy()).max()))
         info = eng.stream_info(sid)
-        assert info["enc_n_steps"] == sc.n_steps == 96 * (c + 1)
+        assert info["enc_n_steps"] == sc.n_steps == 48 * m * (c + 1)
         assert info["llm_cache_len"] == ollm.kv_len(kv)
-    print(f"m=2: worst |logit diff| {worst:.4f}")
+    print(f"m={m}: worst |logit diff| {worst:.4f}")
     assert worst <= 0.15
 
 
