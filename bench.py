@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
+    ap.add_argument("--attn-target-wgs", type=int, default=0, help="profiling aid: isst_op_set_attn_tuning (0 = library default)")
     ap.add_argument("--cpu-layers", type=int, default=32, help="Llama layers actually run by the CPU baseline (time is scaled to all layers)")
     return ap.parse_args()
 
@@ -258,6 +259,9 @@ def main():
     gen = GenConfig(latency_multiplier=1, max_new_tokens=args.gen_tokens, no_repeat_ngram_size=5, no_repeat_ngram_lookback=100,
                     repetition_penalty=1.2, max_llm_cache_size=1000, always_cache_system_prompt=True, beam=args.beam)
     eng, weights, sys_n = build_engine(cfg, args.streams, args.gen_tokens, device, args.beam)
+    if args.attn_target_wgs:
+        from infinisst_amd.engine import load_library
+        load_library().isst_op_set_attn_tuning(args.attn_target_wgs)
     loop = ChunkLoop(eng, cfg, gen, args.streams, sys_n, rank)
 
     def sync_all():

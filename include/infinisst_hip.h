@@ -156,6 +156,8 @@ int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const uint16_t* 
                                 uint16_t* out, float* slabs, int M, int N, int K, int ksplit, float norm_eps, void* hip_stream);
 /* profiling aid: override the GEMM launch heuristic (waves per workgroup, 16-row n-tiles per workgroup); 0 = automatic */
 int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block);
+/* profiling aid: workgroups the decoder attention wants chip-wide before a workgroup's slot span grows beyond 64; 0 = default */
+int isst_op_set_attn_tuning(int target_workgroups);
 int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps,
                       int gelu, void* hip_stream);
 int isst_op_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int rows, int D, float eps, void* hip_stream);

@@ -88,6 +88,7 @@ void gemm_set_tuning(int waves_per_block, int ntiles_per_block);  // 0 = heurist
 bool gemm_tiled_supported(const GemmArgs& g);                      // gemm_tiled.hip: dense shapes (M > 64 or batched)
 int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream);
 bool gemm_mid_supported(const GemmArgs& g);                        // gemm_mid.hip: 17..64 rows, A staged through LDS
+bool gemm_mid_preferred(const GemmArgs& g);                       // ... and long enough a weight stream to pay for the staging
 int launch_gemm_mid(const GemmArgs& g, hipStream_t stream);
 void gemm_mid_set_tuning(int wn);
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,

@@ -685,7 +685,7 @@ int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int e
 int pick_ksplit(int K, int N) {
     (void)N;
     for (int s = K >= 8192 ? 4 : 2; s > 1; s >>= 1)
-        if (K % (128 * s) == 0 && K / (128 * s) >= 4) return s;
+        if (K % (128 * s) == 0 && K / (128 * s) >= 2) return s;
     return 1;
 }
 // slabs[ksplit][M][N] (fp32) = A @ W^T per K slice; reduced by launch_rmsnorm_reduce
@@ -1406,6 +1406,10 @@ extern "C" int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const
 }
 extern "C" int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block) {
     gemm_set_tuning(waves_per_block, ntiles_per_block);
+    return ISST_OK;
+}
+extern "C" int isst_op_set_attn_tuning(int target_workgroups) {
+    llm_attn_set_tuning(target_workgroups);
     return ISST_OK;
 }
 extern "C" int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps, int gelu,

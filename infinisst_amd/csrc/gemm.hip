@@ -336,7 +336,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
         if (!ok || ((g.epi == EPI_RES || g.epi == EPI_BIAS_RES) && !g.res) || (g.epi == EPI_SWIGLU && g.N % 32)) return ISST_ERR_ARG;
         return launch_gemm_tiled(g, stream);
     }
-    if (gemm_mid_supported(g) && !g_force_skinny) {
+    if (gemm_mid_supported(g) && gemm_mid_preferred(g) && !g_force_skinny) {
         if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return ISST_ERR_ARG;
         return launch_gemm_mid(g, stream);
     }

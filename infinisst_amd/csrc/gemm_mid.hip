@@ -183,6 +183,9 @@ bool gemm_mid_supported(const GemmArgs& g) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     return g.batch == 1 && g.M > 16 && g.M <= 64 && g.K % (MID_CK * ks) == 0 && g.N % 16 == 0 && g.lda % 8 == 0 && !g.norm_w;
 }
+// worth it only when the weight stream is long: the encoder's 2-8 MB projections at 48 rows are latency-bound and run
+// faster on the skinny kernel's many 16-column workgroups (11.2 vs 14.9 us for fc2)
+bool gemm_mid_preferred(const GemmArgs& g) { return g.ksplit > 1 || g.epi == EPI_PARTIAL || (long)g.N * g.K >= (8L << 20) || g_mid_wn != 0; }
 
 template <int MT, int NP, int EPI>
 static int launch_mid_cfg(const GemmArgs& g, hipStream_t stream) {

@@ -49,6 +49,7 @@ struct LlmAttnDims {
 // row count): runs of consecutive rows of ONE stream, at most LLM_ATTN_GROUP_ROWS(G) rows each.
 // partial: [rows][heads][slots/64][2 + 128] fp32.
 #define LLM_ATTN_GROUP_ROWS(G) (16 / (G))
+void llm_attn_set_tuning(int target_wgs);  // workgroups wanted before slot spans grow beyond 64 (0 = default)
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s);

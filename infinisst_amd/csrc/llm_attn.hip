@@ -331,6 +331,9 @@ __global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __re
     out[((long)r * heads + h) * HD + dd] = f2bf(O / L);
 }
 
+static int g_attn_target_wgs = 0;  // profiling aid (isst_op_set_attn_tuning): 0 = LLM_ATTN_TARGET_WGS
+void llm_attn_set_tuning(int target_wgs) { g_attn_target_wgs = target_wgs; }
+
 template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                     int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
@@ -357,7 +360,8 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     // then loops over several tiles with a running softmax -- once (kv heads x row groups) alone provide the workgroups
     // (many streams: the per-workgroup prologue, LDS merge and slab traffic are amortised over more keys)
     const int total_tiles = slots / 16;
-    int n_splits = (LLM_ATTN_TARGET_WGS + d.kv_heads * n_groups - 1) / (d.kv_heads * n_groups);
+    const int target = g_attn_target_wgs > 0 ? g_attn_target_wgs : LLM_ATTN_TARGET_WGS;
+    int n_splits = (target + d.kv_heads * n_groups - 1) / (d.kv_heads * n_groups);
     n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
     const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
     n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
