@@ -138,47 +138,50 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
 
     bf16_t* xs = reinterpret_cast<bf16_t*>(red + (long)W * (MT * NTB * 256));  // [M][K] staged rows (AMODE >= 1)
     if constexpr (AMODE >= 1) {
-        float* part = reinterpret_cast<float*>(xs + (long)g.M * g.K);  // [W][16] partial sums, [16] rstd behind them
-        const int nthr = blockDim.x;
-        for (int rr = 0; rr < g.M; ++rr) {
-            const bf16_t* xr = A + (long)(m0 + rr) * g.lda;
+        // rows are staged (and normalised) side by side: each row gets wpr = max(1, W / M) waves, W / wpr rows per round
+        // (one stream: 1 row on all waves; beam search: 4 rows, one wave each, one round)
+        float* part = reinterpret_cast<float*>(xs + (long)g.M * g.K);  // [W] partial sums of squares
+        const int wpr = (W >= g.M) ? W / g.M : 1;   // waves per row
+        const int rpr = W / wpr;                     // rows per round
+        const int my_slot = wave / wpr, my_sub = wave % wpr;
+        for (int r0 = 0; r0 < g.M; r0 += rpr) {
+            const int rr = r0 + my_slot;
+            const bool active = my_slot < rpr && rr < g.M;
             float sq = 0.f;
-            for (int c = threadIdx.x * 8; c < g.K; c += nthr * 8) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(xr + c);
-                *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = v;
-                if constexpr (AMODE == 2) {
-                    float f[8];
-                    unpack8(v, f);
+            if (active) {
+                const bf16_t* xr = A + (long)(m0 + rr) * g.lda;
+                for (int c = (my_sub * 64 + lane) * 8; c < g.K; c += wpr * 512) {
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(xr + c);
+                    *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = v;
+                    if constexpr (AMODE == 2) {
+                        float f[8];
+                        unpack8(v, f);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) sq += f[q] * f[q];
+                        for (int q = 0; q < 8; ++q) sq += f[q] * f[q];
+                    }
                 }
             }
             if constexpr (AMODE == 2) {
                 sq = wave_sum(sq);
-                if (lane == 0) part[wave * 16 + rr] = sq;
-            }
-        }
-        __syncthreads();
-        if constexpr (AMODE == 2) {
-            if ((int)threadIdx.x < g.M) {
-                float t = 0.f;
-                for (int w2 = 0; w2 < W; ++w2) t += part[w2 * 16 + threadIdx.x];
-                part[W * 16 + threadIdx.x] = rsqrtf(t / g.K + g.norm_eps);
-            }
-            __syncthreads();
-            for (int rr = 0; rr < g.M; ++rr) {
-                const float rs = part[W * 16 + rr];
-                for (int c = threadIdx.x * 8; c < g.K; c += nthr * 8) {  // every thread rewrites the chunks it staged
-                    float f[8], nw[8];
-                    unpack8(*reinterpret_cast<const u32x4_t*>(xs + (long)rr * g.K + c), f);
-                    unpack8(*reinterpret_cast<const u32x4_t*>(g.norm_w + c), nw);
+                if (lane == 0) part[wave] = sq;
+                __syncthreads();
+                if (active) {
+                    float t = 0.f;
+                    for (int w2 = 0; w2 < wpr; ++w2) t += part[my_slot * wpr + w2];
+                    const float rs = rsqrtf(t / g.K + g.norm_eps);
+                    for (int c = (my_sub * 64 + lane) * 8; c < g.K; c += wpr * 512) {  // every lane rewrites the chunks it staged
+                        float f[8], nw[8];
+                        unpack8(*reinterpret_cast<const u32x4_t*>(xs + (long)rr * g.K + c), f);
+                        unpack8(*reinterpret_cast<const u32x4_t*>(g.norm_w + c), nw);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) f[q] = nw[q] * bfr(f[q] * rs);
-                    *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = pack8(f);
+                        for (int q = 0; q < 8; ++q) f[q] = nw[q] * bfr(f[q] * rs);
+                        *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = pack8(f);
+                    }
                 }
+                __syncthreads();  // part[] is reused by the next round; the last one publishes the rows
             }
-            __syncthreads();
         }
+        if constexpr (AMODE == 1) __syncthreads();
     }
 
     for (int kt0 = wave; kt0 < KT; kt0 += W * UNR) {
