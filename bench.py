@@ -124,10 +124,17 @@ class ChunkLoop:
         self.c += 1
 
 
-def gemm_roofline(cfg, device, iters=40):
-    """Dominant kernel: gemm_skinny_kernel streaming the gate/up projection of one Llama layer for one token
-    (M=1, N=2*ffn, K=dim, SwiGLU epilogue) -- 235 MB of weights per launch at full size.  Enough distinct weight
-    copies are cycled that no launch finds its weights in the 256 MiB Infinity Cache."""
+def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
+    """Dominant kernel: gemm_skinny_kernel streaming the gate/up projection of one Llama layer for one token (M=1, N=2*ffn,
+    K=dim, fused RMSNorm prologue, SwiGLU epilogue) -- 235 MB of weights per launch at full size, 32 % of the chunk's kernel
+    time.  Two live measurements with HIP events on the launch stream:
+      * `launch_us` (-> achieved): one event pair around `iters` back-to-back launches of exactly that kernel, cycling enough
+        distinct weight copies that no launch finds its weights in the 256 MiB Infinity Cache -- launches pipeline, so this is
+        the kernel's duration, the figure rocprofv3 --kernel-trace reports for it (profiles/);
+      * `in_situ_event_bracket_us`: `chunks` more steps of the loop that was just timed, with an event pair around EVERY
+        decode-pass launch of the kernel inside isst_generate (isst_profile_begin / _end, 288 launches per chunk); a bracket
+        also contains that launch's dispatch latency (~2.5 us), which no kernel-duration figure includes.
+    Neither runs inside the timed region (event records would perturb it)."""
     from infinisst_amd import engine as E
     N, K = 2 * cfg.llm_ffn, cfg.llm_dim
     w_bytes = N * K * 2
@@ -151,6 +158,13 @@ def gemm_roofline(cfg, device, iters=40):
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / iters
+    del packs
+    in_situ, launches = None, 0
+    if loop is not None and eng is not None:
+        eng.profile_begin()
+        for _ in range(chunks):
+            loop.step()
+        in_situ, launches = eng.profile_end()
     algo_bytes = w_bytes + K * 2 + (N // 2) * 2  # weights once + activation row in + bf16 row out
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 --pmc)
@@ -162,6 +176,7 @@ def gemm_roofline(cfg, device, iters=40):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "gemm_skinny_kernel<1,2,EPI_SWIGLU,nt,AMODE=2> (gate/up GEMV with fused RMSNorm)",
             "launch_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": algo_bytes,
+            "in_situ_event_bracket_us": None if in_situ is None else round(in_situ, 2), "in_situ_launches": launches,
             "shape": f"M=1 N={N} K={K} (gate/up of one layer, one token)"}
 
 
@@ -295,8 +310,9 @@ def main():
     base = None
     if rank == 0:
         if not args.no_roofline:
-            roof = gemm_roofline(cfg, device)
-            log(f"roofline probe done: {roof['achieved']} GB/s")
+            in_situ = args.streams == 1 and args.beam == 1
+            roof = gemm_roofline(cfg, device, loop if in_situ else None, eng if in_situ else None)
+            log(f"roofline probe done: {roof['achieved']} GB/s, in-situ bracket {roof['in_situ_event_bracket_us']} us")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 base = cpu_baseline(cfg, gen, weights, sys_n, args.cpu_threads, args.cpu_layers)

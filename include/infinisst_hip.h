@@ -134,6 +134,11 @@ int isst_encode_speech(isst_handle* h, int stream_id, const float* pcm, int n_sa
 /* copy of an intermediate activation of the last call (needs cfg.debug_taps): names "conv_out", "post_proj",
  * "enc_layer_<i>", "enc_out", "shrink", "speech", "llm_embed", "llm_layer_<i>", "llm_final". bf16 bits. */
 int isst_debug_tap(isst_handle* h, const char* name, uint16_t* dst, int64_t max_elems, int64_t* got_elems);
+/* In-situ timing of the dominant kernel for the roofline (bench.py): between _begin and _end every one-token gate/up GEMV
+ * of isst_generate is bracketed by a HIP event pair on the caller's stream; _end synchronises `hip_stream` and returns the
+ * average bracket in microseconds (kernel execution + the dispatch latency of that launch) and the number of launches. */
+int isst_profile_begin(isst_handle* h);
+int isst_profile_end(isst_handle* h, void* hip_stream, double* avg_us, int64_t* launches);
 
 /* unrotated K and V (128 bf16 each) of logical position `pos`, kv head `kv_head`, layer `layer` in the arena of beam
  * `beam` of a stream (beam 0 for greedy streams).  Test aid for the KV ring / beam bookkeeping. */

@@ -78,6 +78,11 @@ struct isst_handle {
     std::vector<std::string> expected;
     bool finalized = false, rope_set = false;
 
+    // in-situ timing of the dominant kernel (isst_profile_begin / _end): HIP event pairs around every decode-pass gate/up GEMV
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
+    size_t prof_used = 0;
+
     // geometry
     int hist = 0;           // receptive field - 1 samples of audio history (399)
     int samples_per_frame = 0, chunk_samples = 0, shrink_factor = 1;
@@ -275,6 +280,7 @@ extern "C" void isst_destroy(isst_handle* h) {
     if (h->tok_host) (void)hipHostFree(h->tok_host);
     if (h->top_val_host) (void)hipHostFree(h->top_val_host);
     if (h->top_idx_host) (void)hipHostFree(h->top_idx_host);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -879,7 +885,22 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         } else {
             CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
             if (fuse) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (h->prof_on && rows == 1) {  // the roofline kernel: one-token gate/up GEMV with the fused RMSNorm
+                    if (h->prof_used + 2 > h->prof_ev.size()) {
+                        for (int k = 0; k < 2; ++k) {
+                            hipEvent_t e;
+                            HIPCHK(hipEventCreate(&e));
+                            h->prof_ev.push_back(e);
+                        }
+                    }
+                    e0 = h->prof_ev[h->prof_used];
+                    e1 = h->prof_ev[h->prof_used + 1];
+                    h->prof_used += 2;
+                    HIPCHK(hipEventRecord(e0, st));
+                }
                 CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
+                if (e1) HIPCHK(hipEventRecord(e1, st));
             } else {
                 CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
                 CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
@@ -1410,6 +1431,26 @@ extern "C" int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const
 }
 extern "C" int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block) {
     gemm_set_tuning(waves_per_block, ntiles_per_block);
+    return ISST_OK;
+}
+extern "C" int isst_profile_begin(isst_handle* h) {
+    if (!h) return ISST_ERR_ARG;
+    h->prof_on = true;
+    h->prof_used = 0;
+    return ISST_OK;
+}
+extern "C" int isst_profile_end(isst_handle* h, void* hip_stream, double* avg_us, int64_t* launches) {
+    if (!h || !avg_us || !launches) return ISST_ERR_ARG;
+    h->prof_on = false;
+    HIPCHK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+        sum += ms * 1e3;
+    }
+    *launches = (int64_t)(h->prof_used / 2);
+    *avg_us = *launches ? sum / *launches : 0.0;
     return ISST_OK;
 }
 extern "C" int isst_op_set_attn_tuning(int target_workgroups) {

@@ -64,7 +64,7 @@ class _StreamInfo(C.Structure):
 EXPORTS = [
     "isst_create", "isst_destroy", "isst_last_error", "isst_load_weight", "isst_set_rope_tables",
     "isst_finalize_weights", "isst_stream_open", "isst_stream_reset", "isst_stream_close", "isst_stream_info_get",
-    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_op_pack_weight",
+    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_end", "isst_op_pack_weight",
     "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
 ]
 
@@ -100,6 +100,8 @@ def load_library(path: Optional[str] = None):
                                        C.POINTER(C.c_int), C.c_void_p]
     lib.isst_debug_tap.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     lib.isst_debug_read_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.isst_profile_begin.argtypes = [C.c_void_p]
+    lib.isst_profile_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.isst_op_pack_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.isst_op_packed_elems.argtypes = [C.c_int, C.c_int]
     lib.isst_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -298,6 +300,15 @@ class Engine:
         v = torch.empty(128, dtype=torch.bfloat16)
         self._check(self.lib.isst_debug_read_kv(self.h, sid, beam, layer, kv_head, pos, k.data_ptr(), v.data_ptr()), "isst_debug_read_kv")
         return k, v
+
+    def profile_begin(self):
+        self._check(self.lib.isst_profile_begin(self.h), "isst_profile_begin")
+
+    def profile_end(self):
+        """(average event bracket in us around the one-token gate/up GEMV, launches timed) since profile_begin."""
+        avg, n = C.c_double(0.0), C.c_int64(0)
+        self._check(self.lib.isst_profile_end(self.h, _stream_ptr(), C.byref(avg), C.byref(n)), "isst_profile_end")
+        return avg.value, n.value
 
     def debug_tap(self, name: str) -> torch.Tensor:
         got = C.c_int64(0)
