@@ -258,7 +258,7 @@ int launch_enc_attention(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long s
                          bf16_t* out, int n_streams, int Q, int heads, int cap, int max_cache, int blocksize, hipStream_t s) {
     if (Q <= 0 || n_streams <= 0) return ISST_OK;
     if (Q % 16 != 0 || cap % 64 != 0 || cap > 1024 || max_cache + Q > cap) return ISST_ERR_ARG;
-    const int QT = (Q % 48 == 0) ? 3 : 1;
+    const int QT = (Q % 48 == 0 && n_streams * (Q / 16) * heads >= 1024) ? 3 : 1;  // few streams: 16-row query blocks give 3x the workgroups (the K rotation is redone per block)
     const size_t lds = (size_t)QT * 16 * (cap + ENC_SPAD) * 2 + (size_t)QT * 16 * ENC_HD * sizeof(float);
     dim3 grid(heads, Q / (QT * 16), n_streams), block(ENC_WAVES * 64);
     static size_t lds_set[2] = {0, 0};
