@@ -27,3 +27,7 @@ bench("prefill qkv x64", 1408, 6144, 4096)
 bench("prefill gateup x64", 1408, 28672, 4096, "swiglu")
 bench("prefill down x64", 1408, 4096, 14336)
 bench("encoder fc1 x64", 3072, 4096, 1024)
+# the conv feature extractor's implicit GEMMs at one stream (wav2vec2-large: 512 channels; k3 s2 x4, k2 s2 x2)
+for name, M, K, lda in (("conv1", 1574, 1536, 1024), ("conv2", 786, 1536, 1024), ("conv3", 392, 1536, 1024), ("conv4", 195, 1536, 1024),
+                        ("conv5", 97, 1024, 1024), ("conv6", 48, 1024, 1024)):
+    bench(name, M, 512, K, lda=lda)
