@@ -296,198 +296,6 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     }
 }
 
-// Span form for many streams: a wave takes several 16-key tiles of the workgroup's slot span, in TWO passes so that neither
-// pass needs the other's registers (<= 128 VGPRs -> 4 waves per SIMD, against 250 VGPRs / 2 waves for a one-pass running
-// softmax, which cannot hide HBM latency with a one-tile prefetch):
-//   pass 1  K tile (next tile prefetched) -> RoPE -> S^T = K.Q^T -> masked, scaled scores to LDS, per-column maximum;
-//   pass 2  scores from LDS -> P = exp(S - max) -> O += P V (next tile's V^T prefetched); no rescaling, the maximum is final.
-// Decode steps only (one row per group, whose own key is the only key of this launch): that key's K comes from the qkv row by
-// pointer select and its V is patched into the one fragment that holds it.  Everything else (operand layouts, the LDS merge
-// of the 4 waves, the slab) is the single-tile kernel's.
-#define SPAN_MAX_TPW 8  // tiles per wave the score buffer is sized for
-template <int G>
-__global__ __launch_bounds__(256, 3) void llm_attn_span_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
-                                                                const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
-                                                                const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
-                                                                const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* vtpool,
-                                                                float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
-                                                                int tiles_per_split) {
-    // scores [4 waves][tpw][64 lanes] x float4 during the passes; afterwards the merge buffers m[4][16], l[4][16], o[4][16][HD+4]
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int sp = blockIdx.x, kvh = blockIdx.y;
-    const int2 grp = groups[blockIdx.z];
-    const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
-    const LlmStreamView v = sv[row_stream[r0]];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int H = d.heads, KV = d.kv_heads;
-    const long ldq = (long)(H + 2 * KV) * HD;
-    const int slots = d.sys_cap + d.ring_cap;
-    const long base = v.kv_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
-    bf16_t* kb = kpool + base;    // [slots][128]
-    bf16_t* vt = vtpool + base;   // [128][slots]
-    const int total = row_pos[r0 + nrows - 1] + 1;
-    const float scale = 0.08838834764831845f;
-    const int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, slots >> 4);
-    const int tpw = tiles_per_split >> 2;
-    f32x4_t* S = reinterpret_cast<f32x4_t*>(smem) + (long)wave * tpw * 64 + lane;  // this lane's score slot of tile i: S[i * 64]
-
-    const int c = fr;
-    const bool cv = c < ncols;
-    const int cpos = cv ? row_pos[r0 + c / G] : -1;
-    float m_w = -INFINITY;
-    {   // ---- pass 1 ----
-        u32x4_t qf[4];
-        {
-            const bf16_t* qh = qkv + (long)(r0 + (cv ? c / G : 0)) * ldq + (long)(kvh * G + (cv ? c % G : 0)) * HD;
-            u32x4_t qraw[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) qraw[s] = *reinterpret_cast<const u32x4_t*>(qh + 32 * s + 8 * fq);
-            rope_row_chunks(qraw, cv ? cpos : 0, fq, rope_cos, rope_sin, qf);
-        }
-        auto key_src = [&](int t, int& jk, bool& k_new) -> const bf16_t* {
-            jk = llm_logical(v, d, t * 16 + fr, total);
-            k_new = jk >= 0 && jk >= v.new_start;
-            return k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : kb + (long)(t * 16 + fr) * HD;
-        };
-        int t = tile_begin + wave, jk_n = -1;
-        bool knew_n = false;
-        u32x4_t kraw_n[4];
-        if (t < tile_end) {
-            const bf16_t* src = key_src(t, jk_n, knew_n);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-        }
-        for (int i = 0; t < tile_end; t += 4, ++i) {
-            const int t0 = t * 16;
-            const int jk = jk_n;
-            const bool k_new = knew_n;
-            u32x4_t kraw[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) kraw[s] = kraw_n[s];
-            if (t + 4 < tile_end) {
-                const bf16_t* src = key_src(t + 4, jk_n, knew_n);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-            }
-            f32x4_t sc = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (__any(jk >= 0)) {
-                if (k_new) {  // append the unrotated K row of this group's own new keys
-                    const int krow = v.row0 + (jk - v.new_start);
-                    if (krow >= r0 && krow < r0 + nrows) {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kraw[s];
-                    }
-                }
-                u32x4_t kf[4];
-                rope_row_chunks(kraw, jk >= 0 ? jk : 0, fq, rope_cos, rope_sin, kf);
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[s]), __builtin_bit_cast(bf16x8_t, qf[s]), st, 0, 0, 0);
-                float mx = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jc = llm_logical(v, d, t0 + 4 * fq + r, total);
-                    const bool ok = jc >= 0 && jc <= cpos;
-                    sc[r] = ok ? st[r] * scale : -INFINITY;
-                    mx = fmaxf(mx, sc[r]);
-                }
-                m_w = fmaxf(m_w, mx);
-            }
-            S[i * 64] = sc;
-        }
-        m_w = fmaxf(m_w, __shfl_xor(m_w, 16, WAVE));
-        m_w = fmaxf(m_w, __shfl_xor(m_w, 32, WAVE));
-    }
-    float l_w = 0.f;
-    f32x4_t o[8];
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) o[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    {   // ---- pass 2 ----
-        auto load_vt = [&](int tt, u32x2_t* dst) {
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) dst[nt] = *reinterpret_cast<const u32x2_t*>(vt + (long)(16 * nt + fr) * slots + tt * 16 + 4 * fq);
-        };
-        // decode step: exactly one key of this launch is visible, the row's own (logical position total - 1)
-        const int jn = total - 1;
-        const int p_new = jn < v.sys_len ? jn : d.sys_cap + (v.ring_start + jn - v.sys_len) % d.ring_cap;
-        const int tile_new = p_new >> 4;
-        int t = tile_begin + wave;
-        u32x2_t vf_n[8];
-        if (t < tile_end) load_vt(t, vf_n);
-        for (int i = 0; t < tile_end; t += 4, ++i) {
-            u32x2_t vf[8];
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) vf[nt] = vf_n[nt];
-            if (t + 4 < tile_end) load_vt(t + 4, vf_n);
-            const f32x4_t sc = S[i * 64];
-            if (t == tile_new) {  // uniform: the row's own key sits in this tile; its V still lives in the qkv row only
-                const int kk = p_new & 15;
-                int r0_o = r0, slots_o = slots;  // opaque: keeps this once-per-workgroup path's address arithmetic out of the loop preheader
-                asm volatile("" : "+s"(r0_o), "+s"(slots_o));
-                const bf16_t* vrow = qkv + (long)r0_o * ldq + (long)(H + KV + kvh) * HD;
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    const uint32_t val = vrow[16 * nt + fr];
-                    if (fq == (kk >> 2)) {
-                        uint32_t w = (kk & 2) ? vf[nt].y : vf[nt].x;
-                        w = (kk & 1) ? ((w & 0x0000ffffu) | (val << 16)) : ((w & 0xffff0000u) | val);
-                        if (kk & 2) vf[nt].y = w; else vf[nt].x = w;
-                    }
-                }
-                // append its V^T column: 128 dims over 64 lanes
-                vt[(long)lane * slots_o + p_new] = vrow[lane];
-                vt[(long)(lane + 64) * slots_o + p_new] = vrow[lane + 64];
-            }
-            float p[4], ls = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = (sc[r] == -INFINITY) ? 0.f : expf(sc[r] - m_w);
-                ls += p[r];
-            }
-            l_w += ls;
-            u32x2_t pp;
-            pp.x = pack_bf(p[0], p[1]);
-            pp.y = pack_bf(p[2], p[3]);
-            const s16x4_t pa = __builtin_bit_cast(s16x4_t, pp);
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf[nt]), o[nt], 0, 0, 0);
-        }
-        l_w += __shfl_xor(l_w, 16, WAVE);
-        l_w += __shfl_xor(l_w, 32, WAVE);
-    }
-    __syncthreads();  // every wave is done with its scores: the buffer becomes the merge area
-    float* mS = smem;                 // [4][16]
-    float* lS = smem + 64;            // [4][16]
-    float* oS = smem + 128;           // [4][16][HD + 4]
-    if (fq == 0) { mS[wave * 16 + fr] = m_w; lS[wave * 16 + fr] = l_w; }
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oS[((long)wave * 16 + 4 * fq + r) * (HD + 4) + 16 * nt + fr] = o[nt][r];
-    __syncthreads();
-    for (int e = tid; e < ncols * HD; e += 256) {
-        const int cc = e / HD, dd = e % HD;
-        float M = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) M = fmaxf(M, mS[w * 16 + cc]);
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float mw = mS[w * 16 + cc];
-            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
-            L += lS[w * 16 + cc] * f;
-            O += oS[((long)w * 16 + cc) * (HD + 4) + dd] * f;
-        }
-        const int row = r0 + cc / G, head = kvh * G + cc % G;
-        float* dst = partial + (((long)row * H + head) * n_splits + sp) * (2 + HD);
-        if (dd == 0) { dst[0] = M; dst[1] = L; }
-        dst[2 + dd] = O;
-    }
-}
-
 // Combine of the split partials (a separate launch on purpose, see the header).  All split loads are issued before
 // the first use (fully unrolled, predicated): two memory round trips instead of one per split.
 template <int COMBINE_MAX_SPLITS>  // splits read per trip: 4 (many streams, long spans) or 32 (one stream, 64-slot spans)
@@ -532,11 +340,7 @@ static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos
                     float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s) {
     dim3 grid(n_splits, d.kv_heads, n_groups), block(256);
     if (max_group_rows * G > 16) return ISST_ERR_ARG;  // one 16-column tile per workgroup (LLM_ATTN_GROUP_ROWS(G) rows)
-    if (tiles_per_split > 4 && max_group_rows == 1) {
-        const size_t merge = (128 + 4 * 16 * (HD + 4)) * sizeof(float), scores = (size_t)tiles_per_split * 64 * 16;  // 4 waves x tpw x 1 KiB
-        hipLaunchKernelGGL((llm_attn_span_kernel<G>), grid, block, merge > scores ? merge : scores, s, qkv, row_stream, row_pos, sv, groups, rope_cos,
-                           rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split);
-    } else if (tiles_per_split > 4)
+    if (tiles_per_split > 4)
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, true>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
                            vtpool, partial, d, layer, n_splits, tiles_per_split);
     else
@@ -559,8 +363,7 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     const int target = g_attn_target_wgs > 0 ? g_attn_target_wgs : LLM_ATTN_TARGET_WGS;
     int n_splits = (target + d.kv_heads * n_groups - 1) / (d.kv_heads * n_groups);
     n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
-    int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
-    if (tiles_per_split > 4 * SPAN_MAX_TPW) tiles_per_split = 4 * SPAN_MAX_TPW;  // score buffer of the span kernel
+    const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
     n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
     int rc;
     switch (G) {
