@@ -847,9 +847,22 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
 
 // one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
 int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_groups, int max_group_rows, bool splice, const char* tap_prefix,
-                hipStream_t st) {
+                hipStream_t st, const StepMeta* hm = nullptr) {
     const isst_config& c = h->cfg;
     const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
+    // one group (one stream's decode step): its metadata travels in the kernel arguments (llm_attn.hip LlmAttnOne)
+    LlmAttnOne one{};
+    if (hm && n_groups == 1) {
+        const int2 g0 = hm->groups[0];
+        bool consecutive = true;
+        for (int k = 1; k < g0.y; ++k) consecutive = consecutive && hm->row_pos[g0.x + k] == hm->row_pos[g0.x] + k;
+        if (consecutive) {
+            one.enabled = 1;
+            one.grp = g0;
+            one.pos0 = hm->row_pos[g0.x];
+            one.v = hm->views[hm->row_stream[g0.x]];
+        }
+    }
     CHK(launch_embed_splice(d.ids, splice ? d.speech_row : nullptr, h->embed, h->speech, h->lx, rows, DL, st));
     if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "embed", h->lx, (int64_t)rows * DL, st));
     // 17..64 rows (one stream's prefill, a 64-stream decode pass): o_proj and down_proj split K over workgroups and the
@@ -877,7 +890,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
         }
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
-                                 h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st));
+                                 h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one));
         if (so > 1) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
             CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
@@ -1160,7 +1173,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
             }
         }
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-        CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st));
+        CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st, &mh));
     }
 
     // ---- finalize (:159-275): open beams become hypotheses, the best one wins ----
@@ -1335,7 +1348,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         HIPCHK(hipMemcpyAsync(h->meta_dev + mh.suppress_offset, h->meta_host + mh.suppress_offset, (size_t)p->n_suppress * 4, hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-    CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st));
+    CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh));
     if (B > 1)
         return beam_decode(h, p, n, stream_ids, prompt_ids, prompt_lens, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);
 
@@ -1388,7 +1401,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             mh.samp[r].ids_off = i * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
         }
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-        CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st));
+        CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st, &mh));
     }
     // ---- 4. state: the cache holds the prompt and every generated token except the last one ----
     for (int i = 0; i < n; ++i) {

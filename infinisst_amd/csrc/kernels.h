@@ -50,9 +50,18 @@ struct LlmAttnDims {
 // partial: [rows][heads][slots/64][2 + 128] fp32.
 #define LLM_ATTN_GROUP_ROWS(G) (16 / (G))
 void llm_attn_set_tuning(int target_wgs);  // workgroups wanted before slot spans grow beyond 64 (0 = default)
+// Launch metadata of a ONE-group launch (one stream's decode step or short prefill) passed by value in the kernel arguments:
+// the workgroups then start their key loads at once instead of after three dependent loads (groups -> row_stream/row_pos ->
+// stream view); with one stream the attention kernel is nothing but such a chain of round trips.
+struct LlmAttnOne {
+    int enabled;
+    int2 grp;        // (first row, row count)
+    int pos0;        // position of the first row; the rows of a group are consecutive positions
+    LlmStreamView v;
+};
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
-                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s);
+                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one = nullptr);
 
 // ---- sampling (sample.hip) ----
 struct SampleStream {

@@ -81,13 +81,13 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
                                                                const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
                                                                const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* vtpool,
                                                                float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
-                                                               int tiles_per_split) {
+                                                               int tiles_per_split, LlmAttnOne one) {
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
     __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
     const int sp = blockIdx.x, kvh = blockIdx.y;
-    const int2 grp = groups[blockIdx.z];
+    const int2 grp = one.enabled ? one.grp : groups[blockIdx.z];
     const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
-    const LlmStreamView v = sv[row_stream[r0]];
+    const LlmStreamView v = one.enabled ? one.v : sv[row_stream[r0]];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int H = d.heads, KV = d.kv_heads;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     const long base = v.kv_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
     bf16_t* kb = kpool + base;    // [slots][128]
     bf16_t* vt = vtpool + base;   // [128][slots]
-    const int total = row_pos[r0 + nrows - 1] + 1;  // keys visible to the last row of the group
+    const int total = (one.enabled ? one.pos0 + nrows - 1 : row_pos[r0 + nrows - 1]) + 1;  // keys visible to the last row of the group
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
     // this wave's 16-slot tiles: tile_begin + wave, + 4, ... below tile_end
     const int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, slots >> 4);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         const int c = ct * 16 + fr;
         const bool cv = c < ncols;
         const int row = r0 + (cv ? c / G : 0);
-        cpos[ct] = cv ? row_pos[row] : -1;
+        cpos[ct] = cv ? (one.enabled ? one.pos0 + (row - r0) : row_pos[row]) : -1;
         const bf16_t* qh = qkv + (long)row * ldq + (long)(kvh * G + (cv ? c % G : 0)) * HD;
         u32x4_t qraw[4];
 #pragma unroll
@@ -337,22 +337,24 @@ void llm_attn_set_tuning(int target_wgs) { g_attn_target_wgs = target_wgs; }
 template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                     int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
-                    float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s) {
+                    float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s, const LlmAttnOne& one) {
     dim3 grid(n_splits, d.kv_heads, n_groups), block(256);
     if (max_group_rows * G > 16) return ISST_ERR_ARG;  // one 16-column tile per workgroup (LLM_ATTN_GROUP_ROWS(G) rows)
     if (tiles_per_split > 4)
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, true>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           vtpool, partial, d, layer, n_splits, tiles_per_split);
+                           vtpool, partial, d, layer, n_splits, tiles_per_split, one);
     else
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, false>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           vtpool, partial, d, layer, n_splits, tiles_per_split);
+                           vtpool, partial, d, layer, n_splits, tiles_per_split, one);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
-                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s) {
+                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one) {
     if (rows <= 0 || n_groups <= 0) return ISST_OK;
+    LlmAttnOne one1{};
+    if (one && one->enabled && n_groups == 1) one1 = *one;
     const int slots = d.sys_cap + d.ring_cap;
     if (slots % 64 != 0 || d.sys_cap % 16 != 0) return ISST_ERR_ARG;
     const int G = d.heads / d.kv_heads;
@@ -367,9 +369,9 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
     int rc;
     switch (G) {
-        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s); break;
-        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s); break;
-        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s); break;
+        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1); break;
+        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1); break;
+        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1); break;
         default: return ISST_ERR_ARG;
     }
     if (rc != ISST_OK) return rc;
