@@ -242,3 +242,31 @@ def test_errors_are_loud():
         eng.generate(GenConfig(max_new_tokens=4), [sid], [np.zeros(1000, np.float32)], [[1, 2, 3]], [[]])
     with pytest.raises(IsstError):  # no free slot
         eng.open_stream()
+
+
+def test_decode_step_graph_replay_is_bit_identical(monkeypatch):
+    """ISST_GRAPH=1: the decode step (metadata upload, decoder stack, sampling, token download) is captured once and replayed as
+    a hipGraph on a non-default stream; tokens and cache lengths must equal the launch-by-launch path exactly."""
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=41)
+    gen = GenConfig(max_new_tokens=7, max_llm_cache_size=150)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 4, stream_id=9)
+
+    def run(graph):
+        if graph:
+            monkeypatch.setenv("ISST_GRAPH", "1")
+        else:
+            monkeypatch.delenv("ISST_GRAPH", raising=False)
+        eng = make_engine(cfg, w, debug_taps=False, max_multiplier=1)
+        sid = eng.open_stream()
+        out = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for c in range(4):
+                seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+                ids, _ = eng.generate(gen, [sid], [seg], [synth.chunk_prompt_ids(cfg, 1, first=(c == 0))], [[]])
+                out.append((ids[0], eng.stream_info(sid)["llm_cache_len"]))
+            torch.cuda.synchronize()
+        eng.close()
+        return out
+
+    assert run(True) == run(False)
