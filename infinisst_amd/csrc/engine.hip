@@ -708,7 +708,7 @@ int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int e
 int pick_ksplit(int K, int N) {
     (void)N;
     for (int s = K >= 8192 ? 4 : 2; s > 1; s >>= 1)
-        if (K % (128 * s) == 0 && K / (128 * s) >= 2) return s;
+        if (K % (256 * s) == 0 && K / (256 * s) >= 1) return s;
     return 1;
 }
 // slabs[ksplit][M][N] (fp32) = A @ W^T per K slice; reduced by launch_rmsnorm_reduce

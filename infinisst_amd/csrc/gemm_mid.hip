@@ -8,11 +8,11 @@
 //   * a workgroup (4 or 8 waves) owns 2 or 4 n-tiles (32 or 64 columns) and ALL rows: A is staged through LDS in full 128-byte lines
 //     (8 rows x 128 B per wave-load, cdna_hip_programming.md section 4 "x operand through LDS in full lines"), written as
 //     ready-made MFMA A fragments ([k-step][m-tile][lane] x 16 B: conflict-free ds_write_b128 and ds_read_b128), double
-//     buffered, one barrier per 128-deep K chunk; every wave reads the same staged fragments;
+//     buffered, one barrier per 256-deep K chunk; every wave reads the same staged fragments;
 //   * a wave owns one PAIR of n-tiles and one of the chunk's four k-steps, so each A fragment it reads from LDS feeds two
 //     MFMAs (LDS bandwidth, not HBM, bounds the skeleton of this kernel: measured with emptied descriptors); the weight
-//     fragments stream straight from the fragment-major packed layout into VGPRs through bounds-checked buffer loads, a
-//     ring of 4 chunks in flight, non-temporal (read once);
+//     fragments stream straight from the fragment-major packed layout into VGPRs through bounds-checked buffer loads, two
+//     chunks in flight, non-temporal (read once);
 //   * the K halves meet in LDS (fixed order: deterministic) and the epilogue applies bias / GELU / residual / SwiGLU with
 //     the reference's bf16 rounding points, exactly as gemm.hip;
 //   * narrow outputs (o_proj, down_proj: N = 4096 -> 64-128 workgroups) additionally split K over workgroups
@@ -20,18 +20,21 @@
 //     anyway (rowops.hip rmsnorm_reduce_kernel), so the split costs no extra launch.
 #include "common.h"
 
-#define MID_CK 128     // K elements per staged chunk (4 k-steps of 32)
-#define MID_RING 4     // chunks in flight per wave: weight fragments and staged A pieces
+#define MID_KSW 2                 // k-steps per wave and chunk
+#define MID_KS (4 * MID_KSW)      // k-steps per chunk
+#define MID_CK (32 * MID_KS)      // K elements per staged chunk (256): one barrier per chunk, 4 * MT MFMAs per wave between barriers
 
 // NP: n-tile pairs per workgroup (1 or 2) -> 32 or 64 columns, 4 * NP waves.  Wave (np, wk) owns the two n-tiles of pair np
-// (for SwiGLU exactly one (gate, up) pair) and k-step wk of every chunk: per chunk it reads its MT A fragments from LDS
-// once and feeds 2 * MT MFMAs on independent accumulators from them.
+// (for SwiGLU exactly one (gate, up) pair) and k-steps wk*KSW .. of every chunk: per chunk it reads its KSW * MT A fragments from
+// LDS once and feeds 2 MFMAs on independent accumulators from each.
 template <int MT, int NP, int EPI>
-__global__ __launch_bounds__(NP * 256) void gemm_mid_kernel(GemmArgs g, int k_chunks, int dbg) {
+__global__ __launch_bounds__(NP * 256, NP == 2 ? 4 : 2) void gemm_mid_kernel(GemmArgs g, int k_chunks, int dbg) {
     constexpr int NW = NP * 4;                     // waves per workgroup
     constexpr int WN = NP * 2;                     // n-tiles per workgroup
-    constexpr int AU = (MT * 4 + NW - 1) / NW;     // staging units (8 rows x 128 B) per wave and chunk
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x [4 k-steps][MT][64 lanes][16 B]; later the K-reduction buffer [4][MT*WN][256] fp32
+    constexpr int UNITS = MT * 2 * MID_KS / 2;     // staging units (8 rows x 128 B = two k-steps) per chunk
+    constexpr int AU = (UNITS + NW - 1) / NW;      // ... per wave
+    constexpr int BUF = MID_KS * MT * 1024;        // bytes of one staged chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x [MID_KS k-steps][MT][64 lanes][16 B]; later the K-reduction buffer [4][MT*WN][256] fp32
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the buffer descriptors below are built from it
     const int np = wave % NP, wk = wave / NP;
@@ -46,29 +49,32 @@ __global__ __launch_bounds__(NP * 256) void gemm_mid_kernel(GemmArgs g, int k_ch
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[mt][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // weight fragments of (chunk c, k-step wk) for the two n-tiles; ring slot = c % 4, reloaded 4 chunks ahead right after use.
-    // Loads go through buffer descriptors that cover exactly this slice of each n-tile: prefetches past the end (and tiles
-    // past N) return zeros without memory traffic and without a branch (a conditional load makes hipcc drain vmcnt(0)).
+    // weight fragments of (chunk c, k-steps wk*KSW + j) for the two n-tiles: two chunks in flight, slot c % 2 reloaded right
+    // after use.  Loads go through buffer descriptors that cover exactly this slice of each n-tile: prefetches past the end
+    // (and tiles past N) return zeros without memory traffic and without a branch (a conditional load makes hipcc drain
+    // vmcnt(0) in the loop).
     __amdgpu_buffer_rsrc_t wrsrc[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const bool wvalid = nt + nb < NTILES && !(dbg & 2);
-        wrsrc[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + ((long)(wvalid ? nt + nb : 0) * KT + (long)chunk0 * 4) * 512, 0,
-                                                      wvalid ? k_chunks * 4096 : 0, 0x00020000);
+        wrsrc[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + ((long)(wvalid ? nt + nb : 0) * KT + (long)chunk0 * MID_KS) * 512, 0,
+                                                      wvalid ? k_chunks * (MID_KS * 1024) : 0, 0x00020000);
     }
-    const int woff = (wk * 64 + lane) * 16;
-    auto load_b = [&](int c, int nb) -> u32x4_t {
-        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc[nb], woff + c * 4096, 0, 2 /* nt: read once */);
+    const int woff = (wk * MID_KSW * 64 + lane) * 16;
+    auto load_b = [&](int c, int j, int nb) -> u32x4_t {
+        return __builtin_amdgcn_raw_buffer_load_b128(wrsrc[nb], woff + c * (MID_KS * 1024) + j * 1024, 0, 2 /* nt: read once */);
     };
-    u32x4_t wf[MID_RING][2];
+    u32x4_t wf[2][MID_KSW][2];
 #pragma unroll
-    for (int u = 0; u < MID_RING; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) wf[u][nb] = load_b(u, nb);
+        for (int j = 0; j < MID_KSW; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) wf[u][j][nb] = load_b(u, j, nb);
 
     // ---- A staging: unit = 8 rows x 128 B (two k-steps); lane -> (row rlo = lane & 7, 16-byte piece p = lane >> 3) ----
-    // register ring of 4 chunks: chunk c+3 is requested while chunk c is computed and written to LDS two barriers later, so an
-    // L2 round trip under full streaming load (1.8-3.3 us, cdna_hip_programming.md section 4) is off the critical path
+    // One register set: chunk c+1 is written to LDS at the START of iteration c (its loads were issued a whole iteration
+    // earlier) and the same registers are re-armed with chunk c+2 right away.
     const int rlo = lane & 7, p = lane >> 3;
     // rows >= M re-read row M-1 (their products land in output rows >= M, which are never stored); chunks past the slice
     // read on inside the row or, past the last row, hit the descriptor's bound
@@ -79,50 +85,57 @@ __global__ __launch_bounds__(NP * 256) void gemm_mid_kernel(GemmArgs g, int k_ch
 #pragma unroll
     for (int a = 0; a < AU; ++a) {
         const int unit = wave + a * NW;
-        const int kp = unit & 1, rg = unit >> 1;
+        const int kp = unit % (MID_KS / 2), rg = unit / (MID_KS / 2);  // k-step pair inside the chunk, 8-row group
         const int row = rg * 8 + rlo;  // 0 .. MT*16-1
         const int grow = min(m0 + row, g.M - 1);
         aoff[a] = (int)(((long)grow * g.lda + (long)chunk0 * MID_CK + kp * 64 + p * 8) * 2);
         const int ks = kp * 2 + (p >> 2), q = p & 3;
         adst[a] = (((ks * MT + (row >> 4)) * 64) + q * 16 + (row & 15)) * 16;
-        if (unit >= MT * 4) adst[a] = -1;
+        if (unit >= UNITS) adst[a] = -1;
     }
-    constexpr int BUF = 4 * MT * 1024;
     auto load_a = [&](int c, int a) -> u32x4_t { return __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[a] + c * (MID_CK * 2), 0, 0); };
-    u32x4_t areg[MID_RING][AU];  // slot c % 4 holds chunk c
+    u32x4_t areg[AU];
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
-#pragma unroll
-        for (int a = 0; a < AU; ++a) areg[u][a] = load_a(u, a);
+    for (int a = 0; a < AU; ++a) areg[a] = load_a(0, a);
 #pragma unroll
     for (int a = 0; a < AU; ++a)
-        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(smem + adst[a]) = areg[0][a];
+        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(smem + adst[a]) = areg[a];
+#pragma unroll
+    for (int a = 0; a < AU; ++a) areg[a] = load_a(1, a);
     __syncthreads();
 
-    for (int c0 = 0; c0 < k_chunks; c0 += MID_RING) {
+    for (int c0 = 0; c0 < k_chunks; c0 += 2) {
 #pragma unroll
-        for (int u = 0; u < MID_RING; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int c = c0 + u;
             if (c < k_chunks) {  // uniform over the workgroup
+                // order inside the wave's (in-order) LDS queue: this chunk's fragment reads FIRST, then the writes of the next chunk --
+                // the MFMAs below wait for the reads only and the ~400-cycle write pass drains underneath them
+                const unsigned char* buf = smem + (c & 1) * BUF + ((wk * MID_KSW * MT) * 64 + lane) * 16;
+                u32x4_t af[MID_KSW][MT];
 #pragma unroll
-                for (int a = 0; a < AU; ++a) areg[(u + 3) % MID_RING][a] = load_a(c + 3, a);
-                const unsigned char* buf = smem + (c & 1) * BUF + ((wk * MT) * 64 + lane) * 16;
-                u32x4_t af[MT];
+                for (int j = 0; j < MID_KSW; ++j)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const u32x4_t*>(buf + mt * 1024);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mt]), __builtin_bit_cast(bf16x8_t, wf[u][nb]), acc[mt][nb], 0, 0, 0);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) wf[u][nb] = load_b(c + MID_RING, nb);
+                    for (int mt = 0; mt < MT; ++mt) af[j][mt] = *reinterpret_cast<const u32x4_t*>(buf + (j * MT + mt) * 1024);
                 if (c + 1 < k_chunks) {
                     unsigned char* nbuf = smem + ((c + 1) & 1) * BUF;
 #pragma unroll
                     for (int a = 0; a < AU; ++a)
-                        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(nbuf + adst[a]) = areg[(u + 1) % MID_RING][a];
+                        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(nbuf + adst[a]) = areg[a];
                 }
+#pragma unroll
+                for (int a = 0; a < AU; ++a) areg[a] = load_a(c + 2, a);
+#pragma unroll
+                for (int j = 0; j < MID_KSW; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[j][mt]), __builtin_bit_cast(bf16x8_t, wf[u][j][nb]), acc[mt][nb], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < MID_KSW; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) wf[u][j][nb] = load_b(c + 2, j, nb);
                 __syncthreads();
             }
         }
@@ -192,7 +205,7 @@ static int launch_mid_cfg(const GemmArgs& g, hipStream_t stream) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     const int NTILES = g.N / 16, WN = NP * 2;
     dim3 grid((NTILES + WN - 1) / WN, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(NP * 256);
-    const size_t lds = (size_t)(NP == 2 ? 16 : 8) * MT * 1024;  // max(A double buffer 8 MT KiB, K-reduction buffer 4 * MT * WN KiB)
+    const size_t lds = (size_t)2 * MID_KS * MT * 1024;  // A double buffer 16 MT KiB >= K-reduction buffer 4 * MT * WN KiB
     hipLaunchKernelGGL((gemm_mid_kernel<MT, NP, EPI>), grid, block, lds, stream, g, g.K / MID_CK / ks, g_mid_dbg);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }

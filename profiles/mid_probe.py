@@ -57,7 +57,7 @@ for M in (22, 64):
             x = res.clone()
             nw = torch.ones(N, device=dev).bfloat16()
             for ks in (2, 4, 8):
-                if K % (128 * ks):
+                if K % (256 * ks):
                     continue
                 for wn in (2, 4):
                     lib.isst_op_set_gemm_tuning(0, wn)
