@@ -10,6 +10,8 @@ Restates the reference's patched HF beam search (the production decoding mode, b
   beam_search_finalize           :159-275   (open beams become hypotheses; best one wins; EOS appended if it fits)
   beam_hypotheses_add            :278-302   (score = sum_logprobs / generated_len ** length_penalty, keep the best n)
   _expand_inputs_for_generation  :305-342   (inputs and KV cache repeated num_beams times)
+`scorer_process`, `BeamHypotheses.add` and `finalize` are pinned against the reference's own functions, executed from their
+source on a stand-in scorer (tests/golden/gen_golden.py::gen_beam_scorer -> beam_scorer.npz, tests/test_oracle_golden.py).
 transformers 4.47.0 cannot be imported here, so `BeamHypotheses.is_done` (early_stopping=False heuristic) and
 `n_tokens_to_keep = max(2, 1 + n_eos) * num_beams` are restated from that release's published code: parity unpinned.
 
@@ -107,6 +109,22 @@ def scorer_process(hyps: BeamHypotheses, done: bool, input_ids: List[List[int]],
     return next_scores, next_tokens, next_parents, done
 
 
+def finalize(hyps: BeamHypotheses, done: bool, seqs: List[List[int]], beam_scores: Sequence[float], kvs, decoder_prompt_len: int,
+             max_length: int, first_eos: int):
+    """beam_search_finalize for batch size 1, one hypothesis kept (patch_hf.py:159-275): open beams become hypotheses unless
+    the scorer is done; the best-scoring hypothesis wins and takes its KV cache along; EOS is appended if it fits."""
+    if not done:
+        for b in range(len(seqs)):
+            hyps.add(seqs[b], beam_scores[b], len(seqs[b]) - decoder_prompt_len, kvs[b])
+    best = sorted(hyps.beams, key=lambda x: x[0])[-1]
+    hyp_tokens, best_kv = best[1], best[2]
+    sent_max_len = min(len(hyp_tokens) + 1, max_length)
+    out = list(hyp_tokens)
+    if len(hyp_tokens) < sent_max_len:
+        out.append(first_eos)  # "inserting only the first eos_token_id"
+    return out, best_kv
+
+
 def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batch: torch.Tensor, kv, speech_cache, rope_llm,
                   rope_enc, encoder_input_ids: Sequence[int], length_penalty: float = 1.0) -> BeamOutput:
     """One chunk with beam search.  `kv` (the stream's cache before this chunk) is not modified; the winning
@@ -150,14 +168,5 @@ def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batc
         step += 1
         if done or len(seqs[0]) >= max_length:  # :920
             break
-    # finalize (:159-275)
-    if not done:
-        for b in range(num_beams):
-            hyps.add(seqs[b], beam_scores[b], len(seqs[b]) - prompt_len, kvs[b])
-    best = sorted(hyps.beams, key=lambda x: x[0])[-1]
-    hyp_tokens, best_kv = best[1], best[2]
-    sent_max_len = min(len(hyp_tokens) + 1, max_length)
-    out = list(hyp_tokens)
-    if len(hyp_tokens) < sent_max_len:
-        out.append(cfg.eos_ids[0])  # "inserting only the first eos_token_id"
+    out, best_kv = finalize(hyps, done, seqs, beam_scores, kvs, prompt_len, max_length, cfg.eos_ids[0])
     return BeamOutput(sequences=out, kv=best_kv, steps=steps, speech_features=feats)

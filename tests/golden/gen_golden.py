@@ -527,6 +527,130 @@ def gen_splice():
         LlamaModel.forward = orig
 
 
+
+# --------------------------------------------------------------------------------------------
+# beam scorer: the reference's own beam_search_process / beam_search_finalize / beam_hypotheses_add
+# (model/patches/patch_hf.py:43-302), executed from their source text on a stand-in scorer object
+# --------------------------------------------------------------------------------------------
+def gen_beam_scorer():
+    """patch_hf.py cannot be imported (transformers 5.15 has no generation.beam_search); its three scorer functions only
+    need torch, UserDict and an object with the BeamSearchScorer / BeamHypotheses attributes they touch, so their definitions
+    are compiled straight from the reference file.  The one third-party piece, BeamHypotheses.is_done (transformers 4.47,
+    early_stopping=False), is restated below and is therefore NOT pinned by this fixture."""
+    import ast
+    from collections import UserDict
+    from typing import Dict, List, Optional, Tuple, Union
+    path = os.path.join(REF, "model", "patches", "patch_hf.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    want = {"beam_search_process", "beam_search_finalize", "beam_hypotheses_add"}
+
+    class KVStandIn:  # the subset of DynamicCache the functions use: DynamicCache(n).update(k, v, layer)
+        def __init__(self, n=0):
+            self.layers = {}
+
+        def update(self, k, v, i):
+            self.layers[i] = (k, v)
+
+    ns = {"torch": torch, "UserDict": UserDict, "Optional": Optional, "Union": Union, "List": List, "Dict": Dict, "Tuple": Tuple,
+          "DynamicCache": KVStandIn}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in want:
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+
+    class Hyps:
+        def __init__(self, num_beams, length_penalty):
+            self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, False
+            self.beams, self.worst_score = [], 1e9
+
+        def __len__(self):
+            return len(self.beams)
+
+        add = ns["beam_hypotheses_add"]
+
+        def is_done(self, best_sum_logprobs, cur_len, decoder_prompt_len=0):  # [3P transformers 4.47, restated]
+            if len(self) < self.num_beams:
+                return False
+            highest_attainable = best_sum_logprobs / (cur_len - decoder_prompt_len) ** self.length_penalty
+            return self.worst_score >= highest_attainable
+
+    class Scorer:
+        process = ns["beam_search_process"]
+        finalize = ns["beam_search_finalize"]
+
+        def __init__(self, B, length_penalty):
+            self.num_beams = self.group_size = B
+            self.num_beam_groups, self.num_beam_hyps_to_keep = 1, 1
+            self.device = torch.device("cpu")
+            self._beam_hyps = [Hyps(B, length_penalty)]
+            self._done = torch.tensor([False])
+
+    out = {}
+    cases = [(4, 1.0, 0.25, 11, 7), (4, 1.0, 0.0, 12, 6), (2, 1.0, 0.4, 13, 9), (4, 0.6, 0.3, 14, 8), (3, 1.0, 0.6, 15, 10)]
+    eos = [901, 908, 909]
+    for ci, (B, lp, p_eos, seed, steps) in enumerate(cases):
+        g = torch.Generator().manual_seed(seed)
+        sc = Scorer(B, lp)
+        prompt_len = 5
+        max_length = prompt_len + steps
+        n_keep = max(2, 1 + len(eos)) * B
+        input_ids = torch.randint(10, 800, (1, prompt_len), generator=g).repeat(B, 1)
+        marker = torch.arange(B, dtype=torch.float32).view(B, 1, 1, 1)  # one-layer "KV": which beam's cache travels where
+        beam_scores = torch.tensor([0.0] + [-1e9] * (B - 1))
+        n_steps = 0
+        for st in range(steps):
+            # candidates: every beam proposes tokens with scores below its own running score, merged and sorted like topk
+            cand = []
+            for b in range(B):
+                for _ in range(n_keep):
+                    tok = int(torch.randint(10, 800, (1,), generator=g))
+                    if float(torch.rand(1, generator=g)) < p_eos:
+                        tok = eos[int(torch.randint(0, len(eos), (1,), generator=g))]
+                    cand.append((float(beam_scores[b]) - float(torch.rand(1, generator=g)) * 3.0, tok, b))
+            cand.sort(key=lambda x: -x[0])
+            cand = cand[:n_keep]
+            ns_ = torch.tensor([[c[0] for c in cand]], dtype=torch.float32)
+            nt_ = torch.tensor([[c[1] for c in cand]])
+            ni_ = torch.tensor([[c[2] for c in cand]])
+            kv = [(marker + 100.0 * st, marker + 100.0 * st + 0.5)]
+            try:
+                res = sc.process(input_ids, ns_, nt_, ni_, pad_token_id=904, eos_token_id=eos, beam_indices=None,
+                                 decoder_prompt_len=prompt_len, past_key_values=kv)
+            except ValueError:
+                break  # fewer than B non-EOS candidates: the reference raises; stop the case here
+            out[f"c{ci}_s{st}_in_ids"] = input_ids.numpy().copy()
+            out[f"c{ci}_s{st}_scores"] = ns_.numpy()[0]
+            out[f"c{ci}_s{st}_tokens"] = nt_.numpy()[0]
+            out[f"c{ci}_s{st}_beams"] = ni_.numpy()[0]
+            out[f"c{ci}_s{st}_next_scores"] = res["next_beam_scores"].numpy()
+            out[f"c{ci}_s{st}_next_tokens"] = res["next_beam_tokens"].numpy()
+            out[f"c{ci}_s{st}_next_beams"] = res["next_beam_indices"].numpy()
+            out[f"c{ci}_s{st}_done"] = np.array(bool(sc._done[0]))
+            out[f"c{ci}_s{st}_n_hyps"] = np.array(len(sc._beam_hyps[0]))
+            out[f"c{ci}_s{st}_worst"] = np.array(sc._beam_hyps[0].worst_score, dtype=np.float64)
+            beam_scores = res["next_beam_scores"]
+            idx = res["next_beam_indices"]
+            input_ids = torch.cat([input_ids[idx], res["next_beam_tokens"].unsqueeze(-1)], dim=-1)  # patch_hf.py beam loop
+            marker = marker[idx]
+            n_steps = st + 1
+            if bool(sc._done[0]) or input_ids.shape[-1] >= max_length:
+                break
+        kv = [(marker + 100.0 * n_steps, marker + 100.0 * n_steps + 0.5)]
+        fin = sc.finalize(input_ids, beam_scores, None, None, max_length=max_length, pad_token_id=904, eos_token_id=eos,
+                          beam_indices=None, decoder_prompt_len=prompt_len, past_key_values=kv)
+        out[f"c{ci}_cfg"] = np.array([B, prompt_len, max_length, n_steps], dtype=np.int64)
+        out[f"c{ci}_lp"] = np.array(lp)
+        out[f"c{ci}_final_ids"] = input_ids.numpy().copy()
+        out[f"c{ci}_final_scores"] = beam_scores.numpy().copy()
+        out[f"c{ci}_sequence"] = fin["sequences"][0].numpy()
+        out[f"c{ci}_sequence_score"] = fin["sequence_scores"].numpy()
+        out[f"c{ci}_kv_marker"] = fin["past_key_values"][0].layers[0][0].reshape(-1).numpy()  # which (step, beam) cache won
+    out["n_cases"] = np.array(len(cases))
+    out["eos"] = np.array(eos)
+    np.savez_compressed(os.path.join(OUT, "beam_scorer.npz"), **out)
+    print("beam_scorer.npz:", len(out), "arrays")
+
+
 def main():
     torch.set_num_threads(4)
     import transformers.models.llama.modeling_llama  # noqa: F401  (before the wandb stub: accelerate probes it)
@@ -541,6 +665,7 @@ def main():
     gen_llm_attention()
     gen_agent()
     gen_splice()
+    gen_beam_scorer()
 
 
 if __name__ == "__main__":

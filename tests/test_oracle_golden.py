@@ -157,3 +157,35 @@ def test_agent_policy_matches_reference(golden_dir, variant):
         target_ids = list(g[f"v{variant}_target_ids"][: int(recs[c][2])])
         assert int(recs[c][2]) == sum(int(r[0]) - 1 for r in recs[: c + 1])  # sequences[0, T:-1] drops the last token
         first = False
+
+
+def test_beam_scorer_matches_reference(golden_dir):
+    """oracle/beam.py's scorer (process / hypotheses.add / finalize) against the reference's own patch_hf.py functions run from
+    their source (gen_golden.gen_beam_scorer): same next beams, same done flag and worst score after every step, same winning
+    sequence, score and KV cache."""
+    from oracle import beam as obeam
+    g = load(golden_dir, "beam_scorer.npz")
+    eos = [int(e) for e in g["eos"]]
+    for ci in range(int(g["n_cases"])):
+        B, prompt_len, max_length, n_steps = (int(v) for v in g[f"c{ci}_cfg"])
+        hyps = obeam.BeamHypotheses(B, float(g[f"c{ci}_lp"]))
+        done = False
+        marker = [float(b) for b in range(B)]  # stands for the beams' KV caches (clone_kv handles plain nested lists)
+        for st in range(n_steps):
+            seqs = [[int(t) for t in row] for row in g[f"c{ci}_s{st}_in_ids"]]
+            kvs = [[[torch.tensor(m + 100.0 * st)]] for m in marker]
+            ns, nt, npar, done = obeam.scorer_process(hyps, done, seqs, [float(x) for x in g[f"c{ci}_s{st}_scores"]],
+                                                      [int(x) for x in g[f"c{ci}_s{st}_tokens"]], [int(x) for x in g[f"c{ci}_s{st}_beams"]],
+                                                      kvs, eos, B, prompt_len)
+            assert nt == [int(x) for x in g[f"c{ci}_s{st}_next_tokens"]], f"case {ci} step {st} tokens"
+            assert npar == [int(x) for x in g[f"c{ci}_s{st}_next_beams"]], f"case {ci} step {st} parents"
+            np.testing.assert_allclose(ns, g[f"c{ci}_s{st}_next_scores"], rtol=0, atol=1e-6)
+            assert done == bool(g[f"c{ci}_s{st}_done"]), f"case {ci} step {st} done flag"
+            assert len(hyps) == int(g[f"c{ci}_s{st}_n_hyps"])
+            assert hyps.worst_score == pytest.approx(float(g[f"c{ci}_s{st}_worst"]), abs=1e-6)
+            marker = [marker[p] for p in npar]
+        seqs = [[int(t) for t in row] for row in g[f"c{ci}_final_ids"]]
+        kvs = [[[torch.tensor(m + 100.0 * n_steps)]] for m in marker]
+        out, best_kv = obeam.finalize(hyps, done, seqs, [float(x) for x in g[f"c{ci}_final_scores"]], kvs, prompt_len, max_length, eos[0])
+        assert out == [int(t) for t in g[f"c{ci}_sequence"]], f"case {ci} winning sequence"
+        assert float(best_kv[0][0]) == float(g[f"c{ci}_kv_marker"][0]), f"case {ci}: the winner must carry its own KV cache"
