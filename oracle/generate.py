@@ -5,8 +5,10 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 Restates what the reference's patched `generate` does on the greedy/sample branch
 (reference model/patches/patch_hf.py:586-624) with the arguments the agent passes
 (reference agents/infinisst.py:307-332).  The processors and `_sample` themselves live in the un-vendored
-transformers==4.47.0 ("parity unpinned"): order RepetitionPenalty -> NoRepeatNGram -> EncoderNoRepeatNGram ->
-SuppressTokens, applied to the fp32 copy of the last position's logits; argmax; stop on EOS or max length.
+transformers==4.47.0: order RepetitionPenalty -> NoRepeatNGram -> EncoderNoRepeatNGram -> SuppressTokens, applied to the
+fp32 copy of the last position's logits; argmax; stop on EOS or max length.  `process_logits` is pinned bit-exactly against
+HF's own processor classes as shipped in this image (transformers 5.15.0, tests/golden/logits_processors.npz); the 4.47.0
+release itself is absent, so the pin is to the upstream implementation of a later version ("parity pinned to 5.15, not 4.47").
 
 Greedy deviation: the reference asserts beam > 1 (agents/infinisst.py:86); the north star asks for greedy,
 which is this path with that assert waived.

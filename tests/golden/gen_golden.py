@@ -651,6 +651,49 @@ def gen_beam_scorer():
     print("beam_scorer.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------------------------
+# logits processors: HF transformers' own classes (the image has 5.15.0; the reference pins 4.47.0 -- the four processors
+# used by agents/infinisst.py:307-332 have had the same semantics since 4.2x)
+# --------------------------------------------------------------------------------------------
+def gen_logits_processors():
+    import transformers
+    from transformers.generation.logits_process import (EncoderNoRepeatNGramLogitsProcessor, NoRepeatNGramLogitsProcessor,
+                                                        RepetitionPenaltyLogitsProcessor, SuppressTokensLogitsProcessor)
+    out = {"transformers_version": np.array(transformers.__version__)}
+    V = 300
+    cases = []
+    g = torch.Generator().manual_seed(77)
+    for ci in range(12):
+        n_ids = [1, 3, 4, 9, 40, 120][ci % 6]
+        n_enc = [0, 2, 5, 30, 100, 100][(ci * 5) % 6]
+        ngram = [5, 3, 2, 5, 4, 1][ci % 6]
+        penalty = [1.2, 1.0, 1.5, 1.2, 1.2, 2.0][ci % 6]
+        small = 12 if ci % 2 else V  # a small alphabet makes repeated n-grams likely
+        ids = torch.randint(0, small, (1, n_ids), generator=g)
+        enc = torch.randint(0, small, (1, max(n_enc, 1)), generator=g)[:, :n_enc]
+        if n_enc >= ngram and n_ids >= ngram:  # make sure an encoder n-gram match exists in some cases
+            enc[0, :ngram - 1] = ids[0, -(ngram - 1):] if ngram > 1 else enc[0, :0]
+        suppress = sorted(set(int(t) for t in torch.randint(0, V, (ci % 4,), generator=g)))
+        scores = torch.randn(1, V, generator=g) * 3
+        s = scores.clone()
+        s = RepetitionPenaltyLogitsProcessor(penalty=penalty)(ids, s) if penalty != 1.0 else s
+        s = NoRepeatNGramLogitsProcessor(ngram)(ids, s)
+        if n_enc > 0:
+            s = EncoderNoRepeatNGramLogitsProcessor(ngram, enc)(ids, s)
+        if suppress:
+            s = SuppressTokensLogitsProcessor(suppress, device="cpu")(ids, s)
+        out[f"c{ci}_ids"] = ids[0].numpy()
+        out[f"c{ci}_enc"] = enc[0].numpy()
+        out[f"c{ci}_suppress"] = np.array(suppress, dtype=np.int64)
+        out[f"c{ci}_cfg"] = np.array([ngram, penalty], dtype=np.float64)
+        out[f"c{ci}_scores"] = scores[0].numpy()
+        out[f"c{ci}_out"] = s[0].numpy()
+        cases.append(ci)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "logits_processors.npz"), **out)
+    print("logits_processors.npz:", len(out), "arrays, transformers", transformers.__version__)
+
+
 def main():
     torch.set_num_threads(4)
     import transformers.models.llama.modeling_llama  # noqa: F401  (before the wandb stub: accelerate probes it)
@@ -666,6 +709,7 @@ def main():
     gen_agent()
     gen_splice()
     gen_beam_scorer()
+    gen_logits_processors()
 
 
 if __name__ == "__main__":

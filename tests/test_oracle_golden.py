@@ -189,3 +189,19 @@ def test_beam_scorer_matches_reference(golden_dir):
         out, best_kv = obeam.finalize(hyps, done, seqs, [float(x) for x in g[f"c{ci}_final_scores"]], kvs, prompt_len, max_length, eos[0])
         assert out == [int(t) for t in g[f"c{ci}_sequence"]], f"case {ci} winning sequence"
         assert float(best_kv[0][0]) == float(g[f"c{ci}_kv_marker"][0]), f"case {ci}: the winner must carry its own KV cache"
+
+
+def test_logits_processors_match_transformers(golden_dir):
+    """oracle.generate.process_logits against HF's own RepetitionPenalty / NoRepeatNGram / EncoderNoRepeatNGram / SuppressTokens
+    processors in the reference's order (agents/infinisst.py:307-332 -> transformers generate).  The vectors come from the image's
+    transformers 5.15.0 (gen_golden.gen_logits_processors); the reference pins 4.47.0, whose four classes behave the same."""
+    from oracle import generate as ogen
+    g = load(golden_dir, "logits_processors.npz")
+    for ci in range(int(g["n_cases"])):
+        ngram, penalty = int(g[f"c{ci}_cfg"][0]), float(g[f"c{ci}_cfg"][1])
+        got = ogen.process_logits(torch.from_numpy(g[f"c{ci}_scores"]), [int(t) for t in g[f"c{ci}_ids"]], [int(t) for t in g[f"c{ci}_enc"]],
+                                  penalty, ngram, ngram, [int(t) for t in g[f"c{ci}_suppress"]]).numpy()
+        ref = g[f"c{ci}_out"]
+        assert np.array_equal(np.isinf(got), np.isinf(ref)), f"case {ci}: banned sets differ"
+        fin = ~np.isinf(ref)
+        assert np.array_equal(got[fin], ref[fin]), f"case {ci}: penalised scores differ"
