@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 
-# ---- [3P transformers 4.47.0] LlamaRMSNorm --------------------------------------------------
+# ---- [3P transformers 4.47.0] LlamaRMSNorm (pinned bit-exactly to the image's transformers 5.15.0: tests/golden/llama_blocks.npz) ----
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     dt = x.dtype
     h = x.float()

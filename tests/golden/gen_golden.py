@@ -694,6 +694,46 @@ def gen_logits_processors():
     print("logits_processors.npz:", len(out), "arrays, transformers", transformers.__version__)
 
 
+# --------------------------------------------------------------------------------------------
+# HF Llama building blocks (LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP, repeat_kv) of the image's transformers 5.15.0
+# --------------------------------------------------------------------------------------------
+@torch.no_grad()
+def gen_llama_blocks():
+    import transformers
+    from transformers.models.llama import modeling_llama as ml
+    from transformers.models.llama.configuration_llama import LlamaConfig
+    out = {"transformers_version": np.array(transformers.__version__)}
+    g = torch.Generator().manual_seed(5)
+    D, I, hd = 64, 160, 16
+    for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        x = (torch.randn(1, 7, D, generator=g) * 2).to(dt)
+        nw = (1 + 0.2 * torch.randn(D, generator=g)).to(dt)
+        norm = ml.LlamaRMSNorm(D, eps=1e-5)
+        norm.weight.data = nw.clone()
+        out[f"{dt_name}_x"] = x.float().numpy()
+        out[f"{dt_name}_norm_w"] = nw.float().numpy()
+        out[f"{dt_name}_norm"] = norm.to(dt)(x).float().detach().numpy()
+        cfg = LlamaConfig(hidden_size=D, intermediate_size=I, hidden_act="silu", mlp_bias=False)
+        mlp = ml.LlamaMLP(cfg)
+        for n in ("gate_proj", "up_proj", "down_proj"):
+            wt = getattr(mlp, n).weight
+            wt.data = (torch.randn(wt.shape, generator=g) * 0.1)
+            out[f"{dt_name}_{n}"] = wt.data.to(dt).float().numpy()
+        out[f"{dt_name}_mlp"] = mlp.to(dt)(x).float().detach().numpy()
+        q = torch.randn(1, 4, 7, hd, generator=g).to(dt)
+        k = torch.randn(1, 2, 7, hd, generator=g).to(dt)
+        ang = torch.randn(1, 7, hd // 2, generator=g)
+        emb = torch.cat((ang, ang), dim=-1)
+        cos, sin = emb.cos().to(dt), emb.sin().to(dt)
+        qr, kr = ml.apply_rotary_pos_emb(q, k, cos, sin)
+        out[f"{dt_name}_q"], out[f"{dt_name}_k"] = q.float().numpy(), k.float().numpy()
+        out[f"{dt_name}_cos"], out[f"{dt_name}_sin"] = cos[0].float().numpy(), sin[0].float().numpy()
+        out[f"{dt_name}_q_rot"], out[f"{dt_name}_k_rot"] = qr.float().numpy(), kr.float().numpy()
+        out[f"{dt_name}_k_rep"] = ml.repeat_kv(k, 2).float().numpy()
+    np.savez_compressed(os.path.join(OUT, "llama_blocks.npz"), **out)
+    print("llama_blocks.npz:", len(out), "arrays, transformers", transformers.__version__)
+
+
 def main():
     torch.set_num_threads(4)
     import transformers.models.llama.modeling_llama  # noqa: F401  (before the wandb stub: accelerate probes it)
@@ -710,6 +750,7 @@ def main():
     gen_splice()
     gen_beam_scorer()
     gen_logits_processors()
+    gen_llama_blocks()
 
 
 if __name__ == "__main__":

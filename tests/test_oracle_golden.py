@@ -205,3 +205,19 @@ def test_logits_processors_match_transformers(golden_dir):
         assert np.array_equal(np.isinf(got), np.isinf(ref)), f"case {ci}: banned sets differ"
         fin = ~np.isinf(ref)
         assert np.array_equal(got[fin], ref[fin]), f"case {ci}: penalised scores differ"
+
+
+@pytest.mark.parametrize("dt_name,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_llama_blocks_match_transformers(golden_dir, dt_name, dt):
+    """oracle.llm's restated HF blocks (LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP) against the classes of the image's
+    transformers 5.15.0 (gen_golden.gen_llama_blocks), bit-exact in fp32 and in bf16 (same op order, same rounding points)."""
+    g = load(golden_dir, "llama_blocks.npz")
+    t = lambda name: torch.from_numpy(g[f"{dt_name}_{name}"]).to(dt)
+    x = t("x")
+    assert torch.equal(ollm.rmsnorm(x, t("norm_w"), 1e-5).float(), torch.from_numpy(g[f"{dt_name}_norm"]))
+    w = {"model.layers.0.mlp.gate_proj.weight": t("gate_proj"), "model.layers.0.mlp.up_proj.weight": t("up_proj"),
+         "model.layers.0.mlp.down_proj.weight": t("down_proj")}
+    assert torch.equal(ollm.mlp(w, 0, x).float(), torch.from_numpy(g[f"{dt_name}_mlp"]))
+    cos, sin = t("cos"), t("sin")
+    assert torch.equal(ollm.apply_rope(t("q"), cos, sin).float(), torch.from_numpy(g[f"{dt_name}_q_rot"]))
+    assert torch.equal(ollm.apply_rope(t("k"), cos, sin).float(), torch.from_numpy(g[f"{dt_name}_k_rot"]))
