@@ -22,9 +22,12 @@
 
 #define LLM_KSPLIT_MAX 4
 // rows up to which the decoder fuses RMSNorm into the following projection (the kernel supports GEMM_FUSED_NORM_MAX_M): every
-// workgroup re-normalises all rows, which costs ~3.6 us per row and layer against 9.4 us for the two norm launches it saves --
-// measured: 1 row 45.4 -> 42.0 ms per chunk fused, 4 rows (beam search) 42.9 fused vs 40.9 ms unfused
-#define LLM_FUSED_NORM_MAX_ROWS 2
+// workgroup re-normalises all rows while its first weight fragments are in flight.  Measured per launch (profiles/prologue_probe.py):
+// free at 1-2 rows, +0.8 us (gate/up) / +1.8 us (q/k/v) at 4 rows against 4.7 us for the norm launch it replaces, +11 us at 8 rows
+// (64 KB of LDS per workgroup: two workgroups per CU); the 8017-workgroup lm_head pays the prologue once per workgroup ROUND
+// (+13 us at 4 rows), so it only fuses up to 2 rows.
+#define LLM_FUSED_NORM_MAX_ROWS 4
+#define LLM_FUSED_NORM_MAX_ROWS_LM_HEAD 2
 namespace {
 
 struct PackedLinear {
@@ -944,7 +947,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         CHK(launch_rmsnorm(h->lx, DL, d.last_rows, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
         if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "final", h->llast, (int64_t)n_last * DL, st));
         CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
-    } else if (n_last <= LLM_FUSED_NORM_MAX_ROWS) {  // decode: rows == last rows, final norm fused into the lm_head projection
+    } else if (n_last <= LLM_FUSED_NORM_MAX_ROWS_LM_HEAD) {  // decode: rows == last rows, final norm fused into the lm_head projection
         CHK(gemm(h, h->lx, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st, 1, 0, 0, 0, h->final_norm, c.rms_eps));
     } else {
         CHK(launch_rmsnorm(h->lx, DL, nullptr, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));

@@ -84,7 +84,10 @@ __device__ __forceinline__ u32x4_t load_w(const u32x4_t* p) {
 template <int MT, int NTB, int EPI, bool NT, int AMODE>
 __global__ void gemm_skinny_kernel(GemmArgs g) {
     constexpr int UNR = gemm_unroll(MT, NTB);
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [W][MT*NTB*4][64], then the staged A rows (AMODE >= 1)
+    // AMODE 0: the reduction buffer [W][MT*NTB*4][64].  AMODE >= 1: the staged A rows [M][K] + [W] partial sums during the k-loop;
+    // the reduction buffer then REUSES the same bytes (one more barrier) -- kept apart, 4 rows needed 41 KB per workgroup: 3 instead
+    // of 4 workgroups per CU and a second round of workgroups for the 896-workgroup gate/up launch (+7 us)
+    extern __shared__ __attribute__((aligned(16))) float red[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int W = blockDim.x >> 6;
@@ -136,7 +139,9 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
         for (int nb = 0; nb < NTB; ++nb) wn[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
     }
 
-    bf16_t* xs = reinterpret_cast<bf16_t*>(red + (long)W * (MT * NTB * 256));  // [M][K] staged rows (AMODE >= 1)
+    // (1-2 rows keep the two areas apart: they fit 4 workgroups per CU anyway and skip the extra barrier)
+    const bool overlay = g.M > 2;
+    bf16_t* xs = reinterpret_cast<bf16_t*>(overlay ? red : red + (long)W * (MT * NTB * 256));  // [M][K] staged rows (AMODE >= 1)
     if constexpr (AMODE >= 1) {
         // rows are staged (and normalised) side by side: each row gets wpr = max(1, W / M) waves, W / wpr rows per round
         // (one stream: 1 row on all waves; beam search: 4 rows, one wave each, one round)
@@ -148,16 +153,29 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
             const int rr = r0 + my_slot;
             const bool active = my_slot < rpr && rr < g.M;
             float sq = 0.f;
+            // (loads go out four at a time: a chunk-by-chunk loop pays one L2 round trip per chunk -- 8 in a row at 4+ rows)
+            const int cstep = wpr * 512, cfirst = (my_sub * 64 + lane) * 8;
             if (active) {
                 const bf16_t* xr = A + (long)(m0 + rr) * g.lda;
-                for (int c = (my_sub * 64 + lane) * 8; c < g.K; c += wpr * 512) {
-                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(xr + c);
-                    *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = v;
-                    if constexpr (AMODE == 2) {
-                        float f[8];
-                        unpack8(v, f);
+                for (int c0 = cfirst; c0 < g.K; c0 += 4 * cstep) {
+                    u32x4_t xv[4];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) sq += f[q] * f[q];
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + u * cstep;
+                        xv[u] = *reinterpret_cast<const u32x4_t*>(xr + (c < g.K ? c : cfirst));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + u * cstep;
+                        if (c < g.K) {
+                            *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = xv[u];
+                            if constexpr (AMODE == 2) {
+                                float f[8];
+                                unpack8(xv[u], f);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) sq += f[q] * f[q];
+                            }
+                        }
                     }
                 }
             }
@@ -169,13 +187,25 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
                     float t = 0.f;
                     for (int w2 = 0; w2 < wpr; ++w2) t += part[my_slot * wpr + w2];
                     const float rs = rsqrtf(t / g.K + g.norm_eps);
-                    for (int c = (my_sub * 64 + lane) * 8; c < g.K; c += wpr * 512) {  // every lane rewrites the chunks it staged
-                        float f[8], nw[8];
-                        unpack8(*reinterpret_cast<const u32x4_t*>(xs + (long)rr * g.K + c), f);
-                        unpack8(*reinterpret_cast<const u32x4_t*>(g.norm_w + c), nw);
+                    for (int c0 = cfirst; c0 < g.K; c0 += 4 * cstep) {  // every lane rewrites the chunks it staged
+                        u32x4_t wv[4];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) f[q] = nw[q] * bfr(f[q] * rs);
-                        *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = pack8(f);
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = c0 + u * cstep;
+                            wv[u] = *reinterpret_cast<const u32x4_t*>(g.norm_w + (c < g.K ? c : cfirst));
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = c0 + u * cstep;
+                            if (c < g.K) {
+                                float f[8], nw[8];
+                                unpack8(*reinterpret_cast<const u32x4_t*>(xs + (long)rr * g.K + c), f);
+                                unpack8(wv[u], nw);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) f[q] = nw[q] * bfr(f[q] * rs);
+                                *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = pack8(f);
+                            }
+                        }
                     }
                 }
                 __syncthreads();  // part[] is reused by the next round; the last one publishes the rows
@@ -219,6 +249,9 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
     }
 
     // ---- cross-wave reduction through LDS: red[wave][(mt*NTB+nb)*4 + r][lane] ----
+    if constexpr (AMODE >= 1) {
+        if (overlay) __syncthreads();  // every wave is done reading the staged rows that `red` overlays
+    }
     constexpr int TILES = MT * NTB;
     float* my = red + (long)wave * (TILES * 256);
 #pragma unroll
@@ -289,7 +322,10 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     while (W > 1 && W > KT) W /= 2;
     while (W > 1 && (size_t)W * MT * ntb * 1024 > 64 * 1024) W /= 2;
     size_t lds = (size_t)W * MT * ntb * 1024;
-    if (AMODE >= 1) lds += (size_t)g.M * g.K * 2 + (W + 1) * 16 * sizeof(float);
+    if (AMODE >= 1) {  // rows + partial sums, overlaid by the reduction buffer after the k-loop
+        const size_t rows = (size_t)g.M * g.K * 2 + (W + 1) * 16 * sizeof(float);
+        lds = g.M > 2 ? (lds > rows ? lds : rows) : lds + rows;
+    }
     dim3 grid(blocks_x, blocks_y, g.batch), block(W * 64);
     if constexpr (MT == 1) {
         if (ntb == 4) {

@@ -6,17 +6,18 @@ import torch
 from infinisst_amd import engine as E
 dev = "cuda"; lib = E.load_library(); P = E._ptr
 K = 4096
+MROWS = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for name, N, epi in (("gate_up", 28672, "swiglu"), ("qkv", 6144, "none"), ("lm_head", 128272, "f32")):
     copies = 4 if N < 100000 else 2
     Np = (N + 15) // 16 * 16
     packs = [E.op_pack_weight((torch.randn(N, K, device=dev) * 0.02).bfloat16()) for _ in range(copies)]
-    x = torch.randn(1, K, device=dev).bfloat16(); nw = torch.ones(K, device=dev).bfloat16()
+    x = torch.randn(MROWS, K, device=dev).bfloat16(); nw = torch.ones(K, device=dev).bfloat16()
     n_out = N // 2 if epi == "swiglu" else N
-    out = torch.empty(1, n_out, device=dev, dtype=torch.float32 if epi == "f32" else torch.bfloat16)
+    out = torch.empty(MROWS, n_out, device=dev, dtype=torch.float32 if epi == "f32" else torch.bfloat16)
     res = {}
     for fused in (True, False):
         def run(i):
-            rc = lib.isst_op_gemm(P(x), K, P(packs[i % copies]), None, None, 0, P(out), n_out, 1, N, K, n_out, E.EPI[epi], P(nw) if fused else None, 1e-5, E._stream_ptr())
+            rc = lib.isst_op_gemm(P(x), K, P(packs[i % copies]), None, None, 0, P(out), n_out, MROWS, N, K, n_out, E.EPI[epi], P(nw) if fused else None, 1e-5, E._stream_ptr())
             assert rc == 0, rc
         for i in range(8): run(i)
         torch.cuda.synchronize()
