@@ -156,7 +156,8 @@ int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const u
                  float norm_eps, void* hip_stream);
 /* the pair the decoder runs at 17..64 rows for o_proj / down_proj (HF LlamaDecoderLayer: residual + mlp/attn output, then the
  * next RMSNorm): slabs[ksplit][M][N] (fp32, caller scratch) = A @ W^T per K slice; x[M][N] = bf16(x + bf16(sum of slabs)) in place;
- * norm_w != NULL: out = LlamaRMSNorm(norm_w, norm_eps)(x).  K % (128 * ksplit) == 0, N % 16 == 0, 16 < M <= 64. */
+ * norm_w != NULL: out = LlamaRMSNorm(norm_w, norm_eps)(x).  N % 16 == 0; 16 < M <= 64: K % (256 * ksplit) == 0; M > 64 (dense kernel):
+ * K % (64 * ksplit) == 0. */
 int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, const uint16_t* norm_w,
                                 uint16_t* out, float* slabs, int M, int N, int K, int ksplit, float norm_eps, void* hip_stream);
 /* profiling aid: override the GEMM launch heuristic (waves per workgroup, 16-row n-tiles per workgroup); 0 = automatic */

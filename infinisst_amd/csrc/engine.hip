@@ -20,7 +20,9 @@
 #include "common.h"
 #include "kernels.h"
 
-#define LLM_KSPLIT_MAX 4
+#define LLM_KSPLIT_MAX 8
+#define LLM_SPLIT_MAX_ROWS 1024  // rows up to which o_proj / down_proj run split-K into slabs (beyond, the dense kernel has the workgroups)
+#define LLM_SLAB_ROWS 2048       // slices x rows the slab buffer holds
 // rows up to which the decoder fuses RMSNorm into the following projection (the kernel supports GEMM_FUSED_NORM_MAX_M): every
 // workgroup re-normalises all rows while its first weight fragments are in flight.  Measured per launch (profiles/prologue_probe.py):
 // free at 1-2 rows, +0.8 us (gate/up) / +1.8 us (q/k/v) at 4 rows against 4.7 us for the norm launch it replaces, +11 us at 8 rows
@@ -141,7 +143,7 @@ struct isst_handle {
     bf16_t *ex = nullptr, *exn = nullptr, *eqkv = nullptr, *eattn = nullptr, *effn = nullptr, *speech = nullptr;
     bf16_t *lx = nullptr, *lxn = nullptr, *lqkv = nullptr, *lqrot = nullptr, *lattn = nullptr, *lact = nullptr, *llast = nullptr;
     float *lpartial = nullptr, *logits = nullptr;
-    float* lslab = nullptr;  // split-K slabs of o_proj / down_proj at 17..64 rows: [LLM_KSPLIT_MAX][64][llm_dim] fp32
+    float* lslab = nullptr;  // split-K slabs of o_proj / down_proj at 17..512 rows: [slices][rows][llm_dim] fp32
     int* out_tok = nullptr;
     float* samp_val = nullptr;  // partial argmax scratch, 64 per stream
     int* samp_idx = nullptr;
@@ -417,7 +419,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->lqrot = h->dalloc<bf16_t>(LR * H * 128); h->lattn = h->dalloc<bf16_t>(LR * H * 128); h->lact = h->dalloc<bf16_t>(LR * c.llm_ffn);
     h->llast = h->dalloc<bf16_t>((size_t)ns * h->max_beams * DL);
     h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * 130);
-    h->lslab = h->dalloc<float>((size_t)LLM_KSPLIT_MAX * 64 * DL);
+    h->lslab = h->dalloc<float>((size_t)LLM_SLAB_ROWS * DL);
     const size_t NB = (size_t)ns * h->max_beams;  // decode rows of a beam step
     h->logits = h->dalloc<float>(NB * h->vocab_pad);
     h->out_tok = h->dalloc<int>(NB);
@@ -706,13 +708,20 @@ int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int e
     return ISST_OK;
 }
 
-// K slices over workgroups for a narrow-N projection at 17..64 rows (measured, profiles/r01/mid_probe.txt: 2 slices for
-// K = 4096, 4 for K = 14336; more slices only add slab traffic)
-int pick_ksplit(int K, int N) {
-    (void)N;
-    for (int s = K >= 8192 ? 4 : 2; s > 1; s >>= 1)
-        if (K % (256 * s) == 0 && K / (256 * s) >= 1) return s;
-    return 1;
+// K slices over workgroups for the narrow-N projections (o_proj, down_proj).  17..64 rows (gemm_mid.hip; measured,
+// profiles/r01/mid_probe.txt): 2 slices for K = 4096, 4 for K = 14336, more only add slab traffic.  65..512 rows (gemm_tiled.hip:
+// 32 column blocks x ceil(rows / 128) row blocks walk all of K alone otherwise -- 217 us for down_proj whatever the row count,
+// profiles/rows_probe.py): enough slices for ~384 workgroups.
+int pick_ksplit(int K, int N, int rows) {
+    if (rows <= 64) {
+        for (int s = K >= 8192 ? 4 : 2; s > 1; s >>= 1)
+            if (K % (256 * s) == 0 && K / (256 * s) >= 1) return s;
+        return 1;
+    }
+    const int blocks = ((N + 127) / 128) * ((rows + 127) / 128);
+    int s = 1;
+    while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= 384 && s * 2 * rows <= LLM_SLAB_ROWS && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
+    return s;
 }
 // slabs[ksplit][M][N] (fp32) = A @ W^T per K slice; reduced by launch_rmsnorm_reduce
 int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, float* slabs, int M, int ksplit, hipStream_t st) {
@@ -884,8 +893,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     // 17..64 rows (one stream's prefill, a 64-stream decode pass): o_proj and down_proj split K over workgroups and the
     // residual + RMSNorm kernel that follows reduces the slabs (gemm_mid.hip); `pending`: lx still lacks the previous
     // layer's down_proj slabs
-    const bool split_rows = rows > 16 && rows <= 64;
-    const int so = split_rows ? pick_ksplit(H * 128, DL) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL) : 1;
+    const bool split_rows = rows > 16 && rows <= LLM_SPLIT_MAX_ROWS;
+    const int so = split_rows ? pick_ksplit(H * 128, DL, rows) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL, rows) : 1;
     const long slab = (long)rows * DL;
     bool pending = false;
     for (int l = 0; l < c.llm_layers; ++l) {
@@ -1492,7 +1501,7 @@ extern "C" int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const
     GemmArgs g{};
     g.A = A; g.lda = lda; g.Wp = packed; g.out = slabs; g.ldo = N; g.out_batch = (long)M * N;
     g.M = M; g.N = N; g.K = K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = N; g.ksplit = ksplit;
-    if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
+    if (!gemm_mid_supported(g) && !gemm_tiled_supported(g)) return ISST_ERR_ARG;
     const int rc = launch_gemm(g, st);
     if (rc != ISST_OK) return rc;
     return launch_rmsnorm_reduce(slabs, (long)M * N, ksplit, x, N, norm_w, out, N, M, N, norm_eps, st);

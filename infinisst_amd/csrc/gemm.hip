@@ -370,14 +370,15 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.batch <= 0) return ISST_OK;
     if (g.K % 32 != 0 || g.N % 16 != 0 || g.lda % 8 != 0) return ISST_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.Wp) & 15)) return ISST_ERR_ARG;
-    if (gemm_tiled_supported(g) && !g_force_skinny) {
-        const bool ok = (g.epi != EPI_BIAS && g.epi != EPI_BIAS_GELU && g.epi != EPI_BIAS_RES) || g.bias;
-        if (!ok || ((g.epi == EPI_RES || g.epi == EPI_BIAS_RES) && !g.res) || (g.epi == EPI_SWIGLU && g.N % 32)) return ISST_ERR_ARG;
-        return launch_gemm_tiled(g, stream);
-    }
     if (gemm_mid_supported(g) && gemm_mid_preferred(g) && !g_force_skinny) {
         if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return ISST_ERR_ARG;
         return launch_gemm_mid(g, stream);
+    }
+    if (gemm_tiled_supported(g) && !g_force_skinny) {
+        const bool ok = (g.epi != EPI_BIAS && g.epi != EPI_BIAS_GELU && g.epi != EPI_BIAS_RES) || g.bias;
+        if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return ISST_ERR_ARG;
+        if (!ok || ((g.epi == EPI_RES || g.epi == EPI_BIAS_RES) && !g.res) || (g.epi == EPI_SWIGLU && g.N % 32)) return ISST_ERR_ARG;
+        return launch_gemm_tiled(g, stream);
     }
     switch (g.epi) {
         case EPI_NONE: return launch_epi<EPI_NONE>(g, stream);

@@ -28,17 +28,21 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs g) {
     const int KT = g.K >> 5, NTILES = g.N >> 4;
     const int m0 = blockIdx.y * TM;
     const int nt0 = blockIdx.x * TN_TILES + wave * 2;
-    const long b = blockIdx.z;
-    const bf16_t* A = g.A + b * g.a_batch;
-    const int steps = g.K / TK;
+    // blockIdx.z: batch index, or -- EPI_PARTIAL, batch == 1 -- the K slice of a split-K launch (narrow N at 65..512 rows: without
+    // it the 32 column blocks of o_proj / down_proj walk all of K alone, 217 us for down_proj whatever the row count)
+    const int ks = (EPI == EPI_PARTIAL && g.ksplit > 1) ? g.ksplit : 1;
+    const long b = (EPI == EPI_PARTIAL) ? 0 : blockIdx.z;
+    const int slice = (EPI == EPI_PARTIAL) ? blockIdx.z : 0;
+    const int steps = g.K / TK / ks;
+    const bf16_t* A = g.A + b * g.a_batch + (long)slice * steps * TK;
 
     // staging role: thread t moves 4 x 16 bytes of row (t >> 1): chunks 4*(t & 1) .. +3
     const int srow = tid >> 1, sc0 = (tid & 1) * 4;
     const int grow = min(m0 + srow, g.M - 1);
     const bf16_t* aptr = A + (long)grow * g.lda + sc0 * 8;
     const bool nv0 = nt0 < NTILES, nv1 = nt0 + 1 < NTILES;
-    const u32x4_t* w0 = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(nv0 ? nt0 : 0) * KT) * 64 + lane;
-    const u32x4_t* w1 = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(nv1 ? nt0 + 1 : 0) * KT) * 64 + lane;
+    const u32x4_t* w0 = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(nv0 ? nt0 : 0) * KT + (long)slice * steps * 2) * 64 + lane;
+    const u32x4_t* w1 = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(nv1 ? nt0 + 1 : 0) * KT + (long)slice * steps * 2) * 64 + lane;
 
     f32x4_t acc[8][2];
 #pragma unroll
@@ -99,7 +103,9 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs g) {
                     const int col = (nt0 + nb) * 16 + fr;
                     if (!(nb ? nv1 : nv0) || col >= g.n_valid) continue;
                     const float s = acc[mt][nb][r];
-                    if constexpr (EPI == EPI_F32) {
+                    if constexpr (EPI == EPI_PARTIAL) {
+                        reinterpret_cast<float*>(g.out)[(long)slice * g.out_batch + (long)row * g.ldo + col] = s;
+                    } else if constexpr (EPI == EPI_F32) {
                         reinterpret_cast<float*>(g.out)[b * g.out_batch + (long)row * g.ldo + col] = bfr(s);
                     } else {
                         float v;
@@ -116,11 +122,15 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs g) {
     }
 }
 
-bool gemm_tiled_supported(const GemmArgs& g) { return g.K % TK == 0 && g.lda % 8 == 0 && !g.norm_w && (g.M > 64 || g.batch > 1); }
+bool gemm_tiled_supported(const GemmArgs& g) {
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    if (g.epi == EPI_PARTIAL && g.batch != 1) return false;
+    return g.K % (TK * ks) == 0 && g.lda % 8 == 0 && !g.norm_w && (g.M > 64 || g.batch > 1);
+}
 
 int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream) {
     const int NTILES = g.N / 16;
-    dim3 grid((NTILES + TN_TILES - 1) / TN_TILES, (g.M + TM - 1) / TM, g.batch), block(256);
+    dim3 grid((NTILES + TN_TILES - 1) / TN_TILES, (g.M + TM - 1) / TM, g.epi == EPI_PARTIAL ? (g.ksplit > 1 ? g.ksplit : 1) : g.batch), block(256);
 #define LAUNCH_T(E) hipLaunchKernelGGL(gemm_tiled_kernel<E>, grid, block, 0, stream, g)
     switch (g.epi) {
         case EPI_NONE: LAUNCH_T(EPI_NONE); break;
@@ -130,6 +140,7 @@ int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream) {
         case EPI_BIAS_RES: LAUNCH_T(EPI_BIAS_RES); break;
         case EPI_SWIGLU: LAUNCH_T(EPI_SWIGLU); break;
         case EPI_F32: LAUNCH_T(EPI_F32); break;
+        case EPI_PARTIAL: LAUNCH_T(EPI_PARTIAL); break;
         default: return ISST_ERR_ARG;
     }
 #undef LAUNCH_T

@@ -259,7 +259,8 @@ def test_gemm_mid_rows_both_widths(M, wn):
         lib.isst_op_set_gemm_tuning(0, 0)
 
 
-@pytest.mark.parametrize("M,N,K,ks", [(22, 256, 1024, 2), (64, 512, 2048, 4), (33, 256, 4096, 8), (17, 4096, 1024, 1)])
+@pytest.mark.parametrize("M,N,K,ks", [(22, 256, 1024, 2), (64, 512, 2048, 4), (33, 256, 4096, 8), (17, 4096, 1024, 1),
+                                      (88, 512, 2048, 8), (200, 256, 1024, 4), (130, 1040, 512, 2)])  # > 64 rows: the dense kernel's K slices
 @pytest.mark.parametrize("with_norm", [True, False])
 def test_gemm_splitk_rmsnorm(M, N, K, ks, with_norm):
     """o_proj / down_proj at 17..64 rows: K split over workgroups into fp32 slabs, reduced by the residual + RMSNorm kernel.
