@@ -36,7 +36,8 @@
 #include "kernels.h"
 
 #define HD 128
-#define LLM_ATTN_TARGET_WGS 1536  // workgroups wanted chip-wide before slot spans grow beyond 64
+#define LLM_ATTN_TARGET_WGS 512   // workgroups wanted chip-wide before slot spans grow beyond 64 (swept 256..4096 at 4..64 streams: fewer, longer
+                                  // spans win; at 64 streams every (stream, kv head) is ONE workgroup and no combine pass is needed)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 // logical position of physical slot t (or -1 for a slot that holds nothing visible)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
                                                                const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
                                                                const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* vtpool,
                                                                float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
-                                                               int tiles_per_split, LlmAttnOne one) {
+                                                               int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct) {
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
     __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
     const int sp = blockIdx.x, kvh = blockIdx.y;
@@ -290,9 +291,13 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             O += oS[w][c][dd] * f;
         }
         const int row = r0 + c / G, head = kvh * G + c % G;
-        float* dst = partial + (((long)row * H + head) * n_splits + sp) * (2 + HD);
-        if (dd == 0) { dst[0] = M; dst[1] = L; }
-        dst[2 + dd] = O;
+        if (out_direct) {  // a single split: this IS the attention output (llm_attn_combine_kernel's arithmetic for one slab)
+            out_direct[((long)row * H + head) * HD + dd] = f2bf(O / L);
+        } else {
+            float* dst = partial + (((long)row * H + head) * n_splits + sp) * (2 + HD);
+            if (dd == 0) { dst[0] = M; dst[1] = L; }
+            dst[2 + dd] = O;
+        }
     }
 }
 
@@ -337,15 +342,15 @@ void llm_attn_set_tuning(int target_wgs) { g_attn_target_wgs = target_wgs; }
 template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                     int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
-                    float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s, const LlmAttnOne& one) {
+                    float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s, const LlmAttnOne& one, bf16_t* out_direct) {
     dim3 grid(n_splits, d.kv_heads, n_groups), block(256);
     if (max_group_rows * G > 16) return ISST_ERR_ARG;  // one 16-column tile per workgroup (LLM_ATTN_GROUP_ROWS(G) rows)
     if (tiles_per_split > 4)
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, true>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           vtpool, partial, d, layer, n_splits, tiles_per_split, one);
+                           vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct);
     else
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, false>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           vtpool, partial, d, layer, n_splits, tiles_per_split, one);
+                           vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
@@ -369,12 +374,13 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
     int rc;
     switch (G) {
-        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1); break;
-        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1); break;
-        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1); break;
+        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
         default: return ISST_ERR_ARG;
     }
     if (rc != ISST_OK) return rc;
+    if (n_splits == 1) return ISST_OK;  // the partial kernel wrote the output itself
     if (n_splits <= 4)
         hipLaunchKernelGGL(llm_attn_combine_kernel<4>, dim3(d.heads, rows), dim3(HD), 0, s, partial, out, d.heads, n_splits);
     else

@@ -270,3 +270,25 @@ def test_decode_step_graph_replay_is_bit_identical(monkeypatch):
         return out
 
     assert run(True) == run(False)
+
+
+@pytest.mark.parametrize("target_wgs", [1, 6])
+def test_attention_span_forms_match_oracle(target_wgs):
+    """The many-stream forms of the decoder attention, forced on one stream through the tuning hook: target 1 = one workgroup per
+    (stream, kv head) walking every key tile with the running softmax and writing the output itself (no combine pass); target 6 =
+    a few multi-tile spans + combine.  Same teacher-forced run as above, same tolerance."""
+    from infinisst_amd.engine import load_library
+    lib = load_library()
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=8, max_llm_cache_size=150, always_cache_system_prompt=True)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=21)
+    eng = make_engine(cfg, w, debug_taps=False)
+    sid = eng.open_stream()
+    lib.isst_op_set_attn_tuning(target_wgs)
+    try:
+        recs = run_chunks(cfg, gen, w, eng, sid, 8, forced=True, evict=True, sys_pin=True)
+    finally:
+        lib.isst_op_set_attn_tuning(0)
+    worst = max(float(np.abs(r[2] - r[3]).max()) for r in recs)
+    print(f"attention target {target_wgs}: worst |logit diff| = {worst:.4f}")
+    assert worst <= LOGIT_TOL
