@@ -419,7 +419,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->lqrot = h->dalloc<bf16_t>(LR * H * 128); h->lattn = h->dalloc<bf16_t>(LR * H * 128); h->lact = h->dalloc<bf16_t>(LR * c.llm_ffn);
     h->llast = h->dalloc<bf16_t>((size_t)ns * h->max_beams * DL);
     h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * 130);
-    h->lslab = h->dalloc<float>((size_t)LLM_SLAB_ROWS * DL);
+    h->lslab = h->dalloc<float>((size_t)LLM_SLAB_ROWS * std::max(DL, (H + 2 * KV) * 128));
     const size_t NB = (size_t)ns * h->max_beams;  // decode rows of a beam step
     h->logits = h->dalloc<float>(NB * h->vocab_pad);
     h->out_tok = h->dalloc<int>(NB);
@@ -721,6 +721,7 @@ int pick_ksplit(int K, int N, int rows) {
     const int blocks = ((N + 127) / 128) * ((rows + 127) / 128);
     int s = 1;
     while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= 384 && s * 2 * rows <= LLM_SLAB_ROWS && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
+    // (the slab buffer holds LLM_SLAB_ROWS rows of the widest projection, so slices x rows <= LLM_SLAB_ROWS fits any N)
     return s;
 }
 // slabs[ksplit][M][N] (fp32) = A @ W^T per K slice; reduced by launch_rmsnorm_reduce
@@ -895,6 +896,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     // layer's down_proj slabs
     const bool split_rows = rows > 16 && rows <= LLM_SPLIT_MAX_ROWS;
     const int so = split_rows ? pick_ksplit(H * 128, DL, rows) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL, rows) : 1;
+    const int sq = (rows > 128 && rows <= LLM_SPLIT_MAX_ROWS) ? pick_ksplit(DL, (H + 2 * KV) * 128, rows) : 1;  // q/k/v: 65..128 rows run on gemm_mid
     const long slab = (long)rows * DL;
     bool pending = false;
     for (int l = 0; l < c.llm_layers; ++l) {
@@ -912,7 +914,12 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             } else {
                 CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             }
-            CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
+            if (sq > 1) {  // 129..1024 rows: the 48 column blocks of the dense kernel get K slices; a small pass sums the slabs to bf16
+                CHK(gemm_partial(h, h->lxn, DL, L.qkv, h->lslab, rows, sq, st));
+                CHK(launch_slab_reduce(h->lslab, (long)rows * (H + 2 * KV) * 128, sq, h->lqkv, (H + 2 * KV) * 128, rows, (H + 2 * KV) * 128, st));
+            } else {
+                CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
+            }
         }
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one));

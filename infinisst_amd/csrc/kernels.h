@@ -25,6 +25,8 @@ int launch_layernorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b
 int launch_rmsnorm(const bf16_t* x, long ldx, const int* rows_idx, const bf16_t* w, bf16_t* out, long ldo, int rows, int D,
                    float eps, hipStream_t s);
 // split-K slabs (gemm_mid.hip EPI_PARTIAL) -> x += sum, then RMSNorm of the updated rows (w == null: update only)
+// out = bf16(sum of fp32 slabs [n_slabs][rows][N])
+int launch_slab_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* out, long ldo, int rows, int N, hipStream_t s);
 int launch_rmsnorm_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* x, long ldx, const bf16_t* w, bf16_t* out, long ldo,
                           int rows, int D, float eps, hipStream_t s);
 int launch_embed_splice(const int* ids, const int* speech_row, const bf16_t* table, const bf16_t* speech, bf16_t* out,

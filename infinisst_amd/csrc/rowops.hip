@@ -262,6 +262,30 @@ int launch_rmsnorm_reduce(const float* slabs, long slab_stride, int n_slabs, bf1
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
+// plain split-K epilogue: out = bf16(sum of the fp32 slabs), slice order (deterministic).  For the q/k/v projection at 129..1024
+// rows, whose consumer (attention) reads bf16 rows; o_proj / down_proj use rmsnorm_reduce_kernel instead.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int n_slabs, bf16_t* __restrict__ out,
+                                                          long ldo, int N) {
+    const long row = blockIdx.y;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c >= N) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < n_slabs; ++k) {
+        const float* sp = slabs + (long)k * slab_stride + row * N + c;
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), b = *reinterpret_cast<const f32x4_t*>(sp + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    }
+    *reinterpret_cast<u32x4_t*>(out + row * ldo + c) = pack8(acc);
+}
+
+int launch_slab_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* out, long ldo, int rows, int N, hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    if (N % 8 != 0 || ldo % 8 != 0 || n_slabs < 1) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((N / 8 + 255) / 256, rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, out, ldo, N);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
 // ------------------------------------------------------------------------------------------------
 // embedding gather + speech splice (reference model/llm.py:86-113): row r takes the speech feature row
 // src_row[r] >= 0, else the embedding of token ids[r].  One wave per row.
