@@ -160,6 +160,11 @@ int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const u
  * K % (64 * ksplit) == 0. */
 int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, const uint16_t* norm_w,
                                 uint16_t* out, float* slabs, int M, int N, int K, int ksplit, float norm_eps, void* hip_stream);
+/* the encoder twin (wav2vec2 TransformerSentenceEncoderLayer: x = residual + Linear(.) with bias, then LayerNorm):
+ * x = bf16(x + bf16(sum of slabs + bias)) in place; ln_w != NULL: out = LayerNorm(ln_w, ln_b, eps)(x). */
+int isst_op_gemm_splitk_layernorm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, uint16_t* x,
+                                  const uint16_t* ln_w, const uint16_t* ln_b, uint16_t* out, float* slabs, int M, int N, int K,
+                                  int ksplit, float eps, void* hip_stream);
 /* profiling aid: override the GEMM launch heuristic (waves per workgroup, 16-row n-tiles per workgroup); 0 = automatic */
 int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block);
 /* profiling aid: workgroups the decoder attention wants chip-wide before a workgroup's slot span grows beyond 64; 0 = default */

@@ -791,9 +791,21 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
     // via a base + sid * stride scheme -> requires contiguous slots; general case: launch per stream
     bool contiguous = true;
     for (int i = 1; i < n; ++i) contiguous = contiguous && (sids[i] == sids[0] + i);
+    // 65..1024 rows (2..21 streams): out_proj and fc2 (N = 1024: 8 column blocks on the dense kernel) split K into fp32 slabs that the
+    // LayerNorm which follows anyway sums up (rowops.hip layernorm_kernel's prologue) -- the encoder twin of the decoder's split path
+    const bool esplit = ER > 64 && ER <= LLM_SPLIT_MAX_ROWS;
+    const int s_out = esplit ? pick_ksplit(D, D, ER) : 1, s_fc2 = esplit ? pick_ksplit(c.enc_ffn, D, ER) : 1;
+    const long eslab = (long)ER * D;
+    const EncLayer* pend = nullptr;  // layer whose fc2 slabs h->ex still lacks
     for (int l = 0; l < c.enc_layers; ++l) {
         const EncLayer& L = h->enc[l];
-        CHK(launch_layernorm(h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+        if (pend) {
+            CHK(launch_layernorm_reduce(h->lslab, eslab, s_fc2, pend->fc2.bias, h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, st));
+            if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l - 1), h->ex, (int64_t)ER * D, st));
+            pend = nullptr;
+        } else {
+            CHK(launch_layernorm(h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+        }
         CHK(gemm(h, h->exn, D, L.qkv, EPI_BIAS, nullptr, 0, h->eqkv, 3 * D, ER, st));
         if (contiguous) {
             bf16_t* kb = h->enc_k + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
@@ -808,13 +820,28 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
                                          h->eattn + (size_t)i * Q * D, 1, Q, c.enc_heads, h->enc_cap, c.max_cache_size, bs, st));
             }
         }
-        CHK(gemm(h, h->eattn, D, L.out, EPI_BIAS_RES, h->ex, D, h->ex, D, ER, st));
-        CHK(launch_layernorm(h->ex, D, L.ln2.w, L.ln2.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+        if (s_out > 1) {
+            CHK(gemm_partial(h, h->eattn, D, L.out, h->lslab, ER, s_out, st));
+            CHK(launch_layernorm_reduce(h->lslab, eslab, s_out, L.out.bias, h->ex, D, L.ln2.w, L.ln2.b, h->exn, D, ER, D, c.enc_ln_eps, st));
+        } else {
+            CHK(gemm(h, h->eattn, D, L.out, EPI_BIAS_RES, h->ex, D, h->ex, D, ER, st));
+            CHK(launch_layernorm(h->ex, D, L.ln2.w, L.ln2.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+        }
         CHK(gemm(h, h->exn, D, L.fc1, EPI_BIAS_GELU, nullptr, 0, h->effn, c.enc_ffn, ER, st));
-        CHK(gemm(h, h->effn, c.enc_ffn, L.fc2, EPI_BIAS_RES, h->ex, D, h->ex, D, ER, st));
-        if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l), h->ex, (int64_t)ER * D, st));
+        if (s_fc2 > 1) {
+            CHK(gemm_partial(h, h->effn, c.enc_ffn, L.fc2, h->lslab, ER, s_fc2, st));
+            pend = &L;
+        } else {
+            CHK(gemm(h, h->effn, c.enc_ffn, L.fc2, EPI_BIAS_RES, h->ex, D, h->ex, D, ER, st));
+            if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l), h->ex, (int64_t)ER * D, st));
+        }
     }
-    CHK(launch_layernorm(h->ex, D, h->enc_ln_out.w, h->enc_ln_out.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+    if (pend) {
+        CHK(launch_layernorm_reduce(h->lslab, eslab, s_fc2, pend->fc2.bias, h->ex, D, h->enc_ln_out.w, h->enc_ln_out.b, h->exn, D, ER, D, c.enc_ln_eps, st));
+        if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(c.enc_layers - 1), h->ex, (int64_t)ER * D, st));
+    } else {
+        CHK(launch_layernorm(h->ex, D, h->enc_ln_out.w, h->enc_ln_out.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
+    }
     CHK(tap(h, "enc_out", h->exn, (int64_t)ER * D, st));
     for (int i = 0; i < n; ++i) {
         StreamState& s = h->streams[sids[i]];
@@ -1512,6 +1539,19 @@ extern "C" int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const
     const int rc = launch_gemm(g, st);
     if (rc != ISST_OK) return rc;
     return launch_rmsnorm_reduce(slabs, (long)M * N, ksplit, x, N, norm_w, out, N, M, N, norm_eps, st);
+}
+extern "C" int isst_op_gemm_splitk_layernorm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, uint16_t* x,
+                                             const uint16_t* ln_w, const uint16_t* ln_b, uint16_t* out, float* slabs, int M, int N, int K, int ksplit,
+                                             float eps, void* hip_stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    if (N % 16 != 0 || !bias) return ISST_ERR_ARG;
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.Wp = packed; g.out = slabs; g.ldo = N; g.out_batch = (long)M * N;
+    g.M = M; g.N = N; g.K = K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = N; g.ksplit = ksplit;
+    if (!gemm_mid_supported(g) && !gemm_tiled_supported(g)) return ISST_ERR_ARG;
+    const int rc = launch_gemm(g, st);
+    if (rc != ISST_OK) return rc;
+    return launch_layernorm_reduce(slabs, (long)M * N, ksplit, bias, x, N, ln_w, ln_b, out, N, M, N, eps, st);
 }
 extern "C" int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block) {
     gemm_set_tuning(waves_per_block, ntiles_per_block);

@@ -22,6 +22,9 @@ int launch_conv0(const bf16_t* audio, long audio_batch, const bf16_t* w, const b
                  const bf16_t* ln_b, bf16_t* out, long out_batch, int T, int C, int k, int stride, int batch, hipStream_t s);
 int launch_layernorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C,
                      float eps, int gelu, hipStream_t s);
+// split-K epilogue of an encoder projection + the LayerNorm that follows: x += bf16(sum of fp32 slabs + bias) in place, out = LN(x)
+int launch_layernorm_reduce(const float* slabs, long slab_stride, int n_slabs, const bf16_t* proj_bias, bf16_t* x, long ldx, const bf16_t* w,
+                            const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps, hipStream_t s);
 int launch_rmsnorm(const bf16_t* x, long ldx, const int* rows_idx, const bf16_t* w, bf16_t* out, long ldo, int rows, int D,
                    float eps, hipStream_t s);
 // split-K slabs (gemm_mid.hip EPI_PARTIAL) -> x += sum, then RMSNorm of the updated rows (w == null: update only)

@@ -83,14 +83,17 @@ int launch_conv0(const bf16_t* audio, long audio_batch, const bf16_t* w, const b
 // LayerNorm over the last dim (+ optional GELU), one wave per row, 8 bf16 per lane per step.
 // torch semantics: statistics and affine in fp32, one rounding to bf16; GELU of the bf16 value, rounded again.
 // ------------------------------------------------------------------------------------------------
+// Optional split-K prologue (slabs != null; encoder out_proj / fc2 at 65..1024 rows): x = bf16(x + bf16(sum of slabs + bias)) is
+// written back first -- the residual update of the projection whose K slices the dense kernel left as fp32 slabs -- then normalised.
 template <int STEPS>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, long ldx, const bf16_t* __restrict__ w,
+__global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ b, bf16_t* out, long ldo,
-                                                        int rows, int C, float eps, int gelu) {
+                                                        int rows, int C, float eps, int gelu, const float* __restrict__ slabs, long slab_stride,
+                                                        int n_slabs, const bf16_t* __restrict__ proj_bias) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16_t* xr = x + row * ldx;
+    bf16_t* xr = x + row * ldx;
     float v[STEPS][8];
     float sum = 0.f;
 #pragma unroll
@@ -98,10 +101,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, long ld
         const int c = (lane + 64 * s) * 8;
         if (c < C) {
             unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
+            if (slabs) {
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pb[8];
+                for (int k = 0; k < n_slabs; ++k) {
+                    const float* sp = slabs + (long)k * slab_stride + row * C + c;
+                    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), a2 = *reinterpret_cast<const f32x4_t*>(sp + 4);
+                    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                    acc[4] += a2.x; acc[5] += a2.y; acc[6] += a2.z; acc[7] += a2.w;
+                }
+                unpack8(*reinterpret_cast<const u32x4_t*>(proj_bias + c), pb);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + bfr(acc[j] + pb[j]));
+                *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum += v[s][j];
         }
     }
+    if (!w) return;
     const float mean = wave_sum(sum) / C;
     float sq = 0.f;
 #pragma unroll
@@ -129,18 +146,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, long ld
     }
 }
 
-int launch_layernorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C,
-                     float eps, int gelu, hipStream_t s) {
+static int launch_layernorm_impl(bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps,
+                                 int gelu, const float* slabs, long slab_stride, int n_slabs, const bf16_t* proj_bias, hipStream_t s) {
     if (rows <= 0) return ISST_OK;
     if (C % 8 != 0 || C > 4096 || ldx % 8 != 0 || ldo % 8 != 0) return ISST_ERR_ARG;
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 512)
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu);
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias);
     else if (C <= 1024)
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu);
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias);
     else
-        hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu);
+        hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+int launch_layernorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C,
+                     float eps, int gelu, hipStream_t s) {
+    return launch_layernorm_impl(const_cast<bf16_t*>(x), ldx, w, b, out, ldo, rows, C, eps, gelu, nullptr, 0, 0, nullptr, s);
+}
+
+// x[rows][C] (in place) += projection slabs + bias, then out = LayerNorm(x) (w == null: update only)
+int launch_layernorm_reduce(const float* slabs, long slab_stride, int n_slabs, const bf16_t* proj_bias, bf16_t* x, long ldx, const bf16_t* w,
+                            const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps, hipStream_t s) {
+    if (!slabs || n_slabs < 1 || !proj_bias) return ISST_ERR_ARG;
+    return launch_layernorm_impl(x, ldx, w, b, out, ldo, rows, C, eps, 0, slabs, slab_stride, n_slabs, proj_bias, s);
 }
 
 // ------------------------------------------------------------------------------------------------

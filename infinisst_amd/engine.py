@@ -65,7 +65,7 @@ EXPORTS = [
     "isst_create", "isst_destroy", "isst_last_error", "isst_load_weight", "isst_set_rope_tables",
     "isst_finalize_weights", "isst_stream_open", "isst_stream_reset", "isst_stream_close", "isst_stream_info_get",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_end", "isst_op_pack_weight",
-    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
 ]
 
 
@@ -108,6 +108,8 @@ def load_library(path: Optional[str] = None):
                                  C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
     lib.isst_op_gemm_splitk_rmsnorm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    lib.isst_op_gemm_splitk_layernorm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
     lib.isst_op_set_gemm_tuning.argtypes = [C.c_int, C.c_int]
     lib.isst_op_set_attn_tuning.argtypes = [C.c_int]
     lib.isst_op_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
@@ -359,6 +361,21 @@ def op_gemm_splitk_rmsnorm(A: torch.Tensor, packed: torch.Tensor, x: torch.Tenso
                                          ksplit, norm_eps, _stream_ptr())
     if rc:
         raise IsstError(f"isst_op_gemm_splitk_rmsnorm -> {rc}")
+    return x, out
+
+
+def op_gemm_splitk_layernorm(A, packed, bias, x, ksplit, ln_w, ln_b, eps=1e-5):
+    """x <- bf16(x + bf16(A @ W^T + bias)) through `ksplit` fp32 K-slabs; returns (x_new, LayerNorm(x_new))."""
+    lib = load_library()
+    M, K = A.shape
+    N = x.shape[1]
+    x = x.clone()
+    out = torch.empty_like(x)
+    slabs = torch.empty((ksplit, M, N), dtype=torch.float32, device=A.device)
+    rc = lib.isst_op_gemm_splitk_layernorm(_ptr(A), A.stride(0), _ptr(packed), _ptr(bias), _ptr(x), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(slabs),
+                                           M, N, K, ksplit, eps, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_gemm_splitk_layernorm -> {rc}")
     return x, out
 
 

@@ -279,3 +279,20 @@ def test_gemm_splitk_rmsnorm(M, N, K, ks, with_norm):
         close_bf16(normed, ollm.rmsnorm(x_new.cpu(), nw, 1e-5), f"splitk norm M{M}", ulps=2.0, atol=1e-3)
     else:
         assert normed is None
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(96, 256, 1024, 2), (384, 1024, 2048, 4), (130, 512, 512, 1)])
+def test_gemm_splitk_layernorm(M, N, K, ks):
+    """Encoder out_proj / fc2 at 65..1024 rows: K slices on the dense kernel, summed (+ bias, + residual) by the LayerNorm kernel.
+    Reference = fairseq TransformerSentenceEncoderLayer: x = residual + Linear(x) (bf16 each), then LayerNorm (fp32 statistics)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf(torch.randn(N, generator=g))
+    x = bf(torch.randn(M, N, generator=g))
+    lw, lb = bf(1 + 0.2 * torch.randn(N, generator=g)), bf(0.1 * torch.randn(N, generator=g))
+    x_new, normed = E.op_gemm_splitk_layernorm(A.to(DEV), E.op_pack_weight(W.to(DEV)), bias.to(DEV), x.to(DEV), ks, lw.to(DEV), lb.to(DEV), 1e-5)
+    torch.cuda.synchronize()
+    close_bf16(x_new, ref_linear(A, W, "bias_res", bias, x), f"splitk-ln x M{M}", ulps=2.5, atol=3.2e-2)
+    ref_ln = torch.nn.functional.layer_norm(x_new.float().cpu(), (N,), lw.float(), lb.float(), 1e-5)
+    close_bf16(normed, bf(ref_ln), f"splitk-ln norm M{M}", ulps=2.0, atol=4e-3)
