@@ -69,13 +69,18 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs g) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) { breg[kk][0] = w0[((long)(t + 1) * 2 + kk) * 64]; breg[kk][1] = w1[((long)(t + 1) * 2 + kk) * 64]; }
         }
+        // all 8 A fragments of a k-tile are requested before its 16 MFMAs (left to itself hipcc emits 2 reads -> wait -> 4 MFMAs,
+        // eight times per k-tile: every group exposes the LDS latency and the matrix pipe idles 70 % of the time)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            u32x4_t af[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) af[mt] = *reinterpret_cast<const u32x4_t*>(&As[cur][a_off(mt * 16 + fr, kk * 4 + fq)]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
-                const u32x4_t af = *reinterpret_cast<const u32x4_t*>(&As[cur][a_off(mt * 16 + fr, kk * 4 + fq)]);
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bcur[kk][0]), acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bcur[kk][1]), acc[mt][1], 0, 0, 0);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mt]), __builtin_bit_cast(bf16x8_t, bcur[kk][0]), acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mt]), __builtin_bit_cast(bf16x8_t, bcur[kk][1]), acc[mt][1], 0, 0, 0);
             }
         }
         if (t + 1 < steps) {
