@@ -90,6 +90,7 @@ struct isst_handle {
         int rows = -1, n_suppress = 0, ngram = 0, enc_ngram = 0;
         float penalty = 0.f;
     } dgraph;
+    bool rot_keys = true;   // ISST_ROT_KEYS=0: rotate cached keys on every read (the reference's schedule) instead of once per chunk
     bool use_graphs = false;  // ISST_GRAPH=1 enables.  Measured on MI355X (1 stream): 35.40 ms per chunk replayed vs 35.28 launched one by
                               // one -- the loop is GPU-bound, the host is ~0.6 ms ahead per pass, and a graph does not shorten the
                               // GPU-side kernel boundaries; it only saves host time (230 launches -> 1 per step)
@@ -134,6 +135,7 @@ struct isst_handle {
     bf16_t *enc_k = nullptr, *enc_v = nullptr;  // [max_streams][enc_layers][heads][enc_cap][64]
     long enc_stream_stride = 0, enc_layer_stride = 0;
     bf16_t *llm_k = nullptr, *llm_v = nullptr;  // [max_streams][llm_layers][kv_heads][sys_cap+ring_cap][128]
+    bf16_t* llm_kr = nullptr;                   // same geometry as llm_k: the keys rotated at their logical position of the current chunk (llm_attn.hip)
     long llm_stream_stride = 0;
     LlmAttnDims adims{};
 
@@ -310,6 +312,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     isst_handle* h = new isst_handle();
     h->cfg = *cfg;
     if (const char* e = getenv("ISST_GRAPH")) h->use_graphs = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_ROT_KEYS")) h->rot_keys = e[0] && e[0] != '0';
     const isst_config& c = h->cfg;
     auto die = [&](int code) { g_create_error = h->err; isst_destroy(h); return code; };
 
@@ -394,6 +397,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->llm_stream_stride = h->adims.layer_stride * c.llm_layers;
     h->llm_k = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams * h->max_beams, true);
     h->llm_v = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams * h->max_beams, true);
+    h->llm_kr = h->dalloc<bf16_t>((size_t)h->llm_stream_stride * c.max_streams * h->max_beams, true);
     h->enc_rope_rows = h->enc_cap;
     h->llm_rope_rows = h->sys_cap + h->ring_cap;
     h->enc_cos = h->dalloc<float>((size_t)h->enc_rope_rows * 32, true);
@@ -444,7 +448,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->meta_bytes = (size_t)LR * 6 * sizeof(int) + NB * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
                     NB * (h->max_ids + h->max_enc_ids) * sizeof(int) + NB * 4 * sizeof(KvCopyOp) + 65536 * sizeof(int) + 8192;
     h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
-    const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
+    const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->llm_kr, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
                           h->window, h->act_a, h->act_b, h->ex, h->exn, h->eqkv, h->eattn, h->effn, h->speech, h->lx, h->lxn, h->lqkv, h->lqrot,
                           h->lattn, h->lact, h->llast, h->lpartial, h->lslab, h->logits, h->out_tok, h->samp_val, h->samp_idx, h->meta_dev};
     for (const void* p : must)
@@ -949,7 +953,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             }
         }
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
-                                 h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one));
+                                 h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one));
         if (so > 1) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
             CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
@@ -1227,6 +1231,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 mh.views[r].kv_offset = h->arena_off(stream_ids[i], b);
                 mh.views[r].new_start = mh.row_pos[r];
                 mh.views[r].row0 = r;
+                mh.views[r].rot_keys = 0;  // beam arenas are re-bound every step: rotate on read
                 mh.groups[r].x = r;
                 mh.groups[r].y = 1;
             }
@@ -1365,6 +1370,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         mh.views[i].kv_offset = h->arena_off(stream_ids[i], 0);
         mh.views[i].new_start = total0[i];
         mh.views[i].row0 = R;
+        mh.views[i].rot_keys = (B == 1 && h->rot_keys) ? 1 : 0;
         row0[i] = R;
         const int len = prompt_lens[i];
         const int* ids = prompt_ids[i];
@@ -1407,6 +1413,11 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         HIPCHK(hipMemcpyAsync(h->meta_dev + mh.suppress_offset, h->meta_host + mh.suppress_offset, (size_t)p->n_suppress * 4, hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+    if (B == 1 && h->rot_keys) {  // rotate the cached keys of every layer ONCE for this chunk (positions are fixed until the next eviction)
+        bool any = false;
+        for (int i = 0; i < n; ++i) any = any || total0[i] > 0;
+        if (any) CHK(launch_llm_rope_cache(md.views, n, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
+    }
     CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh));
     if (B > 1)
         return beam_decode(h, p, n, stream_ids, prompt_ids, prompt_lens, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);

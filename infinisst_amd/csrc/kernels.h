@@ -15,6 +15,8 @@ struct LlmStreamView {
     long kv_offset;  // element offset of this stream's arena inside the K (and V) pool, per layer-0 head-0 base
     int new_start;   // first logical position written by THIS launch (keys >= new_start are read from the qkv rows)
     int row0;        // row of this launch that holds position new_start
+    int rot_keys;    // 1: keys older than this launch are read ALREADY ROTATED from the rotated-key arena (launch_llm_rope_cache filled it
+                     // for this chunk) and the launch's own keys are added to it; 0: rotate on read, as the reference does every pass
 };
 
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
@@ -65,8 +67,14 @@ struct LlmAttnOne {
     LlmStreamView v;
 };
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
-                         int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
+                         int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one = nullptr);
+// Rotated-key arena for one chunk: for every listed stream and EVERY layer, krpool[slot] = RoPE(kpool[slot], logical position of the slot)
+// for the `total` cached keys (views[i].new_start = total).  A key's logical position only changes when the host evicts, i.e. between
+// chunks, so the 10 passes of a chunk (and the row groups of its prefill, which would each rotate the same keys again) read keys
+// rotated once.  Identical bits to rotating on read.
+int launch_llm_rope_cache(const LlmStreamView* sv, int n_streams, const bf16_t* rope_cos, const bf16_t* rope_sin, const bf16_t* kpool, bf16_t* krpool,
+                          LlmAttnDims d, int layers, hipStream_t s);
 
 // ---- sampling (sample.hip) ----
 struct SampleStream {

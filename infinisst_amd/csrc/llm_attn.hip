@@ -80,7 +80,7 @@ template <int G, int CT, bool MULTI>  // G q-heads per kv head, CT column tiles 
 __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
                                                                const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
                                                                const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
-                                                               const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* vtpool,
+                                                               const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                                                                float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
                                                                int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct) {
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     const int slots = d.sys_cap + d.ring_cap;
     const long base = v.kv_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
     bf16_t* kb = kpool + base;    // [slots][128]
+    bf16_t* kr = krpool + base;   // [slots][128] the same keys rotated at their logical position of this chunk (LlmStreamView::rot_keys)
+    const bool rot = v.rot_keys != 0;
     bf16_t* vt = vtpool + base;   // [128][slots]
     const int total = (one.enabled ? one.pos0 + nrows - 1 : row_pos[r0 + nrows - 1]) + 1;  // keys visible to the last row of the group
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     auto key_src = [&](int t, int& jk, bool& k_new) -> const bf16_t* {
         jk = llm_logical(v, d, t * 16 + fr, total);
         k_new = jk >= 0 && jk >= v.new_start;
-        return k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : kb + (long)(t * 16 + fr) * HD;
+        return k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(t * 16 + fr) * HD;
     };
     int t = tile_begin + wave;
     int jk_n = -1;
@@ -211,8 +213,26 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
                 }
             }
         }
+        // rotated-key arena: cached keys arrive rotated; only a tile that holds keys of this launch rotates (all lanes, keeping
+        // the arena value where there is one), and the owner of such a key adds its rotated form to the arena
         u32x4_t kf[4];
-        rope_row_chunks(kraw, jk >= 0 ? jk : 0, fq, rope_cos, rope_sin, kf);
+        if (!rot || tile_has_new) {
+            rope_row_chunks(kraw, jk >= 0 ? jk : 0, fq, rope_cos, rope_sin, kf);
+            if (rot && !k_new) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) kf[s] = kraw[s];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = kraw[s];
+        }
+        if (rot && k_new) {
+            const int krow = v.row0 + (jk - v.new_start);
+            if (krow >= r0 && krow < r0 + nrows) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kr + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
+            }
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             f32x4_t st = {0.f, 0.f, 0.f, 0.f};
@@ -336,26 +356,60 @@ __global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __re
     out[((long)r * heads + h) * HD + dd] = f2bf(O / L);
 }
 
+// ---- rotated-key arena fill (once per chunk): one wave per 16-slot tile, same lane -> key mapping and rotation as above ----
+__global__ __launch_bounds__(256) void llm_rope_cache_kernel(const LlmStreamView* __restrict__ sv, const bf16_t* __restrict__ rope_cos,
+                                                             const bf16_t* __restrict__ rope_sin, const bf16_t* __restrict__ kpool,
+                                                             bf16_t* __restrict__ krpool, LlmAttnDims d, int layers) {
+    const LlmStreamView v = sv[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int slots = d.sys_cap + d.ring_cap;
+    const int t = blockIdx.x * 4 + wave;  // tile
+    if (t >= (slots >> 4)) return;
+    const int total = v.new_start;        // cached keys before this chunk's launches
+    const int jk = llm_logical(v, d, t * 16 + fr, total);
+    if (!__any(jk >= 0)) return;
+    const int lk = blockIdx.y;            // layer * kv_heads + kv head
+    const long base = v.kv_offset + (long)(lk / d.kv_heads) * d.layer_stride + (long)(lk % d.kv_heads) * slots * HD + (long)(t * 16 + fr) * HD;
+    u32x4_t kraw[4], kf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kraw[s] = *reinterpret_cast<const u32x4_t*>(kpool + base + 32 * s + 8 * fq);
+    rope_row_chunks(kraw, jk >= 0 ? jk : 0, fq, rope_cos, rope_sin, kf);
+    if (jk >= 0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(krpool + base + 32 * s + 8 * fq) = kf[s];
+    }
+}
+
+int launch_llm_rope_cache(const LlmStreamView* sv, int n_streams, const bf16_t* rope_cos, const bf16_t* rope_sin, const bf16_t* kpool, bf16_t* krpool,
+                          LlmAttnDims d, int layers, hipStream_t s) {
+    if (n_streams <= 0) return ISST_OK;
+    const int slots = d.sys_cap + d.ring_cap;
+    hipLaunchKernelGGL(llm_rope_cache_kernel, dim3((slots / 16 + 3) / 4, layers * d.kv_heads, n_streams), dim3(256), 0, s, sv, rope_cos, rope_sin, kpool,
+                       krpool, d, layers);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
 static int g_attn_target_wgs = 0;  // profiling aid (isst_op_set_attn_tuning): 0 = LLM_ATTN_TARGET_WGS
 void llm_attn_set_tuning(int target_wgs) { g_attn_target_wgs = target_wgs; }
 
 template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
-                    int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
+                    int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                     float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s, const LlmAttnOne& one, bf16_t* out_direct) {
     dim3 grid(n_splits, d.kv_heads, n_groups), block(256);
     if (max_group_rows * G > 16) return ISST_ERR_ARG;  // one 16-column tile per workgroup (LLM_ATTN_GROUP_ROWS(G) rows)
     if (tiles_per_split > 4)
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, true>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct);
+                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct);
     else
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, false>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct);
+                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
-                         int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* vtpool,
+                         int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one) {
     if (rows <= 0 || n_groups <= 0) return ISST_OK;
     LlmAttnOne one1{};
@@ -374,9 +428,9 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
     int rc;
     switch (G) {
-        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
-        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
-        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
         default: return ISST_ERR_ARG;
     }
     if (rc != ISST_OK) return rc;
