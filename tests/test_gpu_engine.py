@@ -292,3 +292,40 @@ def test_attention_span_forms_match_oracle(target_wgs):
     worst = max(float(np.abs(r[2] - r[3]).max()) for r in recs)
     print(f"attention target {target_wgs}: worst |logit diff| = {worst:.4f}")
     assert worst <= LOGIT_TOL
+
+
+def test_rotated_key_arena_is_bit_identical_to_rotate_on_read(monkeypatch):
+    """ISST_ROT_KEYS=1 (default: cached keys rotated once per chunk into a second arena) against ISST_ROT_KEYS=0 (rotated on every
+    read, the reference's schedule): same RoPE function on the same inputs, so logits must be bit-identical -- across chunks, a pinned
+    system prompt and evictions that shift every ring key's position."""
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=43)
+    gen = GenConfig(max_new_tokens=6, max_llm_cache_size=150, always_cache_system_prompt=True)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 7, stream_id=11)
+    sys_n = len(synth.system_prompt_ids(cfg))
+
+    def run(flag):
+        monkeypatch.setenv("ISST_ROT_KEYS", flag)
+        eng = make_engine(cfg, w, debug_taps=False, max_multiplier=1)
+        sids = [eng.open_stream(), eng.open_stream()]
+        out, ckpts = [], []
+        for c in range(7):
+            seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+            prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            ids, logits = eng.generate(gen, sids, [seg, seg], [prompt, prompt], [[], []], system_prompt_size=sys_n if c == 0 else 0, return_logits=True)
+            out.append((ids, logits.copy()))
+            cur = eng.stream_info(sids[0])["llm_cache_len"]
+            ckpts.append(cur)
+            ev = oag.evict(ckpts, cur, gen.max_llm_cache_size, True, sys_n)
+            if ev is not None:
+                ckpts, new_size = ev
+                for s in sids:
+                    eng.kv_evict(s, new_size, sys_n)
+        eng.close()
+        return out
+
+    a, b = run("1"), run("0")
+    assert len(a) == len(b)
+    for (ia, la), (ib, lb) in zip(a, b):
+        assert ia == ib
+        assert np.array_equal(la, lb)
