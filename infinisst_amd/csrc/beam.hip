@@ -9,7 +9,7 @@
 
 #define HD 128
 
-// ---- copy `count` logical positions starting at p0 between an arena (K [slots][128], V^T [128][slots]) and a buffer
+// ---- copy `count` logical positions starting at p0 between an arena (K [slots][128], V [slots][128]) and a buffer
 //      (K [layers][kv][tcap][128], V [layers][kv][tcap][128], both row-major).  grid = (count, kv_heads, layers * n_ops)
 __global__ __launch_bounds__(128) void kv_positions_copy_kernel(bf16_t* kpool, bf16_t* vtpool, bf16_t* kbuf, bf16_t* vbuf,
                                                                const KvCopyOp* __restrict__ ops, LlmAttnDims d, int layers, int tcap) {
@@ -27,10 +27,10 @@ __global__ __launch_bounds__(128) void kv_positions_copy_kernel(bf16_t* kpool, b
     const long bidx = op.buf_offset + (((long)layer * d.kv_heads + kvh) * tcap + t) * HD + dd;
     if (op.to_arena) {
         kpool[abase + slot * HD + dd] = kbuf[bidx];
-        vtpool[abase + (long)dd * slots + slot] = vbuf[bidx];
+        vtpool[abase + slot * HD + dd] = vbuf[bidx];
     } else {
         kbuf[bidx] = kpool[abase + slot * HD + dd];
-        vbuf[bidx] = vtpool[abase + (long)dd * slots + slot];
+        vbuf[bidx] = vtpool[abase + slot * HD + dd];
     }
 }
 

@@ -1632,7 +1632,7 @@ extern "C" int isst_debug_read_kv(isst_handle* h, int id, int beam, int layer, i
     const long base = h->arena_off(id, beam) + (long)layer * h->adims.layer_stride + (long)kv_head * slots * 128;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(k_out, h->llm_k + base + slot * 128, 256, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy2D(v_out, 2, h->llm_v + base + slot, (size_t)slots * 2, 2, 128, hipMemcpyDeviceToHost));  // V^T column
+    HIPCHK(hipMemcpy(v_out, h->llm_v + base + slot * 128, 256, hipMemcpyDeviceToHost));
     return ISST_OK;
 }
 

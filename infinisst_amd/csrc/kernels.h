@@ -52,7 +52,7 @@ struct LlmAttnDims {
 };
 // causal attention of every row over its stream's keys 0..row_pos, fused with the q rotation and the append of
 // the row's own (unrotated) k, v to the arena; RoPE applied to K on read.  qkv: [rows][(H + 2 KV) * 128].
-// kpool: K [slots][128] per (stream, layer, kv head); vtpool: V transposed [128][slots].  groups[z] = (first row,
+// kpool: K [slots][128] per (stream, layer, kv head); vtpool: V, same layout (row per key).  groups[z] = (first row,
 // row count): runs of consecutive rows of ONE stream, at most LLM_ATTN_GROUP_ROWS(G) rows each.
 // partial: [rows][heads][slots/64][2 + 128] fp32.
 #define LLM_ATTN_GROUP_ROWS(G) (16 / (G))

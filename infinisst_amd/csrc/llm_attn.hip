@@ -7,8 +7,9 @@
 // [pinned system prompt][ring] and eviction is a ring-start advance: a key's rotation angle is its LOGICAL index
 // at read time, so nothing is copied and nothing is re-rotated in memory.
 //
-// Layout in HBM, per stream, layer and kv head:  K [slots][128] bf16 (row per key, unrotated) and V TRANSPOSED
-// [128][slots] (row per dim), slots = sys_cap + ring_cap (multiples of 64).  Logical position p lives in slot p
+// Layout in HBM, per stream, layer and kv head:  K [slots][128] bf16 (row per key, unrotated) and V [slots][128] (row per key: a
+// 16-key tile is one contiguous 4 KiB run for either; the transposed [128][slots] plane this kernel used first streamed at 3.4 TB/s
+// against 5.6 TB/s for rows, profiles/probes/vt_load_probe.hip), slots = sys_cap + ring_cap (multiples of 64).  Logical position p lives in slot p
 // (p < sys_len) or sys_cap + (ring_start + p - sys_len) mod ring_cap.  Attention is a sum over keys, so the kernel
 // walks PHYSICAL 16-slot tiles and derives each slot's logical index (rotation angle, causal mask); dead slots
 // get probability 0.
@@ -26,9 +27,9 @@
 //                                                     in-lane + 2 cross-row shuffles per tile (not per key)
 //   O[c][dim]   += P[c][key] V[key][dim]              v_mfma_f32_16x16x16_bf16: its A layout (4 consecutive k per
 //                                                     lane) IS the C layout of S^T, so P never leaves registers;
-//                                                     B = V^T, 8 bytes per lane
+//                                                     B = V through a wave-private LDS image read with ds_read_b64_tr_b16
 // Keys written by this launch (logical position >= new_start: the prompt rows of a prefill, the row itself in a
-// decode step) are read from the qkv rows; the wave that meets a row's own key appends it (K row + V^T column) to
+// decode step) are read from the qkv rows; the wave that meets a row's own key appends it (K row + V row) to
 // the arena, so every new key is stored exactly once and nobody reads a slot another workgroup writes.
 // The 4 waves' partials meet in LDS; one (m, l, o[128]) slab per (row, head, split) goes to global and a small
 // second kernel combines the splits (a fused last-arriver combine measured slower, see profiles/r01).
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     bf16_t* kb = kpool + base;    // [slots][128]
     bf16_t* kr = krpool + base;   // [slots][128] the same keys rotated at their logical position of this chunk (LlmStreamView::rot_keys)
     const bool rot = v.rot_keys != 0;
-    bf16_t* vt = vtpool + base;   // [128][slots]
+    bf16_t* vb = vtpool + base;   // [slots][128] row per key, like K
     const int total = (one.enabled ? one.pos0 + nrows - 1 : row_pos[r0 + nrows - 1]) + 1;  // keys visible to the last row of the group
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
     // this wave's 16-slot tiles: tile_begin + wave, + 4, ... below tile_end
@@ -138,14 +139,24 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         k_new = jk >= 0 && jk >= v.new_start;
         return k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(t * 16 + fr) * HD;
     };
+    // V tile staging: the lane's value row (16 B x 4, same lane -> (key, dims) map as K) goes to a wave-private LDS image
+    // [16 keys][128 dims] (256-byte rows, 16-byte chunks XOR-swizzled so that row writes and transposed reads both spread over the
+    // banks) and comes back through ds_read_b64_tr_b16 as the P.V B operand: lane (fr, fq) gets V[key 4fq + j][dim 16nt + fr].
+    // The image lives inside this wave's part of the merge buffer oS (free until the end).
+    unsigned char* vimg = reinterpret_cast<unsigned char*>(&oS[wave][0][0]);
+    auto v_off = [](int row, int ch) -> int { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); };
+    int vw_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vw_off[s] = v_off(fr, 4 * s + fq);
+    const int tq = (lane >> 2) & 3, tp = lane & 3;  // transposed read: lane 4q + p of its 16-lane group addresses row 4g + q, 4 dims at 4p
+    int vr_off[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) vr_off[nt] = v_off(4 * fq + tq, 2 * nt + (tp >> 1)) + 8 * (tp & 1);
+
     int t = tile_begin + wave;
     int jk_n = -1;
     bool knew_n = false;
     u32x4_t kraw_n[4];
-    auto load_vt = [&](int tt, u32x2_t* dst) {
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) dst[nt] = *reinterpret_cast<const u32x2_t*>(vt + (long)(16 * nt + fr) * slots + tt * 16 + 4 * fq);
-    };
     if (t < tile_end) {
         const bf16_t* src = key_src(t, jk_n, knew_n);
 #pragma unroll
@@ -158,7 +169,11 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         u32x4_t kraw[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) kraw[s] = kraw_n[s];
-        u32x2_t vf[8];
+        // this tile's values: the lane's key row from the arena, or from the qkv row for a key written by this launch
+        const bf16_t* v_src = k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD : vb + (long)(t0 + fr) * HD;
+        u32x4_t vraw[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) vraw[s] = *reinterpret_cast<const u32x4_t*>(v_src + 32 * s + 8 * fq);
         if (MULTI && t + 4 < tile_end) {  // next tile's keys go in flight before this tile's arithmetic
             const bf16_t* src = key_src(t + 4, jk_n, knew_n);
 #pragma unroll
@@ -172,49 +187,17 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 #pragma unroll
         for (int r = 0; r < 4; ++r) jc[r] = llm_logical(v, d, t0 + 4 * fq + r, total);
 
-        // ---- V^T fragments: B[k = key 4fq + j][n = dim 16 nt + fr] ----
-        if (!tile_has_new) {
-            load_vt(t, vf);
-        } else {  // mixed tile: some keys still live only in the qkv rows -> scalar gather
-            int slots_o = slots;  // opaque: keeps this rare path's address arithmetic out of the loop preheader (registers)
-            asm volatile("" : "+s"(slots_o));
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                bf16_t e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int jj = jc[j];
-                    const int dim = 16 * nt + fr;
-                    if (jj >= 0 && jj >= v.new_start)
-                        e[j] = qkv[(long)(v.row0 + (jj - v.new_start)) * ldq + (long)(H + KV + kvh) * HD + dim];
-                    else
-                        e[j] = vt[(long)dim * slots_o + t0 + 4 * fq + j];
-                }
-                vf[nt].x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
-                vf[nt].y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-            }
-        }
-        // ---- append this group's own new keys (unrotated K row, V^T column) ----
+        // ---- append this group's own new keys (unrotated K row, V row) ----
         if (k_new) {
             const int krow = v.row0 + (jk - v.new_start);
             if (krow >= r0 && krow < r0 + nrows) {
-                int slots_o = slots;
-                asm volatile("" : "+s"(slots_o));
-#pragma unroll
-                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kraw[s];
-                const bf16_t* vrow = qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const u32x4_t vv = *reinterpret_cast<const u32x4_t*>(vrow + 32 * s + 8 * fq);
-                    const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        vt[(long)(32 * s + 8 * fq + e) * slots_o + t0 + fr] = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffff));
+                    *reinterpret_cast<u32x4_t*>(kb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kraw[s];
+                    *reinterpret_cast<u32x4_t*>(vb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = vraw[s];
                 }
             }
         }
-        // rotated-key arena: cached keys arrive rotated; only a tile that holds keys of this launch rotates (all lanes, keeping
-        // the arena value where there is one), and the owner of such a key adds its rotated form to the arena
         u32x4_t kf[4];
         if (!rot || tile_has_new) {
             rope_row_chunks(kraw, jk >= 0 ? jk : 0, fq, rope_cos, rope_sin, kf);
@@ -233,6 +216,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
                 for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kr + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
             }
         }
+        u32x2_t vf[8];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             f32x4_t st = {0.f, 0.f, 0.f, 0.f};
@@ -271,6 +255,14 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             pp.x = pack_bf(p[0], p[1]);
             pp.y = pack_bf(p[2], p[3]);
             const s16x4_t pa = __builtin_bit_cast(s16x4_t, pp);
+            if (ct == 0) {  // values through the wave's LDS image (written as rows, read transposed); EXEC is full here
+#pragma unroll
+                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(vimg + vw_off[s]) = vraw[s];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt)
+                    vf[nt] = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                             (__attribute__((address_space(3))) s16x4_t*)(vimg + vr_off[nt])));
+            }
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 f32x4_t acc = o[ct][nt];
