@@ -157,27 +157,38 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     int jk_n = -1;
     bool knew_n = false;
     u32x4_t kraw_n[4];
+    // the lane's value row of tile tt: from the arena, or from the qkv row for a key written by this launch
+    auto val_src = [&](int tt, int jk, bool k_new) -> const bf16_t* {
+        return k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD : vb + (long)(tt * 16 + fr) * HD;
+    };
+    // MULTI: the next tile's key and value rows go in flight before this tile's arithmetic.  The prefetch is unconditional, clamped
+    // to the wave's last tile (slots % 64 == 0 gives every wave the same tile count): a conditional load makes hipcc branch around it
+    // and drain vmcnt(0).
+    const int t_last = tile_end - 4 + wave;
+    u32x4_t vraw_n[4];
     if (t < tile_end) {
         const bf16_t* src = key_src(t, jk_n, knew_n);
 #pragma unroll
         for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+        const bf16_t* vs = val_src(t, jk_n, knew_n);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) vraw_n[s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
     }
     auto tile_body = [&]() {
         const int t0 = t * 16;
         const int jk = jk_n;
         const bool k_new = knew_n;
-        u32x4_t kraw[4];
+        u32x4_t kraw[4], vraw[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kraw[s] = kraw_n[s];
-        // this tile's values: the lane's key row from the arena, or from the qkv row for a key written by this launch
-        const bf16_t* v_src = k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD : vb + (long)(t0 + fr) * HD;
-        u32x4_t vraw[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) vraw[s] = *reinterpret_cast<const u32x4_t*>(v_src + 32 * s + 8 * fq);
-        if (MULTI && t + 4 < tile_end) {  // next tile's keys go in flight before this tile's arithmetic
-            const bf16_t* src = key_src(t + 4, jk_n, knew_n);
+        for (int s = 0; s < 4; ++s) { kraw[s] = kraw_n[s]; vraw[s] = vraw_n[s]; }
+        if constexpr (MULTI) {
+            const int tn = min(t + 4, t_last);
+            const bf16_t* src = key_src(tn, jk_n, knew_n);
 #pragma unroll
             for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+            const bf16_t* vs = val_src(tn, jk_n, knew_n);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) vraw_n[s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
         }
         const bool tile_live = __any(jk >= 0);
         if (!tile_live) return;
