@@ -445,7 +445,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
             h->fail(ISST_ERR_NOMEM, "beam search allocation failed"); return die(ISST_ERR_NOMEM);
         }
     }
-    h->meta_bytes = (size_t)LR * 6 * sizeof(int) + NB * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
+    h->meta_bytes = (size_t)LR * 8 * sizeof(int) + NB * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
                     NB * (h->max_ids + h->max_enc_ids) * sizeof(int) + NB * 4 * sizeof(KvCopyOp) + 65536 * sizeof(int) + 8192;
     h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
     const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->llm_kr, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
@@ -874,6 +874,7 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
 struct StepMeta {
     int *row_stream, *row_pos, *ids, *speech_row, *last_rows;
     int2* groups;  // attention row groups of this launch
+    int2* units;   // prefill: runs of <= 8 consecutive groups of one stream (llm_attn_prefill_kernel)
     LlmStreamView* views;
     SampleStream* samp;
     int *ids_pool, *enc_pool, *suppress;
@@ -891,6 +892,7 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
     m.ids = reinterpret_cast<int*>(take(LR * 4)); m.speech_row = reinterpret_cast<int*>(take(LR * 4));
     m.last_rows = reinterpret_cast<int*>(take(ns * 4));
     m.groups = reinterpret_cast<int2*>(take(LR * 8));
+    m.units = reinterpret_cast<int2*>(take(LR * 8));
     m.views = reinterpret_cast<LlmStreamView*>(take(ns * sizeof(LlmStreamView)));
     m.samp = reinterpret_cast<SampleStream*>(take(ns * sizeof(SampleStream)));
     m.ids_pool = reinterpret_cast<int*>(take(ns * h->max_ids * 4));
@@ -904,7 +906,7 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
 
 // one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
 int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_groups, int max_group_rows, bool splice, const char* tap_prefix,
-                hipStream_t st, const StepMeta* hm = nullptr) {
+                hipStream_t st, const StepMeta* hm = nullptr, int n_units = 0, int max_unit_groups = 0) {
     const isst_config& c = h->cfg;
     const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
     // one group (one stream's decode step): its metadata travels in the kernel arguments (llm_attn.hip LlmAttnOne)
@@ -953,7 +955,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             }
         }
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
-                                 h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one));
+                                 h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
+                                 max_unit_groups));
         if (so > 1) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
             CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
@@ -1358,7 +1361,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     StepMeta mh = carve(h, h->meta_host), md = carve(h, h->meta_dev);
     std::vector<int> total0(n), gen_count(n, 0), row0(n);
     std::vector<char> done(n, 0);
-    int R = 0, n_groups = 0;
+    int R = 0, n_groups = 0, n_units = 0, max_unit_groups = 0;
     const int gmax = LLM_ATTN_GROUP_ROWS(c.llm_heads / c.llm_kv_heads);
     for (int i = 0; i < n; ++i) {
         StreamState& s = h->streams[stream_ids[i]];
@@ -1395,10 +1398,17 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             index += cnt;
         }
         mh.last_rows[i] = R + len - 1;
+        const int g_first = n_groups;
         for (int t = 0; t < len; t += gmax) {  // attention row groups: consecutive rows of one stream
             mh.groups[n_groups].x = R + t;
             mh.groups[n_groups].y = std::min(gmax, len - t);
             ++n_groups;
+        }
+        for (int g0 = g_first; g0 < n_groups; g0 += 8) {  // units: runs of <= 8 groups of this stream share their key tiles
+            mh.units[n_units].x = g0;
+            mh.units[n_units].y = std::min(8, n_groups - g0);
+            max_unit_groups = std::max(max_unit_groups, mh.units[n_units].y);
+            ++n_units;
         }
         R += len;
         // sampling context
@@ -1418,7 +1428,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         for (int i = 0; i < n; ++i) any = any || total0[i] > 0;
         if (any) CHK(launch_llm_rope_cache(md.views, n, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
     }
-    CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh));
+    CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh, n_units, max_unit_groups));
     if (B > 1)
         return beam_decode(h, p, n, stream_ids, prompt_ids, prompt_lens, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);
 

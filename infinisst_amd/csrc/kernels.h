@@ -68,7 +68,9 @@ struct LlmAttnOne {
 };
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
-                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one = nullptr);
+                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one = nullptr,
+                         const int2* units = nullptr, int n_units = 0, int max_unit_groups = 0);  // units[z] = (first group, groups <= 8) of ONE
+                                                                                              // stream: prefill launches share key tiles per unit
 // Rotated-key arena for one chunk: for every listed stream and EVERY layer, krpool[slot] = RoPE(kpool[slot], logical position of the slot)
 // for the `total` cached keys (views[i].new_start = total).  A key's logical position only changes when the host evicts, i.e. between
 // chunks, so the 10 passes of a chunk (and the row groups of its prefill, which would each rotate the same keys again) read keys

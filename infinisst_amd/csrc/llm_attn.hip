@@ -324,6 +324,225 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Prefill form: one workgroup per (slot split, kv head, UNIT), a unit = up to PREFILL_MAX_WAVES consecutive row groups of one
+// stream (a 22-row prompt = 6 groups of 4 rows x G heads = one unit).  The per-group kernel above makes every row group stream the
+// stream's whole K/V again (6x the bytes: 270 us per layer at 64 streams, bandwidth-bound); here a key tile is loaded ONCE -- wave 0
+// brings the 16 key rows (rotating them if they do not come from the rotated-key arena), wave 1 the 16 value rows -- into
+// double-buffered LDS images, and every wave of the unit (one per row group) consumes it for its own 16 columns: keys as A-operand
+// rows (ds_read_b128), values transposed (ds_read_b64_tr_b16).  A wave covers all keys of the span for its columns, so there is
+// no cross-wave merge; with a single split it writes the attention output itself.
+// ------------------------------------------------------------------------------------------------------------------------
+#define PREFILL_MAX_WAVES 8
+#define LLM_ATTN_PREFILL_TARGET_WGS 512
+template <int G>
+__global__ __launch_bounds__(PREFILL_MAX_WAVES * 64) void llm_attn_prefill_kernel(
+    const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream, const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
+    const int2* __restrict__ groups, const int2* __restrict__ units, const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
+    bf16_t* kpool, bf16_t* krpool, bf16_t* vpool, float* __restrict__ partial, bf16_t* __restrict__ out_direct, LlmAttnDims d, int layer,
+    int n_splits, int tiles_per_split) {
+    __shared__ __attribute__((aligned(16))) unsigned char kimg[2][4096], vimg[2][4096];  // [buffer][16 keys][128 dims], swizzled 16-byte chunks
+    const int sp = blockIdx.x, kvh = blockIdx.y;
+    const int2 unit = units[blockIdx.z];  // (first group, number of groups)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int H = d.heads, KV = d.kv_heads;
+    const long ldq = (long)(H + 2 * KV) * HD;
+    const int slots = d.sys_cap + d.ring_cap;
+    const int2 g_first = groups[unit.x], g_last = groups[unit.x + unit.y - 1];
+    const LlmStreamView v = sv[row_stream[g_first.x]];
+    const int unit_r0 = g_first.x, unit_rows = g_last.x + g_last.y - g_first.x;
+    const int total_u = row_pos[g_last.x + g_last.y - 1] + 1;  // keys visible to the unit's last row
+    const long base = v.kv_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
+    bf16_t* kb = kpool + base;
+    bf16_t* kr = krpool + base;
+    bf16_t* vb = vpool + base;
+    const bool rot = v.rot_keys != 0;
+    const float scale = 0.08838834764831845f;
+    const int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, slots >> 4);
+    const bool active = wave < unit.y;  // waves beyond the unit's groups only take part in the barriers
+    const int2 grp = groups[unit.x + (active ? wave : 0)];
+    const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
+
+    auto v_off = [](int row, int ch) -> int { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); };
+    int rw_off[4];  // row access: this lane's key fr, chunks 4s + fq (writes by the loader waves, K reads by everyone)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rw_off[s] = v_off(fr, 4 * s + fq);
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    int vr_off[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) vr_off[nt] = v_off(4 * fq + tq, 2 * nt + (tp >> 1)) + 8 * (tp & 1);
+
+    // rotated queries of this wave's group
+    u32x4_t qf[4];
+    const int c = fr;
+    const bool cv = active && c < ncols;
+    const int crow = r0 + (cv ? c / G : 0);
+    const int cpos = cv ? row_pos[crow] : -1;
+    {
+        const bf16_t* qh = qkv + (long)crow * ldq + (long)(kvh * G + (cv ? c % G : 0)) * HD;
+        u32x4_t qraw[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qraw[s] = *reinterpret_cast<const u32x4_t*>(qh + 32 * s + 8 * fq);
+        rope_row_chunks(qraw, cv ? cpos : 0, fq, rope_cos, rope_sin, qf);
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4_t o[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) o[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // ---- loader roles: wave 0 stages keys, wave 1 stages values (the launch always has at least two waves) ----
+    const bool load_k = wave == 0;
+    // staging is split in two so that a tile's global loads are in flight for a whole iteration: fetch(t) issues them into
+    // registers, commit(buf) -- one iteration later -- rotates / appends / writes the LDS images
+    u32x4_t raw[4];
+    int f_t0 = 0, f_jk = -1;
+    bool f_new = false;
+    auto fetch = [&](int t) {
+        f_t0 = t * 16;
+        f_jk = llm_logical(v, d, f_t0 + fr, total_u);
+        f_new = f_jk >= 0 && f_jk >= v.new_start;
+        const int krow = v.row0 + (f_jk - v.new_start);
+        const bf16_t* src;
+        if (load_k) src = f_new ? qkv + (long)krow * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(f_t0 + fr) * HD;
+        else src = f_new ? qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD : vb + (long)(f_t0 + fr) * HD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) raw[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+    };
+    auto commit = [&](int buf) {
+        const int krow = v.row0 + (f_jk - v.new_start);
+        const bool mine = f_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;  // a key of this unit's own rows: append it
+        if (load_k) {
+            u32x4_t kf[4];
+            if (!rot || __any(f_new)) {
+                rope_row_chunks(raw, f_jk >= 0 ? f_jk : 0, fq, rope_cos, rope_sin, kf);
+                if (rot && !f_new) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) kf[s] = raw[s];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) kf[s] = raw[s];
+            }
+            if (mine) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    *reinterpret_cast<u32x4_t*>(kb + (long)(f_t0 + fr) * HD + 32 * s + 8 * fq) = raw[s];
+                    if (rot) *reinterpret_cast<u32x4_t*>(kr + (long)(f_t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&kimg[buf][rw_off[s]]) = kf[s];
+        } else {
+            if (mine) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(vb + (long)(f_t0 + fr) * HD + 32 * s + 8 * fq) = raw[s];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&vimg[buf][rw_off[s]]) = raw[s];
+        }
+    };
+    // tiles of the span that hold a key visible to the unit (dead tiles are skipped by everyone alike: total_u is uniform)
+    auto next_live = [&](int t) -> int {
+        while (t < tile_end) {
+            const int j0 = llm_logical(v, d, t * 16 + fr, total_u);
+            if (__any(j0 >= 0)) break;
+            ++t;
+        }
+        return t;
+    };
+    const bool loader = wave < 2;
+    int t = next_live(tile_begin);
+    int tn = t < tile_end ? next_live(t + 1) : tile_end;
+    if (loader && t < tile_end) {
+        fetch(t);
+        commit(0);
+        if (tn < tile_end) fetch(tn);
+    }
+    __syncthreads();
+    int buf = 0;
+    while (t < tile_end) {
+        const int tnn = tn < tile_end ? next_live(tn + 1) : tile_end;
+        if (loader && tn < tile_end) {
+            commit(buf ^ 1);                  // tile tn: requested one iteration ago
+            if (tnn < tile_end) fetch(tnn);   // tile after it: lands during this iteration's arithmetic
+        }
+        if (active) {
+            const int t0 = t * 16;
+            u32x4_t kf[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const u32x4_t*>(&kimg[buf][rw_off[s]]);
+            f32x4_t st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[s]), __builtin_bit_cast(bf16x8_t, qf[s]), st, 0, 0, 0);
+            float sc[4], mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jc = llm_logical(v, d, t0 + 4 * fq + r, total_u);
+                const bool ok = jc >= 0 && jc <= cpos;
+                sc[r] = ok ? st[r] * scale : -INFINITY;
+                mx = fmaxf(mx, sc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            const float m_new = fmaxf(m_run, mx);
+            const float resc = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+            float p[4], ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = (sc[r] == -INFINITY) ? 0.f : expf(sc[r] - m_new);
+                ls += p[r];
+            }
+            ls += __shfl_xor(ls, 16, WAVE);
+            ls += __shfl_xor(ls, 32, WAVE);
+            l_run = l_run * resc + ls;
+            m_run = m_new;
+            float rs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rs[r] = __shfl(resc, 4 * fq + r, WAVE);
+            u32x2_t pp;
+            pp.x = pack_bf(p[0], p[1]);
+            pp.y = pack_bf(p[2], p[3]);
+            const s16x4_t pa = __builtin_bit_cast(s16x4_t, pp);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const u32x2_t vf = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                   (__attribute__((address_space(3))) s16x4_t*)(&vimg[buf][vr_off[nt]])));
+                f32x4_t acc = o[nt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] *= rs[r];
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf), acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();  // the other buffer is staged, this one is free again
+        t = tn;
+        tn = tnn;
+        buf ^= 1;
+    }
+    if (!active) return;
+    // ---- output: o[nt][r] = O[column 4fq + r][dim 16nt + fr]; the column's statistics sit in the lanes fr == column ----
+    float Mr[4], Lr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { Mr[r] = __shfl(m_run, 4 * fq + r, WAVE); Lr[r] = __shfl(l_run, 4 * fq + r, WAVE); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int cc = 4 * fq + r;
+        if (cc >= ncols) continue;
+        const int row = r0 + cc / G, head = kvh * G + cc % G;
+        if (out_direct) {
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) out_direct[((long)row * H + head) * HD + 16 * nt + fr] = f2bf(o[nt][r] / Lr[r]);
+        } else {
+            float* dst = partial + (((long)row * H + head) * n_splits + sp) * (2 + HD);
+            if (fr == 0) { dst[0] = Mr[r]; dst[1] = Lr[r]; }
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) dst[2 + 16 * nt + fr] = o[nt][r];
+        }
+    }
+}
+
 // Combine of the split partials (a separate launch on purpose, see the header).  All split loads are issued before
 // the first use (fully unrolled, predicated): two memory round trips instead of one per split.
 template <int COMBINE_MAX_SPLITS>  // splits read per trip: 4 (many streams, long spans) or 32 (one stream, 64-slot spans)
@@ -393,8 +612,8 @@ int launch_llm_rope_cache(const LlmStreamView* sv, int n_streams, const bf16_t* 
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
-static int g_attn_target_wgs = 0;  // profiling aid (isst_op_set_attn_tuning): 0 = LLM_ATTN_TARGET_WGS
-void llm_attn_set_tuning(int target_wgs) { g_attn_target_wgs = target_wgs; }
+static int g_attn_target_wgs = 0, g_attn_prefill_target_wgs = 0;  // profiling aid (isst_op_set_attn_tuning): 0 = the defaults; bits 16.. = prefill
+void llm_attn_set_tuning(int target_wgs) { g_attn_target_wgs = target_wgs & 0xffff; g_attn_prefill_target_wgs = target_wgs >> 16; }
 
 template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
@@ -411,33 +630,62 @@ static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
+template <int G>
+static int launch_prefill_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups, const int2* units,
+                            int n_units, int waves, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vpool,
+                            float* partial, bf16_t* out_direct, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s) {
+    hipLaunchKernelGGL((llm_attn_prefill_kernel<G>), dim3(n_splits, d.kv_heads, n_units), dim3(64 * waves), 0, s, qkv, row_stream, row_pos, sv, groups,
+                       units, rope_cos, rope_sin, kpool, krpool, vpool, partial, out_direct, d, layer, n_splits, tiles_per_split);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
-                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one) {
+                         float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one, const int2* units,
+                         int n_units, int max_unit_groups) {
     if (rows <= 0 || n_groups <= 0) return ISST_OK;
     LlmAttnOne one1{};
     if (one && one->enabled && n_groups == 1) one1 = *one;
     const int slots = d.sys_cap + d.ring_cap;
     if (slots % 64 != 0 || d.sys_cap % 16 != 0) return ISST_ERR_ARG;
     const int G = d.heads / d.kv_heads;
-    // slot splits: one 64-slot span per workgroup while that fills the chip (one stream: latency), longer spans -- each wave
-    // then loops over several tiles with a running softmax -- once (kv heads x row groups) alone provide the workgroups
-    // (many streams: the per-workgroup prologue, LDS merge and slab traffic are amortised over more keys)
     const int total_tiles = slots / 16;
     const int target = g_attn_target_wgs > 0 ? g_attn_target_wgs : LLM_ATTN_TARGET_WGS;
-    int n_splits = (target + d.kv_heads * n_groups - 1) / (d.kv_heads * n_groups);
-    n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
-    const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
-    n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
     int rc;
-    switch (G) {
-        case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
-        case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
-        case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
-        default: return ISST_ERR_ARG;
+    int n_splits;
+    if (units && n_units > 0 && max_group_rows > 1) {
+        // prefill: a unit (<= 8 row groups of one stream) shares every key tile through LDS (llm_attn_prefill_kernel)
+        if (max_unit_groups < 1 || max_unit_groups > PREFILL_MAX_WAVES || max_group_rows * G > 16) return ISST_ERR_ARG;
+        const int ptarget = g_attn_prefill_target_wgs > 0 ? g_attn_prefill_target_wgs : LLM_ATTN_PREFILL_TARGET_WGS;
+        n_splits = (ptarget + d.kv_heads * n_units - 1) / (d.kv_heads * n_units);
+        n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
+        const int tiles_per_split = (total_tiles + n_splits - 1) / n_splits;
+        n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
+        const int waves = max_unit_groups < 2 ? 2 : max_unit_groups;
+        bf16_t* od = n_splits == 1 ? out : nullptr;
+        switch (G) {
+            case 1: rc = launch_prefill_g<1>(qkv, row_stream, row_pos, sv, groups, units, n_units, waves, rope_cos, rope_sin, kpool, krpool, vtpool, partial, od, d, layer, n_splits, tiles_per_split, s); break;
+            case 2: rc = launch_prefill_g<2>(qkv, row_stream, row_pos, sv, groups, units, n_units, waves, rope_cos, rope_sin, kpool, krpool, vtpool, partial, od, d, layer, n_splits, tiles_per_split, s); break;
+            case 4: rc = launch_prefill_g<4>(qkv, row_stream, row_pos, sv, groups, units, n_units, waves, rope_cos, rope_sin, kpool, krpool, vtpool, partial, od, d, layer, n_splits, tiles_per_split, s); break;
+            default: return ISST_ERR_ARG;
+        }
+    } else {
+        // slot splits: one 64-slot span per workgroup while that fills the chip (one stream: latency), longer spans -- each wave
+        // then loops over several tiles with a running softmax -- once (kv heads x row groups) alone provide the workgroups
+        // (many streams: the per-workgroup prologue, LDS merge and slab traffic are amortised over more keys)
+        n_splits = (target + d.kv_heads * n_groups - 1) / (d.kv_heads * n_groups);
+        n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
+        const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
+        n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
+        switch (G) {
+            case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+            case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+            case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+            default: return ISST_ERR_ARG;
+        }
     }
     if (rc != ISST_OK) return rc;
-    if (n_splits == 1) return ISST_OK;  // the partial kernel wrote the output itself
+    if (n_splits == 1) return ISST_OK;  // the attention kernel wrote the output itself
     if (n_splits <= 4)
         hipLaunchKernelGGL(llm_attn_combine_kernel<4>, dim3(d.heads, rows), dim3(HD), 0, s, partial, out, d.heads, n_splits);
     else
