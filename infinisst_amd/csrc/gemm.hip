@@ -19,9 +19,18 @@
 // B[k = 8(l>>4)+j][col l&15], C/D lane l reg r is (row 4(l>>4)+r, col l&15).
 #include "common.h"
 
-#define GEMM_UNROLL 4
-// k-tiles in flight per wave and batch: halved for the widest variants (MT*NTB >= 6) so that nothing spills
-constexpr int gemm_unroll(int MT, int NTB) { return (MT * NTB >= 6) ? 2 : GEMM_UNROLL; }
+// The weight stream is a statically indexed ring: GEMM_DEPTH stages of GEMM_UNR k-tiles per wave are in flight; every load is an
+// unconditional bounds-checked buffer load (k-tiles past K and n-tiles past N read zeros), so the loop has no branch around a load
+// and hipcc emits counted s_waitcnt vmcnt(n) -- with `cond ? load : 0` it emitted a branch per load, register copies for the
+// rotation and a vmcnt(0) per iteration, which cost 2.3 .. 3.7 us per launch against a pure streaming read of the same bytes
+// (profiles/probes/gemv_fixed_probe.hip: gate/up 39.3 -> 37.0 us, down 22.0 -> 18.3 us, o_proj 9.1 -> 6.6 us for the loads + MFMAs).
+#define GEMM_UNR 2
+#define GEMM_DEPTH 2
+#define GEMM_DEPTH_STAGED 4  // AMODE >= 1: the ring also has to cover the staging / norm prologue
+// (measured and dropped: the whole K extent of a wave in flight at once, 16 loads per wave on 8 waves, for the 384-workgroup q/k/v
+//  launch: 15.1 us against 11.1-12.1 us -- more requests per wave than the memory pipeline takes without stalling the others;
+//  rows staged in LDS without the norm (AMODE 1) for o_proj / down: 8.1 / 20.6 us against 7.3 / 19.0 us with A in the ring)
+#define GEMM_OOB 0x80000000u  // + any in-range offset stays past every descriptor's extent (and does not wrap)
 
 // ------------------------------------------------------------------------------------------------
 // weight packer: src row-major [n_rows][K] (or Conv1d [n_rows][Cin][conv_k]) -> fragment-major tiles
@@ -81,9 +90,9 @@ __device__ __forceinline__ u32x4_t load_w(const u32x4_t* p) {
 // AMODE 2: as 1, and the staged rows are RMS-normalised in LDS ([3P] HF LlamaRMSNorm: var = mean(x^2) in fp32;
 //          bf16(x * rsqrt(var + eps)); bf16(weight * that)) -- removes the separate norm launch in front of the q/k/v,
 //          gate/up and lm_head projections (pure launch latency at M = 1).
-template <int MT, int NTB, int EPI, bool NT, int AMODE>
+template <int MT, int NTB, int EPI, bool NT, int AMODE, int DEPTH>
 __global__ void gemm_skinny_kernel(GemmArgs g) {
-    constexpr int UNR = gemm_unroll(MT, NTB);
+    constexpr int UNR = GEMM_UNR;
     // AMODE 0: the reduction buffer [W][MT*NTB*4][64].  AMODE >= 1: the staged A rows [M][K] + [W] partial sums during the k-loop;
     // the reduction buffer then REUSES the same bytes (one more barrier) -- kept apart, 4 rows needed 41 KB per workgroup: 3 instead
     // of 4 workgroups per CU and a second round of workgroups for the 896-workgroup gate/up launch (+7 us)
@@ -106,77 +115,111 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
 
     const int arow = lane & 15;
     const int kq = (lane >> 4) * 8;
-    const bf16_t* aptr[MT];
-    bool avalid[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int row = m0 + mt * 16 + arow;
-        avalid[mt] = row < g.M;
-        aptr[mt] = A + (long)(avalid[mt] ? row : 0) * g.lda + kq;
-    }
-    const u32x4_t* wptr[NTB];
-    bool wvalid[NTB];
-#pragma unroll
-    for (int nb = 0; nb < NTB; ++nb) {
-        const int nt = nt0 + nb;
-        wvalid[nb] = nt < NTILES;
-        wptr[nb] = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(wvalid[nb] ? nt : 0) * KT) * 64 + lane;
-    }
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
 
-    // the first TWO batches of weight fragments go in flight before anything else (also before the norm prologue)
-    u32x4_t wf[UNR][NTB], wn[UNR][NTB];
+    // descriptors: this workgroup's n-tiles [nt0, nt0 + NTB) clipped to N, and (AMODE 0) its A rows [m0, m0 + 16 MT) clipped to M
+    const int my_tiles = min(NTB, NTILES - nt0);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + (long)nt0 * KT * 512, 0, my_tiles * KT * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A) + (long)m0 * g.lda, 0, (int)(((min(MT * 16, g.M - m0) - 1) * g.lda + g.K) * 2), 0x00020000);  // (lda < K for the conv-as-GEMM views: rows overlap)
+    unsigned woff[NTB], aoff[MT];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-        const int kt = wave + u * W;
+    for (int nb = 0; nb < NTB; ++nb) woff[nb] = (unsigned)((nb * KT * 64 + lane) * 16);
 #pragma unroll
-        for (int nb = 0; nb < NTB; ++nb) wf[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-        const int kt = wave + (UNR + u) * W;
-#pragma unroll
-        for (int nb = 0; nb < NTB; ++nb) wn[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
-    }
+    for (int mt = 0; mt < MT; ++mt) aoff[mt] = (unsigned)(((long)(mt * 16 + arow) * g.lda + kq) * 2);
 
-    // (1-2 rows keep the two areas apart: they fit 4 workgroups per CU anyway and skip the extra barrier)
+    // stage `batch` (k-tiles wave + (batch * UNR + u) * W) -> ring slot d
+    u32x4_t wring[DEPTH][UNR][NTB];
+    u32x4_t aring[DEPTH][UNR][AMODE == 0 ? MT : 1];
+    auto issue = [&](int batch, int d) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int kt = wave + (batch * UNR + u) * W;
+            const bool kv = kt < KT;
+            const unsigned wk = kv ? (unsigned)kt * 1024u : GEMM_OOB, ak = kv ? (unsigned)kt * 64u : GEMM_OOB;
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) wring[d][u][nb] = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[nb] + wk, 0, NT ? 2 : 0);
+            if constexpr (AMODE == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) aring[d][u][mt] = __builtin_amdgcn_raw_buffer_load_b128(ars, aoff[mt] + ak, 0, 0);
+            }
+        }
+    };
+
+    // (1-2 rows keep the two LDS areas apart: they fit 4 workgroups per CU anyway and skip the extra barrier)
     const bool overlay = g.M > 2;
     bf16_t* xs = reinterpret_cast<bf16_t*>(overlay ? red : red + (long)W * (MT * NTB * 256));  // [M][K] staged rows (AMODE >= 1)
+    // AMODE >= 1: rows are staged (and normalised) side by side: each row gets wpr = max(1, W / M) waves, W / wpr rows per round
+    // (one stream: 1 row on all waves; beam search: 4 rows, one wave each, one round)
+    const int wpr = (W >= g.M) ? W / g.M : 1;   // waves per row
+    const int rpr = W / wpr;                     // rows per round
+    const int my_slot = wave / wpr, my_sub = wave % wpr;
+    const int cstep = wpr * 512, cfirst = (my_sub * 64 + lane) * 8;
+    // the first group of the first round (for one stream: everything) is requested BEFORE the weight ring, so that waiting for it
+    // leaves the ring in flight (vmcnt counts in order); the norm weight comes with it instead of after the first barrier
+    u32x4_t xv0[4], nw0[4];
     if constexpr (AMODE >= 1) {
-        // rows are staged (and normalised) side by side: each row gets wpr = max(1, W / M) waves, W / wpr rows per round
-        // (one stream: 1 row on all waves; beam search: 4 rows, one wave each, one round)
+        const bf16_t* xr = A + (long)(m0 + (my_slot < g.M ? my_slot : 0)) * g.lda;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = cfirst + u * cstep;
+            xv0[u] = *reinterpret_cast<const u32x4_t*>(xr + (c < g.K ? c : cfirst));
+            if constexpr (AMODE == 2) nw0[u] = *reinterpret_cast<const u32x4_t*>(g.norm_w + (c < g.K ? c : cfirst));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        issue(d, d);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if constexpr (AMODE >= 1) {
         float* part = reinterpret_cast<float*>(xs + (long)g.M * g.K);  // [W] partial sums of squares
-        const int wpr = (W >= g.M) ? W / g.M : 1;   // waves per row
-        const int rpr = W / wpr;                     // rows per round
-        const int my_slot = wave / wpr, my_sub = wave % wpr;
-        for (int r0 = 0; r0 < g.M; r0 += rpr) {
+        auto stage_group = [&](const u32x4_t (&xv)[4], int rr, int c0, float& sq) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * cstep;
+                if (c < g.K) {
+                    *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = xv[u];
+                    if constexpr (AMODE == 2) {
+                        float f[8];
+                        unpack8(xv[u], f);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) sq += f[q] * f[q];
+                    }
+                }
+            }
+        };
+        auto norm_group = [&](const u32x4_t (&wv)[4], int rr, int c0, float rs) {  // every lane rewrites the chunks it staged
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * cstep;
+                if (c < g.K) {
+                    float f[8], nw[8];
+                    unpack8(*reinterpret_cast<const u32x4_t*>(xs + (long)rr * g.K + c), f);
+                    unpack8(wv[u], nw);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f[q] = nw[q] * bfr(f[q] * rs);
+                    *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = pack8(f);
+                }
+            }
+        };
+        auto round = [&](int r0, bool first) {
             const int rr = r0 + my_slot;
             const bool active = my_slot < rpr && rr < g.M;
             float sq = 0.f;
-            // (loads go out four at a time: a chunk-by-chunk loop pays one L2 round trip per chunk -- 8 in a row at 4+ rows)
-            const int cstep = wpr * 512, cfirst = (my_sub * 64 + lane) * 8;
             if (active) {
                 const bf16_t* xr = A + (long)(m0 + rr) * g.lda;
-                for (int c0 = cfirst; c0 < g.K; c0 += 4 * cstep) {
+                if (first) stage_group(xv0, rr, cfirst, sq);
+                // (loads go out four at a time: a chunk-by-chunk loop pays one L2 round trip per chunk -- 8 in a row at 4+ rows)
+                for (int c0 = first ? cfirst + 4 * cstep : cfirst; c0 < g.K; c0 += 4 * cstep) {
                     u32x4_t xv[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int c = c0 + u * cstep;
                         xv[u] = *reinterpret_cast<const u32x4_t*>(xr + (c < g.K ? c : cfirst));
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int c = c0 + u * cstep;
-                        if (c < g.K) {
-                            *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = xv[u];
-                            if constexpr (AMODE == 2) {
-                                float f[8];
-                                unpack8(xv[u], f);
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) sq += f[q] * f[q];
-                            }
-                        }
-                    }
+                    stage_group(xv, rr, c0, sq);
                 }
             }
             if constexpr (AMODE == 2) {
@@ -187,64 +230,48 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
                     float t = 0.f;
                     for (int w2 = 0; w2 < wpr; ++w2) t += part[my_slot * wpr + w2];
                     const float rs = rsqrtf(t / g.K + g.norm_eps);
-                    for (int c0 = cfirst; c0 < g.K; c0 += 4 * cstep) {  // every lane rewrites the chunks it staged
+                    if (first) norm_group(nw0, rr, cfirst, rs);
+                    for (int c0 = first ? cfirst + 4 * cstep : cfirst; c0 < g.K; c0 += 4 * cstep) {
                         u32x4_t wv[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int c = c0 + u * cstep;
                             wv[u] = *reinterpret_cast<const u32x4_t*>(g.norm_w + (c < g.K ? c : cfirst));
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int c = c0 + u * cstep;
-                            if (c < g.K) {
-                                float f[8], nw[8];
-                                unpack8(*reinterpret_cast<const u32x4_t*>(xs + (long)rr * g.K + c), f);
-                                unpack8(wv[u], nw);
-#pragma unroll
-                                for (int q = 0; q < 8; ++q) f[q] = nw[q] * bfr(f[q] * rs);
-                                *reinterpret_cast<u32x4_t*>(xs + (long)rr * g.K + c) = pack8(f);
-                            }
-                        }
+                        norm_group(wv, rr, c0, rs);
                     }
                 }
                 __syncthreads();  // part[] is reused by the next round; the last one publishes the rows
             }
-        }
+        };
+        round(0, true);
+        for (int r0 = rpr; r0 < g.M; r0 += rpr) round(r0, false);
         if constexpr (AMODE == 1) __syncthreads();
     }
 
-    for (int kt0 = wave; kt0 < KT; kt0 += W * UNR) {
-        u32x4_t af[UNR][MT];
+    const bool avalid = arow < g.M;  // (AMODE >= 1: one m-tile, m0 = 0)
+    const int batches = (KT + W * UNR - 1) / (W * UNR);
+    for (int b0 = 0; b0 < batches; b0 += DEPTH) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int kt = kt0 + u * W;
-            const bool kv = kt < KT;
+        for (int d = 0; d < DEPTH; ++d) {
+            if constexpr (AMODE >= 1) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if constexpr (AMODE >= 1)
-                    af[u][mt] = (kv && avalid[mt]) ? *reinterpret_cast<const u32x4_t*>(xs + (long)arow * g.K + (long)kt * 32 + kq) : zero4;
-                else
-                    af[u][mt] = (kv && avalid[mt]) ? *reinterpret_cast<const u32x4_t*>(aptr[mt] + (long)kt * 32) : zero4;
+                for (int u = 0; u < UNR; ++u) {
+                    const int kt = wave + ((b0 + d) * UNR + u) * W;
+                    aring[d][u][0] = (kt < KT && avalid) ? *reinterpret_cast<const u32x4_t*>(xs + (long)arow * g.K + (long)kt * 32 + kq) : zero4;
+                }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
+            for (int u = 0; u < UNR; ++u)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nb = 0; nb < NTB; ++nb)
-                    acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8_t, af[u][mt]), __builtin_bit_cast(bf16x8_t, wf[u][nb]), acc[mt][nb], 0, 0, 0);
-        // rotate: the batch requested one iteration ago becomes current, and the batch after it is requested now
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int kt = kt0 + (2 * UNR + u) * W;
-#pragma unroll
-            for (int nb = 0; nb < NTB; ++nb) {
-                wf[u][nb] = wn[u][nb];
-                wn[u][nb] = (kt < KT && wvalid[nb]) ? load_w<NT>(wptr[nb] + (long)kt * 64) : zero4;
-            }
+                    for (int nb = 0; nb < NTB; ++nb)
+                        acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aring[d][u][AMODE == 0 ? mt : 0]),
+                                                                             __builtin_bit_cast(bf16x8_t, wring[d][u][nb]), acc[mt][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(b0 + d + DEPTH, d);  // past the end: zeros, never used
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -310,14 +337,13 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     const int KT = g.K / 32, NTILES = g.N / 16;
     // NTB: n-tiles per block (SwiGLU needs the (gate, up) pair in one block)
     const bool swiglu = EPI == EPI_SWIGLU;
-    int ntb = swiglu ? 2 : 1;  // measured (profiles/gemv_sweep.py): one n-tile per workgroup wins for every plain shape, lm_head included
-    if (g_tune_ntb && MT == 1 && (!swiglu || g_tune_ntb % 2 == 0)) ntb = g_tune_ntb;
+    const int ntb = swiglu ? 2 : 1;  // measured (profiles/gemv_sweep.py): one n-tile per workgroup wins for every plain shape, lm_head included
     const int blocks_x = (NTILES + ntb - 1) / ntb;
     const int blocks_y = (g.M + MT * 16 - 1) / (MT * 16);
     // waves per block: enough waves chip-wide to cover HBM latency (>= ~2048), bounded by K-tiles and LDS
     long blocks = (long)blocks_x * blocks_y * g.batch;
     int W = 4;
-    while (W < 16 && blocks * W < 2048 && W * 2 * GEMM_UNROLL <= KT * 2) W *= 2;
+    while (W < 16 && blocks * W < 1536 && W * 2 * GEMM_UNR * GEMM_DEPTH <= KT * 2) W *= 2;  // (384 q/k/v workgroups: 4 waves 11.1 us, 8 waves 11.7-12.2 us)
     if (g_tune_w) W = g_tune_w;
     while (W > 1 && W > KT) W /= 2;
     while (W > 1 && (size_t)W * MT * ntb * 1024 > 64 * 1024) W /= 2;
@@ -327,24 +353,13 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
         lds = g.M > 2 ? (lds > rows ? lds : rows) : lds + rows;
     }
     dim3 grid(blocks_x, blocks_y, g.batch), block(W * 64);
-    if constexpr (MT == 1) {
-        if (ntb == 4) {
-            auto kern = gemm_skinny_kernel<1, 4, EPI, NT, AMODE>;
-            if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
-            hipLaunchKernelGGL(kern, grid, block, lds, stream, g);
-            return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
-        }
-    }
-    if (ntb == 2) {
-        auto kern = gemm_skinny_kernel<MT, 2, EPI, NT, AMODE>;
+    auto go = [&](auto kern) {
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
         hipLaunchKernelGGL(kern, grid, block, lds, stream, g);
-    } else {
-        auto kern = gemm_skinny_kernel<MT, (EPI == EPI_SWIGLU ? 2 : 1), EPI, NT, AMODE>;
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, g);
-    }
-    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+        return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+    };
+    constexpr int NTB = EPI == EPI_SWIGLU ? 2 : 1;
+    return go(gemm_skinny_kernel<MT, NTB, EPI, NT, AMODE, (AMODE >= 1 ? GEMM_DEPTH_STAGED : GEMM_DEPTH)>);
 }
 
 template <int EPI>
@@ -357,7 +372,6 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
         }
         return ISST_ERR_ARG;
     }
-    // (plain LDS staging without the norm, AMODE 1, measured 1.2 us slower per launch than direct A loads: not used)
     const bool single = g.M <= 64 && g.batch == 1;  // weight read exactly once -> non-temporal loads
     if (!single) return launch_cfg<4, EPI, false, 0>(g, stream);
     if (g.M <= 16) return launch_cfg<1, EPI, true, 0>(g, stream);
