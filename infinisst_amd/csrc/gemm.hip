@@ -92,7 +92,7 @@ __device__ __forceinline__ u32x4_t load_w(const u32x4_t* p) {
 //          gate/up and lm_head projections (pure launch latency at M = 1).
 template <int MT, int NTB, int EPI, bool NT, int AMODE, int DEPTH>
 __global__ void gemm_skinny_kernel(GemmArgs g) {
-    constexpr int UNR = GEMM_UNR;
+    constexpr int UNR = (MT * NTB >= 8) ? 1 : GEMM_UNR;  // (4 m-tiles x the SwiGLU pair: the two-k-tile stage spilled)
     // AMODE 0: the reduction buffer [W][MT*NTB*4][64].  AMODE >= 1: the staged A rows [M][K] + [W] partial sums during the k-loop;
     // the reduction buffer then REUSES the same bytes (one more barrier) -- kept apart, 4 rows needed 41 KB per workgroup: 3 instead
     // of 4 workgroups per CU and a second round of workgroups for the 896-workgroup gate/up launch (+7 us)
