@@ -29,7 +29,8 @@
 #define GEMM_DEPTH_STAGED 4  // AMODE >= 1: the ring also has to cover the staging / norm prologue
 // (measured and dropped: the whole K extent of a wave in flight at once, 16 loads per wave on 8 waves, for the 384-workgroup q/k/v
 //  launch: 15.1 us against 11.1-12.1 us -- more requests per wave than the memory pipeline takes without stalling the others;
-//  rows staged in LDS without the norm (AMODE 1) for o_proj / down: 8.1 / 20.6 us against 7.3 / 19.0 us with A in the ring)
+//  rows staged in LDS without the norm (AMODE 1) for o_proj / down: 8.1 / 20.6 us against 7.3 / 19.0 us with A in the ring;
+//  the residual / bias of the epilogue requested before the ring: 33.14 ms per chunk against 33.04 without, same box)
 #define GEMM_OOB 0x80000000u  // + any in-range offset stays past every descriptor's extent (and does not wrap)
 
 // ------------------------------------------------------------------------------------------------
