@@ -718,7 +718,9 @@ int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int e
 // profiles/rows_probe.py): enough slices for ~384 workgroups.
 int pick_ksplit(int K, int N, int rows) {
     if (rows <= 64) {
-        for (int s = K >= 8192 ? 4 : 2; s > 1; s >>= 1)
+        // (N <= 2048 = the encoder's out_proj / fc2, 16..32 column blocks: fc2 20.1 us as GEMM + LayerNorm, 16.6 / 14.7 / 16.5 us with 2 / 4 / 8 slices
+        //  + the reducing LayerNorm; out_proj 14.2 -> 11.5 us with 2: profiles/enc_probe.py)
+        for (int s = (K >= 8192 || (N <= 2048 && K >= 4096)) ? 4 : 2; s > 1; s >>= 1)
             if (K % (256 * s) == 0 && K / (256 * s) >= 1) return s;
         return 1;
     }
@@ -795,9 +797,10 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
     // via a base + sid * stride scheme -> requires contiguous slots; general case: launch per stream
     bool contiguous = true;
     for (int i = 1; i < n; ++i) contiguous = contiguous && (sids[i] == sids[0] + i);
-    // 65..1024 rows (2..21 streams): out_proj and fc2 (N = 1024: 8 column blocks on the dense kernel) split K into fp32 slabs that the
-    // LayerNorm which follows anyway sums up (rowops.hip layernorm_kernel's prologue) -- the encoder twin of the decoder's split path
-    const bool esplit = ER > 64 && ER <= LLM_SPLIT_MAX_ROWS;
+    // 17..1024 rows (1..21 streams): out_proj and fc2 (N = 1024: 16 column blocks on gemm_mid, 8 on the dense kernel) split K into fp32
+    // slabs that the LayerNorm which follows anyway sums up (rowops.hip layernorm_kernel's prologue) -- the encoder twin of the decoder's
+    // split path
+    const bool esplit = ER > 16 && ER <= LLM_SPLIT_MAX_ROWS;
     const int s_out = esplit ? pick_ksplit(D, D, ER) : 1, s_fc2 = esplit ? pick_ksplit(c.enc_ffn, D, ER) : 1;
     const long eslab = (long)ER * D;
     const EncLayer* pend = nullptr;  // layer whose fc2 slabs h->ex still lacks
