@@ -800,7 +800,10 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
     // 17..1024 rows (1..21 streams): out_proj and fc2 (N = 1024: 16 column blocks on gemm_mid, 8 on the dense kernel) split K into fp32
     // slabs that the LayerNorm which follows anyway sums up (rowops.hip layernorm_kernel's prologue) -- the encoder twin of the decoder's
     // split path
-    const bool esplit = ER > 16 && ER <= LLM_SPLIT_MAX_ROWS;
+#ifndef ISST_ESPLIT_MIN_ROWS
+#define ISST_ESPLIT_MIN_ROWS 16
+#endif
+    const bool esplit = ER > ISST_ESPLIT_MIN_ROWS && ER <= LLM_SPLIT_MAX_ROWS;
     const int s_out = esplit ? pick_ksplit(D, D, ER) : 1, s_fc2 = esplit ? pick_ksplit(c.enc_ffn, D, ER) : 1;
     const long eslab = (long)ER * D;
     const EncLayer* pend = nullptr;  // layer whose fc2 slabs h->ex still lacks

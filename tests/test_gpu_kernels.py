@@ -132,6 +132,48 @@ def test_conv1d_as_gemm(k, stride, T):
     close_bf16(out, bf(ref), f"conv k{k}", ulps=2.5, atol=2e-3)
 
 
+@pytest.mark.parametrize("M", [1, 4, 15, 20, 37, 64])
+@pytest.mark.parametrize("N,K", [(48, 160), (272, 96), (16, 32)])
+def test_gemm_skinny_ring_edges_and_poison(M, N, K):
+    """The skinny kernel's weight / A ring issues loads past the end of K unconditionally (bounds-checked buffer loads that must
+    read zeros): K with a partial last stage, fewer k-tiles than the ring is deep, and NaN-filled memory right behind the A rows and
+    the packed weight must not reach any output row < M."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    rows = M + 40
+    Abig = torch.full((rows, K), float("nan"), dtype=torch.bfloat16)
+    Abig[:M] = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    res = bf(torch.randn(M, N, generator=g))
+    Wp_exact = E.op_pack_weight(W.to(DEV))
+    Wbig = torch.full((Wp_exact.numel() + 4096,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Wbig[:Wp_exact.numel()] = Wp_exact.reshape(-1)
+    Wp = Wbig[:Wp_exact.numel()].view_as(Wp_exact)
+    A = Abig.to(DEV)[:M]
+    E.load_library().isst_op_set_gemm_tuning(-1, 0)  # the skinny kernel at every M
+    try:
+        for epi in ("none", "res"):
+            out = E.op_gemm(A, Wp, N, epi, res=res.to(DEV) if epi == "res" else None)
+            torch.cuda.synchronize()
+            assert not torch.isnan(out.float()).any(), f"NaN leaked into {epi} M{M} N{N} K{K}"
+            close_bf16(out, ref_linear(Abig[:M], W, epi, None, res), f"ring edges {epi} M{M} N{N} K{K}", ulps=2.5, atol=2e-3 if epi == "none" else 3.2e-2)
+    finally:
+        E.load_library().isst_op_set_gemm_tuning(0, 0)
+
+
+@pytest.mark.parametrize("T", [9, 41, 100])
+def test_conv1d_as_gemm_few_rows_overlapping(T):
+    """k=3, stride 2 with few output rows: the skinny kernel reads A through a descriptor whose rows overlap (lda < K)."""
+    Cc, k, stride = 64, 3, 2
+    g = torch.Generator().manual_seed(T)
+    x = bf(torch.randn(T, Cc, generator=g))
+    w = bf(torch.randn(Cc, Cc, k, generator=g) * 0.1)
+    bias = bf(torch.randn(Cc, generator=g))
+    To = (T - k) // stride + 1
+    out = E.op_gemm(x.to(DEV), E.op_pack_weight(w.to(DEV), conv_k=k), Cc, "bias", bias=bias.to(DEV), lda=stride * Cc, M=To, K=k * Cc)
+    ref = torch.nn.functional.conv1d(x.t().unsqueeze(0).float(), w.float(), bias.float(), stride=stride)[0].t()
+    close_bf16(out, bf(ref), f"conv k3 T{T}", ulps=2.5, atol=2e-3)
+
+
 @pytest.mark.parametrize("C,gelu", [(64, True), (512, True), (512, False), (1024, False), (1024, True), (128, False)])
 def test_layernorm(C, gelu):
     g = torch.Generator().manual_seed(C)
