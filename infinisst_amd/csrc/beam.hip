@@ -11,7 +11,7 @@
 
 // ---- copy `count` logical positions starting at p0 between an arena (K [slots][128], V [slots][128]) and a buffer
 //      (K [layers][kv][tcap][128], V [layers][kv][tcap][128], both row-major).  grid = (count, kv_heads, layers * n_ops)
-__global__ __launch_bounds__(128) void kv_positions_copy_kernel(bf16_t* kpool, bf16_t* vtpool, bf16_t* kbuf, bf16_t* vbuf,
+__global__ __launch_bounds__(128) void kv_positions_copy_kernel(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf,
                                                                const KvCopyOp* __restrict__ ops, LlmAttnDims d, int layers, int tcap) {
     const int t = blockIdx.x, kvh = blockIdx.y;
     const int layer = blockIdx.z % layers;
@@ -25,19 +25,23 @@ __global__ __launch_bounds__(128) void kv_positions_copy_kernel(bf16_t* kpool, b
     else { int x = op.ring_start + (p - op.sys_len); x %= d.ring_cap; slot = (long)d.sys_cap + x; }
     const long abase = op.arena_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
     const long bidx = op.buf_offset + (((long)layer * d.kv_heads + kvh) * tcap + t) * HD + dd;
+    // (krpool: the keys rotated at their position of this chunk, LlmStreamView::rot_keys -- travels with K so that the beams' arenas
+    //  can be read through it like a greedy stream's)
     if (op.to_arena) {
         kpool[abase + slot * HD + dd] = kbuf[bidx];
         vtpool[abase + slot * HD + dd] = vbuf[bidx];
+        if (krpool) krpool[abase + slot * HD + dd] = krbuf[bidx];
     } else {
         kbuf[bidx] = kpool[abase + slot * HD + dd];
         vbuf[bidx] = vtpool[abase + slot * HD + dd];
+        if (krpool) krbuf[bidx] = krpool[abase + slot * HD + dd];
     }
 }
 
-int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* kbuf, bf16_t* vbuf, const KvCopyOp* ops, int n_ops, int max_count,
+int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf, const KvCopyOp* ops, int n_ops, int max_count,
                              LlmAttnDims d, int layers, int tcap, hipStream_t s) {
     if (n_ops <= 0 || max_count <= 0) return ISST_OK;
-    hipLaunchKernelGGL(kv_positions_copy_kernel, dim3(max_count, d.kv_heads, layers * n_ops), dim3(HD), 0, s, kpool, vtpool, kbuf, vbuf, ops,
+    hipLaunchKernelGGL(kv_positions_copy_kernel, dim3(max_count, d.kv_heads, layers * n_ops), dim3(HD), 0, s, kpool, vtpool, krpool, kbuf, vbuf, krbuf, ops,
                        d, layers, tcap);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }

@@ -156,7 +156,7 @@ struct isst_handle {
 
     // beam search (max_beams > 1): one KV arena per (stream, beam), tail buffers, scoring scratch
     int max_beams = 1, tcap = 0, nbuf = 0;
-    bf16_t *tbuf_k = nullptr, *tbuf_v = nullptr;  // [max_streams][nbuf][layers][kv][tcap][128]
+    bf16_t *tbuf_k = nullptr, *tbuf_v = nullptr, *tbuf_kr = nullptr;  // [max_streams][nbuf][layers][kv][tcap][128]
     long tbuf_stride = 0;
     float *lse_max = nullptr, *lse_sum = nullptr, *cand_val = nullptr, *top_val = nullptr;
     int *cand_idx = nullptr, *top_idx = nullptr;
@@ -435,13 +435,14 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         h->tbuf_stride = (long)c.llm_layers * KV * h->tcap * 128;
         h->tbuf_k = h->dalloc<bf16_t>((size_t)h->tbuf_stride * h->nbuf * ns);
         h->tbuf_v = h->dalloc<bf16_t>((size_t)h->tbuf_stride * h->nbuf * ns);
+        h->tbuf_kr = h->dalloc<bf16_t>((size_t)h->tbuf_stride * h->nbuf * ns);
         h->lse_max = h->dalloc<float>(NB * 64);
         h->lse_sum = h->dalloc<float>(NB * 64);
         h->cand_val = h->dalloc<float>(NB * 64 * BEAM_TOPK);
         h->cand_idx = h->dalloc<int>(NB * 64 * BEAM_TOPK);
         h->top_val = h->dalloc<float>(NB * BEAM_TOPK);
         h->top_idx = h->dalloc<int>(NB * BEAM_TOPK);
-        if (!h->tbuf_k || !h->tbuf_v || !h->lse_max || !h->lse_sum || !h->cand_val || !h->cand_idx || !h->top_val || !h->top_idx) {
+        if (!h->tbuf_k || !h->tbuf_v || !h->tbuf_kr || !h->lse_max || !h->lse_sum || !h->cand_val || !h->cand_idx || !h->top_val || !h->top_idx) {
             h->fail(ISST_ERR_NOMEM, "beam search allocation failed"); return die(ISST_ERR_NOMEM);
         }
     }
@@ -1092,7 +1093,7 @@ int flush_copies(isst_handle* h, std::vector<KvCopyOp>& ops, const StepMeta& mh,
         HIPCHK(hipStreamSynchronize(st));  // the pinned op list may still be read by the previous batch
         std::memcpy(mh.ops, ops.data() + o, sizeof(KvCopyOp) * n);
         HIPCHK(hipMemcpyAsync(md.ops, mh.ops, sizeof(KvCopyOp) * n, hipMemcpyHostToDevice, st));
-        CHK(launch_kv_positions_copy(h->llm_k, h->llm_v, h->tbuf_k, h->tbuf_v, md.ops, n, max_count, h->adims, h->cfg.llm_layers, h->tcap, st));
+        CHK(launch_kv_positions_copy(h->llm_k, h->llm_v, h->rot_keys ? h->llm_kr : nullptr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, md.ops, n, max_count, h->adims, h->cfg.llm_layers, h->tcap, st));
     }
     ops.clear();
     return ISST_OK;
@@ -1240,7 +1241,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 mh.views[r].kv_offset = h->arena_off(stream_ids[i], b);
                 mh.views[r].new_start = mh.row_pos[r];
                 mh.views[r].row0 = r;
-                mh.views[r].rot_keys = 0;  // beam arenas are re-bound every step: rotate on read
+                mh.views[r].rot_keys = h->rot_keys ? 1 : 0;  // every beam's arena carries its rotated keys (pre-pass over all arenas + position copies)
                 mh.groups[r].x = r;
                 mh.groups[r].y = 1;
             }
@@ -1379,7 +1380,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         mh.views[i].kv_offset = h->arena_off(stream_ids[i], 0);
         mh.views[i].new_start = total0[i];
         mh.views[i].row0 = R;
-        mh.views[i].rot_keys = (B == 1 && h->rot_keys) ? 1 : 0;
+        mh.views[i].rot_keys = h->rot_keys ? 1 : 0;
         row0[i] = R;
         const int len = prompt_lens[i];
         const int* ids = prompt_ids[i];
@@ -1428,11 +1429,21 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         std::memcpy(mh.suppress, p->suppress_tokens, (size_t)p->n_suppress * 4);
         HIPCHK(hipMemcpyAsync(h->meta_dev + mh.suppress_offset, h->meta_host + mh.suppress_offset, (size_t)p->n_suppress * 4, hipMemcpyHostToDevice, st));
     }
+    if (B > 1 && h->rot_keys) {  // the rotated-key pre-pass below also covers arenas 1 .. B-1 (the prefill itself only reads views 0 .. n-1)
+        int nv = n;
+        for (int i = 0; i < n; ++i)
+            for (int b = 1; b < B; ++b) {
+                mh.views[nv] = mh.views[i];
+                mh.views[nv].kv_offset = h->arena_off(stream_ids[i], b);
+                ++nv;
+            }
+    }
     HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-    if (B == 1 && h->rot_keys) {  // rotate the cached keys of every layer ONCE for this chunk (positions are fixed until the next eviction)
+    if (h->rot_keys) {  // rotate the cached keys of every layer ONCE for this chunk (positions are fixed until the next eviction)
         bool any = false;
         for (int i = 0; i < n; ++i) any = any || total0[i] > 0;
-        if (any) CHK(launch_llm_rope_cache(md.views, n, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
+        // (beam search: views n .. n*B-1, written above, are the other beams' arenas of the same streams -- they hold the same cached keys)
+        if (any) CHK(launch_llm_rope_cache(md.views, n * B, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
     }
     CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh, n_units, max_unit_groups));
     if (B > 1)

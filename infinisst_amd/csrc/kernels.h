@@ -100,7 +100,7 @@ struct KvCopyOp {
     int to_arena;       // 0: arena -> buffer, 1: buffer -> arena
     int pad;
 };
-int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* kbuf, bf16_t* vbuf, const KvCopyOp* ops, int n_ops, int max_count,
+int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf, const KvCopyOp* ops, int n_ops, int max_count,
                              LlmAttnDims d, int layers, int tcap, hipStream_t s);
 int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* psum, int rows, hipStream_t s);
 int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,

@@ -96,3 +96,44 @@ def test_beam_decisions_follow_oracle():
         eng.close_stream(sid)
     print(f"beam vs oracle: {same} identical, {near_tie} explained by near-ties")
     assert same >= 3
+
+
+def test_beam_rotated_key_arena_is_bit_identical_to_rotate_on_read(monkeypatch):
+    """The beams' arenas are read through the once-per-chunk rotated-key arena like a greedy stream's (pre-pass over all arenas, rotated
+    keys travelling with every position copy).  Against ISST_ROT_KEYS=0 (every key rotated on every read): the same outputs and the
+    same KV in every beam's arena, across chunks, a pinned system prompt and evictions."""
+    from oracle import agent as oag
+    cfg = toy_config()
+    B = 3
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=44)
+    gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=150, always_cache_system_prompt=True)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 7, stream_id=12)
+    sys_n = len(synth.system_prompt_ids(cfg))
+
+    def run(flag):
+        monkeypatch.setenv("ISST_ROT_KEYS", flag)
+        eng = Engine(cfg, max_streams=2, max_multiplier=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=150, max_system_prompt=64, max_beams=B)
+        eng.load_weights(w)
+        sid = eng.open_stream()
+        outs, kvs, ckpts, prev = [], [], [], []
+        for c in range(7):
+            seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+            prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            ids, _ = eng.generate(gen, [sid], [seg], [prompt], [prev[-100:]], system_prompt_size=sys_n if c == 0 else 0)
+            outs.append(ids[0])
+            prev.extend(ids[0][:-1])
+            cur = eng.stream_info(sid)["llm_cache_len"]
+            kvs.append([kv_of(eng, sid, cur, beam=b) for b in range(B)])
+            ckpts.append(cur)
+            ev = oag.evict(ckpts, cur, gen.max_llm_cache_size, True, sys_n)
+            if ev is not None:
+                ckpts, new_size = ev
+                eng.kv_evict(sid, new_size, sys_n)
+        eng.close()
+        return outs, kvs
+
+    (oa, ka), (ob, kb) = run("1"), run("0")
+    assert oa == ob
+    for c, (xa, xb) in enumerate(zip(ka, kb)):
+        for b in range(B):
+            assert torch.equal(xa[b][0], xb[b][0]) and torch.equal(xa[b][1], xb[b][1]), f"chunk {c} beam {b}: KV differs between the two key schedules"
