@@ -345,6 +345,9 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     long blocks = (long)blocks_x * blocks_y * g.batch;
     int W = 4;
     while (W < 16 && blocks * W < 1536 && W * 2 * GEMM_UNR * GEMM_DEPTH <= KT * 2) W *= 2;  // (384 q/k/v workgroups: 4 waves 11.1 us, 8 waves 11.7-12.2 us)
+    // 3+ rows through the fused norm (beam search): with 4 waves each wave stages and normalises a whole row (8 chunks per lane, two
+    // dependent groups of loads); 8 waves give every row two waves and one group (beam 4: 36.13 -> 35.99 ms per chunk, same box)
+    if (AMODE == 2 && g.M > 2 && ntb == 1 && W < 8 && KT >= 64) W = 8;
     if (g_tune_w) W = g_tune_w;
     while (W > 1 && W > KT) W /= 2;
     while (W > 1 && (size_t)W * MT * ntb * 1024 > 64 * 1024) W /= 2;

@@ -650,7 +650,9 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     if (slots % 64 != 0 || d.sys_cap % 16 != 0) return ISST_ERR_ARG;
     const int G = d.heads / d.kv_heads;
     const int total_tiles = slots / 16;
-    const int target = g_attn_target_wgs > 0 ? g_attn_target_wgs : LLM_ATTN_TARGET_WGS;
+    // (up to 4 groups -- 4 streams, or the 4 beams of one -- still prefer one 64-slot span per workgroup: beam 4 36.4 -> 36.2 ms per chunk,
+    //  4 greedy streams 40.25 -> 39.97; from 8 groups on the longer spans win: 45.8 vs 46.7 ms)
+    const int target = g_attn_target_wgs > 0 ? g_attn_target_wgs : (n_groups <= 4 ? 2 * LLM_ATTN_TARGET_WGS : LLM_ATTN_TARGET_WGS);
     int rc;
     int n_splits;
     if (units && n_units > 0 && max_group_rows > 1) {
