@@ -24,11 +24,11 @@
 #define MID_KS (4 * MID_KSW)      // k-steps per chunk
 #define MID_CK (32 * MID_KS)      // K elements per staged chunk (256): one barrier per chunk, 4 * MT MFMAs per wave between barriers
 
-// NP: n-tile pairs per workgroup (1 or 2) -> 32 or 64 columns, 4 * NP waves.  Wave (np, wk) owns the two n-tiles of pair np
+// NP: n-tile pairs per workgroup (1, 2 or 4) -> 32, 64 or 128 columns, 4 * NP waves.  Wave (np, wk) owns the two n-tiles of pair np
 // (for SwiGLU exactly one (gate, up) pair) and k-steps wk*KSW .. of every chunk: per chunk it reads its KSW * MT A fragments from
 // LDS once and feeds 2 MFMAs on independent accumulators from each.
 template <int MT, int NP, int EPI>
-__global__ __launch_bounds__(NP * 256, NP == 2 ? 4 : 2) void gemm_mid_kernel(GemmArgs g, int k_chunks, int dbg) {
+__global__ __launch_bounds__(NP * 256, NP == 2 ? 4 : (NP == 4 ? 4 : 2)) void gemm_mid_kernel(GemmArgs g, int k_chunks, int dbg) {
     constexpr int NW = NP * 4;                     // waves per workgroup
     constexpr int WN = NP * 2;                     // n-tiles per workgroup
     constexpr int UNITS = MT * 2 * MID_KS / 2;     // staging units (8 rows x 128 B = two k-steps) per chunk
@@ -209,7 +209,13 @@ static int launch_mid_cfg(const GemmArgs& g, hipStream_t stream) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     const int NTILES = g.N / 16, WN = NP * 2;
     dim3 grid((NTILES + WN - 1) / WN, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(NP * 256);
-    const size_t lds = (size_t)2 * MID_KS * MT * 1024;  // A double buffer 16 MT KiB >= K-reduction buffer 4 * MT * WN KiB
+    size_t lds = (size_t)2 * MID_KS * MT * 1024;  // A double buffer 16 MT KiB >= K-reduction buffer 4 * MT * WN KiB (NP <= 2)
+    if ((size_t)4 * MT * WN * 1024 > lds) lds = (size_t)4 * MT * WN * 1024;
+    if (lds > 64 * 1024) {
+        static bool attr = false;
+        if (!attr && hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<MT, NP, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+        attr = true;
+    }
     hipLaunchKernelGGL((gemm_mid_kernel<MT, NP, EPI>), grid, block, lds, stream, g, g.K / MID_CK / ks, g_mid_dbg);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
@@ -222,8 +228,13 @@ static int launch_mid_wn(const GemmArgs& g, hipStream_t stream) {
     int wn;
     if (g.M <= 32) wn = g.N >= 16384 ? 4 : 2;
     else wn = ((long)(g.N / 64) * ks >= 192) ? 4 : 2;
-    if (g_mid_wn == 2 || g_mid_wn == 4) wn = g_mid_wn;
-    if (wn == 4) return launch_mid_cfg<MT, 2, EPI>(g, stream);
+    // the widest projections (gate/up, lm_head: >= 192 workgroups even at 128 columns) take 128 columns and 16 waves: A is staged half as
+    // often -- at 64 rows its L2->LDS traffic equals the weight bytes otherwise (gate/up 53.8 -> 44.3 us, the weight-only time; 22 rows
+    // 42.9 -> 41.7; q/k/v, o_proj, down lose: too few workgroups)
+    if (ks == 1 && g.N / 128 >= 192) wn = 8;
+    if (g_mid_wn == 2 || g_mid_wn == 4 || g_mid_wn == 8) wn = g_mid_wn;
+    if (wn == 8) return launch_mid_cfg<MT, 4, EPI>(g, stream);
+    if (wn >= 4) return launch_mid_cfg<MT, 2, EPI>(g, stream);
     return launch_mid_cfg<MT, 1, EPI>(g, stream);
 }
 

@@ -48,7 +48,7 @@ for M in (22, 64):
         out = torch.empty(M, N // 2 if epi == 'swiglu' else N, device=dev, dtype=torch.bfloat16)
         slabs = torch.empty(8, M, N, device=dev, dtype=torch.float32)
         line = f"M={M:3d} {name:8s} W={mb:6.1f} MB :"
-        for label, tune in (("skinny", (-1, 0)), ("mid wn2", (0, 2)), ("mid wn4", (0, 4)), ("wn4 noA", (0, 4 + 16)), ("wn4 noW", (0, 4 + 32)), ("wn4 none", (0, 4 + 48))):
+        for label, tune in (("skinny", (-1, 0)), ("mid wn2", (0, 2)), ("mid wn4", (0, 4)), ("mid wn8", (0, 8)), ("wn4 noA", (0, 4 + 16)), ("wn4 noW", (0, 4 + 32)), ("wn4 none", (0, 4 + 48))):
             lib.isst_op_set_gemm_tuning(*tune)
             t = timeit(lambda i: gemm_raw(A, Wps[i % COPIES], N, K, epi, res, out))
             line += f"  {label} {t:6.1f} us ({mb / t / 1e3 * 1e3:5.0f} GB/s)"

@@ -265,7 +265,7 @@ def test_gemm_tiled_swiglu():
 
 
 @pytest.mark.parametrize("M", [17, 22, 40, 64])
-@pytest.mark.parametrize("wn", [2, 4])
+@pytest.mark.parametrize("wn", [2, 4, 8])
 def test_gemm_mid_rows_both_widths(M, wn):
     """17..64 rows go through gemm_mid.hip (A staged in LDS); both workgroup widths, every epilogue, ragged N; and the
     result must agree with the 1..16-row kernel's arithmetic (same products, different fp32 summation order)."""
