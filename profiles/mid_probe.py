@@ -46,7 +46,7 @@ for M in (22, 64):
         res = torch.randn(M, N, device=dev).bfloat16() if epi == "res" else None
         mb = N * K * 2 / 1e6
         out = torch.empty(M, N // 2 if epi == 'swiglu' else N, device=dev, dtype=torch.bfloat16)
-        slabs = torch.empty(8, M, N, device=dev, dtype=torch.float32)
+        slabs = torch.empty(16, M, N, device=dev, dtype=torch.float32)
         line = f"M={M:3d} {name:8s} W={mb:6.1f} MB :"
         for label, tune in (("skinny", (-1, 0)), ("mid wn2", (0, 2)), ("mid wn4", (0, 4)), ("mid wn8", (0, 8)), ("wn4 noA", (0, 4 + 16)), ("wn4 noW", (0, 4 + 32)), ("wn4 none", (0, 4 + 48))):
             lib.isst_op_set_gemm_tuning(*tune)
@@ -56,10 +56,10 @@ for M in (22, 64):
         if epi == "res":
             x = res.clone()
             nw = torch.ones(N, device=dev).bfloat16()
-            for ks in (2, 4, 8):
+            for ks in (2, 4, 8, 16):
                 if K % (256 * ks):
                     continue
-                for wn in (2, 4):
+                for wn in (2, 4, 8):
                     lib.isst_op_set_gemm_tuning(0, wn)
                     t = timeit(lambda i: splitk_raw(A, Wps[i % COPIES], x, nw, out, slabs, N, K, ks))
                     line += f"  splitK{ks}/wn{wn}+norm {t:6.1f}"
