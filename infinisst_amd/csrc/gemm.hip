@@ -9,10 +9,11 @@
 //   * weights are re-laid out ONCE at load time into MFMA-fragment-major order
 //         Wp[n_tile][k_tile][lane 0..63][8 bf16]   (n_tile = 16 rows of W, k_tile = 32 columns)
 //     so that the B operand of v_mfma_f32_16x16x32_bf16 for (n_tile,k_tile) is one fully contiguous 1 KiB
-//     global_load_dwordx4 per wave -- no LDS round trip, no 64-byte row fragments;
+//     buffer_load_dwordx4 per wave -- no LDS round trip, no 64-byte row fragments;
 //   * a workgroup owns NTB n-tiles and all of K; its waves interleave k-tiles (wave w takes kt = w, w+W, ..),
 //     so the block streams one contiguous [NTB][K/32] KiB run; partial sums meet in LDS once at the end;
-//   * A (activations, L2-resident) goes straight to VGPRs in the A-operand layout; rows >= M are not loaded;
+//   * A (activations, L2-resident) goes straight to VGPRs in the A-operand layout through a bounds-checked descriptor (rows >= M read
+//     zeros), in the same ring of loads as the weights; after an RMSNorm and at <= 8 rows it is staged and normalised in LDS instead;
 //   * the epilogue applies bias / GELU / residual / SwiGLU with the reference's bf16 rounding points.
 //
 // Operand maps (cdna_hip_programming.md section 3): A lane l holds A[row l&15][k = 8(l>>4)+j], B lane l holds
@@ -326,8 +327,9 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
 }
 
 // tuning overrides for profiles/gemv_sweep.py (0 = heuristic)
-static int g_tune_w = 0, g_tune_ntb = 0, g_force_skinny = 0;
-void gemm_set_tuning(int w, int ntb) { g_tune_w = w < 0 ? 0 : w; g_tune_ntb = ntb; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }  // w < 0: never use the tiled kernel
+static int g_tune_w = 0, g_force_skinny = 0;
+// w: waves per workgroup of the skinny kernel (0 = heuristic, < 0 = never use the mid / tiled kernels); ntb: passed on to gemm_mid (its width / timing knobs)
+void gemm_set_tuning(int w, int ntb) { g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
 
 static inline bool gemm_can_stage(const GemmArgs& g) {
     return g.batch == 1 && g.M <= 16 && (size_t)g.M * g.K * 2 <= 64 * 1024 && g.M <= GEMM_FUSED_NORM_MAX_M;
