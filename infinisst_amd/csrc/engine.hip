@@ -91,6 +91,7 @@ struct isst_handle {
         float penalty = 0.f;
     } dgraph;
     bool rot_keys = true;   // ISST_ROT_KEYS=0: rotate cached keys on every read (the reference's schedule) instead of once per chunk
+    bool beam_shared = true;  // ISST_BEAM_SHARED=0: every beam reads its whole arena (B x the attention traffic) instead of sharing the prefix pass
     bool use_graphs = false;  // ISST_GRAPH=1 enables.  Measured on MI355X (1 stream): 35.40 ms per chunk replayed vs 35.28 launched one by
                               // one -- the loop is GPU-bound, the host is ~0.6 ms ahead per pass, and a graph does not shorten the
                               // GPU-side kernel boundaries; it only saves host time (230 launches -> 1 per step)
@@ -313,6 +314,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->cfg = *cfg;
     if (const char* e = getenv("ISST_GRAPH")) h->use_graphs = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_ROT_KEYS")) h->rot_keys = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
     const isst_config& c = h->cfg;
     auto die = [&](int code) { g_create_error = h->err; isst_destroy(h); return code; };
 
@@ -913,7 +915,7 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
 
 // one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
 int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_groups, int max_group_rows, bool splice, const char* tap_prefix,
-                hipStream_t st, const StepMeta* hm = nullptr, int n_units = 0, int max_unit_groups = 0) {
+                hipStream_t st, const StepMeta* hm = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0) {
     const isst_config& c = h->cfg;
     const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
     // one group (one stream's decode step): its metadata travels in the kernel arguments (llm_attn.hip LlmAttnOne)
@@ -963,7 +965,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         }
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
-                                 max_unit_groups));
+                                 max_unit_groups, n_beam_wgs));
         if (so > 1) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
             CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
@@ -1226,13 +1228,16 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
             CHK(flush_copies(h, ops, mh, md, st));
         }
         if (all_done || step >= p->max_new_tokens) break;  // :920
-        // ---- next forward pass: one row per (stream, beam) ----
+        // ---- next forward pass: one row per (stream, beam).  Shared-prefix form (llm_attn.hip, LlmStreamView::n_beams): the B rows of a
+        //      stream are ONE attention group over arena 0 for everything older than this chunk's generated tokens (identical in all
+        //      arenas) plus one workgroup per beam for the <= 4 tiles that differ; otherwise every beam is its own group over its arena ----
         const int nr = n * B;
+        const bool shared = h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;
         for (int i = 0; i < n; ++i) {
             const StreamState& ss = h->streams[stream_ids[i]];
             for (int b = 0; b < B; ++b) {
                 const int r = i * B + b;
-                mh.row_stream[r] = r;  // view index
+                mh.row_stream[r] = shared ? i * B : r;  // view index
                 mh.row_pos[r] = total0[i] + prompt_lens[i] + step - 1;
                 mh.ids[r] = bs[i].seq[b].back();
                 mh.last_rows[r] = r;
@@ -1240,14 +1245,22 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 mh.views[r].ring_start = ss.llm_ring_start;
                 mh.views[r].kv_offset = h->arena_off(stream_ids[i], b);
                 mh.views[r].new_start = mh.row_pos[r];
-                mh.views[r].row0 = r;
+                mh.views[r].row0 = shared ? i * B : r;
                 mh.views[r].rot_keys = h->rot_keys ? 1 : 0;  // every beam's arena carries its rotated keys (pre-pass over all arenas + position copies)
-                mh.groups[r].x = r;
-                mh.groups[r].y = 1;
+                mh.views[r].n_beams = shared ? B : 0;
+                mh.views[r].tail_start = total0[i] + prompt_lens[i];
+                mh.views[r].beam_stride = h->llm_stream_stride;
+                if (shared) {
+                    mh.groups[i].x = i * B;
+                    mh.groups[i].y = B;
+                } else {
+                    mh.groups[r].x = r;
+                    mh.groups[r].y = 1;
+                }
             }
         }
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-        CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st, &mh));
+        CHK(llm_forward(h, md, nr, nr, shared ? n : nr, shared ? B : 1, false, nullptr, st, &mh, 0, 0, shared ? B : 0));
     }
 
     // ---- finalize (:159-275): open beams become hypotheses, the best one wins ----
@@ -1381,6 +1394,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         mh.views[i].new_start = total0[i];
         mh.views[i].row0 = R;
         mh.views[i].rot_keys = h->rot_keys ? 1 : 0;
+        mh.views[i].n_beams = 0;
         row0[i] = R;
         const int len = prompt_lens[i];
         const int* ids = prompt_ids[i];

@@ -17,6 +17,13 @@ struct LlmStreamView {
     int row0;        // row of this launch that holds position new_start
     int rot_keys;    // 1: keys older than this launch are read ALREADY ROTATED from the rotated-key arena (launch_llm_rope_cache filled it
                      // for this chunk) and the launch's own keys are added to it; 0: rotate on read, as the reference does every pass
+    // beam search, shared-prefix form (n_beams > 1): the group's rows are the B beams of ONE stream at the same position.  Their arenas
+    // (kv_offset + b * beam_stride) are identical below logical position tail_start, so the ordinary slot-split workgroups read those
+    // keys ONCE, from arena 0, for all beams' columns; keys >= tail_start (written during this chunk: per beam) and the step's own key
+    // (row row0 + b) belong to B extra workgroups, one per beam, which only that beam's columns listen to
+    int n_beams;
+    int tail_start;
+    long beam_stride;
 };
 
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
@@ -69,7 +76,7 @@ struct LlmAttnOne {
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one = nullptr,
-                         const int2* units = nullptr, int n_units = 0, int max_unit_groups = 0);  // units[z] = (first group, groups <= 8) of ONE
+                         const int2* units = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0);  // units[z] = (first group, groups <= 8) of ONE
                                                                                               // stream: prefill launches share key tiles per unit
 // Rotated-key arena for one chunk: for every listed stream and EVERY layer, krpool[slot] = RoPE(kpool[slot], logical position of the slot)
 // for the `total` cached keys (views[i].new_start = total).  A key's logical position only changes when the host evicts, i.e. between

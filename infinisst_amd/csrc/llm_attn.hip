@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
                                                                const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
                                                                const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                                                                float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
-                                                               int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct) {
+                                                               int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct, int n_extra) {
+    // n_splits: partial slabs per (row, head) = gridDim.x; the last n_extra of them are the per-beam workgroups of the shared-prefix form
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
     __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
     const int sp = blockIdx.x, kvh = blockIdx.y;
@@ -95,7 +96,10 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     const int H = d.heads, KV = d.kv_heads;
     const long ldq = (long)(H + 2 * KV) * HD;
     const int slots = d.sys_cap + d.ring_cap;
-    const long base = v.kv_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
+    const bool shared = n_extra > 0 && v.n_beams > 1;
+    const bool tailwg = shared && sp >= n_splits - n_extra;  // this workgroup: the per-beam keys of beam `beam`
+    const int beam = tailwg ? sp - (n_splits - n_extra) : 0;
+    const long base = v.kv_offset + (long)beam * v.beam_stride + (long)layer * d.layer_stride + (long)kvh * slots * HD;
     bf16_t* kb = kpool + base;    // [slots][128]
     bf16_t* kr = krpool + base;   // [slots][128] the same keys rotated at their logical position of this chunk (LlmStreamView::rot_keys)
     const bool rot = v.rot_keys != 0;
@@ -103,7 +107,16 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     const int total = (one.enabled ? one.pos0 + nrows - 1 : row_pos[r0 + nrows - 1]) + 1;  // keys visible to the last row of the group
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
     // this wave's 16-slot tiles: tile_begin + wave, + 4, ... below tile_end
-    const int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, slots >> 4);
+    int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, slots >> 4);
+    if (tailwg) {  // the (<= 4, host-checked) ring tiles that hold logical positions tail_start .. total-1: wave w takes the w-th
+        const int ring_tiles = d.ring_cap >> 4, ring_tile0 = d.sys_cap >> 4;
+        const int s_first = (v.ring_start + (v.tail_start - v.sys_len)) % d.ring_cap, s_last = (v.ring_start + (total - 1 - v.sys_len)) % d.ring_cap;
+        const int t_first = s_first >> 4, t_last_r = s_last >> 4;
+        const int n_tail = (t_last_r - t_first + ring_tiles) % ring_tiles + 1;
+        const int mine = ring_tile0 + (t_first + wave) % ring_tiles;
+        tile_begin = mine - wave;  // t = tile_begin + wave below
+        tile_end = wave < n_tail ? mine + 1 : mine;
+    }
 
     // ---- rotated query fragments: B[k = dim][n = column c], c = ct*16 + fr -> (row r0 + c / G, head kvh*G + c % G) ----
     u32x4_t qf[CT][4];
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     auto key_src = [&](int t, int& jk, bool& k_new) -> const bf16_t* {
         jk = llm_logical(v, d, t * 16 + fr, total);
         k_new = jk >= 0 && jk >= v.new_start;
-        return k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(t * 16 + fr) * HD;
+        return k_new ? qkv + (long)(v.row0 + beam + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(t * 16 + fr) * HD;
     };
     // V tile staging: the lane's value row (16 B x 4, same lane -> (key, dims) map as K) goes to a wave-private LDS image
     // [16 keys][128 dims] (256-byte rows, 16-byte chunks XOR-swizzled so that row writes and transposed reads both spread over the
@@ -159,12 +172,12 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     u32x4_t kraw_n[4];
     // the lane's value row of tile tt: from the arena, or from the qkv row for a key written by this launch
     auto val_src = [&](int tt, int jk, bool k_new) -> const bf16_t* {
-        return k_new ? qkv + (long)(v.row0 + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD : vb + (long)(tt * 16 + fr) * HD;
+        return k_new ? qkv + (long)(v.row0 + beam + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD : vb + (long)(tt * 16 + fr) * HD;
     };
     // MULTI: the next tile's key and value rows go in flight before this tile's arithmetic.  The prefetch is unconditional, clamped
     // to the wave's last tile (slots % 64 == 0 gives every wave the same tile count): a conditional load makes hipcc branch around it
     // and drain vmcnt(0).
-    const int t_last = tile_end - 4 + wave;
+    const int t_last = tailwg ? t : tile_end - 4 + wave;
     u32x4_t vraw_n[4];
     if (t < tile_end) {
         const bf16_t* src = key_src(t, jk_n, knew_n);
@@ -199,8 +212,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         for (int r = 0; r < 4; ++r) jc[r] = llm_logical(v, d, t0 + 4 * fq + r, total);
 
         // ---- append this group's own new keys (unrotated K row, V row) ----
-        if (k_new) {
-            const int krow = v.row0 + (jk - v.new_start);
+        if (k_new && (!shared || tailwg)) {  // (shared-prefix beams: beam b's own workgroup appends beam b's key to arena b)
+            const int krow = v.row0 + beam + (jk - v.new_start);
             if (krow >= r0 && krow < r0 + nrows) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -220,8 +233,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 #pragma unroll
             for (int s = 0; s < 4; ++s) kf[s] = kraw[s];
         }
-        if (rot && k_new) {
-            const int krow = v.row0 + (jk - v.new_start);
+        if (rot && k_new && (!shared || tailwg)) {
+            const int krow = v.row0 + beam + (jk - v.new_start);
             if (krow >= r0 && krow < r0 + nrows) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kr + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
@@ -238,7 +251,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             float sc[4], mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool ok = jc[r] >= 0 && jc[r] <= cpos[ct];
+                bool ok = jc[r] >= 0 && jc[r] <= cpos[ct];
+                if (shared) ok = ok && (tailwg ? (jc[r] >= v.tail_start && (ct * 16 + fr) / G == beam) : jc[r] < v.tail_start);
                 sc[r] = ok ? st[r] * scale : -INFINITY;
                 mx = fmaxf(mx, sc[r]);
             }
@@ -618,15 +632,16 @@ void llm_attn_set_tuning(int target_wgs) { g_attn_target_wgs = target_wgs & 0xff
 template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                     int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
-                    float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s, const LlmAttnOne& one, bf16_t* out_direct) {
-    dim3 grid(n_splits, d.kv_heads, n_groups), block(256);
+                    float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s, const LlmAttnOne& one, bf16_t* out_direct,
+                    int n_extra) {
+    dim3 grid(n_splits, d.kv_heads, n_groups), block(256);  // n_splits includes the n_extra per-beam workgroups
     if (max_group_rows * G > 16) return ISST_ERR_ARG;  // one 16-column tile per workgroup (LLM_ATTN_GROUP_ROWS(G) rows)
     if (tiles_per_split > 4)
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, true>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct);
+                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct, n_extra);
     else
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, false>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct);
+                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct, n_extra);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
@@ -642,7 +657,7 @@ static int launch_prefill_g(const bf16_t* qkv, const int* row_stream, const int*
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one, const int2* units,
-                         int n_units, int max_unit_groups) {
+                         int n_units, int max_unit_groups, int n_beam_wgs) {
     if (rows <= 0 || n_groups <= 0) return ISST_OK;
     LlmAttnOne one1{};
     if (one && one->enabled && n_groups == 1) one1 = *one;
@@ -679,10 +694,13 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
         n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
         const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
         n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
+        // shared-prefix beam groups (LlmStreamView::n_beams): one more workgroup (and partial slab) per beam; they need the one-tile-per-wave form
+        if (n_beam_wgs > 0 && tiles_per_split > 4) return ISST_ERR_ARG;
+        n_splits += n_beam_wgs;
         switch (G) {
-            case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
-            case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
-            case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr); break;
+            case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr, n_beam_wgs); break;
+            case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr, n_beam_wgs); break;
+            case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr, n_beam_wgs); break;
             default: return ISST_ERR_ARG;
         }
     }

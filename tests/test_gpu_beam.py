@@ -27,8 +27,14 @@ def kv_of(eng, sid, n, beam=0):
     return torch.stack(ks), torch.stack(vs)
 
 
+@pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("eos", [True, False])
-def test_beam_kv_bookkeeping_is_exact(eos):
+def test_beam_kv_bookkeeping_is_exact(eos, shared, monkeypatch):
+    """shared=False (ISST_BEAM_SHARED=0): every beam attends over its own arena with exactly the greedy kernel's decomposition, so the
+    arenas must equal the teacher-forced greedy replay BIT FOR BIT -- this pins the bookkeeping.  shared=True (default): the prefix pass
+    is shared between the beams and the per-beam keys sit in extra workgroups; the softmax blocks are cut differently, so the attention
+    output (and through it the next layers' K/V) may differ by a bf16 rounding: same positions, same bookkeeping, values within 2 ulps."""
+    monkeypatch.setenv("ISST_BEAM_SHARED", "1" if shared else "0")
     cfg = toy_config() if eos else toy_config().replace(eos_ids=())
     if eos:  # make EOS likely enough that hypotheses get closed early: many ids count as EOS
         cfg = cfg.replace(eos_ids=(1001, 1008, 1009, 7, 8, 9))
@@ -57,8 +63,13 @@ def test_beam_kv_bookkeeping_is_exact(eos):
         kg, vg = kv_of(eng, g, ng)
         for b in range(B):
             kb, vb = kv_of(eng, a, na, beam=b)
-            bad_k = [p for p in range(na) if not torch.equal(kb[p], kg[p])]
-            bad_v = [p for p in range(na) if not torch.equal(vb[p], vg[p])]
+            if shared:
+                # within two bf16 roundings of the row's largest element (upstream rounding flips act on the scale of the vector, not of each element)
+                same = lambda x, y: float((x.float() - y.float()).abs().max()) <= 2.0 ** -6 * float(y.float().abs().max())
+            else:
+                same = torch.equal
+            bad_k = [p for p in range(na) if not same(kb[p], kg[p])]
+            bad_v = [p for p in range(na) if not same(vb[p], vg[p])]
             assert not bad_k and not bad_v, (f"chunk {c}: arena of beam {b} differs from the replayed winner path at K positions {bad_k[:12]} "
                                              f"V positions {bad_v[:12]} (cache {na}, prompt {len(prompt)}, winner {win}; "
                                              f"max|dK| {float((kb.float() - kg.float()).abs().max()):.4f})")
