@@ -20,6 +20,7 @@
 #include "common.h"
 #include "kernels.h"
 
+#define KV_OPS_SLOTS 8  // batches of beam-search KV position copies that may be enqueued between two stream synchronisations
 #define LLM_KSPLIT_MAX 8
 #define LLM_SPLIT_MAX_ROWS 1024  // rows up to which o_proj / down_proj run split-K into slabs (beyond, the dense kernel has the workgroups)
 #define LLM_SLAB_ROWS 2048       // slices x rows the slab buffer holds
@@ -91,6 +92,7 @@ struct isst_handle {
         float penalty = 0.f;
     } dgraph;
     bool rot_keys = true;   // ISST_ROT_KEYS=0: rotate cached keys on every read (the reference's schedule) instead of once per chunk
+    int kv_ops_used = 0;      // slots of the pinned KV-copy op list handed out since the stream was last known idle (flush_copies)
     bool beam_shared = true;  // ISST_BEAM_SHARED=0: every beam reads its whole arena (B x the attention traffic) instead of sharing the prefix pass
     bool use_graphs = false;  // ISST_GRAPH=1 enables.  Measured on MI355X (1 stream): 35.40 ms per chunk replayed vs 35.28 launched one by
                               // one -- the loop is GPU-bound, the host is ~0.6 ms ahead per pass, and a graph does not shorten the
@@ -449,7 +451,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         }
     }
     h->meta_bytes = (size_t)LR * 8 * sizeof(int) + NB * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
-                    NB * (h->max_ids + h->max_enc_ids) * sizeof(int) + NB * 4 * sizeof(KvCopyOp) + 65536 * sizeof(int) + 8192;
+                    NB * (h->max_ids + h->max_enc_ids) * sizeof(int) + NB * 4 * sizeof(KvCopyOp) * KV_OPS_SLOTS + 65536 * sizeof(int) + 8192;
     h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
     const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->llm_kr, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
                           h->window, h->act_a, h->act_b, h->ex, h->exn, h->eqkv, h->eattn, h->effn, h->speech, h->lx, h->lxn, h->lqkv, h->lqrot,
@@ -906,7 +908,7 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
     m.samp = reinterpret_cast<SampleStream*>(take(ns * sizeof(SampleStream)));
     m.ids_pool = reinterpret_cast<int*>(take(ns * h->max_ids * 4));
     m.enc_pool = reinterpret_cast<int*>(take(ns * h->max_enc_ids * 4));
-    m.ops = reinterpret_cast<KvCopyOp*>(take(ns * 4 * sizeof(KvCopyOp)));
+    m.ops = reinterpret_cast<KvCopyOp*>(take(ns * 4 * sizeof(KvCopyOp) * KV_OPS_SLOTS));
     m.step_bytes = (size_t)(p - base);
     m.suppress_offset = m.step_bytes;
     m.suppress = reinterpret_cast<int*>(take(65536 * 4));
@@ -1084,7 +1086,9 @@ void push_copy(isst_handle* h, std::vector<KvCopyOp>& ops, int sid, int beam, in
     op.to_arena = to_arena ? 1 : 0;
     ops.push_back(op);
 }
-// enqueue `ops` (all of them are independent of each other) and clear the list
+// enqueue `ops` (all of them are independent of each other) and clear the list.  The pinned op list has KV_OPS_SLOTS slots used in
+// turn, so that a batch does not have to wait for the previous one's upload: the caller synchronises the stream once per beam step
+// (candidate download) and calls kv_ops_synced(); a slot is only reused after such a point
 int flush_copies(isst_handle* h, std::vector<KvCopyOp>& ops, const StepMeta& mh, const StepMeta& md, hipStream_t st) {
     if (ops.empty()) return ISST_OK;
     const size_t cap = (size_t)h->cfg.max_streams * h->max_beams * 4;
@@ -1092,10 +1096,15 @@ int flush_copies(isst_handle* h, std::vector<KvCopyOp>& ops, const StepMeta& mh,
         const int n = (int)std::min(cap, ops.size() - o);
         int max_count = 0;
         for (int i = 0; i < n; ++i) max_count = std::max(max_count, ops[o + i].count);
-        HIPCHK(hipStreamSynchronize(st));  // the pinned op list may still be read by the previous batch
-        std::memcpy(mh.ops, ops.data() + o, sizeof(KvCopyOp) * n);
-        HIPCHK(hipMemcpyAsync(md.ops, mh.ops, sizeof(KvCopyOp) * n, hipMemcpyHostToDevice, st));
-        CHK(launch_kv_positions_copy(h->llm_k, h->llm_v, h->rot_keys ? h->llm_kr : nullptr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, md.ops, n, max_count, h->adims, h->cfg.llm_layers, h->tcap, st));
+        if (h->kv_ops_used >= KV_OPS_SLOTS) {  // every slot may still be read by an upload in flight
+            HIPCHK(hipStreamSynchronize(st));
+            h->kv_ops_used = 0;
+        }
+        const size_t slot = (size_t)h->kv_ops_used++ * cap;
+        std::memcpy(mh.ops + slot, ops.data() + o, sizeof(KvCopyOp) * n);
+        HIPCHK(hipMemcpyAsync(md.ops + slot, mh.ops + slot, sizeof(KvCopyOp) * n, hipMemcpyHostToDevice, st));
+        CHK(launch_kv_positions_copy(h->llm_k, h->llm_v, h->rot_keys ? h->llm_kr : nullptr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, md.ops + slot, n, max_count, h->adims,
+                                     h->cfg.llm_layers, h->tcap, st));
     }
     ops.clear();
     return ISST_OK;
@@ -1112,6 +1121,10 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
     const double lp = p->length_penalty == 0.f ? 1.0 : (double)p->length_penalty;
     std::vector<BeamStream> bs(n);
     std::vector<KvCopyOp> ops;
+    if (h->kv_ops_used) {  // batches of an earlier call that ended without a synchronisation in between (finalize)
+        HIPCHK(hipStreamSynchronize(st));
+        h->kv_ops_used = 0;
+    }
     for (int i = 0; i < n; ++i) {
         bs[i].seq.assign(B, std::vector<int>(prompt_ids[i], prompt_ids[i] + prompt_lens[i]));
         bs[i].score.assign(B, -1e9f);
@@ -1150,6 +1163,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         HIPCHK(hipMemcpyAsync(h->top_val_host, h->top_val, sizeof(float) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(h->top_idx_host, h->top_idx, sizeof(int) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        h->kv_ops_used = 0;  // every earlier copy batch has run
 
         // ---- scorer (beam_search_process, :43-157) ----
         bool all_done = true;
