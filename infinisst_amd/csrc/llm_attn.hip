@@ -694,8 +694,8 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
         n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
         const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
         n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
-        // shared-prefix beam groups (LlmStreamView::n_beams): one more workgroup (and partial slab) per beam; they need the one-tile-per-wave form
-        if (n_beam_wgs > 0 && tiles_per_split > 4) return ISST_ERR_ARG;
+        // shared-prefix beam groups (LlmStreamView::n_beams): one more workgroup (and partial slab) per beam (each of its waves takes one tile,
+        // in either form of the kernel)
         n_splits += n_beam_wgs;
         switch (G) {
             case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr, n_beam_wgs); break;

@@ -148,3 +148,41 @@ def test_beam_rotated_key_arena_is_bit_identical_to_rotate_on_read(monkeypatch):
     for c, (xa, xb) in enumerate(zip(ka, kb)):
         for b in range(B):
             assert torch.equal(xa[b][0], xb[b][0]) and torch.equal(xa[b][1], xb[b][1]), f"chunk {c} beam {b}: KV differs between the two key schedules"
+
+
+@pytest.mark.parametrize("target_wgs", [0, 8])
+def test_beam_shared_prefix_agrees_with_per_beam_arenas(monkeypatch, target_wgs):
+    """The shared-prefix attention (one group per stream + one workgroup per beam) against one group per beam, three streams at once, with
+    the default slot splits and with long multi-tile spans (target 8 workgroups: the running-softmax form of the kernel): the two cut the
+    softmax differently, so sequences may part at near-ties -- most must be identical."""
+    from infinisst_amd.engine import load_library
+    cfg = toy_config()
+    B = 4
+    gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=400)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=45)
+
+    def run(flag):
+        monkeypatch.setenv("ISST_BEAM_SHARED", flag)
+        eng = Engine(cfg, max_streams=3, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
+        eng.load_weights(w)
+        load_library().isst_op_set_attn_tuning(target_wgs)
+        try:
+            sids = [eng.open_stream() for _ in range(3)]
+            outs = []
+            prev = [[] for _ in sids]
+            for c in range(3):
+                segs = [synth.synthetic_audio(cfg.chunk_samples * 3, stream_id=70 + k)[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples] for k in range(3)]
+                prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+                ids, _ = eng.generate(gen, sids, segs, [prompt] * 3, [p[-100:] for p in prev])
+                outs.extend(ids)
+                for k in range(3):
+                    prev[k].extend(ids[k][:-1])
+        finally:
+            load_library().isst_op_set_attn_tuning(0)
+            eng.close()
+        return outs
+
+    a, b = run("1"), run("0")
+    same = sum(x == y for x, y in zip(a, b))
+    print(f"shared vs per-beam arenas (target {target_wgs}): {same}/{len(a)} identical sequences")
+    assert same >= len(a) - 3
