@@ -239,6 +239,12 @@ int main() {
             report(nm, chain_us([&](int k) { g.Wp = w[k % nbuf]; if (launch_gemm(g, st) != ISST_OK) { printf("launch failed\n"); exit(1); } }, chain, st));
         }
         gemm_set_tuning(0, 0);
+        for (int rows_m = 2; rows_m <= 4; ++rows_m) {  // beam rows through the same launch
+            g.M = rows_m;
+            char nm[64]; snprintf(nm, 64, "product launch_gemm, %d rows", rows_m);
+            report(nm, chain_us([&](int k) { g.Wp = w[k % nbuf]; if (launch_gemm(g, st) != ISST_OK) { printf("launch failed\n"); exit(1); } }, chain, st));
+        }
+        g.M = 1;
         report("product launch_gemm", chain_us([&](int k) { g.Wp = w[k % nbuf]; if (launch_gemm(g, st) != ISST_OK) { printf("launch failed\n"); exit(1); } }, chain, st));
         for (int n_wg : {1024, 2048}) {
             const long per_wg = (long)(bytes / 16) / n_wg;
