@@ -233,7 +233,7 @@ int main() {
         g.norm_w = s.norm ? nw : nullptr; g.norm_eps = 1e-5f; g.ksplit = 0;
         printf("%s: N %d K %d, %.1f MB, pool %d buffers\n", s.name, s.N, s.K, bytes / 1e6, nbuf);
         auto report = [&](const char* what, float us) { printf("    %-58s %7.2f us  %5.2f TB/s\n", what, us, bytes / us / 1e6); fflush(stdout); };
-        for (int tw : {4, 8, 16}) {
+        for (int tw : {2, 4, 8, 16}) {
             gemm_set_tuning(tw, 0);
             char nm[64]; snprintf(nm, 64, "product launch_gemm, %d waves", tw);
             report(nm, chain_us([&](int k) { g.Wp = w[k % nbuf]; if (launch_gemm(g, st) != ISST_OK) { printf("launch failed\n"); exit(1); } }, chain, st));
