@@ -186,3 +186,49 @@ def test_beam_shared_prefix_agrees_with_per_beam_arenas(monkeypatch, target_wgs)
     same = sum(x == y for x, y in zip(a, b))
     print(f"shared vs per-beam arenas (target {target_wgs}): {same}/{len(a)} identical sequences")
     assert same >= len(a) - 3
+
+
+def test_beam_shared_prefix_survives_evictions_and_ring_wrap():
+    """Shared-prefix beam attention over a small, wrapping KV ring: 10 chunks with an eviction after most of them, so that the per-beam
+    tail tiles straddle the ring's end and the pinned system prompt.  After every chunk each beam's arena must hold the KV of the winner
+    path -- compared (within two bf16 roundings of a row's largest element, see test_beam_kv_bookkeeping_is_exact) with a greedy stream
+    that is teacher-forced along the same path and evicted in lockstep."""
+    from oracle import agent as oag
+    cfg = toy_config().replace(eos_ids=())
+    B = 4
+    gen_b = GenConfig(max_new_tokens=7, beam=B, max_llm_cache_size=150, always_cache_system_prompt=True)
+    gen_g = GenConfig(max_new_tokens=7, beam=1, max_llm_cache_size=150, always_cache_system_prompt=True)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=46)
+    eng = Engine(cfg, max_streams=2, max_multiplier=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=150, max_system_prompt=64, max_beams=B)
+    eng.load_weights(w)
+    a, g = eng.open_stream(), eng.open_stream()
+    audio = synth.synthetic_audio(cfg.chunk_samples * 10, stream_id=21)
+    sys_n = len(synth.system_prompt_ids(cfg))
+    prev, ckpts, evictions, ring_starts = [], [], 0, set()
+    for c in range(10):
+        seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        pin = sys_n if c == 0 else 0
+        outs, _ = eng.generate(gen_b, [a], [seg], [prompt], [prev[-100:]], system_prompt_size=pin)
+        win = outs[0]
+        outs_g, _ = eng.generate(gen_g, [g], [seg], [prompt], [prev[-100:]], system_prompt_size=pin, forced_tokens=[win])
+        assert outs_g[0] == win
+        na, ng = eng.stream_info(a)["llm_cache_len"], eng.stream_info(g)["llm_cache_len"]
+        assert na == ng
+        kg, vg = kv_of(eng, g, ng)
+        for b in range(B):
+            kb, vb = kv_of(eng, a, na, beam=b)
+            for name, x, y in (("K", kb, kg), ("V", vb, vg)):
+                err = (x.float() - y.float()).abs().amax(dim=-1)
+                tol = 2.0 ** -6 * y.float().abs().amax(dim=-1)
+                bad = torch.nonzero(err > tol).flatten().tolist()
+                assert not bad, f"chunk {c} beam {b}: {name} differs from the replayed winner path at positions {bad[:10]} (cache {na}, worst {float(err.max()):.4f})"
+        prev.extend(win[:-1])
+        ckpts.append(na)
+        ev = oag.evict(ckpts, na, gen_b.max_llm_cache_size, True, sys_n)
+        if ev is not None:
+            ckpts, new_size = ev
+            eng.kv_evict(a, new_size, sys_n)
+            eng.kv_evict(g, new_size, sys_n)
+            evictions += 1
+    assert evictions >= 4, f"only {evictions} evictions: the ring never wrapped"
