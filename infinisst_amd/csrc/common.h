@@ -87,6 +87,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream);
 void gemm_set_tuning(int waves_per_block, int ntiles_per_block);  // 0 = heuristic; profiling aid
 bool gemm_tiled_supported(const GemmArgs& g);                      // gemm_tiled.hip: dense shapes (M > 64 or batched)
 int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream);
+void gemm_tiled_set_raster(int on);                                // profiling aid: 0 = plain (column block, row block) grid
 bool gemm_mid_supported(const GemmArgs& g);                        // gemm_mid.hip: 17..64 rows, A staged through LDS
 bool gemm_mid_preferred(const GemmArgs& g);                       // ... and long enough a weight stream to pay for the staging
 int launch_gemm_mid(const GemmArgs& g, hipStream_t stream);

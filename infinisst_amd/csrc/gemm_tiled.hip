@@ -21,13 +21,31 @@
 __device__ __forceinline__ int a_off(int row, int chunk) { return row * TK + ((chunk ^ (row & 7)) << 3); }  // bf16 elements
 
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs g, int raster) {
     __shared__ __attribute__((aligned(16))) bf16_t As[2][TM * TK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int KT = g.K >> 5, NTILES = g.N >> 4;
-    const int m0 = blockIdx.y * TM;
-    const int nt0 = blockIdx.x * TN_TILES + wave * 2;
+    // XCD-aware rasterisation (raster != 0: 1-D launch of 8 * n_per workgroups).  Workgroups go to the 8 XCDs round-robin, and with the
+    // plain (column block, row block) grid the ~64 workgroups an XCD runs at a time are 64 column blocks of ONE row block: its L2 shares the
+    // A rows 64 ways and the weights not at all, so every row block re-reads all of W through the fabric -- at 1408 rows 11 x 235 MB for
+    // gate/up in 405 us = 6.4 TB/s: the kernel was bound by memory-side bandwidth, not by MFMA or LDS (the same 6.0 / 5.3 / 7.6 TB/s fall
+    // out of down_proj, q/k/v and a 4096 x 8192 x 8192 square).  Here XCD c takes a contiguous run of the tile sequence, and the sequence
+    // walks patches of 8 column blocks x all row blocks, column fastest: an XCD's 64 concurrent workgroups are 8 x 8 tiles, A and W
+    // both shared 8 ways in its L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (raster) {
+        const int X = (NTILES + TN_TILES - 1) / TN_TILES, Y = (g.M + TM - 1) / TM;
+        const int n_per = gridDim.x >> 3;
+        const int S = (blockIdx.x & 7) * n_per + (blockIdx.x >> 3);
+        if (S >= X * Y) return;  // padding of the 1-D grid (uniform over the workgroup)
+        const int patch = S / (8 * Y), r = S - patch * (8 * Y);
+        const int pw = min(8, X - patch * 8);
+        by = r / pw;
+        bx = patch * 8 + r % pw;
+    }
+    const int m0 = by * TM;
+    const int nt0 = bx * TN_TILES + wave * 2;
     // blockIdx.z: batch index, or -- EPI_PARTIAL, batch == 1 -- the K slice of a split-K launch (narrow N at 65..512 rows: without
     // it the 32 column blocks of o_proj / down_proj walk all of K alone, 217 us for down_proj whatever the row count)
     const int ks = (EPI == EPI_PARTIAL && g.ksplit > 1) ? g.ksplit : 1;
@@ -133,10 +151,22 @@ bool gemm_tiled_supported(const GemmArgs& g) {
     return g.K % (TK * ks) == 0 && g.lda % 8 == 0 && !g.norm_w && (g.M > 64 || g.batch > 1);
 }
 
+static int g_tiled_raster = 1;  // tuning hook (gemm_tiled_set_raster): 0 = plain 2-D grid always, 1 = heuristic, 2 = rasterised always
+void gemm_tiled_set_raster(int on) { g_tiled_raster = on; }
+
 int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream) {
     const int NTILES = g.N / 16;
     dim3 grid((NTILES + TN_TILES - 1) / TN_TILES, (g.M + TM - 1) / TM, g.epi == EPI_PARTIAL ? (g.ksplit > 1 ? g.ksplit : 1) : g.batch), block(256);
-#define LAUNCH_T(E) hipLaunchKernelGGL(gemm_tiled_kernel<E>, grid, block, 0, stream, g)
+    // (worth it from ~1.5 rounds of workgroups on: gate/up at 1408 rows, 2464 tiles, 403 -> 356 us = 821 -> 928 TFLOP/s, a 4096 x 8192 x 8192
+    //  square 988 -> 1025; grids that are resident all at once already put (few column blocks) x (all row blocks) on an XCD and gain nothing:
+    //  q/k/v at 1408 rows, 528 tiles, 103 -> 110 us -- profiles/raster_probe.py)
+    const int raster = (g_tiled_raster == 1 ? grid.x * grid.y >= 768 : g_tiled_raster == 2) && grid.y > 1 ? 1 : 0;
+    if (raster) {
+        const unsigned tiles = grid.x * grid.y;
+        grid.x = ((tiles + 7) / 8) * 8;
+        grid.y = 1;
+    }
+#define LAUNCH_T(E) hipLaunchKernelGGL(gemm_tiled_kernel<E>, grid, block, 0, stream, g, raster)
     switch (g.epi) {
         case EPI_NONE: LAUNCH_T(EPI_NONE); break;
         case EPI_BIAS: LAUNCH_T(EPI_BIAS); break;
