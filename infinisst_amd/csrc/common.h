@@ -82,6 +82,14 @@ struct GemmArgs {
     float norm_eps;
     int ksplit;                                    // EPI_PARTIAL: K slices over workgroups (slab stride = out_batch elements)
 };
+// rows above which the 17..64-row machinery (gemm_mid.hip, split-K slabs + reducing RMSNorm) replaces the skinny kernel.  At 13..16 rows
+// every 16-column workgroup of the skinny kernel still pulls all of A through L2 -- as many bytes as the weight stream -- and the
+// residual + RMSNorm is a launch of its own (profiles/mid16_probe.py, 16 rows: q/k/v 15.6 -> 13.3 us, gate/up 43.7 -> 41.0,
+// o_proj + norm 15.4 -> 12.8, down + norm 32.2 -> 25.5).  End to end, same box: 16 streams 56.2 -> 53.6 ms per chunk, 15: 57.8 -> 55.9,
+// 14: 56.8 -> 55.3, 13: 55.6 -> 55.5; from 9 rows on it loses (12 streams 52.6 -> 53.3, 9: 47.6 -> 49.1), hence 12
+#ifndef ISST_MID_MIN_ROWS
+#define ISST_MID_MIN_ROWS 12
+#endif
 #define GEMM_FUSED_NORM_MAX_M 8  // rows for which the GEMM stages (and optionally RMS-normalises) A in LDS
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 void gemm_set_tuning(int waves_per_block, int ntiles_per_block);  // 0 = heuristic; profiling aid
@@ -92,5 +100,6 @@ bool gemm_mid_supported(const GemmArgs& g);                        // gemm_mid.h
 bool gemm_mid_preferred(const GemmArgs& g);                       // ... and long enough a weight stream to pay for the staging
 int launch_gemm_mid(const GemmArgs& g, hipStream_t stream);
 void gemm_mid_set_tuning(int wn);
+void gemm_mid_set_min_rows(int rows);                              // rows above which gemm_mid replaces the skinny kernel (default 16)
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,
                        int tile_phase, int conv_k, hipStream_t stream);

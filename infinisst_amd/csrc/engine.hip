@@ -938,7 +938,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     // 17..64 rows (one stream's prefill, a 64-stream decode pass): o_proj and down_proj split K over workgroups and the
     // residual + RMSNorm kernel that follows reduces the slabs (gemm_mid.hip); `pending`: lx still lacks the previous
     // layer's down_proj slabs
-    const bool split_rows = rows > 16 && rows <= LLM_SPLIT_MAX_ROWS;
+    const bool split_rows = rows > ISST_MID_MIN_ROWS && rows <= LLM_SPLIT_MAX_ROWS;
     const int so = split_rows ? pick_ksplit(H * 128, DL, rows) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL, rows) : 1;
     const int sq = (rows > 128 && rows <= LLM_SPLIT_MAX_ROWS) ? pick_ksplit(DL, (H + 2 * KV) * 128, rows) : 1;  // q/k/v: 65..128 rows run on gemm_mid
     const long slab = (long)rows * DL;

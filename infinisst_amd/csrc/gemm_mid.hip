@@ -1,4 +1,4 @@
-// Packed-weight GEMM for 17..64 rows on gfx950:  out[M,N] = epi(A[M,K] @ W[N,K]^T), weights read exactly once.
+// Packed-weight GEMM for 13..64 rows on gfx950:  out[M,N] = epi(A[M,K] @ W[N,K]^T), weights read exactly once.
 //
 // Where it runs: the LLM prefill of one stream (22-66 prompt rows, reference model/llm.py:86-113 -> LlamaDecoderLayer) and
 // every decode pass of a 64-stream batch (64 rows, one per stream).  These are still weight-streaming problems (HBM-bound),
@@ -189,6 +189,8 @@ __global__ __launch_bounds__(NP * 256, NP == 2 ? 4 : (NP == 4 ? 4 : 2)) void gem
     }
 }
 
+static int g_mid_min_rows = ISST_MID_MIN_ROWS;  // rows from which (exclusive) the kernel takes over from the skinny one (gemm_mid_set_min_rows)
+void gemm_mid_set_min_rows(int rows) { g_mid_min_rows = rows; }
 static int g_mid_max_rows = 64;  // above 64 rows the kernel runs 64-row m-blocks (grid.z) that re-read the weights through L2
 static int g_mid_wn = 0, g_mid_dbg = 0;  // tuning override (profiles/mid_probe.py): 0 = heuristic; bits 4-5: timing-only builds (A / W descriptor emptied)
 void gemm_mid_set_tuning(int wn) { g_mid_wn = wn & 15; g_mid_dbg = (wn >> 4) & 3; if (wn >> 8) g_mid_max_rows = wn >> 8; }
@@ -198,7 +200,7 @@ bool gemm_mid_supported(const GemmArgs& g) {
     // up to 64 rows always; 65..128 rows as two 64-row blocks for the short weight streams only (q/k/v at 88 rows: 35 us against 56 us
     // on the 128x128 dense kernel, whose 48 column blocks leave most CUs idle; gate/up is faster there: profiles/rows_probe.py)
     const int max_rows = (g.ksplit <= 1 && (long)g.N * g.K <= (32L << 20) && g_mid_max_rows < 128) ? 128 : g_mid_max_rows;
-    return g.batch == 1 && g.M > 16 && g.M <= max_rows && g.K % (MID_CK * ks) == 0 && g.N % 16 == 0 && g.lda % 8 == 0 && !g.norm_w;
+    return g.batch == 1 && g.M > g_mid_min_rows && g.M <= max_rows && g.K % (MID_CK * ks) == 0 && g.N % 16 == 0 && g.lda % 8 == 0 && !g.norm_w;
 }
 // worth it only when the weight stream is long: the encoder's 2-8 MB projections at 48 rows are latency-bound and run
 // faster on the skinny kernel's many 16-column workgroups (11.2 vs 14.9 us for fc2)
@@ -240,6 +242,7 @@ static int launch_mid_wn(const GemmArgs& g, hipStream_t stream) {
 
 template <int EPI>
 static int launch_mid_mt(const GemmArgs& g, hipStream_t stream) {
+    if (g.M <= 16) return launch_mid_wn<1, EPI>(g, stream);
     if (g.M <= 32) return launch_mid_wn<2, EPI>(g, stream);
     if (g.M <= 48) return launch_mid_wn<3, EPI>(g, stream);
     return launch_mid_wn<4, EPI>(g, stream);

@@ -264,10 +264,10 @@ def test_gemm_tiled_swiglu():
     close_bf16(out, torch.nn.functional.silu(gg) * uu, "tiled swiglu", ulps=3, atol=2e-3)
 
 
-@pytest.mark.parametrize("M", [17, 22, 40, 64])
+@pytest.mark.parametrize("M", [13, 16, 17, 22, 40, 64])
 @pytest.mark.parametrize("wn", [2, 4, 8])
 def test_gemm_mid_rows_both_widths(M, wn):
-    """17..64 rows go through gemm_mid.hip (A staged in LDS); both workgroup widths, every epilogue, ragged N; and the
+    """13..64 rows go through gemm_mid.hip (A staged in LDS); all workgroup widths, every epilogue, ragged N; and the
     result must agree with the 1..16-row kernel's arithmetic (same products, different fp32 summation order)."""
     lib = E.load_library()
     g = torch.Generator().manual_seed(M * 10 + wn)
@@ -301,7 +301,7 @@ def test_gemm_mid_rows_both_widths(M, wn):
         lib.isst_op_set_gemm_tuning(0, 0)
 
 
-@pytest.mark.parametrize("M,N,K,ks", [(22, 256, 1024, 2), (64, 512, 2048, 4), (33, 256, 4096, 8), (17, 4096, 1024, 1),
+@pytest.mark.parametrize("M,N,K,ks", [(13, 256, 1024, 2), (16, 512, 2048, 4), (22, 256, 1024, 2), (64, 512, 2048, 4), (33, 256, 4096, 8), (17, 4096, 1024, 1),
                                       (88, 512, 2048, 8), (200, 256, 1024, 4), (130, 1040, 512, 2)])  # > 64 rows: the dense kernel's K slices
 @pytest.mark.parametrize("with_norm", [True, False])
 def test_gemm_splitk_rmsnorm(M, N, K, ks, with_norm):
