@@ -94,9 +94,9 @@ def test_full_size_batched_equals_single(full):
     eng.close_stream(b)
 
 
-@pytest.mark.parametrize("n", [4, 8])
+@pytest.mark.parametrize("n", [4, 8, 14, 16])
 def test_full_size_multi_stream_batch_matches_single_stream(full, n):
-    """(8 streams: prefill 176 rows -- q/k/v as K slices + slab reduce too.)  4 streams in one call take different kernels from one stream (prefill 88 rows: split-K slabs on the dense kernel, q/k/v on
+    """(14 / 16 streams: the decode passes run on gemm_mid + split-K slabs with the reducing RMSNorm instead of the skinny kernel.  8 streams: prefill 176 rows -- q/k/v as K slices + slab reduce too.)  4 streams in one call take different kernels from one stream (prefill 88 rows: split-K slabs on the dense kernel, q/k/v on
     two 64-row blocks; decode 4 rows: fused norm with the LDS overlay).  Same inputs on every stream, teacher-forced with the
     single-stream tokens: the logits of every stream must agree with the single-stream run to bf16 noise (the two paths sum the
     same products in different fp32 orders; at this width that moves logits by ~0.07 on average, see the test above) and must be
