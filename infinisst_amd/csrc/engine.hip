@@ -22,8 +22,15 @@
 
 #define KV_OPS_SLOTS 8  // batches of beam-search KV position copies that may be enqueued between two stream synchronisations
 #define LLM_KSPLIT_MAX 8
-#define LLM_SPLIT_MAX_ROWS 1024  // rows up to which o_proj / down_proj run split-K into slabs (beyond, the dense kernel has the workgroups)
-#define LLM_SLAB_ROWS 2048       // slices x rows the slab buffer holds
+#ifndef LLM_SPLIT_TARGET_WGS
+#define LLM_SPLIT_TARGET_WGS 768
+#endif
+#ifndef LLM_SPLIT_MAX_ROWS
+#define LLM_SPLIT_MAX_ROWS 2048  // rows up to which o_proj / down_proj run split-K into slabs (beyond, the dense kernel has the workgroups)
+#endif
+#ifndef LLM_SLAB_ROWS
+#define LLM_SLAB_ROWS 4096       // slices x rows the slab buffer holds
+#endif
 // rows up to which the decoder fuses RMSNorm into the following projection (the kernel supports GEMM_FUSED_NORM_MAX_M): every
 // workgroup re-normalises all rows while its first weight fragments are in flight.  Measured per launch (profiles/prologue_probe.py):
 // free at 1-2 rows, +0.8 us (gate/up) / +1.8 us (q/k/v) at 4 rows against 4.7 us for the norm launch it replaces, +11 us at 8 rows
@@ -721,6 +728,8 @@ int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int e
 // profiles/r01/mid_probe.txt): 2 slices for K = 4096, 4 for K = 14336, more only add slab traffic.  65..512 rows (gemm_tiled.hip:
 // 32 column blocks x ceil(rows / 128) row blocks walk all of K alone otherwise -- 217 us for down_proj whatever the row count,
 // profiles/rows_probe.py): enough slices for ~384 workgroups.
+// (the dense kernel keeps 3 workgroups per CU resident, 768 chip-wide: slicing up to that count instead of 384 and up to 2048 rows instead of
+//  1024 gave, same box, 64 / 32 / 16 / 8 streams 100.6 -> 99.7 / 71.5 -> 70.0 / 53.8 -> 53.4 / 45.9 -> 45.3 ms per chunk; 1152 was worse again at 16-32)
 int pick_ksplit(int K, int N, int rows) {
     if (rows <= 64) {
         // (N <= 2048 = the encoder's out_proj / fc2, 16..32 column blocks: fc2 20.1 us as GEMM + LayerNorm, 16.6 / 14.7 / 16.5 us with 2 / 4 / 8 slices
@@ -731,7 +740,7 @@ int pick_ksplit(int K, int N, int rows) {
     }
     const int blocks = ((N + 127) / 128) * ((rows + 127) / 128);
     int s = 1;
-    while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= 384 && s * 2 * rows <= LLM_SLAB_ROWS && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
+    while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= LLM_SPLIT_TARGET_WGS && s * 2 * rows <= LLM_SLAB_ROWS && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
     // (the slab buffer holds LLM_SLAB_ROWS rows of the widest projection, so slices x rows <= LLM_SLAB_ROWS fits any N)
     return s;
 }
