@@ -173,6 +173,10 @@ class Engine:
         self.c_cfg = make_c_config(cfg, max_streams, max_multiplier, max_prompt_len, max_new_tokens,
                                    max_llm_cache_size, max_system_prompt, debug_taps, max_beams)
         self.max_new_tokens = max_new_tokens
+        r64 = lambda x: (x + 63) // 64 * 64
+        # rows the library wants from isst_set_rope_tables (engine.hip isst_create: sys_cap + ring_cap, enc_cap)
+        self._llm_rope_rows = r64(max_system_prompt) + r64(max_llm_cache_size + max_prompt_len + max_new_tokens + 8)
+        self._enc_rope_rows = r64(cfg.max_cache_size + cfg.block_size * max_multiplier)
         self.h = C.c_void_p()
         rc = self.lib.isst_create(C.byref(self.c_cfg), C.byref(self.h))
         if rc != 0:
@@ -213,7 +217,7 @@ class Engine:
             if rc == -5 and not strict:
                 continue
             self._check(rc, f"isst_load_weight({name})")
-        rows_e, rows_l = 1024, 1 << 14
+        rows_e, rows_l = max(1024, self._enc_rope_rows), max(1 << 14, self._llm_rope_rows)
         ec, es = rope.encoder_tables(self.cfg, rows_e, enc_inv_freq)
         lc, ls = rope.llm_tables(self.cfg, rows_l)
         self._check(self.lib.isst_set_rope_tables(self.h, C.c_void_p(ec.data_ptr()), C.c_void_p(es.data_ptr()), rows_e,

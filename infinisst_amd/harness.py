@@ -36,7 +36,9 @@ LLAMA31_SYSTEM_HEADER_TOKENS = 25           # reference agents/infinisst.py:264:
 
 
 def _ids(x) -> List[int]:
-    """apply_chat_template may return a tensor / nested list (batch of 1) / flat list."""
+    """apply_chat_template may return a tensor / nested list (batch of 1) / flat list / a BatchEncoding (transformers >= 5)."""
+    if hasattr(x, "keys") and "input_ids" in x:
+        x = x["input_ids"]
     if hasattr(x, "tolist"):
         x = x.tolist()
     if len(x) > 0 and isinstance(x[0], (list, tuple)):
@@ -77,6 +79,24 @@ class ChatPrompt:
             else:
                 ids[0] = int(self.tok.eos_token_id)
         return ids
+
+
+DEFAULT_SPEECH_START_TOKEN = "<sp_start>"   # reference train/dataset.py:54
+DEFAULT_SPEECH_END_TOKEN = "<sp_end>"       # reference train/dataset.py:55
+PAD_TOKEN = "<|finetune_right_pad_id|>"     # reference agents/infinisst.py:140
+
+
+def preprocess_tokenizer(tokenizer, max_multiplier: int = 4) -> dict:
+    """What `SpeechLlamaForCausalLM.preprocess(tokenizer, max_multiplier, resize=False)` does to the tokenizer and reads from it
+    (reference model/llm.py:148-190): add `<sp_patch>`, `<sp_start>`, `<sp_end>`, `<latency_1..max>` as special tokens (and the pad
+    token if it has no id) and look up the ids the speech splice keys on.  Returns the ModelConfig fields they determine."""
+    tokenizer.add_tokens([DEFAULT_SPEECH_PATCH_TOKEN, DEFAULT_SPEECH_START_TOKEN, DEFAULT_SPEECH_END_TOKEN] +
+                         [DEFAULT_LATENCY_TOKEN.format(i) for i in range(1, max_multiplier + 1)], special_tokens=True)
+    if getattr(tokenizer, "pad_token_id", None) is None and getattr(tokenizer, "pad_token", None):
+        tokenizer.add_tokens([tokenizer.pad_token], special_tokens=True)
+    ids = tokenizer.convert_tokens_to_ids
+    return {"sp_patch_id": int(ids(DEFAULT_SPEECH_PATCH_TOKEN)), "user_id": int(ids("user")), "assistant_id": int(ids("assistant")),
+            "start_header_id": int(ids("<|start_header_id|>")), "vocab": len(tokenizer)}
 
 
 def non_language_ids(tokenizer, bad_words: Sequence[str] = ("(", "（")) -> List[int]:
@@ -145,7 +165,8 @@ def split_units(text: str, latency_unit: str) -> List[str]:
 
 
 def laal(delays: Sequence[float], source_length: float, reference_units: int) -> Optional[float]:
-    """Length-adaptive average lagging (Papi et al. 2022; the metric StreamLAAL segments and averages) in ms:
+    """DIAGNOSTIC ONLY -- scoring stays with the reference's own StreamLAAL / SimulEval tooling on `instances.log`; this number is
+    printed next to the log as a sanity check and is not a replacement for it.  Length-adaptive average lagging (Papi et al. 2022; the metric StreamLAAL segments and averages) in ms:
     (1/tau) sum_{i<=tau} d_i - (i-1) * |X| / max(|Y|, |Y*|),  tau = first unit emitted once the whole source was read."""
     n = len(delays)
     if n == 0:

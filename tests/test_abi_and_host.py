@@ -199,3 +199,123 @@ def test_checkpoint_split_matches_reference_key_layout(tmp_path):
     bad["model.norm.weight"] = torch.zeros(3)
     with pytest.raises(ValueError, match="model.norm.weight"):
         checkpoint.split_state_dict(cfg, bad)
+
+
+def test_checkpoint_key_layouts_and_geometry_inference(tmp_path):
+    """The three layouts a checkpoint can arrive in (pruned `pytorch_model.bin`; the flat dict train/prune_bin.py consumes, every key
+    prefixed `model.`; a Lightning file with a `state_dict` wrapper) load to the same tensors, and the model geometry is
+    recovered from the shapes alone (the reference reads it from `--model-name` / `--w2v2-path`, agents/infinisst.py:150-171)."""
+    from infinisst_amd import checkpoint
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.float32, seed=5)
+    pruned, flat, wrapped = tmp_path / "a.bin", tmp_path / "b.bin", tmp_path / "c.bin"
+    torch.save(w, pruned)
+    torch.save({"model." + k: v for k, v in w.items()}, flat)
+    torch.save({"state_dict": {"model." + k: v for k, v in w.items()}, "epoch": 3}, wrapped)
+    ref, _, _ = checkpoint.load_checkpoint(cfg, str(pruned))
+    for path in (flat, wrapped):
+        out, _, skipped = checkpoint.load_checkpoint(cfg, str(path))
+        assert set(out) == set(ref) and not skipped
+        assert all(torch.equal(out[k], ref[k]) for k in ref)
+    got = checkpoint.infer_config(checkpoint.load_state_dict_file(str(flat)), block_size=cfg.block_size, max_cache_size=cfg.max_cache_size)
+    for f in ("conv_layers", "conv_bias", "enc_dim", "enc_layers", "enc_heads", "enc_ffn", "shrink_layers", "llm_dim", "llm_layers",
+              "llm_heads", "llm_kv_heads", "llm_ffn", "vocab"):
+        assert getattr(got, f) == getattr(cfg, f) or list(map(tuple, getattr(got, f))) == list(map(tuple, getattr(cfg, f))), f
+    full = full_config()
+    shapes = {k: torch.empty(s, device="meta") for k, s in synth.weight_shapes(full).items()}
+    inferred = checkpoint.infer_config(shapes)
+    assert synth.weight_shapes(inferred) == synth.weight_shapes(full)
+
+
+def test_effective_new_cache_size_covers_stale_checkpoints():
+    """`cache_checkpoints` survives utterances (reference agents/infinisst.py:106): the size handed to the library must stay inside
+    the evictable range for every integer the checkpoint loop can produce, following Python's slice semantics where those are sane."""
+    from infinisst_amd.agent import effective_new_cache_size as f
+    assert f(500, 1010, 66) == 500                 # ordinary
+    assert f(944, 1010, 66) == 944 and f(945, 1010, 66) == 944 and f(5000, 1010, 66) == 944   # would overlap the pinned prefix
+    assert f(-190, 1010, 66) == 820                # k[:, :, 190:]
+    assert f(-2000, 1010, 66) == 0                 # slice past the end: empty tail
+    assert f(0, 1010, 66) == 0 and f(3, 2, 5) == 0
+
+
+class _RecordingEngine(_FakeEngine):
+    instances = []
+
+    def __init__(self, cfg, **kw):
+        super().__init__(np.random.default_rng(3))
+        self.cfg, self.kw, self.loaded = cfg, kw, None
+        _RecordingEngine.instances.append(self)
+
+    def load_weights(self, weights, enc_inv_freq=None):
+        self.loaded = (dict(weights), enc_inv_freq)
+
+
+def test_agent_constructs_from_args_alone(tmp_path, monkeypatch):
+    """`InfiniSST(args)` -- the only way SimulEval builds an agent -- runs load_model(args): real transformers tokenizer from
+    `--model-name` (+ the speech / latency tokens), `--suppress-non-language` scan, geometry + weights from `--state-dict-path`,
+    engine sized from the flags, chat-template prompts (reference agents/infinisst.py:69-113,130-183).  The engine class is
+    replaced by a recorder here (no GPU); tests/test_gpu_agent_args.py runs the same construction on the real library."""
+    import argparse
+    import infinisst_amd.agent as A
+    from tiny_tokenizer import build_tokenizer_dir
+    cfg = toy_config()
+    model_dir = build_tokenizer_dir(tmp_path, cfg)
+    w = synth.random_weights(cfg, dtype=torch.float32, seed=9)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)) * 1.02
+    state = {"model." + k: v for k, v in w.items()}  # un-pruned flat layout
+    for i in range(cfg.enc_layers):
+        state[f"model.model.speech_encoder.speech_encoder.encoder.layers.{i}.self_attn.rotary_emb.freqs"] = freqs
+    state["model.model.speech_encoder.speech_encoder.encoder.pos_conv.0.bias"] = torch.zeros(cfg.enc_dim)
+    ckpt = tmp_path / "pytorch_model.bin"
+    torch.save(state, ckpt)
+    monkeypatch.setattr(A, "Engine", _RecordingEngine)
+    _RecordingEngine.instances.clear()
+    parser = argparse.ArgumentParser()
+    A.InfiniSST.add_args(parser)
+    args = parser.parse_args(["--model-name", model_dir, "--state-dict-path", str(ckpt), "--w2v2-type", "w2v2", "--w2v2-path", "unused.pt",
+                              "--length-shrink-cfg", "[(128,2,2)] * 2", "--block-size", "48", "--max-cache-size", "576", "--xpos", "0",
+                              "--max-llm-cache-size", "150", "--always-cache-system-prompt", "--max-new-tokens", "10", "--beam", "4",
+                              "--no-repeat-ngram-size", "5", "--latency-multiplier", "1", "--min-start-sec", "0", "--suppress-non-language"])
+    agent = A.InfiniSST(args)
+    eng = _RecordingEngine.instances[-1]
+    assert agent.engine is eng and eng.loaded is not None
+    assert set(eng.loaded[0]) == set(w) and torch.equal(eng.loaded[1], freqs)
+    assert all(t.dtype == torch.bfloat16 for t in eng.loaded[0].values())
+    got = eng.cfg
+    assert (got.llm_dim, got.llm_layers, got.llm_heads, got.llm_kv_heads, got.vocab) == (cfg.llm_dim, cfg.llm_layers, cfg.llm_heads, cfg.llm_kv_heads, cfg.vocab)
+    assert (got.sp_patch_id, got.user_id, got.assistant_id, got.start_header_id) == (cfg.sp_patch_id, cfg.user_id, cfg.assistant_id, cfg.start_header_id)
+    assert got.eos_ids == cfg.eos_ids and got.block_size == 48 and got.max_cache_size == 576 and got.rope_theta == cfg.rope_theta
+    assert eng.kw["max_beams"] == 4 and eng.kw["max_llm_cache_size"] == 150 and eng.kw["max_multiplier"] == 4
+    assert agent.bad_words_ids == [7] and agent.llama31
+    first, later = agent.prompt_fn(True, 1), agent.prompt_fn(False, 1)
+    assert later == synth.chunk_prompt_ids(cfg, 1, first=False)
+    assert eng.kw["max_system_prompt"] == agent.system_prompt_size == len(first) - len(later) + 1
+    assert eng.kw["max_prompt_len"] >= len(agent.prompt_fn(True, 4))
+    # one utterance through policy(): READ/WRITE actions, the pinned prefix, detokenised output through the real tokenizer
+    acts, st = A.feed_segments(agent, synth.synthetic_audio(cfg.chunk_samples * 3), cfg.chunk_samples)
+    assert eng.calls[0]["pin"] == agent.system_prompt_size and eng.calls[0]["prompt_len"] == len(first)
+    assert type(acts[-1]).__name__ == "WriteAction" and acts[-1].finished
+    assert all(isinstance(a.content, str) for a in acts if hasattr(a, "content"))
+    with pytest.raises(NotImplementedError):
+        A.InfiniSST(parser.parse_args(["--model-name", model_dir, "--state-dict-path", str(ckpt), "--xpos", "1", "--block-size", "48"]))
+    with pytest.raises(ValueError, match="length-shrink-cfg"):
+        bad = parser.parse_args(["--model-name", model_dir, "--state-dict-path", str(ckpt), "--xpos", "0", "--block-size", "48",
+                                 "--length-shrink-cfg", "[(128,2,2)] * 3"])
+        A.InfiniSST(bad)
+
+
+def test_policy_closes_the_instance_when_the_last_step_brings_no_audio():
+    """The evaluator's final step may carry no new samples (length an exact multiple of the segment size): a ReadAction then never
+    finishes the instance; the agent answers WriteAction('', finished=True) without calling the library."""
+    cfg = toy_config()
+    eng = _FakeEngine(np.random.default_rng(1))
+    agent = InfiniSST(default_args(), engine=eng, model_cfg=cfg)
+    st = agent.build_states()
+    st.source_sample_rate = 16000
+    st.source.extend([0.01] * cfg.chunk_samples)
+    agent.policy(st)
+    n_calls = len(eng.calls)
+    assert type(agent.policy(st)).__name__ == "ReadAction" and len(eng.calls) == n_calls   # nothing new, source still open
+    st.source_finished = True
+    act = agent.policy(st)
+    assert type(act).__name__ == "WriteAction" and act.content == "" and act.finished and len(eng.calls) == n_calls
