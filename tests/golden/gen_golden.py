@@ -734,6 +734,131 @@ def gen_llama_blocks():
     print("llama_blocks.npz:", len(out), "arrays, transformers", transformers.__version__)
 
 
+# ------------------------------------------------------------------ 10. chunk prompts (_prepare_inputs) ------------
+def gen_prompts():
+    """The reference's own `_prepare_inputs` (agents/infinisst.py:225-268) over two tokenizers whose `apply_chat_template` returns
+    tensors as transformers 4.47 does: the hand-written stub (tests/stub_tokenizer.py) and a real transformers tokenizer with a
+    Llama-3.1-shaped jinja chat template (tests/tiny_tokenizer.py).  Stored: ids of the first and of a later chunk and
+    `system_prompt_size` for multipliers 1..4, llama31 and llama3 branches."""
+    import importlib
+    import tempfile
+    import transformers
+    sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..")))
+    from stub_tokenizer import StubTokenizer
+    from tiny_tokenizer import build_tokenizer_dir
+    from infinisst_amd import harness
+    from infinisst_amd.config import toy_config
+    ag = importlib.import_module("agents.infinisst")
+    cfg = toy_config()
+
+    class TensorTemplate:  # 4.47 semantics: return_tensors='pt' -> a LongTensor (batch, len)
+        def __init__(self, tok):
+            self.tok = tok
+            self.eos_token_id = tok.eos_token_id
+
+        def apply_chat_template(self, batch, **kw):
+            kw.pop("return_tensors", None)
+            r = self.tok.apply_chat_template(batch, **kw)
+            if hasattr(r, "keys"):
+                r = r["input_ids"]
+            return torch.tensor(r, dtype=torch.long)
+
+    hf = transformers.AutoTokenizer.from_pretrained(build_tokenizer_dir(tempfile.mkdtemp(), cfg), padding_side="right", use_fast=False)
+    hf.pad_token = harness.PAD_TOKEN
+    harness.preprocess_tokenizer(hf, 4)
+    out = {}
+    for tname, tok in (("stub", StubTokenizer(cfg)), ("hf", hf)):
+        for llama31 in (1, 0):
+            for m in (1, 2, 3, 4):
+                agent = object.__new__(ag.InfiniSST)
+                agent.args = types.SimpleNamespace(block_size=cfg.block_size)
+                agent.latency_multiplier, agent.source_lang, agent.target_lang = m, "English", "German"
+                agent.tokenizer, agent.llama31 = TensorTemplate(tok), bool(llama31)
+                agent.model = types.SimpleNamespace(device=torch.device("cpu"))
+                first = agent._prepare_inputs(types.SimpleNamespace(speech_cache=None))
+                later = agent._prepare_inputs(types.SimpleNamespace(speech_cache=object()))
+                key = f"{tname}_l31{llama31}_m{m}"
+                out[key + "_first"] = first[0].numpy()
+                out[key + "_later"] = later[0].numpy()
+                out[key + "_sys"] = np.array(agent.system_prompt_size)
+    np.savez_compressed(os.path.join(OUT, "prompts.npz"), **out)
+    print("prompts.npz", len(out))
+
+
+# ------------------------------------------------------------------ 11. secondary pins against transformers classes ----
+def gen_hf_conv_extractor():
+    """Secondary cross-check of the oracle's restated fairseq conv extractor (mode=layer_norm, conv_bias): transformers'
+    Wav2Vec2LayerNormConvLayer stack (the HF port of the same fairseq module, `feat_extract_norm="layer"`), fp32 and bf16."""
+    import transformers
+    from transformers.models.wav2vec2.modeling_wav2vec2 import Wav2Vec2FeatureEncoder
+    from transformers import Wav2Vec2Config
+    from infinisst_amd import synth
+    from infinisst_amd.config import toy_config
+    from oracle.speech_encoder import ENC
+    cfg = toy_config()
+    hc = Wav2Vec2Config(feat_extract_norm="layer", conv_dim=[c for c, _, _ in cfg.conv_layers], conv_kernel=[k for _, k, _ in cfg.conv_layers],
+                        conv_stride=[s for _, _, s in cfg.conv_layers], conv_bias=True, feat_extract_activation="gelu",
+                        num_feat_extract_layers=len(cfg.conv_layers))
+    out = {}
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        w = synth.random_weights(cfg, dtype=dtype, std=0.3, norm_jitter=0.1, seed=77)
+        fe = Wav2Vec2FeatureEncoder(hc).eval()
+        for i, layer in enumerate(fe.conv_layers):
+            p = f"{ENC}feature_extractor.conv_layers.{i}."
+            layer.conv.weight.data = w[p + "0.weight"].float().clone()
+            layer.conv.bias.data = w[p + "0.bias"].float().clone()
+            layer.layer_norm.weight.data = w[p + "2.1.weight"].float().clone()
+            layer.layer_norm.bias.data = w[p + "2.1.bias"].float().clone()
+        fe = fe.to(dtype)
+        audio = torch.from_numpy(synth.synthetic_audio(cfg.first_chunk_offset + cfg.chunk_samples, stream_id=5)).unsqueeze(0).to(dtype)
+        with torch.no_grad():
+            y = fe(audio)  # (1, C, T)
+        out[f"{tag}_audio"] = audio.float().numpy()
+        out[f"{tag}_out"] = y.float().numpy()
+    out["seed"] = np.array(77)
+    np.savez_compressed(os.path.join(OUT, "hf_conv_extractor.npz"), **out)
+    print("hf_conv_extractor.npz", len(out), "transformers", transformers.__version__)
+
+
+def gen_hf_llama_model():
+    """Secondary cross-check of the oracle's restated decoder composition (layer order, residuals, causal mask with and without a
+    non-empty cache, final norm, lm_head): transformers' LlamaForCausalLM (llama3 rotary scaling) on a prefill, a chunked second
+    prefill over the cache and a one-token decode step.  fp32 (composition) and bf16 (rounding points).  HF rotates K before
+    caching and the reference's patch re-rotates an unrotated cache at 0..T-1 -- identical while nothing is evicted, which is the
+    case here."""
+    import transformers
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from infinisst_amd import synth
+    from infinisst_amd.config import toy_config
+    cfg = toy_config()
+    rope = {"rope_type": "llama3", "rope_theta": cfg.rope_theta, "factor": cfg.rope_factor, "low_freq_factor": cfg.rope_low_freq_factor,
+            "high_freq_factor": cfg.rope_high_freq_factor, "original_max_position_embeddings": cfg.rope_original_max_pos}
+    hc = LlamaConfig(hidden_size=cfg.llm_dim, intermediate_size=cfg.llm_ffn, num_hidden_layers=cfg.llm_layers,
+                     num_attention_heads=cfg.llm_heads, num_key_value_heads=cfg.llm_kv_heads, head_dim=cfg.llm_head_dim, vocab_size=cfg.vocab,
+                     rms_norm_eps=cfg.rms_eps, max_position_embeddings=131072, rope_parameters=rope, attention_bias=False,
+                     mlp_bias=False, tie_word_embeddings=False, attn_implementation="eager")
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    ids = [torch.randint(3, 900, (1, n), generator=g) for n in (23, 9, 1)]
+    for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        w = synth.random_weights(cfg, dtype=dtype, std=0.05, norm_jitter=0.05, seed=31)
+        model = LlamaForCausalLM(hc).eval()
+        sd = {k: v.float() for k, v in w.items() if k.startswith("model.layers.") or k in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+        model = model.to(dtype)
+        past = None
+        for step, x in enumerate(ids):
+            with torch.no_grad():
+                r = model(input_ids=x, past_key_values=past, use_cache=True)
+            past = r.past_key_values
+            out[f"{tag}_ids_{step}"] = x[0].numpy()
+            out[f"{tag}_logits_{step}"] = r.logits[0].float().numpy()
+    out["seed"] = np.array(31)
+    np.savez_compressed(os.path.join(OUT, "hf_llama_model.npz"), **out)
+    print("hf_llama_model.npz", len(out), "transformers", transformers.__version__)
+
+
 def main():
     torch.set_num_threads(4)
     import transformers.models.llama.modeling_llama  # noqa: F401  (before the wandb stub: accelerate probes it)
@@ -751,6 +876,9 @@ def main():
     gen_beam_scorer()
     gen_logits_processors()
     gen_llama_blocks()
+    gen_prompts()
+    gen_hf_conv_extractor()
+    gen_hf_llama_model()
 
 
 if __name__ == "__main__":

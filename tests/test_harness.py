@@ -98,3 +98,31 @@ def test_char_units_and_laal_known_answer():
     # a longer hypothesis is not rewarded: gamma uses max(|Y|, |Y*|)
     assert H.laal([1000.0, 2000.0, 3000.0, 4000.0, 4000.0], 4000.0, 4) == pytest.approx((1000 + 1200 + 1400 + 1600) / 4)
     assert H.laal([], 4000.0, 4) is None
+
+
+def test_chat_prompt_matches_reference_prepare_inputs(golden_dir):
+    """§8 row a2 pinned: tests/golden/prompts.npz holds the ids the REFERENCE's own `_prepare_inputs` (agents/infinisst.py:225-268)
+    produced over the stub tokenizer and over a real transformers tokenizer with a Llama-3.1-shaped chat template, first and later
+    chunks, multipliers 1..4, llama31 (`[:, 25:]`) and llama3 (`[:, 0] = eos`) branches.  `harness.ChatPrompt` must reproduce them
+    bit for bit, and `synth.chunk_prompt_ids` (what the engine is benchmarked on) must equal the later-chunk layout."""
+    import os
+    import transformers
+    from tiny_tokenizer import build_tokenizer_dir
+    g = np.load(os.path.join(golden_dir, "prompts.npz"))
+    cfg = toy_config()
+    import tempfile
+    hf = transformers.AutoTokenizer.from_pretrained(build_tokenizer_dir(tempfile.mkdtemp(), cfg), padding_side="right", use_fast=False)
+    hf.pad_token = H.PAD_TOKEN
+    H.preprocess_tokenizer(hf, 4)
+    for tname, tok in (("stub", StubTokenizer(cfg)), ("hf", hf)):
+        for llama31 in (1, 0):
+            for m in (1, 2, 3, 4):
+                key = f"{tname}_l31{llama31}_m{m}"
+                p = H.ChatPrompt(tok, "English", "German", cfg.block_size, llama31=bool(llama31))
+                first, later = p(True, m), p(False, m)
+                assert first == g[key + "_first"].tolist(), key
+                assert later == g[key + "_later"].tolist(), key
+                assert p.system_prompt_size == int(g[key + "_sys"]), key
+                if llama31:
+                    assert later == synth.chunk_prompt_ids(cfg, m, first=False), key
+                    assert len(first) - p.system_prompt_size == len(later) - 1

@@ -221,3 +221,50 @@ def test_llama_blocks_match_transformers(golden_dir, dt_name, dt):
     cos, sin = t("cos"), t("sin")
     assert torch.equal(ollm.apply_rope(t("q"), cos, sin).float(), torch.from_numpy(g[f"{dt_name}_q_rot"]))
     assert torch.equal(ollm.apply_rope(t("k"), cos, sin).float(), torch.from_numpy(g[f"{dt_name}_k_rot"]))
+
+
+@pytest.mark.parametrize("tag,dtype,atol", [("fp32", torch.float32, 2e-5), ("bf16", torch.bfloat16, 0.0)])
+def test_conv_extractor_matches_hf_wav2vec2_feature_encoder(golden_dir, tag, dtype, atol):
+    """SECONDARY pin: the oracle's restated fairseq ConvFeatureExtractionModel(mode=layer_norm, conv_bias) against
+    transformers 5.15's Wav2Vec2FeatureEncoder(feat_extract_norm="layer") -- the HF port of that fairseq module.  fairseq itself is
+    absent, so the extractor stays "parity unpinned" against fairseq 0.12.2; this shows the restated op order (conv -> LN over
+    channels -> GELU) and its bf16 rounding points equal an independent implementation of the same architecture."""
+    g = load(golden_dir, "hf_conv_extractor.npz")
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=dtype, std=0.3, norm_jitter=0.1, seed=int(g["seed"]))
+    audio = torch.from_numpy(g[f"{tag}_audio"]).to(dtype)
+    with torch.no_grad():
+        y = oenc.conv_feature_extractor(w, cfg, audio).float().numpy()
+    ref = g[f"{tag}_out"]
+    assert y.shape == ref.shape
+    d = np.abs(y - ref)
+    if dtype == torch.bfloat16:
+        # HF normalises in bf16 where fairseq's Fp32LayerNorm (restated by the oracle) normalises in fp32 and casts back: values may
+        # differ by one bf16 ulp of an O(1) number where the two roundings fall on different sides
+        assert d.max() <= 0.04 and d.mean() <= 2e-3, (d.max(), d.mean())
+    else:
+        assert d.max() <= atol, d.max()
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("fp32", torch.float32, 3e-5), ("bf16", torch.bfloat16, 0.08)])
+def test_decoder_stack_matches_hf_llama_model(golden_dir, tag, dtype, tol):
+    """SECONDARY pin: the oracle's composition of the decoder (layer order, residual adds, causal masking of a
+    prefill, of a chunked prefill over a non-empty cache and of a decode step, final norm, lm_head over all positions) against
+    transformers 5.15's LlamaForCausalLM with llama3 rotary scaling.  Unrotated-K caching + re-rotation at 0..T-1
+    (patch_llm.py:286-299) equals HF's rotate-then-cache as long as nothing is evicted."""
+    g = load(golden_dir, "hf_llama_model.npz")
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=dtype, std=0.05, norm_jitter=0.05, seed=int(g["seed"]))
+    kv = ollm.new_kv(cfg)
+    rope = ollm.llm_rope_tables(cfg, 256, dtype)
+    for step in range(3):
+        ids = torch.from_numpy(g[f"{tag}_ids_{step}"])
+        with torch.no_grad():
+            logits = ollm.model_forward(w, cfg, ids, kv, rope, all_logits=True).float().numpy()
+        ref = g[f"{tag}_logits_{step}"]
+        assert logits.shape == ref.shape
+        d = np.abs(logits - ref)
+        assert d.max() <= tol, f"{tag} step {step}: max |d| {d.max()}"
+        if dtype == torch.float32:
+            assert np.array_equal(logits.argmax(-1), ref.argmax(-1))
+    assert ollm.kv_len(kv) == 23 + 9 + 1
