@@ -108,6 +108,18 @@ int isst_stream_reset(isst_handle* h, int stream_id);
 int isst_stream_close(isst_handle* h, int stream_id);
 int isst_stream_info_get(isst_handle* h, int stream_id, isst_stream_info* out);
 
+/* State import: resume a stream from saved caches -- the library-side form of handing a `states.speech_cache` /
+ * `states.past_key_values` back to the model (agents/infinisst.py:50-67, :334-336).  Tests and bench.py also use it to put a stream
+ * into its steady state (KV ~ max_llm_cache_size, encoder window saturated, rings about to wrap) without running 40 chunks.
+ * Host pointers, bf16 bits.  One call per layer; every layer must be given the same total / sys_len / ring_start (resp. len / n_steps / ring_start).
+ *   llm:  k, v [kv_heads][total][128], UNROTATED keys in logical order (= past_key_values[layer][0/1][0]); the first sys_len entries go to the
+ *         pinned region; ring_start = physical ring slot logical position sys_len is written to (any value in [0, ring capacity));
+ *   enc:  k, v [heads][len][64] (= speech_cache.layers[layer].k / .v), n_steps = speech_cache.n_steps (frames consumed so far);
+ *   audio history: the last (receptive field - 1 = 399) samples consumed, bf16 (= the tail of speech_cache.src). */
+int isst_stream_import_llm_kv(isst_handle* h, int stream_id, int layer, const uint16_t* k, const uint16_t* v, int total, int sys_len, int ring_start);
+int isst_stream_import_enc_kv(isst_handle* h, int stream_id, int layer, const uint16_t* k, const uint16_t* v, int len, int n_steps, int ring_start);
+int isst_stream_import_audio_history(isst_handle* h, int stream_id, const uint16_t* samples, int n);
+
 /* ---- the hot path: model.generate(...) for n streams (agents/infinisst.py:307-332) ----
  * pcm[i]: n_samples new fp32 samples of stream i as prepared by _prepare_speech (zero-padded to a multiple of
  *   block_size/4*1280 samples; WITHOUT the 399-sample first-chunk offset: the library keeps that history itself);
@@ -144,7 +156,37 @@ int isst_profile_end(isst_handle* h, void* hip_stream, double* avg_us, int64_t* 
  * `beam` of a stream (beam 0 for greedy streams).  Test aid for the KV ring / beam bookkeeping. */
 int isst_debug_read_kv(isst_handle* h, int stream_id, int beam, int layer, int kv_head, int pos, uint16_t* k_out, uint16_t* v_out);
 
+/* Beam-search test aid for ONE-stream calls: between _begin and _end every beam step of isst_generate records, per beam row, the device's
+ * top `n_keep = max(2, 1 + n_eos) * num_beams` processed log-probs (values and token ids, before the beam score is added;
+ * patch_hf.py:833-878) and the beam scores; with n_steps > 0 the search continues along the caller's (token, parent) choices
+ * forced_tokens / forced_parents [n_steps][num_beams] instead of its own (teacher forcing against oracle/beam.py). */
+int isst_debug_beam_trace_begin(isst_handle* h, int num_beams, const int* forced_tokens, const int* forced_parents, int n_steps);
+int isst_debug_beam_trace_step(isst_handle* h, int step, int* rows, int* n_keep, float* top_val, int* top_idx, float* beam_scores, int max_elems);
+int isst_debug_beam_trace_end(isst_handle* h, int* n_steps);
+
 /* ---- per-kernel entry points (parity tests and micro-benchmarks); all pointers are DEVICE pointers ---- */
+/* Host half of the splice (model/llm.py:86-113): the (user, assistant) header pairs of a prompt as a row map with the reference's slice
+ * semantics -- row_src[t] >= 0: prompt token row_src[t]; < 0: speech feature -1 - row_src[t]; *n_rows <= len rows come out (fewer than len
+ * when the encoder produced fewer features than the prompt has patch slots; surplus features are dropped).  Host pointers, row_src holds len ints. */
+int isst_op_splice_map(const int* ids, int len, int user_id, int assistant_id, int start_header_id, int n_features, int* row_src, int* n_rows);
+/* out[r] = speech_row[r] >= 0 ? speech[speech_row[r]] : table[ids[r]]   (rows of D bf16): the splice of model/llm.py:86-113 once the
+ * host has turned the header pairs into a row map (speech_row may be NULL: plain embedding lookup). */
+int isst_op_embed_splice(const int* ids, const int* speech_row, const uint16_t* table, const uint16_t* speech, uint16_t* out, int rows, int D,
+                         void* hip_stream);
+/* uni_mha_forward's attention core (patch_speech_encoder.py:797-915) for one stream and one layer: qkv [Q][3 * heads * 64] (q | k | v rows
+ * after the projections, q NOT yet scaled), K ring [heads][cap][64] / V ring [heads][64][cap] holding min(prefix, max_cache) cached keys from
+ * physical slot ring_start on; appends the Q new keys / values to the rings, returns out [Q][heads * 64].  rope tables fp32 [cap][32]. */
+int isst_op_enc_attention(const uint16_t* qkv, uint16_t* kring, uint16_t* vring, int ring_start, int prefix, const float* rope_cos,
+                          const float* rope_sin, int rope_round_each, uint16_t* out, int Q, int heads, int cap, int max_cache, int blocksize,
+                          void* hip_stream);
+/* llama_sdpa_attention_new_forward's core (patch_llm.py:258-332) for one stream and one layer: qkv [rows][(heads + 2 kv_heads) * 128] of `rows`
+ * consecutive positions pos0 .. pos0+rows-1 over an arena K / rotated-K scratch / V, each [kv_heads][sys_cap + ring_cap][128], that holds pos0
+ * cached entries (unrotated keys; logical p < sys_len in slot p, else sys_cap + (ring_start + p - sys_len) mod ring_cap); appends the rows' own
+ * k / v, returns out [rows][heads * 128].  rot_keys: fill and use the rotated-key scratch (the library's default) or rotate on read.
+ * rope tables bf16 [>= pos0 + rows][64].  Runs the prefill kernel for rows > 16 / (heads / kv_heads), the decode kernel + combine otherwise. */
+int isst_op_llm_attention(const uint16_t* qkv, int rows, int pos0, uint16_t* kpool, uint16_t* krpool, uint16_t* vpool, int heads, int kv_heads,
+                          int sys_cap, int ring_cap, int sys_len, int ring_start, const uint16_t* rope_cos, const uint16_t* rope_sin, int rot_keys,
+                          uint16_t* out, void* hip_stream);
 /* W [n_rows][K] row-major bf16 (conv_k > 0: Conv1d weight [n_rows][K/conv_k][conv_k]) -> packed tiles */
 int isst_op_pack_weight(const uint16_t* w, uint16_t* packed, int n_rows, int K, int conv_k, void* hip_stream);
 int64_t isst_op_packed_elems(int n_rows, int K);

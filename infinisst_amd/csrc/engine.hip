@@ -173,6 +173,13 @@ struct isst_handle {
     float* top_val_host = nullptr;
     int* top_idx_host = nullptr;
 
+    // beam-search test aid (isst_debug_beam_trace_*): per-step candidate lists of a ONE-stream call and optional teacher forcing
+    struct BeamTraceStep { int rows, n_keep; std::vector<float> val; std::vector<int> idx; std::vector<float> score; };
+    bool btrace_on = false;
+    int btrace_beams = 0;
+    std::vector<int> bforce_tok, bforce_par;  // [steps][beams]
+    std::vector<BeamTraceStep> btrace;
+
     std::map<std::string, Tap> taps;
     long arena_off(int sid, int beam) const { return ((long)sid * max_beams + beam) * llm_stream_stride; }
 
@@ -1026,6 +1033,35 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     return ISST_OK;
 }
 
+// The speech splice as a row map.  The reference rebuilds the embedding sequence with torch.cat of three SLICES per (user, assistant) header
+// pair (model/llm.py:86-113):   filled = cat(filled[:u+3], speech[index : index + (a-u-5)], filled[a-2:])
+// Slices clamp, so when the encoder produced FEWER features than the prompt has patch slots -- the padded last segment of an utterance at
+// multiplier m > 1 brings 12..12(m-1) features for 12m slots -- the sequence simply gets shorter: the surplus patch rows never reach the
+// decoder; surplus FEATURES are dropped (:105).  Restated literally on row descriptors: desc[t] >= 0: prompt token desc[t]; < 0: feature -1 - desc[t].
+int splice_rows(const int* ids, int len, int user_id, int assistant_id, int start_header_id, int S, std::vector<int>& desc) {
+    std::vector<int> users, assists;
+    for (int t = 1; t < len; ++t) {
+        if (ids[t - 1] != start_header_id) continue;
+        if (ids[t] == user_id) users.push_back(t);
+        if (ids[t] == assistant_id) assists.push_back(t);
+    }
+    desc.resize(len);
+    for (int t = 0; t < len; ++t) desc[t] = t;
+    int index = 0;
+    for (size_t q = 0; q < users.size() && q < assists.size(); ++q) {
+        const int u = users[q], a = assists[q], cnt = a - u - 5;
+        if (cnt < 0) return ISST_ERR_ARG;
+        const int cur = (int)desc.size();
+        const int head = std::min(u + 3, cur), tail = std::min(std::max(a - 2, 0), cur);
+        std::vector<int> nd(desc.begin(), desc.begin() + head);
+        for (int k = std::min(index, S); k < std::min(index + cnt, S); ++k) nd.push_back(-1 - k);
+        nd.insert(nd.end(), desc.begin() + tail, desc.end());
+        desc.swap(nd);
+        index += cnt;
+    }
+    return ISST_OK;
+}
+
 int check_ready(isst_handle* h) {
     if (!h->finalized) return h->fail(ISST_ERR_STATE, "weights not finalized (isst_finalize_weights)");
     return ISST_OK;
@@ -1121,7 +1157,7 @@ int flush_copies(isst_handle* h, std::vector<KvCopyOp>& ops, const StepMeta& mh,
 
 // decode phase of a beam call; the prefill (on arena 0 of every stream) has already produced h->logits rows 0..n-1
 int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const int* const* prompt_ids, const int* prompt_lens,
-                const int* const* prev_target_ids, const int* n_prev, const std::vector<int>& total0, int* const* out_ids, int* out_lens,
+                const std::vector<int>& rows_len /* KV entries the prompt wrote (<= prompt_lens after a short splice) */, const int* const* prev_target_ids, const int* n_prev, const std::vector<int>& total0, int* const* out_ids, int* out_lens,
                 StepMeta& mh, StepMeta& md, hipStream_t st) {
     const isst_config& c = h->cfg;
     const int B = p->num_beams, V = c.vocab;
@@ -1142,11 +1178,11 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         bs[i].hyps.length_penalty = lp;
         for (int b = B; b < h->nbuf; ++b) bs[i].free_bufs.push_back(b);  // slots 0..B-1 are reorder temporaries
         // the prompt's KV was written to arena 0: replicate it into the other beams' arenas (they are identical before it)
-        push_copy(h, ops, stream_ids[i], 0, 0, total0[i], prompt_lens[i], false);
+        push_copy(h, ops, stream_ids[i], 0, 0, total0[i], rows_len[i], false);
     }
     CHK(flush_copies(h, ops, mh, md, st));
     for (int i = 0; i < n; ++i)
-        for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], prompt_lens[i], true);
+        for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], rows_len[i], true);
     CHK(flush_copies(h, ops, mh, md, st));
 
     int step = 0;  // tokens already chosen per beam
@@ -1180,7 +1216,18 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         for (int i = 0; i < n; ++i) {
             BeamStream& S = bs[i];
             const int prompt_len = prompt_lens[i];
-            const int P0 = total0[i] + prompt_len;  // first position written by the decode phase
+            const int P0 = total0[i] + rows_len[i];  // first position written by the decode phase
+            std::vector<int>& ntok = next_tok[i];
+            std::vector<int>& npar = parents[i];
+            if (S.done) {
+                // a finished batch entry is skipped by the scorer (patch_hf.py:83-92: pad tokens, zero scores, its hypotheses untouched)
+                // while the other streams of the call go on; its rows still ride through the forward pass (their KV beyond the
+                // winner's tail is never read: llm_total is set from the winning hypothesis)
+                const int pad = c.n_eos ? c.eos_ids[0] : 0;
+                for (int b = 0; b < B; ++b) { ntok.push_back(pad); npar.push_back(b); S.seq[b].push_back(pad); }
+                S.score.assign(B, 0.f);
+                continue;
+            }
             struct Cand { float val; long flat; };
             std::vector<Cand> cands;
             for (int b = 0; b < rows_per; ++b)
@@ -1190,12 +1237,22 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                     if (idx < 0 || idx >= V) continue;
                     cands.push_back({h->top_val_host[r * BEAM_TOPK + j] + S.score[b], (long)b * V + idx});
                 }
+            if (h->btrace_on && i == 0) {
+                isst_handle::BeamTraceStep ts;
+                ts.rows = rows_per; ts.n_keep = n_keep;
+                for (int b = 0; b < rows_per; ++b) {
+                    for (int j = 0; j < n_keep; ++j) {
+                        ts.val.push_back(h->top_val_host[b * BEAM_TOPK + j]);
+                        ts.idx.push_back(h->top_idx_host[b * BEAM_TOPK + j]);
+                    }
+                    ts.score.push_back(S.score[b]);
+                }
+                h->btrace.push_back(std::move(ts));
+            }
             std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b2) { return a.val > b2.val || (a.val == b2.val && a.flat < b2.flat); });
             if ((int)cands.size() > n_keep) cands.resize(n_keep);
             const int cur_len = (int)S.seq[0].size() + 1;
             std::vector<float> nscore;
-            std::vector<int>& ntok = next_tok[i];
-            std::vector<int>& npar = parents[i];
             for (size_t rank = 0; rank < cands.size(); ++rank) {
                 const int b = (int)(cands[rank].flat / V), tok = (int)(cands[rank].flat % V);
                 bool is_eos = false;
@@ -1225,6 +1282,17 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
             }
             if ((int)ntok.size() < B) return h->fail(ISST_ERR_STATE, "beam search: fewer than %d non-EOS candidates", B);
             if (!cands.empty()) S.done = S.done || S.hyps.is_done((double)cands[0].val, cur_len, prompt_len);
+            if (h->btrace_on && i == 0 && (size_t)(step + 1) * B <= h->bforce_tok.size()) {
+                // teacher forcing (test aid): continue with the caller's (token, parent) choices; a beam's score is its parent's score plus
+                // the processed log-prob of the forced token, read back from the device's score row
+                for (int b = 0; b < B; ++b) {
+                    const int tok = h->bforce_tok[(size_t)step * B + b], par = h->bforce_par[(size_t)step * B + b];
+                    if (tok < 0 || tok >= V || par < 0 || par >= rows_per) return h->fail(ISST_ERR_ARG, "forced beam choice (%d, %d) out of range at step %d", tok, par, step);
+                    float lp = 0.f;
+                    HIPCHK(hipMemcpy(&lp, h->logits + (size_t)(i * rows_per + par) * h->vocab_pad + tok, sizeof(float), hipMemcpyDeviceToHost));
+                    ntok[b] = tok; npar[b] = par; nscore[b] = S.score[par] + lp;
+                }
+            }
             // input_ids = cat(input_ids[beam_idx], tokens)  (:899)
             std::vector<std::vector<int>> nseq(B);
             for (int b = 0; b < B; ++b) { nseq[b] = S.seq[npar[b]]; nseq[b].push_back(ntok[b]); }
@@ -1238,14 +1306,14 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         //      the stop test, so that finalize sees arena b == beam b ----
         if (step - 1 > 0) {
             for (int i = 0; i < n; ++i) {
-                const int P0 = total0[i] + prompt_lens[i];
+                const int P0 = total0[i] + rows_len[i];
                 std::set<int> needed;
                 for (int b = 0; b < B; ++b) if (parents[i][b] != b) needed.insert(parents[i][b]);
                 for (int src : needed) push_copy(h, ops, stream_ids[i], src, src, P0, step - 1, false);
             }
             CHK(flush_copies(h, ops, mh, md, st));
             for (int i = 0; i < n; ++i) {
-                const int P0 = total0[i] + prompt_lens[i];
+                const int P0 = total0[i] + rows_len[i];
                 for (int b = 0; b < B; ++b) if (parents[i][b] != b) push_copy(h, ops, stream_ids[i], b, parents[i][b], P0, step - 1, true);
             }
             CHK(flush_copies(h, ops, mh, md, st));
@@ -1261,7 +1329,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
             for (int b = 0; b < B; ++b) {
                 const int r = i * B + b;
                 mh.row_stream[r] = shared ? i * B : r;  // view index
-                mh.row_pos[r] = total0[i] + prompt_lens[i] + step - 1;
+                mh.row_pos[r] = total0[i] + rows_len[i] + step - 1;
                 mh.ids[r] = bs[i].seq[b].back();
                 mh.last_rows[r] = r;
                 mh.views[r].sys_len = ss.llm_sys;
@@ -1271,7 +1339,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 mh.views[r].row0 = shared ? i * B : r;
                 mh.views[r].rot_keys = h->rot_keys ? 1 : 0;  // every beam's arena carries its rotated keys (pre-pass over all arenas + position copies)
                 mh.views[r].n_beams = shared ? B : 0;
-                mh.views[r].tail_start = total0[i] + prompt_lens[i];
+                mh.views[r].tail_start = total0[i] + rows_len[i];
                 mh.views[r].beam_stride = h->llm_stream_stride;
                 if (shared) {
                     mh.groups[i].x = i * B;
@@ -1290,7 +1358,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
     for (int i = 0; i < n; ++i) {
         BeamStream& S = bs[i];
         const int prompt_len = prompt_lens[i];
-        const int P0 = total0[i] + prompt_len;
+        const int P0 = total0[i] + rows_len[i];
         if (!S.done)
             for (int b = 0; b < B; ++b) {
                 BeamHyp hyp;
@@ -1402,7 +1470,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
 
     // ---- 2. prefill rows, speech splice map (model/llm.py:86-113) ----
     StepMeta mh = carve(h, h->meta_host), md = carve(h, h->meta_dev);
-    std::vector<int> total0(n), gen_count(n, 0), row0(n);
+    std::vector<int> total0(n), gen_count(n, 0), row0(n), rows_len(n);  // rows_len: decoder rows (= KV entries) of the prompt after the splice
     std::vector<char> done(n, 0);
     int R = 0, n_groups = 0, n_units = 0, max_unit_groups = 0;
     const int gmax = LLM_ATTN_GROUP_ROWS(c.llm_heads / c.llm_kv_heads);
@@ -1421,31 +1489,23 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         row0[i] = R;
         const int len = prompt_lens[i];
         const int* ids = prompt_ids[i];
-        for (int t = 0; t < len; ++t) {
+        std::vector<int> desc;
+        if (splice_rows(ids, len, c.user_id, c.assistant_id, c.start_header_id, S, desc) != ISST_OK)
+            return h->fail(ISST_ERR_ARG, "stream %d: malformed prompt (an assistant header before the end of its user turn)", stream_ids[i]);
+        const int elen = (int)desc.size();
+        if (elen < 1) return h->fail(ISST_ERR_ARG, "stream %d: empty prompt after the speech splice", stream_ids[i]);
+        rows_len[i] = elen;
+        for (int t = 0; t < elen; ++t) {
             mh.row_stream[R + t] = i;
             mh.row_pos[R + t] = total0[i] + t;
-            mh.ids[R + t] = ids[t];
-            mh.speech_row[R + t] = -1;
+            mh.ids[R + t] = desc[t] >= 0 ? ids[desc[t]] : 0;
+            mh.speech_row[R + t] = desc[t] >= 0 ? -1 : i * S + (-1 - desc[t]);
         }
-        // user / assistant header pairs
-        std::vector<int> users, assists;
-        for (int t = 1; t < len; ++t) {
-            if (ids[t - 1] != c.start_header_id) continue;
-            if (ids[t] == c.user_id) users.push_back(t);
-            if (ids[t] == c.assistant_id) assists.push_back(t);
-        }
-        int index = 0;
-        for (size_t q = 0; q < users.size() && q < assists.size(); ++q) {
-            const int u = users[q], a = assists[q], cnt = a - u - 5;
-            if (cnt < 0 || index + cnt > S) return h->fail(ISST_ERR_ARG, "stream %d: prompt has %d speech slots but the encoder produced %d features", stream_ids[i], index + cnt, S);
-            for (int k = 0; k < cnt; ++k) mh.speech_row[R + u + 3 + k] = i * S + index + k;
-            index += cnt;
-        }
-        mh.last_rows[i] = R + len - 1;
+        mh.last_rows[i] = R + elen - 1;
         const int g_first = n_groups;
-        for (int t = 0; t < len; t += gmax) {  // attention row groups: consecutive rows of one stream
+        for (int t = 0; t < elen; t += gmax) {  // attention row groups: consecutive rows of one stream
             mh.groups[n_groups].x = R + t;
-            mh.groups[n_groups].y = std::min(gmax, len - t);
+            mh.groups[n_groups].y = std::min(gmax, elen - t);
             ++n_groups;
         }
         for (int g0 = g_first; g0 < n_groups; g0 += 8) {  // units: runs of <= 8 groups of this stream share their key tiles
@@ -1454,8 +1514,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             max_unit_groups = std::max(max_unit_groups, mh.units[n_units].y);
             ++n_units;
         }
-        R += len;
-        // sampling context
+        R += elen;
+        // sampling context (the processors see the prompt's ids, patch tokens included: input_ids is not shortened)
         std::memcpy(mh.ids_pool + (size_t)i * h->max_ids, ids, (size_t)len * 4);
         const int ne = n_prev ? n_prev[i] : 0;
         if (ne) std::memcpy(mh.enc_pool + (size_t)i * h->max_enc_ids, prev_target_ids[i], (size_t)ne * 4);
@@ -1484,7 +1544,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     }
     CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh, n_units, max_unit_groups));
     if (B > 1)
-        return beam_decode(h, p, n, stream_ids, prompt_ids, prompt_lens, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);
+        return beam_decode(h, p, n, stream_ids, prompt_ids, prompt_lens, rows_len, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);
 
     // ---- 3. greedy loop (patch_hf.py:606-624 -> HF _sample) ----
     std::vector<int> active(n);
@@ -1562,7 +1622,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             const int i = active[r];
             const int tok = out_ids[i][gen_count[i] - 1];
             mh.row_stream[r] = i;
-            mh.row_pos[r] = total0[i] + prompt_lens[i] + gen_count[i] - 1;
+            mh.row_pos[r] = total0[i] + rows_len[i] + gen_count[i] - 1;
             mh.views[i].new_start = mh.row_pos[r];
             mh.views[i].row0 = r;
             mh.groups[r].x = r;
@@ -1579,7 +1639,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     // ---- 4. state: the cache holds the prompt and every generated token except the last one ----
     for (int i = 0; i < n; ++i) {
         StreamState& s = h->streams[stream_ids[i]];
-        s.llm_total = total0[i] + prompt_lens[i] + gen_count[i] - 1;
+        s.llm_total = total0[i] + rows_len[i] + gen_count[i] - 1;
         s.chunks++;
         out_lens[i] = gen_count[i];
     }
@@ -1710,5 +1770,193 @@ extern "C" int isst_debug_tap(isst_handle* h, const char* name, uint16_t* dst, i
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(dst, it->second.dev, (size_t)nel * 2, hipMemcpyDeviceToHost));
     }
+    return ISST_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// stream state import: resume a stream from saved caches (states.speech_cache / states.past_key_values of the reference,
+// agents/infinisst.py:50-67); also how tests and bench.py put a stream into its steady state without running 40 chunks first
+// --------------------------------------------------------------------------------------------
+extern "C" int isst_stream_import_llm_kv(isst_handle* h, int id, int layer, const uint16_t* k, const uint16_t* v, int total, int sys_len, int ring_start) {
+    if (!h) return ISST_ERR_ARG;
+    if (id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", id);
+    const isst_config& c = h->cfg;
+    if (!k || !v || layer < 0 || layer >= c.llm_layers) return h->fail(ISST_ERR_ARG, "isst_stream_import_llm_kv: bad argument");
+    if (total < 0 || sys_len < 0 || sys_len > total || sys_len > h->sys_cap || total - sys_len > h->ring_cap || ring_start < 0 || ring_start >= h->ring_cap)
+        return h->fail(ISST_ERR_ARG, "isst_stream_import_llm_kv: total %d / sys_len %d / ring_start %d do not fit the arena (sys %d, ring %d slots)", total, sys_len,
+                       ring_start, h->sys_cap, h->ring_cap);
+    const int KV = c.llm_kv_heads, slots = h->sys_cap + h->ring_cap;
+    std::vector<bf16_t> ks((size_t)KV * slots * 128, 0), vs((size_t)KV * slots * 128, 0);
+    for (int kvh = 0; kvh < KV; ++kvh)
+        for (int p = 0; p < total; ++p) {
+            const long slot = p < sys_len ? p : (long)h->sys_cap + (ring_start + (p - sys_len)) % h->ring_cap;
+            std::memcpy(&ks[((size_t)kvh * slots + slot) * 128], k + ((size_t)kvh * total + p) * 128, 256);
+            std::memcpy(&vs[((size_t)kvh * slots + slot) * 128], v + ((size_t)kvh * total + p) * 128, 256);
+        }
+    HIPCHK(hipDeviceSynchronize());
+    for (int b = 0; b < h->max_beams; ++b) {  // the arenas of a stream's beams are identical between chunks
+        const long base = h->arena_off(id, b) + (long)layer * h->adims.layer_stride;
+        HIPCHK(hipMemcpy(h->llm_k + base, ks.data(), ks.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->llm_v + base, vs.data(), vs.size() * 2, hipMemcpyHostToDevice));
+    }
+    StreamState& s = h->streams[id];
+    s.llm_total = total; s.llm_sys = sys_len; s.llm_ring_start = ring_start;
+    if (s.chunks == 0) s.chunks = 1;
+    return ISST_OK;
+}
+
+extern "C" int isst_stream_import_enc_kv(isst_handle* h, int id, int layer, const uint16_t* k, const uint16_t* v, int len, int n_steps, int ring_start) {
+    if (!h) return ISST_ERR_ARG;
+    if (id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", id);
+    const isst_config& c = h->cfg;
+    if (!k || !v || layer < 0 || layer >= c.enc_layers) return h->fail(ISST_ERR_ARG, "isst_stream_import_enc_kv: bad argument");
+    const int cap = h->enc_cap, H = c.enc_heads;
+    if (len < 0 || len > cap || n_steps < len || ring_start < 0 || ring_start >= cap)
+        return h->fail(ISST_ERR_ARG, "isst_stream_import_enc_kv: len %d / n_steps %d / ring_start %d do not fit a ring of %d slots", len, n_steps, ring_start, cap);
+    std::vector<bf16_t> ks((size_t)H * cap * 64, 0), vs((size_t)H * 64 * cap, 0);  // K [heads][cap][64], V transposed [heads][64][cap]
+    for (int hd = 0; hd < H; ++hd)
+        for (int j = 0; j < len; ++j) {
+            const int slot = (ring_start + j) % cap;
+            std::memcpy(&ks[((size_t)hd * cap + slot) * 64], k + ((size_t)hd * len + j) * 64, 128);
+            for (int d = 0; d < 64; ++d) vs[((size_t)hd * 64 + d) * cap + slot] = v[((size_t)hd * len + j) * 64 + d];
+        }
+    HIPCHK(hipDeviceSynchronize());
+    const size_t base = (size_t)id * h->enc_stream_stride + (size_t)layer * h->enc_layer_stride;
+    HIPCHK(hipMemcpy(h->enc_k + base, ks.data(), ks.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->enc_v + base, vs.data(), vs.size() * 2, hipMemcpyHostToDevice));
+    StreamState& s = h->streams[id];
+    s.enc_start = ring_start; s.enc_len = len; s.enc_steps = n_steps;
+    if (s.chunks == 0) s.chunks = 1;
+    return ISST_OK;
+}
+
+extern "C" int isst_stream_import_audio_history(isst_handle* h, int id, const uint16_t* samples, int n) {
+    if (!h) return ISST_ERR_ARG;
+    if (id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", id);
+    if (!samples || n != h->hist) return h->fail(ISST_ERR_ARG, "isst_stream_import_audio_history: exactly %d samples (receptive field - 1) are kept", h->hist);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(h->audio_hist + (size_t)id * round_up(h->hist, 8), samples, (size_t)n * 2, hipMemcpyHostToDevice));
+    return ISST_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// beam-search test aid: candidate trace + teacher forcing of a one-stream call
+// --------------------------------------------------------------------------------------------
+extern "C" int isst_debug_beam_trace_begin(isst_handle* h, int num_beams, const int* forced_tokens, const int* forced_parents, int n_steps) {
+    if (!h || num_beams < 1 || n_steps < 0 || (n_steps > 0 && (!forced_tokens || !forced_parents))) return h ? h->fail(ISST_ERR_ARG, "isst_debug_beam_trace_begin: bad argument") : ISST_ERR_ARG;
+    h->btrace_on = true;
+    h->btrace_beams = num_beams;
+    h->btrace.clear();
+    h->bforce_tok.assign(forced_tokens, forced_tokens + (size_t)n_steps * num_beams);
+    h->bforce_par.assign(forced_parents, forced_parents + (size_t)n_steps * num_beams);
+    return ISST_OK;
+}
+extern "C" int isst_debug_beam_trace_step(isst_handle* h, int step, int* rows, int* n_keep, float* top_val, int* top_idx, float* beam_scores, int max_elems) {
+    if (!h || !rows || !n_keep) return ISST_ERR_ARG;
+    if (step < 0 || step >= (int)h->btrace.size()) return h->fail(ISST_ERR_NOTFOUND, "no beam trace for step %d (%d recorded)", step, (int)h->btrace.size());
+    const auto& t = h->btrace[step];
+    *rows = t.rows; *n_keep = t.n_keep;
+    const int ne = t.rows * t.n_keep;
+    if (top_val && top_idx && max_elems >= ne) {
+        std::memcpy(top_val, t.val.data(), sizeof(float) * ne);
+        std::memcpy(top_idx, t.idx.data(), sizeof(int) * ne);
+    }
+    if (beam_scores && max_elems >= t.rows) std::memcpy(beam_scores, t.score.data(), sizeof(float) * t.rows);
+    return ISST_OK;
+}
+extern "C" int isst_debug_beam_trace_end(isst_handle* h, int* n_steps) {
+    if (!h) return ISST_ERR_ARG;
+    if (n_steps) *n_steps = (int)h->btrace.size();
+    h->btrace_on = false;
+    h->bforce_tok.clear();
+    h->bforce_par.clear();
+    return ISST_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// kernel-level entry points of the splice and the two attention kernels (parity tests replay the reference-generated fixtures
+// tests/golden/{splice,encoder,llm_attention}.npz through them); all pointers are DEVICE pointers
+// --------------------------------------------------------------------------------------------
+extern "C" int isst_op_embed_splice(const int* ids, const int* speech_row, const uint16_t* table, const uint16_t* speech, uint16_t* out, int rows, int D,
+                                    void* hip_stream) {
+    if (!ids || !table || !out) return ISST_ERR_ARG;
+    return launch_embed_splice(ids, speech_row, table, speech, out, rows, D, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int isst_op_enc_attention(const uint16_t* qkv, uint16_t* kring, uint16_t* vring, int ring_start, int prefix, const float* rope_cos,
+                                     const float* rope_sin, int rope_round_each, uint16_t* out, int Q, int heads, int cap, int max_cache, int blocksize,
+                                     void* hip_stream) {
+    if (!qkv || !kring || !vring || !rope_cos || !rope_sin || !out || ring_start < 0 || ring_start >= cap || prefix < 0) return ISST_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    EncStreamView hv{ring_start, prefix};
+    EncStreamView* dv = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dv), sizeof hv) != hipSuccess) return ISST_ERR_NOMEM;
+    int rc = ISST_ERR_HIP;
+    if (hipMemcpy(dv, &hv, sizeof hv, hipMemcpyHostToDevice) == hipSuccess)
+        rc = launch_enc_attention(qkv, kring, vring, 0, dv, rope_cos, rope_sin, rope_round_each, out, 1, Q, heads, cap, max_cache, blocksize, st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == ISST_OK) rc = ISST_ERR_HIP;
+    (void)hipFree(dv);
+    return rc;
+}
+
+extern "C" int isst_op_llm_attention(const uint16_t* qkv, int rows, int pos0, uint16_t* kpool, uint16_t* krpool, uint16_t* vpool, int heads, int kv_heads,
+                                     int sys_cap, int ring_cap, int sys_len, int ring_start, const uint16_t* rope_cos, const uint16_t* rope_sin, int rot_keys,
+                                     uint16_t* out, void* hip_stream) {
+    if (!qkv || !kpool || !krpool || !vpool || !rope_cos || !rope_sin || !out || rows < 1 || pos0 < 0 || heads < 1 || kv_heads < 1 || heads % kv_heads)
+        return ISST_ERR_ARG;
+    const int G = heads / kv_heads, slots = sys_cap + ring_cap;
+    if ((G != 1 && G != 2 && G != 4) || slots % 64 || sys_cap % 16 || sys_len < 0 || sys_len > sys_cap || ring_start < 0 || ring_start >= ring_cap ||
+        pos0 + rows - sys_len > ring_cap)
+        return ISST_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    LlmAttnDims d{};
+    d.heads = heads; d.kv_heads = kv_heads; d.sys_cap = sys_cap; d.ring_cap = ring_cap; d.layer_stride = (long)kv_heads * slots * 128;
+    LlmStreamView v{};
+    v.sys_len = sys_len; v.ring_start = ring_start; v.kv_offset = 0; v.new_start = pos0; v.row0 = 0; v.rot_keys = rot_keys ? 1 : 0;
+    const int gmax = LLM_ATTN_GROUP_ROWS(G);
+    std::vector<int> row_stream(rows, 0), row_pos(rows);
+    for (int r = 0; r < rows; ++r) row_pos[r] = pos0 + r;
+    std::vector<int2> groups, units;
+    for (int t = 0; t < rows; t += gmax) groups.push_back(make_int2(t, std::min(gmax, rows - t)));
+    int max_unit_groups = 0;
+    for (int g0 = 0; g0 < (int)groups.size(); g0 += 8) {
+        units.push_back(make_int2(g0, std::min(8, (int)groups.size() - g0)));
+        max_unit_groups = std::max(max_unit_groups, units.back().y);
+    }
+    const size_t off_pos = sizeof(int) * rows, off_view = off_pos + sizeof(int) * rows, off_groups = (off_view + sizeof v + 15) / 16 * 16,
+                 off_units = off_groups + sizeof(int2) * groups.size(), meta_bytes = off_units + sizeof(int2) * units.size();
+    std::vector<unsigned char> hostm(meta_bytes);
+    std::memcpy(hostm.data(), row_stream.data(), sizeof(int) * rows);
+    std::memcpy(hostm.data() + off_pos, row_pos.data(), sizeof(int) * rows);
+    std::memcpy(hostm.data() + off_view, &v, sizeof v);
+    std::memcpy(hostm.data() + off_groups, groups.data(), sizeof(int2) * groups.size());
+    std::memcpy(hostm.data() + off_units, units.data(), sizeof(int2) * units.size());
+    unsigned char* meta = nullptr;
+    float* partial = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&meta), meta_bytes) != hipSuccess) return ISST_ERR_NOMEM;
+    if (hipMalloc(reinterpret_cast<void**>(&partial), sizeof(float) * (size_t)rows * heads * (slots / 64) * 130) != hipSuccess) { (void)hipFree(meta); return ISST_ERR_NOMEM; }
+    int rc = hipMemcpy(meta, hostm.data(), meta_bytes, hipMemcpyHostToDevice) == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+    const LlmStreamView* dv = reinterpret_cast<const LlmStreamView*>(meta + off_view);
+    if (rc == ISST_OK && rot_keys && pos0 > 0) rc = launch_llm_rope_cache(dv, 1, rope_cos, rope_sin, kpool, krpool, d, 1, st);
+    if (rc == ISST_OK) {
+        LlmAttnOne one{};
+        if (groups.size() == 1) { one.enabled = 1; one.grp = groups[0]; one.pos0 = pos0; one.v = v; }
+        rc = launch_llm_attention(qkv, reinterpret_cast<const int*>(meta), reinterpret_cast<const int*>(meta + off_pos), dv,
+                                  reinterpret_cast<const int2*>(meta + off_groups), (int)groups.size(), gmax, rope_cos, rope_sin, kpool, krpool, vpool, partial, out, d,
+                                  0, rows, st, &one, reinterpret_cast<const int2*>(meta + off_units), (int)units.size(), max_unit_groups, 0);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == ISST_OK) rc = ISST_ERR_HIP;
+    (void)hipFree(meta);
+    (void)hipFree(partial);
+    return rc;
+}
+
+extern "C" int isst_op_splice_map(const int* ids, int len, int user_id, int assistant_id, int start_header_id, int n_features, int* row_src, int* n_rows) {
+    if (!ids || len < 1 || !row_src || !n_rows || n_features < 0) return ISST_ERR_ARG;
+    std::vector<int> desc;
+    const int rc = splice_rows(ids, len, user_id, assistant_id, start_header_id, n_features, desc);
+    if (rc != ISST_OK) return rc;
+    *n_rows = (int)desc.size();  // <= len
+    std::memcpy(row_src, desc.data(), sizeof(int) * desc.size());
     return ISST_OK;
 }

@@ -64,6 +64,9 @@ class _StreamInfo(C.Structure):
 EXPORTS = [
     "isst_create", "isst_destroy", "isst_last_error", "isst_load_weight", "isst_set_rope_tables",
     "isst_finalize_weights", "isst_stream_open", "isst_stream_reset", "isst_stream_close", "isst_stream_info_get",
+    "isst_stream_import_llm_kv", "isst_stream_import_enc_kv", "isst_stream_import_audio_history",
+    "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
+    "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_end", "isst_op_pack_weight",
     "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
 ]
@@ -92,6 +95,18 @@ def load_library(path: Optional[str] = None):
     lib.isst_stream_close.argtypes = [C.c_void_p, C.c_int]
     lib.isst_stream_info_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(_StreamInfo)]
     lib.isst_kv_evict.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.isst_stream_import_llm_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.isst_stream_import_enc_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.isst_stream_import_audio_history.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.isst_debug_beam_trace_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.isst_debug_beam_trace_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.isst_debug_beam_trace_end.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.isst_op_splice_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    lib.isst_op_embed_splice.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.isst_op_enc_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.isst_op_llm_attention.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.isst_generate.argtypes = [C.c_void_p, C.POINTER(_GenParams), C.c_int, C.POINTER(C.c_int),
                                   C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
@@ -245,6 +260,59 @@ class Engine:
 
     def kv_evict(self, sid: int, new_cache_size: int, keep_prefix: int):
         self._check(self.lib.isst_kv_evict(self.h, sid, new_cache_size, keep_prefix), "isst_kv_evict")
+
+    # ---------------------------------------------------------------- state import (resume / steady-state set-up)
+    def import_llm_kv(self, sid: int, kv, sys_len: int, ring_start: int = 0):
+        """`kv`: past_key_values as a list over layers of (K, V), each (1, kv_heads, T, 128) bf16 with UNROTATED keys
+        (the reference's patched cache, model/patches/patch_llm.py:280-284); the first `sys_len` entries become the pinned prefix."""
+        if len(kv) != self.cfg.llm_layers:
+            raise IsstError(f"{len(kv)} layers given, the model has {self.cfg.llm_layers}")
+        for layer, (k, v) in enumerate(kv):
+            k = k.detach().to("cpu", torch.bfloat16).reshape(self.cfg.llm_kv_heads, -1, 128).contiguous()
+            v = v.detach().to("cpu", torch.bfloat16).reshape(self.cfg.llm_kv_heads, -1, 128).contiguous()
+            self._check(self.lib.isst_stream_import_llm_kv(self.h, sid, layer, C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), k.shape[1],
+                                                           sys_len, ring_start), "isst_stream_import_llm_kv")
+
+    def import_speech_cache(self, sid: int, layers, n_steps: int, audio_tail=None, ring_start: int = 0):
+        """`layers`: per encoder layer (K, V), each (heads, T, 64) bf16 with unrotated keys (= speech_cache.layers[i].k / .v, reference
+        model/speech_encoder.py:80-97); `n_steps` = speech_cache.n_steps; `audio_tail`: the last 399 samples of speech_cache.src."""
+        if len(layers) != self.cfg.enc_layers:
+            raise IsstError(f"{len(layers)} layers given, the encoder has {self.cfg.enc_layers}")
+        for layer, (k, v) in enumerate(layers):
+            k = k.detach().to("cpu", torch.bfloat16).reshape(self.cfg.enc_heads, -1, 64).contiguous()
+            v = v.detach().to("cpu", torch.bfloat16).reshape(self.cfg.enc_heads, -1, 64).contiguous()
+            self._check(self.lib.isst_stream_import_enc_kv(self.h, sid, layer, C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), k.shape[1],
+                                                           n_steps, ring_start), "isst_stream_import_enc_kv")
+        if audio_tail is not None:
+            a = torch.as_tensor(audio_tail).detach().to("cpu", torch.bfloat16).reshape(-1).contiguous()
+            self._check(self.lib.isst_stream_import_audio_history(self.h, sid, C.c_void_p(a.data_ptr()), a.numel()), "isst_stream_import_audio_history")
+
+    # ---------------------------------------------------------------- beam-search test aid
+    def beam_trace_begin(self, num_beams: int, forced_tokens=None, forced_parents=None):
+        ft = np.ascontiguousarray(np.asarray(forced_tokens if forced_tokens is not None else [], dtype=np.int32).reshape(-1))
+        fp = np.ascontiguousarray(np.asarray(forced_parents if forced_parents is not None else [], dtype=np.int32).reshape(-1))
+        steps = ft.size // num_beams
+        self._check(self.lib.isst_debug_beam_trace_begin(self.h, num_beams, ft.ctypes.data if steps else None, fp.ctypes.data if steps else None, steps),
+                    "isst_debug_beam_trace_begin")
+
+    def beam_trace_end(self):
+        """-> list over steps of (top_val [rows][n_keep], top_idx [rows][n_keep], beam_scores [rows])."""
+        n = C.c_int(0)
+        out = []
+        step = 0
+        while True:
+            rows, keep = C.c_int(0), C.c_int(0)
+            if self.lib.isst_debug_beam_trace_step(self.h, step, C.byref(rows), C.byref(keep), None, None, None, 0) != 0:
+                break
+            val = np.zeros((rows.value, keep.value), dtype=np.float32)
+            idx = np.zeros((rows.value, keep.value), dtype=np.int32)
+            sc = np.zeros(rows.value, dtype=np.float32)
+            self._check(self.lib.isst_debug_beam_trace_step(self.h, step, C.byref(rows), C.byref(keep), val.ctypes.data, idx.ctypes.data,
+                                                            sc.ctypes.data, val.size), "isst_debug_beam_trace_step")
+            out.append((val, idx, sc))
+            step += 1
+        self._check(self.lib.isst_debug_beam_trace_end(self.h, C.byref(n)), "isst_debug_beam_trace_end")
+        return out
 
     # ---------------------------------------------------------------- hot path
     def generate(self, gen: GenConfig, stream_ids: Sequence[int], pcm: Sequence[np.ndarray],
@@ -427,3 +495,54 @@ def op_sample(logits: torch.Tensor, ids, enc_ids, suppress, penalty, ngram, enc_
     if rc:
         raise IsstError(f"isst_op_sample -> {rc}")
     return int(out.item())
+
+
+def op_splice_map(ids: Sequence[int], user_id: int, assistant_id: int, start_header_id: int, n_features: int) -> list:
+    """Row map of the speech splice (host logic of the library): entry >= 0 = prompt token index, < 0 = speech feature -1 - entry."""
+    lib = load_library()
+    a = np.ascontiguousarray(np.asarray(ids, dtype=np.int32))
+    out = np.zeros(a.size, dtype=np.int32)
+    n = C.c_int(0)
+    rc = lib.isst_op_splice_map(a.ctypes.data, a.size, user_id, assistant_id, start_header_id, n_features, out.ctypes.data, C.byref(n))
+    if rc:
+        raise IsstError(f"isst_op_splice_map -> {rc}")
+    return out[: n.value].tolist()
+
+
+def op_embed_splice(ids: torch.Tensor, speech_row: Optional[torch.Tensor], table: torch.Tensor, speech: Optional[torch.Tensor]) -> torch.Tensor:
+    """out[r] = speech[speech_row[r]] if speech_row[r] >= 0 else table[ids[r]] (int32 device tensors, bf16 tables)."""
+    lib = load_library()
+    rows, D = ids.numel(), table.shape[1]
+    out = torch.empty((rows, D), dtype=torch.bfloat16, device=table.device)
+    rc = lib.isst_op_embed_splice(_ptr(ids), _ptr(speech_row), _ptr(table), _ptr(speech), _ptr(out), rows, D, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_embed_splice -> {rc}")
+    return out
+
+
+def op_enc_attention(qkv: torch.Tensor, kring: torch.Tensor, vring: torch.Tensor, ring_start: int, prefix: int, rope_cos: torch.Tensor,
+                     rope_sin: torch.Tensor, round_each: bool, heads: int, max_cache: int, blocksize: int) -> torch.Tensor:
+    """qkv (Q, 3*heads*64) bf16; kring (heads, cap, 64), vring (heads, 64, cap) are updated in place; -> (Q, heads*64)."""
+    lib = load_library()
+    Q, cap = qkv.shape[0], kring.shape[1]
+    out = torch.empty((Q, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    rc = lib.isst_op_enc_attention(_ptr(qkv), _ptr(kring), _ptr(vring), ring_start, prefix, _ptr(rope_cos), _ptr(rope_sin), int(round_each), _ptr(out),
+                                   Q, heads, cap, max_cache, blocksize, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_enc_attention -> {rc}")
+    return out
+
+
+def op_llm_attention(qkv: torch.Tensor, pos0: int, kpool: torch.Tensor, krpool: torch.Tensor, vpool: torch.Tensor, heads: int, kv_heads: int,
+                     sys_cap: int, ring_cap: int, sys_len: int, ring_start: int, rope_cos: torch.Tensor, rope_sin: torch.Tensor,
+                     rot_keys: bool = True) -> torch.Tensor:
+    """qkv (rows, (heads + 2 kv_heads) * 128) bf16 at positions pos0..; pools (kv_heads, sys_cap + ring_cap, 128) updated in place;
+    rope tables bf16 (>= pos0 + rows, 64); -> (rows, heads * 128)."""
+    lib = load_library()
+    rows = qkv.shape[0]
+    out = torch.empty((rows, heads * 128), dtype=torch.bfloat16, device=qkv.device)
+    rc = lib.isst_op_llm_attention(_ptr(qkv), rows, pos0, _ptr(kpool), _ptr(krpool), _ptr(vpool), heads, kv_heads, sys_cap, ring_cap, sys_len, ring_start,
+                                   _ptr(rope_cos), _ptr(rope_sin), int(rot_keys), _ptr(out), _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_llm_attention -> {rc}")
+    return out

@@ -319,3 +319,25 @@ def test_policy_closes_the_instance_when_the_last_step_brings_no_audio():
     st.source_finished = True
     act = agent.policy(st)
     assert type(act).__name__ == "WriteAction" and act.content == "" and act.finished and len(eng.calls) == n_calls
+
+
+def test_splice_row_map_matches_reference_fixture(golden_dir):
+    """The library's host half of the speech splice (engine.hip splice_rows, exported as isst_op_splice_map) against
+    tests/golden/splice.npz = the reference's SpeechLlamaModel.forward (model/llm.py:86-113): system + user turn, later-chunk layout,
+    surplus features; plus the shortfall case (fewer features than patch slots: the reference's slices shorten the sequence), checked
+    against the oracle's literal torch.cat restatement."""
+    g = np.load(os.path.join(golden_dir, "splice.npz"))
+    user, assist, sh, _ = (int(x) for x in g["ids_cfg"])
+    for case in range(3):
+        ids, feats, table = g[f"ids_{case}"], torch.from_numpy(g[f"feats_{case}"]), torch.from_numpy(g[f"table_{case}"])
+        m = E.op_splice_map(ids, user, assist, sh, feats.shape[0])
+        out = torch.stack([table[ids[t]] if t >= 0 else feats[-1 - t] for t in m])
+        assert torch.equal(out, torch.from_numpy(g[f"embeds_{case}"])), case
+    cfg = toy_config().replace(user_id=user, assistant_id=assist, start_header_id=sh)
+    ids, table = g["ids_1"], torch.from_numpy(g["table_1"])  # 24 patch slots
+    for n_feat in (0, 5, 12, 23, 24, 30):
+        feats = torch.from_numpy(g["feats_1"])[:n_feat] if n_feat <= 24 else torch.cat([torch.from_numpy(g["feats_1"])] * 2)[:n_feat]
+        m = E.op_splice_map(ids, user, assist, sh, n_feat)
+        ref = ollm.splice_speech(cfg, torch.from_numpy(ids), table[ids], feats)
+        assert len(m) == ref.shape[0] == len(ids) - max(0, 24 - n_feat)
+        assert torch.equal(torch.stack([table[ids[t]] if t >= 0 else feats[-1 - t] for t in m]), ref), n_feat
