@@ -1,35 +1,93 @@
 #!/usr/bin/env python3
 """Benchmark of the InfiniSST hot path on MI355X: xRT (audio-seconds per wall-second), whole job.
 
-    python bench.py --gpus 1 --steps 64 --warmup 40
+    python bench.py                                   # 1 GPU
+    python bench.py --gpus N --steps K --warmup W     # N GPUs: starts the N ranks itself (torch.distributed.run as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # ... or is started as the ranks (the driver's form)
 
 A "step" is one 960 ms chunk of every stream of this rank through the whole per-chunk path (the body of the
 reference's policy(), agents/infinisst.py:287-361): H2D of the chunk, conv extractor, streaming encoder, shrink +
 projector, Llama-3.1-8B prefill of the 22-token chunk prompt and greedy decode, then the chunk-wise KV eviction.
 Workload = BASELINE.json configs[1]: InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 1 stream
 per GPU, synthetic 16 kHz audio, random-init weights; EOS is disabled so that every chunk
-runs the worst case max_new_tokens = 10 forward passes (1 prefill + 9 decode steps).  The warm-up fills the LLM KV
-cache to its steady state (max_llm_cache_size = 1000 + pinned system prompt, eviction active) and saturates the
-encoder window (576 frames).  N ranks = N independent replicas (stream-parallel, no collective); the barrier and the
-max-over-ranks reduction are the only cross-rank traffic.
+runs the worst case max_new_tokens = 10 forward passes (1 prefill + 9 decode steps).
+
+Steady state by construction, whatever --warmup is: before the first step every stream's state is IMPORTED
+(isst_stream_import_*): LLM KV = pinned system prompt + 31 chunks' worth of entries with the matching checkpoint list, so
+every step runs over >= 1000 cached entries and ends with a whole-chunk eviction; encoder rings hold the full 576-frame
+window (K = 624 per step); both rings start close to their physical end so they wrap inside the timed region.
+
+N ranks = N independent replicas (stream-parallel, no collective: SURVEY 8(e)); global stream ids are dealt to the ranks
+by streams.assign_streams; the barrier and the max/sum reductions of the timing are the only cross-rank traffic.
 
 Rank 0 prints ONE JSON line.  Extra objects: `roofline` for the dominant kernel (the packed-weight skinny GEMM
-streaming Llama weights, HBM-bound) measured live with HIP events on the launch stream, and `cpu_baseline` (the
-CPU oracle timed on this box's host cores on one steady-state chunk, N=1 only).
+streaming Llama weights, HBM-bound) measured live with HIP events on the launch stream; `cpu_baseline` (the CPU oracle
+timed on this box's host cores over 4 steady-state chunks, N=1 only); `streams64` (N=1 only): the same loop re-run in this
+process with 64 concurrent streams on the GPU = BASELINE.json configs[2].
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (configs[1] = 1)")
+    ap.add_argument("--gen-tokens", type=int, default=10, help="max_new_tokens per chunk (production: 10 x multiplier)")
+    ap.add_argument("--beam", type=int, default=1, help="num_beams (1 = greedy, the north-star mode; 4 = the reference's production setting)")
+    ap.add_argument("--toy", action="store_true", help="toy dimensions (plumbing check, not a valid benchmark)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-streams64", action="store_true", help="skip the 64-streams-per-GPU leg (configs[2]) that follows the timed region at N=1")
+    ap.add_argument("--streams64-steps", type=int, default=16)
+    ap.add_argument("--cold-start", action="store_true", help="do NOT import the steady state: streams start empty (first-chunk behaviour; then use --warmup >= 40)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
+    ap.add_argument("--cpu-chunks", type=int, default=4, help="steady-state chunks the CPU baseline runs")
+    ap.add_argument("--attn-target-wgs", type=int, default=0, help="profiling aid: isst_op_set_attn_tuning (0 = library default)")
+    ap.add_argument("--cpu-layers", type=int, default=32, help="Llama layers actually run by the CPU baseline (time is scaled to all layers)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0 = pick a free one)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="LAUNCHER SELF-TEST, no compute and no GPU: every rank sleeps instead of stepping the engine and the ranks meet over gloo; "
+                         "the JSON line is marked dry_run and is not a measurement (tests/test_streams_gloo.py)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: this process -- which never touches HIP -- starts
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>` as a CHILD process (never exec: a process image
+    swap after GPU initialisation takes the node down on this pool, and a child keeps the rule trivially true), lets the ranks
+    write to the inherited stdout/stderr (rank 0 prints the JSON line) and returns the launcher's exit code."""
+    import socket
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse()
+    if _a.gpus > 1:  # before torch is imported: the parent only waits for its children
+        sys.exit(spawn_ranks(_a))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -50,51 +108,64 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (configs[1] = 1)")
-    ap.add_argument("--gen-tokens", type=int, default=10, help="max_new_tokens per chunk (production: 10 x multiplier)")
-    ap.add_argument("--beam", type=int, default=1, help="num_beams (1 = greedy, the north-star mode; 4 = the reference's production setting)")
-    ap.add_argument("--toy", action="store_true", help="toy dimensions (plumbing check, not a valid benchmark)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
-    ap.add_argument("--attn-target-wgs", type=int, default=0, help="profiling aid: isst_op_set_attn_tuning (0 = library default)")
-    ap.add_argument("--cpu-layers", type=int, default=32, help="Llama layers actually run by the CPU baseline (time is scaled to all layers)")
-    return ap.parse_args()
-
-
-def build_engine(cfg, n_streams, gen_tokens, device, beams=1):
+def build_engine(cfg, n_streams, gen_tokens, device, beams=1, weights=None):
     from infinisst_amd.engine import Engine
     sys_n = len(synth.system_prompt_ids(cfg))
     eng = Engine(cfg, max_streams=n_streams, max_multiplier=1, max_prompt_len=sys_n + 32, max_new_tokens=max(gen_tokens, 10),
                  max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=beams)
-    log("engine created")
-    w = synth.random_weights_device(cfg, device)
-    torch.cuda.synchronize()
-    log("random weights drawn on device")
-    eng.load_weights(w)
+    log(f"engine created ({n_streams} stream slots)")
+    if weights is None:
+        weights = synth.random_weights_device(cfg, device)
+        torch.cuda.synchronize()
+        log("random weights drawn on device")
+    eng.load_weights(weights)
     log("weights packed into the library")
-    return eng, w, sys_n
+    return eng, weights, sys_n
+
+
+STEADY_CHUNKS = 31  # chunks' worth of LLM KV behind the system prompt in the imported steady state: 31 x (22 + 9) = 961 entries
 
 
 class ChunkLoop:
     """The per-chunk control logic of policy() for the streams of one rank (generate + whole-chunk eviction)."""
 
-    def __init__(self, eng, cfg, gen, n_streams, sys_n, rank):
+    def __init__(self, eng, cfg, gen, stream_ids, sys_n):
+        """`stream_ids`: GLOBAL stream ids of this rank (streams.assign_streams); they seed the audio."""
         self.eng, self.cfg, self.gen, self.sys_n = eng, cfg, gen, sys_n
-        self.sids = [eng.open_stream() for _ in range(n_streams)]
+        self.sids = [eng.open_stream() for _ in stream_ids]
         n_chunks = 64
-        self.audio = [synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=rank * 1000 + i) for i in range(n_streams)]
+        self.audio = [synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=g) for g in stream_ids]
         self.n_chunks = n_chunks
-        self.ckpts = [[] for _ in range(n_streams)]
-        self.targets = [[] for _ in range(n_streams)]
+        self.ckpts = [[] for _ in stream_ids]
+        self.targets = [[] for _ in stream_ids]
         self.first = True
         self.c = 0
         self.evictions = 0
+
+    def import_steady_state(self, device):
+        """Every stream starts where a long-running stream is ("warm up >= 40 chunks (or pre-fill)"): LLM KV = system prompt +
+        STEADY_CHUNKS chunks of (22 prompt + 9 fed) entries with the checkpoint list the agent would hold, encoder rings = the full
+        window, audio history = real samples; ring starts near the physical end of both rings so that they wrap within a few steps.
+        The contents are random bf16 of the scale the model produces (they do not influence the timing)."""
+        cfg, eng = self.cfg, self.eng
+        per_chunk = len(synth.chunk_prompt_ids(cfg, 1, first=False)) + self.gen.max_new_tokens - 1
+        total = self.sys_n + STEADY_CHUNKS * per_chunk
+        g = torch.Generator(device=device)
+        g.manual_seed(7)
+        kv = [[torch.randn((cfg.llm_kv_heads, total, cfg.llm_head_dim), device=device, generator=g).bfloat16().cpu() for _ in range(2)]
+              for _ in range(cfg.llm_layers)]
+        enc = [[(0.6 * torch.randn((cfg.enc_heads, cfg.max_cache_size, cfg.enc_head_dim), device=device, generator=g)).bfloat16().cpu() for _ in range(2)]
+               for _ in range(cfg.enc_layers)]
+        ring_cap = 64 * ((1000 + (self.sys_n + 32) + max(self.gen.max_new_tokens, 10) + 8 + 63) // 64)  # engine.hip isst_create
+        enc_cap = 64 * ((cfg.max_cache_size + cfg.block_size + 63) // 64)
+        for i, sid in enumerate(self.sids):
+            eng.import_llm_kv(sid, kv, sys_len=self.sys_n, ring_start=(ring_cap - 200 + 13 * i) % ring_cap)
+            tail = torch.from_numpy(self.audio[i][-cfg.first_chunk_offset:].copy())
+            eng.import_speech_cache(sid, enc, n_steps=cfg.block_size * 40, audio_tail=tail, ring_start=(enc_cap - 100 + 7 * i) % enc_cap)
+            first_ck = self.sys_n + per_chunk  # cache length after the first chunk (system prompt + its turn), then one more turn each
+            self.ckpts[i] = [first_ck + k * per_chunk for k in range(STEADY_CHUNKS)]
+            assert self.ckpts[i][-1] == total
+        self.first = False
 
     def step(self):
         cfg, gen = self.cfg, self.gen
@@ -122,6 +193,51 @@ class ChunkLoop:
                 self.evictions += 1
         self.first = False
         self.c += 1
+
+
+def chunk_algorithmic_bytes(cfg, n_streams, passes, kv_len):
+    """HBM bytes one chunk of `n_streams` batched streams has to move -- every pass streams the Llama weights once (shared by
+    the batch) and every stream's KV; the speech encoder's weights once plus its KV window per stream."""
+    llm_w = 2 * (cfg.llm_layers * (cfg.llm_dim * (cfg.llm_heads + 2 * cfg.llm_kv_heads) * cfg.llm_head_dim + cfg.llm_heads * cfg.llm_head_dim * cfg.llm_dim +
+                                   3 * cfg.llm_dim * cfg.llm_ffn) + cfg.vocab * cfg.llm_dim)
+    kv_per_entry = 2 * cfg.llm_kv_heads * cfg.llm_head_dim * 2 * cfg.llm_layers
+    enc_w = 2 * (cfg.enc_layers * (4 * cfg.enc_dim * cfg.enc_dim + 2 * cfg.enc_dim * cfg.enc_ffn) + cfg.enc_dim * cfg.conv_dim)
+    enc_kv = cfg.enc_layers * 2 * (cfg.max_cache_size + cfg.block_size) * cfg.enc_dim * 2
+    return passes * (llm_w + n_streams * kv_per_entry * kv_len) + enc_w + n_streams * enc_kv
+
+
+def run_streams64(cfg, gen, weights, device, args):
+    """BASELINE.json configs[2] in the same process: 64 concurrent streams on this GPU (shared weights, per-stream KV), steady state
+    imported, a few warm-up steps, `--streams64-steps` timed.  Reported next to the one-stream line."""
+    n = 64
+    eng, _, sys_n = build_engine(cfg, n, args.gen_tokens, device, 1, weights)
+    loop = ChunkLoop(eng, cfg, gen, list(range(n)), sys_n)
+    loop.import_steady_state(device)
+    for _ in range(3):
+        loop.step()
+    torch.cuda.synchronize()
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(args.streams64_steps):
+        s0 = time.perf_counter()
+        loop.step()
+        lat.append(time.perf_counter() - s0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    info = eng.stream_info(loop.sids[0])
+    ms = 1e3 * dt / args.streams64_steps
+    algo = chunk_algorithmic_bytes(cfg, n, args.gen_tokens, info["llm_cache_len"])
+    achieved = algo / (ms * 1e-3) / 1e9
+    out = {"workload": "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 64 streams on 1 MI355X (BASELINE.json configs[2])",
+           "streams": n, "steps": args.streams64_steps, "ms_per_step": round(ms, 3), "xrt": round(0.96 * n * args.streams64_steps / dt, 2),
+           "p50_chunk_latency_ms": round(1e3 * float(np.percentile(lat, 50)), 3), "p95_chunk_latency_ms": round(1e3 * float(np.percentile(lat, 95)), 3),
+           "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "evictions_per_stream": loop.evictions // n,
+           "roofline": {"kernel": "whole chunk (all kernels of one 64-stream step)", "bound": "hbm", "algorithmic_bytes_per_step": algo,
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "note": "the 1408-row prefill GEMMs and the encoder are MFMA-bound, so the HBM fraction of the whole step understates them; "
+                                "per-kernel figures: profiles/"}}
+    eng.close()
+    return out
 
 
 def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
@@ -167,24 +283,27 @@ def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
         in_situ, launches = eng.profile_end()
     algo_bytes = w_bytes + K * 2 + (N // 2) * 2  # weights once + activation row in + bf16 row out
     achieved = algo_bytes / (ms * 1e-3) / 1e9
-    traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 --pmc)
+    traffic, traffic_source = None, None  # HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 --pmc)
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath) and N == 28672 and K == 4096:
         with open(tpath) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            tj = json.load(f)
+        traffic = tj.get("hbm_bytes_per_launch")
+        traffic_source = ("constant read from profiles/roofline_traffic.json = separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this "
+                          f"kernel ({tj.get('collected', 'see profiles/README.md')}); PMC counters cannot be read inside this run")
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "gemm_skinny_kernel<1,2,EPI_SWIGLU,nt,AMODE=2> (gate/up GEMV with fused RMSNorm)",
             "launch_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": algo_bytes,
             "in_situ_event_bracket_us": None if in_situ is None else round(in_situ, 2), "in_situ_launches": launches,
             "shape": f"M=1 N={N} K={K} (gate/up of one layer, one token)"}
 
 
-def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=4):
-    """The CPU oracle (oracle/, PyTorch eager bf16 -- the reference has no CPU path, agents/infinisst.py:153) on a
-    bounded sample of ONE steady-state chunk: the full speech encoder, then prefill + decode passes through
-    `llm_layers_run` of the Llama layers (+ final norm and lm_head); the layer-stack time is scaled to all layers.
-    LLM KV pre-filled to the steady-state length, encoder window saturated."""
+def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=32, n_chunks=4):
+    """The CPU oracle (oracle/, PyTorch eager bf16 -- the reference has no CPU path, agents/infinisst.py:153) on a bounded sample of
+    `n_chunks` consecutive steady-state chunks of one stream: the full speech encoder, then prefill + decode passes through
+    `llm_layers_run` of the Llama layers (+ final norm and lm_head; the layer-stack time is scaled to all layers when fewer are run),
+    with the whole-chunk eviction between the chunks.  LLM KV pre-filled to the steady-state length, encoder window saturated."""
     from oracle import generate as ogen
     from oracle import llm as ollm
     from oracle import speech_encoder as oenc
@@ -197,7 +316,9 @@ def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=4):
     log(f"cpu baseline: weights of encoder + {run_layers} llama layers on the host, {nthreads} threads")
     sub = cfg.replace(llm_layers=run_layers, eos_ids=())
     g = torch.Generator().manual_seed(3)
-    L = sys_n + gen.max_llm_cache_size - 40
+    prompt = synth.chunk_prompt_ids(cfg, 1, first=False)
+    per_chunk = len(prompt) + gen.max_new_tokens - 1
+    L = sys_n + STEADY_CHUNKS * per_chunk
     kv = [[(0.5 * torch.randn(1, cfg.llm_kv_heads, L, cfg.llm_head_dim, generator=g)).bfloat16() for _ in range(2)]
           for _ in range(run_layers)]
     sc = oenc.new_cache(cfg)
@@ -209,51 +330,87 @@ def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=4):
         lc.v = (0.5 * torch.randn(cfg.enc_heads, cfg.max_cache_size, cfg.enc_head_dim, generator=g)).bfloat16()
     rope_l = ollm.llm_rope_tables(cfg, L + 256, torch.bfloat16)
     rope_e = oenc.make_rope(cfg)
-    audio = torch.from_numpy(synth.synthetic_audio(cfg.chunk_samples, stream_id=99)).unsqueeze(0).bfloat16()
-    prompt = synth.chunk_prompt_ids(cfg, 1, first=False)
-    with torch.inference_mode():
-        t0 = time.perf_counter()
-        feats, _ = oenc.encode_speech(w, sub, audio, sc, 1, rope_e)
-        t_enc = time.perf_counter() - t0
-        log(f"cpu baseline: encoder {t_enc:.2f} s")
-        # time the layer stack and the head separately so that only the stack is scaled
-        seq = list(prompt)
-        t_stack = t_head = 0.0
-        n_pass = 0
-        for step in range(gen.max_new_tokens):
-            ids = torch.tensor(seq if step == 0 else seq[-1:])
-            t1 = time.perf_counter()
-            emb = torch.nn.functional.embedding(ids, w["model.embed_tokens.weight"])
-            if step == 0:
-                emb = ollm.splice_speech(sub, ids, emb, feats[0])
-            x = emb.unsqueeze(0)
-            for i in range(run_layers):
-                p = f"model.layers.{i}."
-                h = ollm.rmsnorm(x, w[p + "input_layernorm.weight"], cfg.rms_eps)
-                x = x + ollm.attention(w, sub, i, h, kv, rope_l)
-                h = ollm.rmsnorm(x, w[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-                x = x + ollm.mlp(w, i, h)
-            t2 = time.perf_counter()
-            x = ollm.rmsnorm(x, w["model.norm.weight"], cfg.rms_eps)
-            logits = torch.nn.functional.linear(x[0, -1:], w["lm_head.weight"])[0].float()
-            scores = ogen.process_logits(logits, seq, [], gen.repetition_penalty, gen.no_repeat_ngram_size,
-                                         gen.no_repeat_ngram_size, ())
-            seq.append(int(torch.argmax(scores)))
-            t3 = time.perf_counter()
-            t_stack += t2 - t1
-            t_head += t3 - t2
-            n_pass += 1
-            if step == 0:
-                log(f"cpu baseline: prefill over {run_layers} layers {t2 - t1:.2f} s")
+    audio_all = synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=99)
     scale = cfg.llm_layers / run_layers
-    dt = t_enc + t_stack * scale + t_head
-    measured = t_enc + t_stack + t_head
+    per_chunk_s, measured = [], 0.0
+    n_pass = 0
+    with torch.inference_mode():
+        for c in range(n_chunks):
+            audio = torch.from_numpy(audio_all[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]).unsqueeze(0).bfloat16()
+            t0 = time.perf_counter()
+            feats, _ = oenc.encode_speech(w, sub, audio, sc, 1, rope_e)
+            t_enc = time.perf_counter() - t0
+            # time the layer stack and the head separately so that only the stack is scaled
+            seq = list(prompt)
+            t_stack = t_head = 0.0
+            for step in range(gen.max_new_tokens):
+                ids = torch.tensor(seq if step == 0 else seq[-1:])
+                t1 = time.perf_counter()
+                emb = torch.nn.functional.embedding(ids, w["model.embed_tokens.weight"])
+                if step == 0:
+                    emb = ollm.splice_speech(sub, ids, emb, feats[0])
+                x = emb.unsqueeze(0)
+                for i in range(run_layers):
+                    p = f"model.layers.{i}."
+                    h = ollm.rmsnorm(x, w[p + "input_layernorm.weight"], cfg.rms_eps)
+                    x = x + ollm.attention(w, sub, i, h, kv, rope_l)
+                    h = ollm.rmsnorm(x, w[p + "post_attention_layernorm.weight"], cfg.rms_eps)
+                    x = x + ollm.mlp(w, i, h)
+                t2 = time.perf_counter()
+                x = ollm.rmsnorm(x, w["model.norm.weight"], cfg.rms_eps)
+                logits = torch.nn.functional.linear(x[0, -1:], w["lm_head.weight"])[0].float()
+                scores = ogen.process_logits(logits, seq, [], gen.repetition_penalty, gen.no_repeat_ngram_size,
+                                             gen.no_repeat_ngram_size, ())
+                seq.append(int(torch.argmax(scores)))
+                t3 = time.perf_counter()
+                t_stack += t2 - t1
+                t_head += t3 - t2
+                n_pass += 1
+            # the last sampled token is never fed: the cache grew by prompt + (passes - 1); then evict one chunk (agents/infinisst.py:354-361)
+            for layer in kv:
+                for j in (0, 1):
+                    layer[j] = torch.cat([layer[j][:, :, :sys_n], layer[j][:, :, -(STEADY_CHUNKS * per_chunk):]], dim=2)
+            per_chunk_s.append(t_enc + t_stack * scale + t_head)
+            measured += t_enc + t_stack + t_head
+            log(f"cpu baseline: chunk {c}: encoder {t_enc:.2f} s, layer stack {t_stack:.2f} s, head {t_head:.2f} s")
+    dt = float(np.mean(per_chunk_s))
     return {"value": round(0.96 / dt, 4), "unit": "xRT (audio-s/wall-s), 1 stream", "cores": nthreads, "kind": "port",
-            "sample": f"1 steady-state chunk (0.96 s audio): full speech encoder + {len(prompt)}-token prefill + {n_pass - 1} decode "
-                      f"passes through {run_layers} of {cfg.llm_layers} Llama layers (+ norm, lm_head, processors); measured "
-                      f"{measured:.1f} s, layer-stack time scaled x{scale:g} -> {dt:.1f} s per chunk; LLM KV {L} entries, encoder window "
+            "sample": f"{n_chunks} consecutive steady-state chunks ({0.96 * n_chunks:.2f} s audio) of one stream: full speech encoder + {len(prompt)}-token "
+                      f"prefill + {gen.max_new_tokens - 1} decode passes per chunk through {run_layers} of {cfg.llm_layers} Llama layers (+ norm, lm_head, "
+                      f"processors), eviction between chunks; measured {measured:.1f} s"
+                      + (f", layer-stack time scaled x{scale:g}" if scale != 1 else "") +
+                      f" -> {dt:.2f} s per chunk (p50 {float(np.percentile(per_chunk_s, 50)):.2f} s); LLM KV {L} entries, encoder window "
                       f"{cfg.max_cache_size}; torch {torch.__version__} bf16 eager, {nthreads} threads of {cores} cores",
-            "chunk_seconds": round(dt, 3)}
+            "chunk_seconds": round(dt, 3), "p50_chunk_seconds": round(float(np.percentile(per_chunk_s, 50)), 3), "chunks": n_chunks}
+
+
+def dry_run(args, world, rank):
+    """Launcher self-test (no GPU, no compute): the ranks meet over gloo, deal the global stream ids, "step" by sleeping, and go through
+    exactly the barrier / max-over-ranks / gather path of a real run."""
+    if world > 1:
+        dist.init_process_group("gloo")
+    mine = S.assign_streams(args.streams * world, rank, world)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    lat = []
+    for _ in range(args.steps):
+        s0 = time.perf_counter()
+        time.sleep(0.002 * (1 + rank))
+        lat.append(time.perf_counter() - s0)
+    elapsed_local = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    elapsed = S.max_over_ranks(elapsed_local)
+    audio_s = S.sum_over_ranks(0.96 * args.steps * len(mine))
+    all_lat = S.gather_floats(lat)
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN of the launcher (no compute, not a measurement)", "dry_run": True, "value": round(audio_s / elapsed, 3),
+                          "unit": "audio-seconds per wall-second", "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "steps": args.steps, "warmup": args.warmup, "streams_of_rank0": mine, "latencies_gathered": len(all_lat),
+                          "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -262,8 +419,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -277,7 +435,11 @@ def main():
     if args.attn_target_wgs:
         from infinisst_amd.engine import load_library
         load_library().isst_op_set_attn_tuning(args.attn_target_wgs)
-    loop = ChunkLoop(eng, cfg, gen, args.streams, sys_n, rank)
+    mine = S.assign_streams(args.streams * world, rank, world)  # global stream ids of this rank: stream_id mod n_gpu
+    loop = ChunkLoop(eng, cfg, gen, mine, sys_n)
+    if not args.cold_start:
+        loop.import_steady_state(device)
+        log(f"steady state imported: KV {eng.stream_info(loop.sids[0])['llm_cache_len']} entries, encoder window {eng.stream_info(loop.sids[0])['enc_cache_len']}")
 
     def sync_all():
         torch.cuda.synchronize()
@@ -290,7 +452,9 @@ def main():
         if i == 0:
             log("first chunk done")
     sync_all()
-    log(f"warm-up done ({args.warmup} chunks, KV {eng.stream_info(loop.sids[0])['llm_cache_len']} entries)")
+    ev0 = loop.evictions
+    kv_min = eng.stream_info(loop.sids[0])["llm_cache_len"]
+    log(f"warm-up done ({args.warmup} chunks, KV {kv_min} entries)")
     lat = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -301,21 +465,29 @@ def main():
     elapsed_local = time.perf_counter() - t0
     sync_all()
     elapsed = S.max_over_ranks(elapsed_local, device if world > 1 else None)
-    audio_s = S.sum_over_ranks(0.96 * args.steps * args.streams, device if world > 1 else None)
+    audio_s = S.sum_over_ranks(0.96 * args.steps * len(mine), device if world > 1 else None)
     all_lat = S.gather_floats(lat, device if world > 1 else None)
     info = eng.stream_info(loop.sids[0])
+    timed_evictions = loop.evictions - ev0
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
 
     roof = None
     base = None
+    s64 = None
     if rank == 0:
         if not args.no_roofline:
             in_situ = args.streams == 1 and args.beam == 1
             roof = gemm_roofline(cfg, device, loop if in_situ else None, eng if in_situ else None)
             log(f"roofline probe done: {roof['achieved']} GB/s, in-situ bracket {roof['in_situ_event_bracket_us']} us")
+        if world == 1 and args.streams == 1 and args.beam == 1 and not args.toy and not args.no_streams64:
+            try:
+                s64 = run_streams64(cfg, gen, weights, device, args)
+                log(f"64-stream leg done: {s64['xrt']} xRT, {s64['ms_per_step']} ms per step")
+            except Exception as e:  # report, never hide
+                s64 = {"failed": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                base = cpu_baseline(cfg, gen, weights, sys_n, args.cpu_threads, args.cpu_layers)
+                base = cpu_baseline(cfg, gen, weights, sys_n, args.cpu_threads, args.cpu_layers, args.cpu_chunks)
                 log(f"cpu baseline done: {base['value']} xRT")
             except Exception as e:  # report, never hide
                 base = {"value": None, "unit": "xRT (audio-s/wall-s), 1 stream", "cores": os.cpu_count(), "kind": "port",
@@ -329,6 +501,7 @@ def main():
             "value": round(value, 3),
             "unit": "audio-seconds per wall-second",
             "n_gpus": world,
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -342,14 +515,20 @@ def main():
                         if args.streams == 1 else
                         f"InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, {args.streams} streams per MI355X "
                         "(BASELINE.json configs[2] shape)"),
-                       "streams_per_gpu": args.streams, "chunk_ms": 960, "prompt_tokens": 22, "forward_passes_per_chunk": args.gen_tokens,
-                       "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "greedy": args.beam == 1, "num_beams": args.beam,
-                       "parallelism": f"stream-parallel replicas x{world}, no collective", "evictions_per_stream": loop.evictions // max(1, args.streams)},
+                       "streams_per_gpu": args.streams, "streams_total": args.streams * world, "chunk_ms": 960, "prompt_tokens": 22,
+                       "forward_passes_per_chunk": args.gen_tokens,
+                       "llm_kv_entries": info["llm_cache_len"], "llm_kv_entries_at_timed_start": kv_min, "encoder_window": info["enc_cache_len"],
+                       "steady_state": "cold start (--cold-start)" if args.cold_start else
+                                       "imported before the first step (KV, checkpoints, encoder window, audio history)",
+                       "greedy": args.beam == 1, "num_beams": args.beam,
+                       "parallelism": f"stream-parallel replicas x{world}, no collective",
+                       "evictions_per_stream": timed_evictions // max(1, len(mine)), "evictions_counted_over": "the timed steps"},
             "p50_chunk_latency_ms": round(1e3 * float(np.percentile(all_lat, 50)), 3),
             "p95_chunk_latency_ms": round(1e3 * float(np.percentile(all_lat, 95)), 3),
             "xrt_per_gpu": round(value / world, 3),
             "roofline": roof,
             "cpu_baseline": base,
+            "streams64": s64,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -77,6 +77,7 @@ class BeamStepRecord:
     next_tokens: List[int]
     next_parents: List[int]
     next_scores: List[float]
+    beam_scores_in: List[float] = field(default_factory=list)  # the beams' scores BEFORE this step (scores[b] = processed log-probs + beam_scores_in[b])
 
 
 @dataclass
@@ -161,7 +162,7 @@ def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batc
         cand_beams = [int(i) // V for i in top.indices]
         cand_tokens = [int(i) % V for i in top.indices]
         ns, nt, npar, done = scorer_process(hyps, done, seqs, cand_scores, cand_tokens, cand_beams, kvs, cfg.eos_ids, num_beams, prompt_len)
-        steps.append(BeamStepRecord(rows, cand_scores, cand_tokens, cand_beams, nt, npar, ns))
+        steps.append(BeamStepRecord(rows, cand_scores, cand_tokens, cand_beams, nt, npar, ns, list(beam_scores)))
         seqs = [seqs[p] + [t] for p, t in zip(npar, nt)]  # input_ids[beam_idx] + token
         kvs = [clone_kv(kvs[p]) for p in npar]  # _temporary_reorder_cache
         beam_scores = ns

@@ -82,7 +82,7 @@ class W2V2RoPECache:
 # --------------------------------------------------------------------------------------------
 # rotary embedding  [3P rotary_embedding_torch, restated; parity unpinned]
 # --------------------------------------------------------------------------------------------
-def enc_rope_tables(max_pos: int, head_dim: int, theta: float, mode: str):
+def enc_rope_tables(max_pos: int, head_dim: int, theta: float, mode: str, inv_freq: Optional[torch.Tensor] = None):
     """cos/sin tables (max_pos, head_dim//2) in fp32 for RotaryEmbedding(dim=head_dim, theta).
 
     mode "bf16": what the module computes after `speech_encoder.to(bf16)` (reference agents/infinisst.py:173):
@@ -90,6 +90,8 @@ def enc_rope_tables(max_pos: int, head_dim: int, theta: float, mode: str):
     cos/sin rounded to bf16.  mode "fp32": everything fp32.
     """
     inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+    if inv_freq is not None:  # the module's `freqs` Parameter as a checkpoint carries it (strict load_state_dict overwrites the initial value)
+        inv = inv_freq.float()
     pos = torch.arange(max_pos, dtype=torch.float32)
     if mode == "bf16":
         inv = inv.bfloat16()
@@ -267,9 +269,9 @@ def new_cache(cfg) -> W2V2RoPECache:
     return W2V2RoPECache(max_steps=cfg.max_cache_size, layers=[LayerCache() for _ in range(cfg.enc_layers)])
 
 
-def make_rope(cfg, max_pos: Optional[int] = None):
+def make_rope(cfg, max_pos: Optional[int] = None, inv_freq: Optional[torch.Tensor] = None):
     n = max_pos or (cfg.max_cache_size + 8 * cfg.block_size * 4)
-    cos, sin = enc_rope_tables(n, cfg.enc_head_dim, cfg.enc_rope_theta, cfg.enc_rope_mode)
+    cos, sin = enc_rope_tables(n, cfg.enc_head_dim, cfg.enc_rope_theta, cfg.enc_rope_mode, inv_freq)
     return cos, sin, cfg.enc_rope_mode
 
 

@@ -77,7 +77,77 @@ def test_beam_kv_bookkeeping_is_exact(eos, shared, monkeypatch):
     print("winner lengths ok; final cache", eng.stream_info(a)["llm_cache_len"])
 
 
+LP_TOL = 0.15  # processed log-probs: the logit tolerance of tests/test_gpu_engine.py (measured worst at toy width: 0.035)
+GAP = 0.1      # an oracle candidate whose neighbours are further away than this is "decisive": the device must rank the same token there
+
+
+def _oracle_beam(w, cfg, gen, B, prompt, audio, rope_l, rope_e):
+    x = torch.cat([torch.zeros(cfg.first_chunk_offset), torch.from_numpy(audio)])
+    return obeam.beam_generate(w, cfg, gen, B, prompt, x.unsqueeze(0).bfloat16(), ollm.new_kv(cfg), oenc.new_cache(cfg), rope_l, rope_e, [])
+
+
+def test_beam_teacher_forced_candidates_match_oracle():
+    """Teacher-forced beam search (patch_hf.py:833-913): the engine continues along the ORACLE's (token, parent) choices, so both sides
+    are in the same state at every step, and the device's per-beam processed log-probs -- top 2B values and token ids, what the scorer
+    consumes -- are compared step by step: values within LP_TOL, identical candidate ids wherever the oracle's neighbouring candidates
+    are further apart than GAP, beam scores within LP_TOL per step taken."""
+    cfg = toy_config().replace(eos_ids=())  # no EOS: every step has B live beams on both sides
+    B = 4
+    gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=400)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=47)
+    eng = Engine(cfg, max_streams=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
+    eng.load_weights(w)
+    rope_l, rope_e = ollm.llm_rope_tables(cfg, 1024, torch.bfloat16), oenc.make_rope(cfg)
+    n_keep = 2 * B
+    worst_v = worst_s = 0.0
+    checked_ids = decisive_ids = 0
+    for trial in range(4):
+        sid = eng.open_stream()
+        audio = synth.synthetic_audio(cfg.chunk_samples, stream_id=90 + trial)
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=True)
+        ref = _oracle_beam(w, cfg, gen, B, prompt, audio, rope_l, rope_e)
+        assert len(ref.steps) == gen.max_new_tokens
+        eng.beam_trace_begin(B, [st.next_tokens for st in ref.steps], [st.next_parents for st in ref.steps])
+        outs, _ = eng.generate(gen, [sid], [audio], [prompt], [[]])
+        trace = eng.beam_trace_end()
+        assert len(trace) == len(ref.steps)
+        for step, (st, (val, idx, sc)) in enumerate(zip(ref.steps, trace)):
+            rows = 1 if step == 0 else B
+            assert val.shape == (rows, n_keep)
+            for b in range(rows):
+                lp = (st.scores[b] - st.beam_scores_in[b]).float()       # the oracle's processed log-probs of beam b
+                top = torch.topk(lp, n_keep + 1)
+                ov, oi = top.values.numpy(), top.indices.numpy()
+                dv = np.abs(val[b] - ov[:n_keep])
+                worst_v = max(worst_v, float(dv.max()))
+                assert dv.max() <= LP_TOL, f"trial {trial} step {step} beam {b}: top log-probs differ by {dv.max():.3f}"
+                for j in range(n_keep):
+                    checked_ids += 1
+                    lo = ov[j - 1] - ov[j] if j > 0 else np.inf
+                    hi = ov[j] - ov[j + 1]
+                    if min(lo, hi) > GAP:
+                        decisive_ids += 1
+                        assert idx[b, j] == oi[j], f"trial {trial} step {step} beam {b} rank {j}: token {idx[b, j]} vs oracle {oi[j]}"
+                    else:  # a near-tie may swap ranks, but the token must come from the oracle's neighbourhood of that rank
+                        near = {int(t) for t, v_ in zip(top.indices.tolist(), top.values.tolist()) if abs(v_ - ov[j]) <= GAP}
+                        near |= {int(t) for t in torch.nonzero((lp - float(ov[j])).abs() <= GAP).flatten().tolist()}
+                        assert int(idx[b, j]) in near, f"trial {trial} step {step} beam {b} rank {j}: token {idx[b, j]} is not within GAP of the oracle's rank"
+                ds = abs(float(sc[b]) - float(st.beam_scores_in[b]))
+                worst_s = max(worst_s, ds)
+                assert ds <= LP_TOL * max(1, step), f"trial {trial} step {step} beam {b}: beam score {sc[b]} vs {st.beam_scores_in[b]}"
+        # forced along the oracle's path, the open beams ARE the oracle's: the winner may only differ at a near-tie of final scores
+        finals = sorted((s_ / (len(ref.steps) ** 1.0) for s_ in ref.steps[-1].next_scores), reverse=True)
+        if finals[0] - finals[1] > GAP:
+            assert outs[0] == ref.sequences[len(prompt):], f"trial {trial}: {outs[0]} vs {ref.sequences[len(prompt):]}"
+        eng.close_stream(sid)
+    print(f"teacher-forced beam: worst |d log-prob| {worst_v:.4f}, worst |d beam score| {worst_s:.4f}, {decisive_ids}/{checked_ids} candidate ids decisive")
+    assert decisive_ids > 0
+
+
 def test_beam_decisions_follow_oracle():
+    """Free-running beam search against the oracle's restatement of patch_hf.py:43-302,687-967: every trial must produce the
+    oracle's sequence, unless its FIRST divergent step (located with the candidate trace: the merged candidate order of the device
+    against the oracle's) is a near-tie of the oracle's own candidate scores at that step."""
     cfg = toy_config()
     B = 4
     gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=400)
@@ -85,28 +155,82 @@ def test_beam_decisions_follow_oracle():
     eng = Engine(cfg, max_streams=8, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
     eng.load_weights(w)
     rope_l, rope_e = ollm.llm_rope_tables(cfg, 1024, torch.bfloat16), oenc.make_rope(cfg)
+    V = cfg.vocab
     same = near_tie = 0
     for trial in range(8):
         sid = eng.open_stream()
         audio = synth.synthetic_audio(cfg.chunk_samples, stream_id=50 + trial)
         prompt = synth.chunk_prompt_ids(cfg, 1, first=True)
-        x = torch.cat([torch.zeros(cfg.first_chunk_offset), torch.from_numpy(audio)])
-        ref = obeam.beam_generate(w, cfg, gen, B, prompt, x.unsqueeze(0).bfloat16(), ollm.new_kv(cfg), oenc.new_cache(cfg), rope_l, rope_e, [])
+        ref = _oracle_beam(w, cfg, gen, B, prompt, audio, rope_l, rope_e)
+        eng.beam_trace_begin(B)
         outs, _ = eng.generate(gen, [sid], [audio], [prompt], [[]])
+        trace = eng.beam_trace_end()
         ref_new = ref.sequences[len(prompt):]
         if outs[0] == ref_new:
             same += 1
         else:
-            # the oracle's own candidate margins tell whether a flip is a near-tie under bf16 noise
-            gaps = []
-            for st in ref.steps:
-                cs = st.cand_scores
-                gaps.append(min(abs(cs[j] - cs[j + 1]) for j in range(min(len(cs) - 1, 2 * B))))
-            assert min(gaps) < 0.08, f"trial {trial}: sequences differ ({outs[0]} vs {ref_new}) without a near-tie (min gap {min(gaps):.3f})"
+            first = None
+            for step, st in enumerate(ref.steps):
+                if step >= len(trace):
+                    first = step
+                    break
+                val, idx, sc = trace[step]
+                merged = sorted(((float(val[b, j] + sc[b]), b * V + int(idx[b, j])) for b in range(val.shape[0]) for j in range(val.shape[1])),
+                                key=lambda t: (-t[0], t[1]))[:len(st.cand_tokens)]
+                dev_order = [f for _, f in merged]
+                ref_order = [b * V + t for b, t in zip(st.cand_beams, st.cand_tokens)]
+                if dev_order != ref_order:
+                    first = step
+                    break
+            assert first is not None, f"trial {trial}: sequences differ ({outs[0]} vs {ref_new}) although every step's candidate order agrees"
+            cs = ref.steps[min(first, len(ref.steps) - 1)].cand_scores
+            gap = min(abs(cs[j] - cs[j + 1]) for j in range(len(cs) - 1))
+            assert gap < 0.08, (f"trial {trial}: sequences differ ({outs[0]} vs {ref_new}); first divergent step {first} has no near-tie "
+                                f"(min candidate gap {gap:.3f})")
             near_tie += 1
         eng.close_stream(sid)
-    print(f"beam vs oracle: {same} identical, {near_tie} explained by near-ties")
-    assert same >= 3
+    print(f"beam vs oracle: {same} identical, {near_tie} diverged at a near-tie of that step's candidates")
+    assert same + near_tie == 8 and same >= 3
+
+
+def test_beam_finished_stream_is_frozen_while_batch_mates_continue():
+    """the scorer must skip a stream whose search is done (patch_hf.py:83-92) while other streams of the call keep decoding --
+    otherwise the finished stream goes on closing hypotheses and its winner / KV tail depend on its batch mates.  Stream A (finishes
+    early: many ids count as EOS) is run next to a copy of itself and next to the longest-running stream found; the row count of the
+    passes is 2B in both calls (finished streams' rows ride along), so A's tokens, cache length and KV must be IDENTICAL."""
+    cfg = toy_config().replace(eos_ids=(1001, 1008, 1009, 7, 8, 9))
+    B = 4
+    gen = GenConfig(max_new_tokens=8, beam=B, max_llm_cache_size=400)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=48)
+    eng = Engine(cfg, max_streams=2, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
+    eng.load_weights(w)
+    prompt = synth.chunk_prompt_ids(cfg, 1, first=True)
+    steps = {}
+    for seed in range(200, 216):  # how many scorer steps does each candidate stream take on its own?
+        sid = eng.open_stream()
+        eng.beam_trace_begin(B)
+        eng.generate(gen, [sid], [synth.synthetic_audio(cfg.chunk_samples, stream_id=seed)], [prompt], [[]])
+        steps[seed] = len(eng.beam_trace_end())
+        eng.close_stream(sid)
+    a_seed, b_seed = min(steps, key=steps.get), max(steps, key=steps.get)
+    print(f"scorer steps per candidate: {steps}; A = {a_seed} ({steps[a_seed]} steps), B = {b_seed} ({steps[b_seed]} steps)")
+    assert steps[a_seed] + 2 <= steps[b_seed], "no early-finishing stream among the candidates"
+    audio_a, audio_b = synth.synthetic_audio(cfg.chunk_samples, stream_id=a_seed), synth.synthetic_audio(cfg.chunk_samples, stream_id=b_seed)
+
+    def run(mate_audio):
+        s0, s1 = eng.open_stream(), eng.open_stream()
+        outs, _ = eng.generate(gen, [s0, s1], [audio_a, mate_audio], [prompt, prompt], [[], []])
+        n = eng.stream_info(s0)["llm_cache_len"]
+        kv = [kv_of(eng, s0, n, beam=b) for b in range(B)]
+        eng.close_stream(s0)
+        eng.close_stream(s1)
+        return outs, n, kv
+
+    (o_self, n_self, kv_self), (o_long, n_long, kv_long) = run(audio_a), run(audio_b)
+    assert o_self[0] == o_self[1], "two copies of one stream in a batch must agree"
+    assert o_long[0] == o_self[0] and n_long == n_self, f"stream A changed with its batch mate: {o_long[0]} (cache {n_long}) vs {o_self[0]} (cache {n_self})"
+    for b in range(B):
+        assert torch.equal(kv_long[b][0], kv_self[b][0]) and torch.equal(kv_long[b][1], kv_self[b][1]), f"arena {b} of stream A differs"
 
 
 def test_beam_rotated_key_arena_is_bit_identical_to_rotate_on_read(monkeypatch):

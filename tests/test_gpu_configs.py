@@ -125,3 +125,81 @@ def test_long_stream_is_bounded_and_o1():
         assert info["enc_cache_len"] <= cfg.max_cache_size + cfg.block_size
     print(f"long stream: worst |logit diff| over sampled chunks {worst:.4f}")
     assert worst <= 0.15
+
+
+def test_update_multiplier_mid_stream_matches_oracle():
+    """`update_multiplier` between chunks (reference agents/infinisst.py:125-128, model/speech_encoder.py:143-145): one stream runs
+    m = 1, 2, 2, 1, 3, 1 with its encoder cache and LLM KV alive -- block size, speech-token count and max_new_tokens change from call
+    to call while the rings carry over.  Teacher-forced logits against the oracle on the same schedule."""
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=35)
+    eng = Engine(cfg, max_streams=1, max_multiplier=3, max_prompt_len=160, max_new_tokens=30, max_llm_cache_size=600, max_system_prompt=64)
+    eng.load_weights(w)
+    sid = eng.open_stream()
+    schedule = [1, 2, 2, 1, 3, 1]
+    audio = synth.synthetic_audio(cfg.chunk_samples * sum(schedule), stream_id=17)
+    kv, sc = ollm.new_kv(cfg), oenc.new_cache(cfg)
+    rope_l, rope_e = ollm.llm_rope_tables(cfg, 2048, torch.bfloat16), oenc.make_rope(cfg)
+    pos, worst, frames = 0, 0.0, 0
+    for c, m in enumerate(schedule):
+        gen = GenConfig(latency_multiplier=m, max_new_tokens=min(10 * m, 8), max_llm_cache_size=600)
+        n = cfg.chunk_samples * m
+        seg = audio[pos:pos + n]
+        pos += n
+        prompt = synth.chunk_prompt_ids(cfg, m, first=(c == 0))
+        x = torch.from_numpy(seg)
+        if c == 0:
+            x = torch.cat([torch.zeros(cfg.first_chunk_offset), x])
+        ref = ogen.generate(w, cfg, gen, prompt, x.unsqueeze(0).bfloat16(), kv, sc, rope_l, rope_e, [])
+        forced = ref.sequences[len(prompt):]
+        outs, logits = eng.generate(gen, [sid], [seg], [prompt], [[]], forced_tokens=[forced], return_logits=True)
+        assert outs[0] == forced
+        for s, rl in enumerate(ref.step_logits):
+            worst = max(worst, float(np.abs(logits[0, s] - rl.float().numpy()).max()))
+        frames += 48 * m
+        info = eng.stream_info(sid)
+        assert info["enc_n_steps"] == sc.n_steps == frames and info["llm_cache_len"] == ollm.kv_len(kv)
+        assert info["enc_cache_len"] == sc.layers[0].k.shape[1]
+    print(f"multiplier schedule {schedule}: worst |logit diff| {worst:.4f}")
+    assert worst <= 0.15
+
+
+def test_agent_multiplier_2_with_a_short_last_segment_matches_oracle_agent():
+    """at m = 2 the last segment of an utterance is padded to whole 960 ms chunks, so a tail <= 960 ms yields 12 speech
+    features for a prompt with 24 patch slots.  The reference's slices just splice the shorter run (model/llm.py:101-110): the agent must
+    emit the final translation, with the same cache length and token ids as the oracle agent."""
+    from infinisst_amd.agent import InfiniSST, WriteAction, default_args
+    from oracle import agent as oag
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=36)
+    m = 2
+    args = default_args(latency_multiplier=m, max_latency_multiplier=2, max_new_tokens=6, max_llm_cache_size=400)
+    eng = Engine(cfg, max_streams=1, max_multiplier=2, max_prompt_len=160, max_new_tokens=16, max_llm_cache_size=400, max_system_prompt=64)
+    eng.load_weights(w)
+    agent = InfiniSST(args, engine=eng, model_cfg=cfg)
+    gen = GenConfig(latency_multiplier=m, max_new_tokens=6, max_llm_cache_size=400)
+    oa = oag.OracleAgent(w, cfg, gen, lambda first: synth.chunk_prompt_ids(cfg, m, first), system_prompt_size=agent.system_prompt_size)
+    seg = cfg.chunk_samples * m
+    wav = synth.synthetic_audio(seg * 2 + 5000, stream_id=23)   # two full 1920 ms segments + a 312 ms tail -> one padded chunk, 12 features
+    st, so = agent.build_states(), oa.build_states()
+    st.source_sample_rate = so.source_sample_rate = 16000
+    margins, last = [], None
+    for pos in range(0, wav.shape[0], seg):
+        piece = wav[pos:pos + seg].tolist()
+        st.source.extend(piece)
+        so.source.extend(piece)
+        st.source_finished = so.source_finished = pos + seg >= wav.shape[0]
+        last = agent.policy(st)
+        oa.policy(so)
+        for sc in oa.last_output.step_scores[:-1]:
+            top2 = torch.topk(sc, 2).values
+            margins.append(float(top2[0] - top2[1]))
+    assert isinstance(last, WriteAction) and last.finished
+    assert oa.last_output.speech_features.shape[0] == 12, "the oracle saw a 12-feature tail"
+    got, ref = list(st.target_ids), list(so.target_ids)
+    print("agent ids:", got, "oracle ids:", ref)
+    first_tie = next((i for i, mg in enumerate(margins) if mg <= 0.3), len(margins))
+    k = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
+    assert k >= min(first_tie, len(ref))
+    if got == ref:
+        assert eng.stream_info(st.stream_id)["llm_cache_len"] == ollm.kv_len(so.past_key_values)

@@ -123,3 +123,148 @@ def test_full_size_multi_stream_batch_matches_single_stream(full, n):
         assert d.mean() <= 0.15 and d.max() <= 1.0
     eng1.close_stream(s1)
     eng4.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Production steady state at full size: LLM KV ~ 1000 entries behind the pinned system prompt, encoder window saturated
+# (K = 576 + 48 = 624 keys), both rings wrapping, an eviction between the chunks, 10 forward passes per chunk.
+# ------------------------------------------------------------------------------------------------------------------------
+N_RING = 975          # evictable LLM entries before chunk 1 (+ sys_n pinned): chunk 1 ends at 975 + 22 + 9 = 1006 > 1000 -> eviction
+KEEP_AFTER = 944      # tail kept by the eviction between the chunks (agents/infinisst.py:354-361)
+
+
+def _random_state(cfg, sys_n, seed=5):
+    """A random-but-plausible stream state (bf16): K/V of the scale the random-init model produces (std ~ 1 for Llama's k/v
+    projections of normalised rows, ~ 0.6 for the encoder's), handed identically to the oracle and to the library."""
+    g = torch.Generator().manual_seed(seed)
+    L = sys_n + N_RING
+    kv = [[torch.randn(1, cfg.llm_kv_heads, L, cfg.llm_head_dim, generator=g).bfloat16() for _ in range(2)] for _ in range(cfg.llm_layers)]
+    enc = [[(0.6 * torch.randn(cfg.enc_heads, cfg.max_cache_size, cfg.enc_head_dim, generator=g)).bfloat16() for _ in range(2)]
+           for _ in range(cfg.enc_layers)]
+    src = torch.from_numpy(synth.synthetic_audio(cfg.first_chunk_offset + cfg.chunk_samples, stream_id=777)).bfloat16().unsqueeze(0)
+    return kv, enc, src
+
+
+def _oracle_cache(cfg, enc, src, dtype):
+    sc = oenc.new_cache(cfg)
+    sc.n_steps, sc.src_len, sc.src = 48 * 20, cfg.block_size, src.to(dtype)
+    for lc, (k, v) in zip(sc.layers, enc):
+        lc.k, lc.v = k.to(dtype).clone(), v.to(dtype).clone()
+    return sc
+
+
+def _import_state(eng, sid, cfg, sys_n, kv, enc, src, llm_ring_start, enc_ring_start):
+    eng.import_llm_kv(sid, kv, sys_len=sys_n, ring_start=llm_ring_start)
+    eng.import_speech_cache(sid, enc, n_steps=48 * 20, audio_tail=src[0, -cfg.first_chunk_offset:], ring_start=enc_ring_start)
+
+
+@pytest.fixture(scope="module")
+def steady(full):
+    """Oracle legs (fp32 arithmetic and the reference's bf16 arithmetic) of two steady-state chunks, computed once."""
+    cfg, w_dev, eng, sys_n = full
+    w = {k: v.cpu() for k, v in w_dev.items()}
+    w32 = {k: v.float() for k, v in w.items()}
+    kv0, enc0, src0 = _random_state(cfg, sys_n)
+    gen = GenConfig(max_new_tokens=10)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=4242)
+    kv = [[t.clone() for t in layer] for layer in kv0]
+    kv32 = [[t.float() for t in layer] for layer in kv0]
+    sc, sc32 = _oracle_cache(cfg, enc0, src0, torch.bfloat16), _oracle_cache(cfg, enc0, src0, torch.float32)
+    rope_e = oenc.make_rope(cfg)
+    rope_l, rope_l32 = ollm.llm_rope_tables(cfg, 2048, torch.bfloat16), ollm.llm_rope_tables(cfg, 2048, torch.float32)
+    prompt = synth.chunk_prompt_ids(cfg, 1, first=False)
+    chunks = []
+    for c in range(2):
+        x = torch.from_numpy(audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]).unsqueeze(0).bfloat16()
+        with torch.inference_mode():
+            ref32 = ogen.generate(w32, cfg, gen, prompt, x.float(), kv32, sc32, rope_l32, rope_e, [])
+            forced = ref32.sequences[len(prompt):]
+            ref = ogen.generate(w, cfg, gen, prompt, x, kv, sc, rope_l, rope_e, [], forced_tokens=forced)
+        chunks.append(dict(forced=forced, logits32=[l.float().numpy() for l in ref32.step_logits], logits=[l.float().numpy() for l in ref.step_logits],
+                           feats=ref.speech_features.float(), kv_len=ollm.kv_len(kv), enc_len=sc.layers[0].k.shape[1], enc_steps=sc.n_steps))
+        if c == 0:  # whole-chunk eviction as the agent does it: pinned prefix + the last KEEP_AFTER entries
+            for cache in (kv, kv32):
+                for layer in cache:
+                    for j in (0, 1):
+                        layer[j] = torch.cat([layer[j][:, :, :sys_n], layer[j][:, :, -KEEP_AFTER:]], dim=2)
+    del w32
+    return dict(kv0=kv0, enc0=enc0, src0=src0, audio=audio, prompt=prompt, gen=gen, chunks=chunks)
+
+
+def _check_against_noise_floor(tag, logits, ch, s):
+    truth = ch["logits32"][s]
+    e_ref, e_hip = np.abs(ch["logits"][s] - truth), np.abs(logits - truth)
+    print(f"{tag} step {s}: bf16-oracle err mean {e_ref.mean():.4f} max {e_ref.max():.4f} | HIP err mean {e_hip.mean():.4f} max {e_hip.max():.4f}"
+          f" | argmax fp32/bf16/HIP {int(np.argmax(truth))}/{int(np.argmax(ch['logits'][s]))}/{int(np.argmax(logits))}", flush=True)
+    assert e_hip.mean() <= 1.5 * e_ref.mean() + 0.005
+    assert e_hip.max() <= 1.5 * e_ref.max() + 0.05
+    top2 = np.sort(truth)[-2:]
+    if top2[1] - top2[0] > 2.5 * e_ref.max():
+        assert int(np.argmax(logits)) == int(np.argmax(truth))
+
+
+def test_full_size_steady_state_matches_oracle(full, steady):
+    """configs[1] where production runs it: KV 1041 -> 1072 entries (decode attention over 17+ slot splits, the pinned
+    region and a ring that wraps), encoder K = 624 with bf16 rotary positions above 256 (`enc_rope_mode="bf16"`) and a wrapping ring,
+    10 passes per chunk, an eviction (ring-start advance + re-indexing of every key) between the two chunks.  Same noise-floor
+    criterion as the two-chunk test above."""
+    cfg, _, eng, sys_n = full
+    st = steady
+    sid = eng.open_stream()
+    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
+    _import_state(eng, sid, cfg, sys_n, st["kv0"], st["enc0"], st["src0"], llm_ring_start=ring_cap - 500, enc_ring_start=600)
+    assert eng.stream_info(sid)["llm_cache_len"] == sys_n + N_RING and eng.stream_info(sid)["enc_cache_len"] == cfg.max_cache_size
+    for c, ch in enumerate(st["chunks"]):
+        seg = st["audio"][c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+        outs, logits = eng.generate(st["gen"], [sid], [seg], [st["prompt"]], [[]], forced_tokens=[ch["forced"]], return_logits=True)
+        assert outs[0] == ch["forced"] and len(ch["forced"]) == 10
+        feat = eng.debug_tap("speech").view(-1, cfg.llm_dim).float()
+        d = (feat - ch["feats"]).abs()
+        print(f"chunk {c}: speech features max |d| {float(d.max()):.4f}")
+        assert float(d.max()) <= 0.06 + 0.02 * float(ch["feats"].abs().max())
+        for s in range(10):
+            _check_against_noise_floor(f"steady chunk {c}", logits[0, s], ch, s)
+        info = eng.stream_info(sid)
+        assert info["llm_cache_len"] == ch["kv_len"] and info["enc_cache_len"] == ch["enc_len"] and info["enc_n_steps"] == ch["enc_steps"]
+        if c == 0:
+            eng.kv_evict(sid, KEEP_AFTER, sys_n)
+    eng.close_stream(sid)
+
+
+def test_full_size_64_streams_steady_state(full, steady):
+    """configs[2] at full size: 64 concurrent streams in ONE call -- 1408-row prefill on the dense GEMM with the
+    XCD rasterisation, 64-row decode passes on gemm_mid, one workgroup per (stream, kv head) in the decode attention -- all in the
+    steady state above.  Stream 0 carries exactly the single-stream test's audio and state and is held to the ORACLE (noise-floor
+    criterion); streams 17 and 63 (other audio) are held to the single-stream engine on the same inputs."""
+    cfg, w_dev, eng1, sys_n = full
+    st = steady
+    n = 64
+    eng = Engine(cfg, max_streams=n, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n)
+    eng.load_weights(w_dev)
+    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
+    sids = [eng.open_stream() for _ in range(n)]
+    for i, sid in enumerate(sids):
+        _import_state(eng, sid, cfg, sys_n, st["kv0"], st["enc0"], st["src0"], llm_ring_start=(ring_cap - 500 + 37 * i) % ring_cap,
+                      enc_ring_start=(600 + 11 * i) % 640)
+    ch = st["chunks"][0]
+    segs = [st["audio"][:cfg.chunk_samples]] + [synth.synthetic_audio(cfg.chunk_samples, stream_id=9000 + i) for i in range(1, n)]
+    singles = {}
+    for i in (17, 63):  # single-stream reference runs (free-running: their tokens teacher-force the batch)
+        s1 = eng1.open_stream()
+        _import_state(eng1, s1, cfg, sys_n, st["kv0"], st["enc0"], st["src0"], llm_ring_start=5, enc_ring_start=0)
+        singles[i] = eng1.generate(st["gen"], [s1], [segs[i]], [st["prompt"]], [[]], return_logits=True)
+        eng1.close_stream(s1)
+    forced = [ch["forced"] if i == 0 else (singles[i][0][0] if i in singles else None) for i in range(n)]
+    outs, logits = eng.generate(st["gen"], sids, segs, [st["prompt"]] * n, [[]] * n, forced_tokens=forced, return_logits=True)
+    assert outs[0] == ch["forced"]
+    for s in range(10):
+        _check_against_noise_floor("64 streams, stream 0", logits[0, s], ch, s)
+    for i in (17, 63):
+        o1, l1 = singles[i]
+        assert outs[i] == o1[0]
+        d = np.abs(logits[i][:len(o1[0])] - l1[0][:len(o1[0])])
+        print(f"stream {i} of 64 vs single-stream engine: mean |d| {d.mean():.4f} max {d.max():.4f}")
+        assert d.mean() <= 0.15 and d.max() <= 1.0
+    for i, sid in enumerate(sids):
+        assert eng.stream_info(sid)["llm_cache_len"] == sys_n + N_RING + len(st["prompt"]) + len(outs[i]) - 1
+    eng.close()

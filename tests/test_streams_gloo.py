@@ -39,3 +39,38 @@ def test_stream_partition_and_aggregate_gloo():
     expect = 0.96 * 10 * 7 / 4.0  # all ranks' audio / slowest rank's time
     assert abs(x0 - expect) < 1e-9 and abs(x1 - expect) < 1e-9
     assert l0 == l1 == [0.01] * 3 + [0.02] * 3
+
+
+def _run_bench(*flags, timeout=300):
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_starts_its_own_ranks_and_relays_rank0_json():
+    """`python bench.py --gpus 2` typed as is (no launcher): the parent starts torch.distributed.run as a child, the ranks rendezvous
+    on 127.0.0.1, deal the global stream ids (stream_id mod n_gpu), time their steps behind barriers, reduce max/sum over ranks,
+    and rank 0's JSON line arrives on the parent's stdout.  --dry-run replaces the GPU work by a sleep and RCCL by gloo -- the
+    launcher, partition and reduction code is the code of a real run."""
+    import json
+    r = _run_bench("--dry-run", "--gpus", "2", "--steps", "3", "--streams", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["n_gpus"] == 2 and j["ranks_seen"] == 2
+    assert j["streams_of_rank0"] == [0, 2, 4] and j["latencies_gathered"] == 6
+    assert j["ms_per_step"] >= 4.0  # the slower rank (4 ms per step) sets the time
+
+
+def test_bench_parent_reports_a_failing_rank():
+    """Without --dry-run on a box without GPUs every rank fails loudly (no CPU fallback); the parent must exit non-zero and print no JSON line."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without GPU")
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--toy", "--no-cpu-baseline")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
