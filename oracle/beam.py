@@ -169,5 +169,5 @@ def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batc
         step += 1
         if done or len(seqs[0]) >= max_length:  # :920
             break
-    out, best_kv = finalize(hyps, done, seqs, beam_scores, kvs, prompt_len, max_length, cfg.eos_ids[0])
+    out, best_kv = finalize(hyps, done, seqs, beam_scores, kvs, prompt_len, max_length, cfg.eos_ids[0] if cfg.eos_ids else 0)
     return BeamOutput(sequences=out, kv=best_kv, steps=steps, speech_features=feats)

@@ -92,7 +92,7 @@ def test_agent_from_simuleval_args_runs_an_utterance_like_the_oracle(tmp_path):
                               "--ctc-finetuned", "True", "--length-shrink-cfg", "[(128,2,2)] * 2", "--block-size", "48", "--max-cache-size", "576",
                               "--xpos", "0", "--max-llm-cache-size", "150", "--always-cache-system-prompt", "--max-new-tokens", "6", "--beam", "1",
                               "--no-repeat-ngram-lookback", "100", "--no-repeat-ngram-size", "5", "--repetition-penalty", "1.2",
-                              "--latency-multiplier", "1", "--max-latency-multiplier", "2", "--min-start-sec", "0", "--suppress-non-language",
+                              "--latency-multiplier", "1", "--max-latency-multiplier", "4", "--min-start-sec", "0", "--suppress-non-language",
                               "--source-lang", "English", "--target-lang", "German"])
     agent = InfiniSST(args)   # <- everything SimulEval does
     assert agent.bad_words_ids == [7] and agent.cfg.vocab == cfg.vocab and agent.cfg.eos_ids == cfg.eos_ids
@@ -105,7 +105,7 @@ def test_agent_from_simuleval_args_runs_an_utterance_like_the_oracle(tmp_path):
     import transformers
     tok = transformers.AutoTokenizer.from_pretrained(model_dir, padding_side="right", use_fast=False)
     tok.pad_token = H.PAD_TOKEN
-    H.preprocess_tokenizer(tok, 2)
+    H.preprocess_tokenizer(tok, 4)
     ref_prompt = H.ChatPrompt(tok, "English", "German", cfg.block_size, True)
     gen = GenConfig(max_new_tokens=6, max_llm_cache_size=150, suppress_tokens=(7,))
     oa = oag.OracleAgent(w, cfg, gen, lambda first: ref_prompt(first, 1), system_prompt_size=agent.system_prompt_size)

@@ -181,7 +181,7 @@ def test_agent_multiplier_2_with_a_short_last_segment_matches_oracle_agent():
     oa = oag.OracleAgent(w, cfg, gen, lambda first: synth.chunk_prompt_ids(cfg, m, first), system_prompt_size=agent.system_prompt_size)
     seg = cfg.chunk_samples * m
     wav = synth.synthetic_audio(seg * 2 + 5000, stream_id=23)   # two full 1920 ms segments + a 312 ms tail -> one padded chunk, 12 features
-    st, so = agent.build_states(), oa.build_states()
+    st, so = agent.states, oa.build_states()  # (the agent's constructor has opened its stream, as SimulEval's base class does)
     st.source_sample_rate = so.source_sample_rate = 16000
     margins, last = [], None
     for pos in range(0, wav.shape[0], seg):
