@@ -81,7 +81,54 @@ struct GemmArgs {
     const bf16_t* norm_w;                          // non-null: A rows are RMS-normalised on load (HF LlamaRMSNorm) with this weight
     float norm_eps;
     int ksplit;                                    // EPI_PARTIAL: K slices over workgroups (slab stride = out_batch elements)
+    // non-null (M <= ATTN_MERGE_MAX_ROWS, K = heads * 128, EPI_RES): A is NOT read; the rows are the Llama attention output merged on load from
+    // the split-KV partials of llm_attn_partial_kernel, [M][K / 128][attn_splits][ATTN_SLAB] fp32 = (unnormalised O[128], running max, sum) per split
+    const float* attn_partial;
+    int attn_splits;
 };
+#define ATTN_MERGE_MAX_ROWS 2
+#define ATTN_MERGE_MAX_SPLITS 32
+#define ATTN_SLAB 132  // floats per (row, head, split) slab: O[0..127], max, sum, 2 x pad -- 528 B, so that a slab is 33 whole 16-byte stores
+// Merge of the split-KV attention partials of one (row, head) for the two output dims a lane owns: the ONE definition of this arithmetic
+// (llm_attn_combine_kernel and the o_proj GEMV's merge-on-load prologue both call it, so a row gives the same bits through either).
+// src: [n_splits][2 + 128] fp32; every load is issued before the first use.  Returns bf16(O / L) of dims 2 lane, 2 lane + 1, packed.
+// (split into a load half and a math half so that a caller can put several heads' loads -- and other loads -- in flight before the first use;
+//  MAXS >= n_splits is the unroll bound: slabs past n_splits fall outside the descriptor's extent and read zeros at no traffic)
+template <int MAXS>
+struct AttnMergeLoads {
+    u32x2_t st;        // lane s: (max, sum) of split s
+    u32x2_t os[MAXS];  // the lane's two dims of every split's O
+};
+// AUX: cache policy of the loads (0 = default; 16 = sc1: bypass this CU's L1 -- slabs another workgroup of the SAME launch stored write-through)
+template <int MAXS, int AUX = 0>
+__device__ __forceinline__ void attn_merge_issue(const float* __restrict__ src, int n_splits, int lane, AttnMergeLoads<MAXS>& ld) {
+    // one descriptor over exactly the n_splits slabs: a uniform (SGPR) slab offset plus one per-lane offset, no per-load address registers
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, n_splits * (ATTN_SLAB * 4), 0x00020000);
+    ld.st = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)lane * (ATTN_SLAB * 4u) + 512u, 0, AUX);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) ld.os[s] = __builtin_amdgcn_raw_buffer_load_b64(rs, 8u * (unsigned)lane, s * (ATTN_SLAB * 4), AUX);
+}
+template <int MAXS>
+__device__ __forceinline__ uint32_t attn_merge_finish(const AttnMergeLoads<MAXS>& ld, int n_splits, int lane) {
+    const bool mine = lane < n_splits;
+    const float m = mine ? __uint_as_float(ld.st.x) : -INFINITY;
+    const float M = wave_max(m);
+    const float w = (m == -INFINITY) ? 0.f : expf(m - M);  // -inf: split without a live key for this row
+    const float L = wave_sum(mine ? __uint_as_float(ld.st.y) * w : 0.f);
+    float O0 = 0.f, O1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const float ws = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), s));
+        O0 = __builtin_fmaf(__uint_as_float(ld.os[s].x), ws, O0);
+        O1 = __builtin_fmaf(__uint_as_float(ld.os[s].y), ws, O1);
+    }
+    return pack_bf(O0 / L, O1 / L);
+}
+__device__ __forceinline__ uint32_t attn_merge_pair(const float* __restrict__ src, int n_splits, int lane) {
+    AttnMergeLoads<ATTN_MERGE_MAX_SPLITS> ld;
+    attn_merge_issue<ATTN_MERGE_MAX_SPLITS>(src, n_splits, lane, ld);
+    return attn_merge_finish<ATTN_MERGE_MAX_SPLITS>(ld, n_splits, lane);
+}
 // rows above which the 17..64-row machinery (gemm_mid.hip, split-K slabs + reducing RMSNorm) replaces the skinny kernel.  At 13..16 rows
 // every 16-column workgroup of the skinny kernel still pulls all of A through L2 -- as many bytes as the weight stream -- and the
 // residual + RMSNorm is a launch of its own (profiles/mid16_probe.py, 16 rows: q/k/v 15.6 -> 13.3 us, gate/up 43.7 -> 41.0,

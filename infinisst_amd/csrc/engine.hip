@@ -101,6 +101,14 @@ struct isst_handle {
     bool rot_keys = true;   // ISST_ROT_KEYS=0: rotate cached keys on every read (the reference's schedule) instead of once per chunk
     int kv_ops_used = 0;      // slots of the pinned KV-copy op list handed out since the stream was last known idle (flush_copies)
     bool beam_shared = true;  // ISST_BEAM_SHARED=0: every beam reads its whole arena (B x the attention traffic) instead of sharing the prefix pass
+    // The split-KV combine of a one-stream decode step is a launch of its own (4.75 us + a 2.6 us gap per layer and pass).  Two ways to remove
+    // that launch are built, tested bit-identical (tests/test_gpu_engine.py, test_gpu_kernels.py) and measured -- neither wins on MI355X, so both
+    // stay opt-in (profiles/r02/combine_fusion.txt):
+    bool inline_combine = false;  // ISST_INLINE_COMBINE=1: the last workgroup of a kv head to arrive combines inside the attention launch (write-through
+                                  // slabs, drained, agent-scope counter, sc1 reads): 32.39-32.66 ms per chunk against 32.09-32.18 -- the hand-off's
+                                  // round trips through memory cost what the kernel boundary costs
+    bool fuse_combine = false;    // ISST_FUSE_COMBINE=1: the o_proj GEMV merges the partials while it stages its A row (gemm.hip AMODE 3): every one of
+                                  // its 256 workgroups re-reads all 316 KB of slabs through L2 -- 33.7 ms per chunk against 32.3
     bool use_graphs = false;  // ISST_GRAPH=1 enables.  Measured on MI355X (1 stream): 35.40 ms per chunk replayed vs 35.28 launched one by
                               // one -- the loop is GPU-bound, the host is ~0.6 ms ahead per pass, and a graph does not shorten the
                               // GPU-side kernel boundaries; it only saves host time (230 launches -> 1 per step)
@@ -155,6 +163,7 @@ struct isst_handle {
     bf16_t *ex = nullptr, *exn = nullptr, *eqkv = nullptr, *eattn = nullptr, *effn = nullptr, *speech = nullptr;
     bf16_t *lx = nullptr, *lxn = nullptr, *lqkv = nullptr, *lqrot = nullptr, *lattn = nullptr, *lact = nullptr, *llast = nullptr;
     float *lpartial = nullptr, *logits = nullptr;
+    int* attn_cnt = nullptr;
     float* lslab = nullptr;  // split-K slabs of o_proj / down_proj at 17..512 rows: [slices][rows][llm_dim] fp32
     int* out_tok = nullptr;
     float* samp_val = nullptr;  // partial argmax scratch, 64 per stream
@@ -330,6 +339,8 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->cfg = *cfg;
     if (const char* e = getenv("ISST_GRAPH")) h->use_graphs = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_ROT_KEYS")) h->rot_keys = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_FUSE_COMBINE")) h->fuse_combine = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
     const isst_config& c = h->cfg;
     auto die = [&](int code) { g_create_error = h->err; isst_destroy(h); return code; };
@@ -440,7 +451,8 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->lx = h->dalloc<bf16_t>(LR * DL); h->lxn = h->dalloc<bf16_t>(LR * DL); h->lqkv = h->dalloc<bf16_t>(LR * (H + 2 * KV) * 128);
     h->lqrot = h->dalloc<bf16_t>(LR * H * 128); h->lattn = h->dalloc<bf16_t>(LR * H * 128); h->lact = h->dalloc<bf16_t>(LR * c.llm_ffn);
     h->llast = h->dalloc<bf16_t>((size_t)ns * h->max_beams * DL);
-    h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * 130);
+    h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * ATTN_SLAB);
+    h->attn_cnt = h->dalloc<int>(64, true);  // arrival counters of the in-kernel split-KV combine (llm_attn.hip), one per kv head; zero between launches
     h->lslab = h->dalloc<float>((size_t)LLM_SLAB_ROWS * std::max(DL, (H + 2 * KV) * 128));
     const size_t NB = (size_t)ns * h->max_beams;  // decode rows of a beam step
     h->logits = h->dalloc<float>(NB * h->vocab_pad);
@@ -981,15 +993,26 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
             }
         }
+        // one or two decode rows: no combine launch -- o_proj merges the split-KV partials while it stages its A row (gemm.hip AMODE 3)
+        int merge_splits = 0;
+        const bool merge_in_oproj = h->fuse_combine && !h->inline_combine && so == 1 && rows <= ATTN_MERGE_MAX_ROWS && n_units == 0 && n_beam_wgs == 0;
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
-                                 max_unit_groups, n_beam_wgs));
+                                 max_unit_groups, n_beam_wgs, merge_in_oproj ? &merge_splits : nullptr, h->inline_combine ? h->attn_cnt : nullptr));
         if (so > 1) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
             CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
         } else {
-            CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
+            if (merge_splits > 0) {
+                GemmArgs g{};
+                g.A = h->lattn; g.lda = H * 128; g.Wp = L.o.wp; g.res = h->lx; g.ldres = DL; g.out = h->lx; g.ldo = DL;
+                g.M = rows; g.N = L.o.N; g.K = L.o.K; g.batch = 1; g.epi = EPI_RES; g.n_valid = L.o.n_valid;
+                g.attn_partial = h->lpartial; g.attn_splits = merge_splits;
+                CHK(launch_gemm(g, st));
+            } else {
+                CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
+            }
             if (fuse) {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (h->prof_on && rows == 1) {  // the roofline kernel: one-token gate/up GEMV with the fused RMSNorm
@@ -1934,7 +1957,7 @@ extern "C" int isst_op_llm_attention(const uint16_t* qkv, int rows, int pos0, ui
     unsigned char* meta = nullptr;
     float* partial = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&meta), meta_bytes) != hipSuccess) return ISST_ERR_NOMEM;
-    if (hipMalloc(reinterpret_cast<void**>(&partial), sizeof(float) * (size_t)rows * heads * (slots / 64) * 130) != hipSuccess) { (void)hipFree(meta); return ISST_ERR_NOMEM; }
+    if (hipMalloc(reinterpret_cast<void**>(&partial), sizeof(float) * (size_t)rows * heads * (slots / 64) * ATTN_SLAB) != hipSuccess) { (void)hipFree(meta); return ISST_ERR_NOMEM; }
     int rc = hipMemcpy(meta, hostm.data(), meta_bytes, hipMemcpyHostToDevice) == hipSuccess ? ISST_OK : ISST_ERR_HIP;
     const LlmStreamView* dv = reinterpret_cast<const LlmStreamView*>(meta + off_view);
     if (rc == ISST_OK && rot_keys && pos0 > 0) rc = launch_llm_rope_cache(dv, 1, rope_cos, rope_sin, kpool, krpool, d, 1, st);
@@ -1959,4 +1982,20 @@ extern "C" int isst_op_splice_map(const int* ids, int len, int user_id, int assi
     *n_rows = (int)desc.size();  // <= len
     std::memcpy(row_src, desc.data(), sizeof(int) * desc.size());
     return ISST_OK;
+}
+
+// split-KV merge, as the combine launch and as the o_proj GEMV's A-staging prologue (parity test: the two must give the same bits)
+extern "C" int isst_op_attn_combine(const float* partial, uint16_t* out, int heads, int rows, int n_splits, void* hip_stream) {
+    if (!partial || !out) return ISST_ERR_ARG;
+    return launch_llm_attn_combine(partial, out, heads, rows, n_splits, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_gemm_attn_merge(const float* partial, int n_splits, const uint16_t* packed, const uint16_t* res, int64_t ldres, uint16_t* out,
+                                       int64_t ldo, int M, int N, int K, void* hip_stream) {
+    if (!partial || !packed || !out) return ISST_ERR_ARG;
+    GemmArgs g{};
+    g.lda = K; g.Wp = packed; g.res = res; g.ldres = ldres; g.out = out; g.ldo = ldo;
+    if (!res) return ISST_ERR_ARG;
+    g.M = M; g.N = round_up(N, 16); g.K = K; g.batch = 1; g.epi = EPI_RES; g.n_valid = N;
+    g.attn_partial = partial; g.attn_splits = n_splits;
+    return launch_gemm(g, reinterpret_cast<hipStream_t>(hip_stream));
 }

@@ -92,8 +92,12 @@ __device__ __forceinline__ u32x4_t load_w(const u32x4_t* p) {
 // AMODE 2: as 1, and the staged rows are RMS-normalised in LDS ([3P] HF LlamaRMSNorm: var = mean(x^2) in fp32;
 //          bf16(x * rsqrt(var + eps)); bf16(weight * that)) -- removes the separate norm launch in front of the q/k/v,
 //          gate/up and lm_head projections (pure launch latency at M = 1).
-template <int MT, int NTB, int EPI, bool NT, int AMODE, int DEPTH>
-__global__ void gemm_skinny_kernel(GemmArgs g) {
+// AMODE 3: as 1, but the staged rows do not exist in memory yet: they are the Llama attention output, merged here from the split-KV
+//          partials of llm_attn_partial_kernel (GemmArgs::attn_partial; common.h attn_merge_pair = the combine kernel's arithmetic) while
+//          the weight ring is in flight -- o_proj at one or two decode rows; removes the combine launch between attention and o_proj
+//          (4.75 us + a 2.6 us gap per layer and pass, profiles/r01/trace_busy_v9.txt).
+template <int MT, int NTB, int EPI, bool NT, int AMODE, int DEPTH, int MS = 0>  // MS: AMODE 3's unroll bound of the split-KV merge (>= attn_splits)
+__global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(GemmArgs g) {
     constexpr int UNR = (MT * NTB >= 8) ? 1 : GEMM_UNR;  // (4 m-tiles x the SwiGLU pair: the two-k-tile stage spilled)
     // AMODE 0: the reduction buffer [W][MT*NTB*4][64].  AMODE >= 1: the staged A rows [M][K] + [W] partial sums during the k-loop;
     // the reduction buffer then REUSES the same bytes (one more barrier) -- kept apart, 4 rows needed 41 KB per workgroup: 3 instead
@@ -159,7 +163,23 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
     // the first group of the first round (for one stream: everything) is requested BEFORE the weight ring, so that waiting for it
     // leaves the ring in flight (vmcnt counts in order); the norm weight comes with it instead of after the first barrier
     u32x4_t xv0[4], nw0[4];
-    if constexpr (AMODE >= 1) {
+    // AMODE 3: wave w merges heads w, w + W, ..: 64 lanes x 2 dims = one head's 128 outputs.  The loads of the wave's first NH heads (all of
+    // them at 32 heads on 8 waves; 2 + 2 MS registers per head and lane, which is why this instance is bounded to 512 threads: 256 VGPRs)
+    // go out BEFORE the weight ring: vmcnt counts in order, so waiting for them leaves the ring in flight, and the merge arithmetic runs
+    // under the weights' HBM latency
+    constexpr int MS1 = MS > 0 ? MS : 1;
+    constexpr int NH = MS == 0 ? 1 : (MS <= 20 ? 4 : 2);
+    AttnMergeLoads<MS1> mg[NH];
+    if constexpr (AMODE == 3) {
+        const int H = g.K >> 7;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int hh = wave + i * W < H ? wave + i * W : (wave < H ? wave : 0);
+            attn_merge_issue<MS1>(g.attn_partial + ((long)m0 * H + hh) * g.attn_splits * ATTN_SLAB, g.attn_splits, lane, mg[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (AMODE == 1 || AMODE == 2) {
         const bf16_t* xr = A + (long)(m0 + (my_slot < g.M ? my_slot : 0)) * g.lda;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -175,7 +195,23 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    if constexpr (AMODE >= 1) {
+    if constexpr (AMODE == 3) {
+        const int H = g.K >> 7;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int hh = wave + i * W;
+            const uint32_t v = attn_merge_finish<MS1>(mg[i], g.attn_splits, lane);
+            if (hh < H) *reinterpret_cast<uint32_t*>(xs + hh * 128 + 2 * lane) = v;
+        }
+        for (int r = 0; r < g.M; ++r)  // further heads / the second row: one more round trip each (behind the ring)
+            for (int hh = wave + (r == 0 ? NH * W : 0); hh < H; hh += W) {
+                AttnMergeLoads<MS1> m1;
+                attn_merge_issue<MS1>(g.attn_partial + ((long)(m0 + r) * H + hh) * g.attn_splits * ATTN_SLAB, g.attn_splits, lane, m1);
+                *reinterpret_cast<uint32_t*>(xs + (long)r * g.K + hh * 128 + 2 * lane) = attn_merge_finish<MS1>(m1, g.attn_splits, lane);
+            }
+        __syncthreads();
+    }
+    if constexpr (AMODE == 1 || AMODE == 2) {
         float* part = reinterpret_cast<float*>(xs + (long)g.M * g.K);  // [W] partial sums of squares
         auto stage_group = [&](const u32x4_t (&xv)[4], int rr, int c0, float& sq) {
 #pragma unroll
@@ -327,15 +363,15 @@ __global__ void gemm_skinny_kernel(GemmArgs g) {
 }
 
 // tuning overrides for profiles/gemv_sweep.py (0 = heuristic)
-static int g_tune_w = 0, g_force_skinny = 0;
+static int g_tune_w = 0, g_force_skinny = 0, g_tune_merge_w = 0;
 // w: waves per workgroup of the skinny kernel (0 = heuristic, < 0 = never use the mid / tiled kernels); ntb: passed on to gemm_mid (its width / timing knobs)
-void gemm_set_tuning(int w, int ntb) { if (w >= 200000) { gemm_mid_set_min_rows(w - 200000); return; } if (w >= 100000) { gemm_tiled_set_raster(w - 100000); return; } g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
+void gemm_set_tuning(int w, int ntb) { if (w >= 300000) { g_tune_merge_w = w - 300000; return; } if (w >= 200000) { gemm_mid_set_min_rows(w - 200000); return; } if (w >= 100000) { gemm_tiled_set_raster(w - 100000); return; } g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
 
 static inline bool gemm_can_stage(const GemmArgs& g) {
     return g.batch == 1 && g.M <= 16 && (size_t)g.M * g.K * 2 <= 64 * 1024 && g.M <= GEMM_FUSED_NORM_MAX_M;
 }
 
-template <int MT, int EPI, bool NT, int AMODE>
+template <int MT, int EPI, bool NT, int AMODE, int MS = 0>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     const int KT = g.K / 32, NTILES = g.N / 16;
     // NTB: n-tiles per block (SwiGLU needs the (gate, up) pair in one block)
@@ -350,6 +386,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     // 3+ rows through the fused norm (beam search): with 4 waves each wave stages and normalises a whole row (8 chunks per lane, two
     // dependent groups of loads); 8 waves give every row two waves and one group (beam 4: 36.13 -> 35.99 ms per chunk, same box)
     if (AMODE == 2 && g.M > 2 && ntb == 1 && W < 8 && KT >= 64) W = 8;
+    if (AMODE == 3) W = g_tune_merge_w ? (g_tune_merge_w > 8 ? 8 : g_tune_merge_w) : 8;  // 32 heads: 4 per wave, all in flight before the weight ring
     if (g_tune_w) W = g_tune_w;
     while (W > 1 && W > KT) W /= 2;
     while (W > 1 && (size_t)W * MT * ntb * 1024 > 64 * 1024) W /= 2;
@@ -365,11 +402,24 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
         return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
     };
     constexpr int NTB = EPI == EPI_SWIGLU ? 2 : 1;
-    return go(gemm_skinny_kernel<MT, NTB, EPI, NT, AMODE, (AMODE >= 1 ? GEMM_DEPTH_STAGED : GEMM_DEPTH)>);
+    return go(gemm_skinny_kernel<MT, NTB, EPI, NT, AMODE, (AMODE >= 1 ? GEMM_DEPTH_STAGED : GEMM_DEPTH), MS>);
 }
 
 template <int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
+    if (g.attn_partial) {  // o_proj of one or two decode rows with the split-KV merge as its A-staging prologue
+        if constexpr (EPI == EPI_RES) {
+            if (g.batch == 1 && g.M <= ATTN_MERGE_MAX_ROWS && g.K % 128 == 0 && g.attn_splits >= 1 && g.attn_splits <= ATTN_MERGE_MAX_SPLITS && !g.norm_w &&
+                (size_t)g.M * g.K * 2 <= 64 * 1024) {
+                // unroll bound of the merge = registers held per lane while its loads are in flight: the smallest instance that covers the splits
+                if (g.attn_splits <= 8) return launch_cfg<1, EPI, true, 3, 8>(g, stream);
+                if (g.attn_splits <= 16) return launch_cfg<1, EPI, true, 3, 16>(g, stream);
+                if (g.attn_splits <= 20) return launch_cfg<1, EPI, true, 3, 20>(g, stream);
+                return launch_cfg<1, EPI, true, 3, 32>(g, stream);
+            }
+        }
+        return ISST_ERR_ARG;
+    }
     if (g.norm_w) {
         // fused norm: decode shapes only; every block re-normalises its rows, free at M <= 8 and wasteful beyond
         // (callers run the norm kernel first for larger M)
@@ -389,12 +439,12 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
 int launch_gemm(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.batch <= 0) return ISST_OK;
     if (g.K % 32 != 0 || g.N % 16 != 0 || g.lda % 8 != 0) return ISST_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.Wp) & 15)) return ISST_ERR_ARG;
-    if (gemm_mid_supported(g) && gemm_mid_preferred(g) && !g_force_skinny) {
+    if ((!g.attn_partial && (reinterpret_cast<uintptr_t>(g.A) & 15)) || (reinterpret_cast<uintptr_t>(g.Wp) & 15)) return ISST_ERR_ARG;
+    if (!g.attn_partial && gemm_mid_supported(g) && gemm_mid_preferred(g) && !g_force_skinny) {
         if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return ISST_ERR_ARG;
         return launch_gemm_mid(g, stream);
     }
-    if (gemm_tiled_supported(g) && !g_force_skinny) {
+    if (!g.attn_partial && gemm_tiled_supported(g) && !g_force_skinny) {
         const bool ok = (g.epi != EPI_BIAS && g.epi != EPI_BIAS_GELU && g.epi != EPI_BIAS_RES) || g.bias;
         if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return ISST_ERR_ARG;
         if (!ok || ((g.epi == EPI_RES || g.epi == EPI_BIAS_RES) && !g.res) || (g.epi == EPI_SWIGLU && g.N % 32)) return ISST_ERR_ARG;

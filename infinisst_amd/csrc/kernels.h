@@ -76,8 +76,14 @@ struct LlmAttnOne {
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one = nullptr,
-                         const int2* units = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0);  // units[z] = (first group, groups <= 8) of ONE
+                         const int2* units = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0, int* defer_combine = nullptr,
+                         int* arrive_counters = nullptr);
+                         // arrive_counters != null (>= kv_heads zeroed ints): a ONE-group launch combines its splits itself (last-arriver form, llm_attn.hip)
+                         // defer_combine != null: more than one slot split -> NO combine launch, *defer_combine = the split count and `partial` holds the
+                         // (max, sum, O) slabs for the consumer to merge (GemmArgs::attn_partial); one split -> *defer_combine = 0, `out` is written  // units[z] = (first group, groups <= 8) of ONE
                                                                                               // stream: prefill launches share key tiles per unit
+// the combine pass alone: partial [rows][heads][n_splits][2 + 128] fp32 -> out [rows][heads * 128] bf16
+int launch_llm_attn_combine(const float* partial, bf16_t* out, int heads, int rows, int n_splits, hipStream_t s);
 // Rotated-key arena for one chunk: for every listed stream and EVERY layer, krpool[slot] = RoPE(kpool[slot], logical position of the slot)
 // for the `total` cached keys (views[i].new_start = total).  A key's logical position only changes when the host evicts, i.e. between
 // chunks, so the 10 passes of a chunk (and the row groups of its prefill, which would each rotate the same keys again) read keys

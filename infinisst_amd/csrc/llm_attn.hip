@@ -83,10 +83,13 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
                                                                const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
                                                                const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                                                                float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
-                                                               int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct, int n_extra) {
+                                                               int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct, int n_extra,
+                                                               bf16_t* __restrict__ out_final, int* arrive) {
+    // arrive != null (one row group per launch, more than one split): the last workgroup of a kv head to arrive combines the splits itself
     // n_splits: partial slabs per (row, head) = gridDim.x; the last n_extra of them are the per-beam workgroups of the shared-prefix form
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
     __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
+    __shared__ int s_ticket;
     const int sp = blockIdx.x, kvh = blockIdx.y;
     const int2 grp = one.enabled ? one.grp : groups[blockIdx.z];
     const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
@@ -314,28 +317,63 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             for (int r = 0; r < 4; ++r) oS[wave][ct * 16 + 4 * fq + r][16 * nt + fr] = o[ct][nt][r];
     }
     __syncthreads();
-    for (int e = tid; e < ncols * HD; e += 256) {
-        const int c = e / HD, dd = e % HD;
+    // four dims per thread: a slab leaves the workgroup as whole 16-byte stores
+    const bool inline_combine = arrive != nullptr && !out_direct;
+    for (int e = tid; e < ncols * (HD / 4); e += 256) {
+        const int c = e / (HD / 4), d4 = (e % (HD / 4)) * 4;
         float M = -INFINITY;
 #pragma unroll
         for (int w = 0; w < 4; ++w) M = fmaxf(M, mS[w][c]);
-        float L = 0.f, O = 0.f;
+        float L = 0.f;
+        f32x4_t O = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const float mw = mS[w][c];
             const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
             L += lS[w][c] * f;
-            O += oS[w][c][dd] * f;
+            const f32x4_t ov = *reinterpret_cast<const f32x4_t*>(&oS[w][c][d4]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) O[q] += ov[q] * f;
         }
         const int row = r0 + c / G, head = kvh * G + c % G;
-        if (out_direct) {  // a single split: this IS the attention output (llm_attn_combine_kernel's arithmetic for one slab)
-            out_direct[((long)row * H + head) * HD + dd] = f2bf(O / L);
+        if (out_direct) {  // a single split: this IS the attention output (the combine's arithmetic for one slab)
+            u32x2_t pk;
+            pk.x = pack_bf(O[0] / L, O[1] / L);
+            pk.y = pack_bf(O[2] / L, O[3] / L);
+            *reinterpret_cast<u32x2_t*>(out_direct + ((long)row * H + head) * HD + d4) = pk;
         } else {
-            float* dst = partial + (((long)row * H + head) * n_splits + sp) * (2 + HD);
-            if (dd == 0) { dst[0] = M; dst[1] = L; }
-            dst[2 + dd] = O;
+            float* dst = partial + (((long)row * H + head) * n_splits + sp) * ATTN_SLAB;
+            const u32x4_t ob = __builtin_bit_cast(u32x4_t, O);
+            u32x4_t sb;
+            sb.x = __float_as_uint(M); sb.y = __float_as_uint(L); sb.z = 0u; sb.w = 0u;
+            if (inline_combine) {  // write-through (sc1): the reducing workgroup may sit on another XCD, whose L2 never sees this one's lines
+                const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc(dst, 0, ATTN_SLAB * 4, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(ob, ds, (unsigned)d4 * 4u, 0, 16);
+                if (d4 == 0) __builtin_amdgcn_raw_buffer_store_b128(sb, ds, HD * 4u, 0, 16);
+            } else {
+                *reinterpret_cast<u32x4_t*>(dst + d4) = ob;
+                if (d4 == 0) *reinterpret_cast<u32x4_t*>(dst + HD) = sb;
+            }
         }
     }
+    if (!inline_combine) return;
+    // ---- in-launch combine (cdna_hip_programming.md Guideline 16, the counter form; MI355X_MICROARCH.md visibility table, row 1): every slab byte
+    //      was stored sc1; every storing wave drains its stores; after the workgroup's barrier ONE lane adds to the (kv head's) arrival counter at
+    //      agent scope; the workgroup whose add returns n_splits - 1 is the last arriver: it alone reads all the slabs of its columns, with sc1
+    //      loads only (nothing here reads them through L1), merges them (common.h attn_merge_*: the combine kernel's arithmetic) and writes the
+    //      attention output.  It also re-arms the counter: launches are stream-ordered, the next one finds 0 ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(arrive + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != n_splits - 1) return;
+    for (int c = wave; c < ncols; c += 4) {
+        const int row = r0 + c / G, head = kvh * G + c % G;
+        AttnMergeLoads<ATTN_MERGE_MAX_SPLITS> ld;
+        attn_merge_issue<ATTN_MERGE_MAX_SPLITS, 16>(partial + ((long)row * H + head) * n_splits * ATTN_SLAB, n_splits, lane, ld);
+        *reinterpret_cast<uint32_t*>(out_final + ((long)row * H + head) * HD + 2 * lane) = attn_merge_finish<ATTN_MERGE_MAX_SPLITS>(ld, n_splits, lane);
+    }
+    if (tid == 0) __hip_atomic_store(arrive + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -549,47 +587,26 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64) void llm_attn_prefill_kerne
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) out_direct[((long)row * H + head) * HD + 16 * nt + fr] = f2bf(o[nt][r] / Lr[r]);
         } else {
-            float* dst = partial + (((long)row * H + head) * n_splits + sp) * (2 + HD);
-            if (fr == 0) { dst[0] = Mr[r]; dst[1] = Lr[r]; }
+            float* dst = partial + (((long)row * H + head) * n_splits + sp) * ATTN_SLAB;
+            if (fr == 0) { dst[HD] = Mr[r]; dst[HD + 1] = Lr[r]; }
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) dst[2 + 16 * nt + fr] = o[nt][r];
+            for (int nt = 0; nt < 8; ++nt) dst[16 * nt + fr] = o[nt][r];
         }
     }
 }
 
-// Combine of the split partials (a separate launch on purpose, see the header).  All split loads are issued before
-// the first use (fully unrolled, predicated): two memory round trips instead of one per split.
-template <int COMBINE_MAX_SPLITS>  // splits read per trip: 4 (many streams, long spans) or 32 (one stream, 64-slot spans)
-__global__ __launch_bounds__(128) void llm_attn_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int heads,
-                                                               int n_splits) {
-    const int h = blockIdx.x, r = blockIdx.y, dd = threadIdx.x;
-    const float* src = partial + ((long)r * heads + h) * n_splits * (2 + HD);
-    float M = -INFINITY, L = 0.f, O = 0.f;
-    for (int s0 = 0; s0 < n_splits; s0 += COMBINE_MAX_SPLITS) {  // one trip in either configuration (<= 2048 slots)
-        float ms[COMBINE_MAX_SPLITS], ls[COMBINE_MAX_SPLITS], os[COMBINE_MAX_SPLITS];
-#pragma unroll
-        for (int s = 0; s < COMBINE_MAX_SPLITS; ++s) {
-            const bool ok = s0 + s < n_splits;
-            const float* p = src + (long)(ok ? s0 + s : 0) * (2 + HD);
-            ms[s] = ok ? p[0] : -INFINITY;
-            ls[s] = p[1];
-            os[s] = p[2 + dd];
-        }
-        float Mn = M;
-#pragma unroll
-        for (int s = 0; s < COMBINE_MAX_SPLITS; ++s) Mn = fmaxf(Mn, ms[s]);
-        const float f0 = (M == -INFINITY) ? 0.f : expf(M - Mn);
-        L *= f0;
-        O *= f0;
-#pragma unroll
-        for (int s = 0; s < COMBINE_MAX_SPLITS; ++s) {
-            const float w = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - Mn);  // -inf: split without a live key for this row
-            L += ls[s] * w;
-            O += os[s] * w;
-        }
-        M = Mn;
-    }
-    out[((long)r * heads + h) * HD + dd] = f2bf(O / L);
+// Combine of the split partials as a launch of its own (many rows; one decode row merges inside the o_proj GEMV instead: gemm.hip AMODE 3).
+// All split loads are issued before the first use (fully unrolled, predicated): two memory round trips instead of one per split.
+__global__ __launch_bounds__(64) void llm_attn_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out, int heads, int n_splits) {
+    const int h = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const float* src = partial + ((long)r * heads + h) * n_splits * ATTN_SLAB;
+    *reinterpret_cast<uint32_t*>(out + ((long)r * heads + h) * HD + 2 * lane) = attn_merge_pair(src, n_splits, lane);
+}
+
+int launch_llm_attn_combine(const float* partial, bf16_t* out, int heads, int rows, int n_splits, hipStream_t s) {
+    if (n_splits < 1 || n_splits > ATTN_MERGE_MAX_SPLITS) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(llm_attn_combine_kernel, dim3(heads, rows), dim3(64), 0, s, partial, out, heads, n_splits);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
 // ---- rotated-key arena fill (once per chunk): one wave per 16-slot tile, same lane -> key mapping and rotation as above ----
@@ -633,15 +650,15 @@ template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                     int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                     float* partial, LlmAttnDims d, int layer, int n_splits, int tiles_per_split, hipStream_t s, const LlmAttnOne& one, bf16_t* out_direct,
-                    int n_extra) {
+                    int n_extra, bf16_t* out_final, int* arrive) {
     dim3 grid(n_splits, d.kv_heads, n_groups), block(256);  // n_splits includes the n_extra per-beam workgroups
     if (max_group_rows * G > 16) return ISST_ERR_ARG;  // one 16-column tile per workgroup (LLM_ATTN_GROUP_ROWS(G) rows)
     if (tiles_per_split > 4)
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, true>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct, n_extra);
+                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct, n_extra, out_final, arrive);
     else
         hipLaunchKernelGGL((llm_attn_partial_kernel<G, 1, false>), grid, block, 0, s, qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool,
-                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct, n_extra);
+                           krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, out_direct, n_extra, out_final, arrive);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
@@ -657,7 +674,7 @@ static int launch_prefill_g(const bf16_t* qkv, const int* row_stream, const int*
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
                          int n_groups, int max_group_rows, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one, const int2* units,
-                         int n_units, int max_unit_groups, int n_beam_wgs) {
+                         int n_units, int max_unit_groups, int n_beam_wgs, int* defer_combine, int* arrive_counters) {
     if (rows <= 0 || n_groups <= 0) return ISST_OK;
     LlmAttnOne one1{};
     if (one && one->enabled && n_groups == 1) one1 = *one;
@@ -670,12 +687,14 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     const int target = g_attn_target_wgs > 0 ? g_attn_target_wgs : (n_groups <= 4 ? 2 * LLM_ATTN_TARGET_WGS : LLM_ATTN_TARGET_WGS);
     int rc;
     int n_splits;
+    bool inline_combine = false;
     if (units && n_units > 0 && max_group_rows > 1) {
         // prefill: a unit (<= 8 row groups of one stream) shares every key tile through LDS (llm_attn_prefill_kernel)
         if (max_unit_groups < 1 || max_unit_groups > PREFILL_MAX_WAVES || max_group_rows * G > 16) return ISST_ERR_ARG;
         const int ptarget = g_attn_prefill_target_wgs > 0 ? g_attn_prefill_target_wgs : LLM_ATTN_PREFILL_TARGET_WGS;
         n_splits = (ptarget + d.kv_heads * n_units - 1) / (d.kv_heads * n_units);
         n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
+        if (n_splits > ATTN_MERGE_MAX_SPLITS) n_splits = ATTN_MERGE_MAX_SPLITS;  // (very long caches: longer spans instead of more slabs)
         const int tiles_per_split = (total_tiles + n_splits - 1) / n_splits;
         n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
         const int waves = max_unit_groups < 2 ? 2 : max_unit_groups;
@@ -692,23 +711,33 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
         // (many streams: the per-workgroup prologue, LDS merge and slab traffic are amortised over more keys)
         n_splits = (target + d.kv_heads * n_groups - 1) / (d.kv_heads * n_groups);
         n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
+        if (n_splits + n_beam_wgs > ATTN_MERGE_MAX_SPLITS) n_splits = ATTN_MERGE_MAX_SPLITS - n_beam_wgs;
         const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
         n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
         // shared-prefix beam groups (LlmStreamView::n_beams): one more workgroup (and partial slab) per beam (each of its waves takes one tile,
         // in either form of the kernel)
         n_splits += n_beam_wgs;
+        // one row group (one stream's decode step) whose workgroups all fit the chip at one per CU: the last workgroup of a kv head to arrive
+        // combines the splits inside this launch -- no combine launch, no boundary (the hand-off form this is measured for: one workgroup per CU)
+        int hip_cus = 256;
+        inline_combine = arrive_counters != nullptr && n_groups == 1 && n_beam_wgs == 0 && n_splits > 1 && d.kv_heads <= 64 && n_splits * d.kv_heads <= hip_cus;
+        bf16_t* od = n_splits == 1 ? out : nullptr;
+        int* arr = inline_combine ? arrive_counters : nullptr;
         switch (G) {
-            case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr, n_beam_wgs); break;
-            case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr, n_beam_wgs); break;
-            case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, n_splits == 1 ? out : nullptr, n_beam_wgs); break;
+            case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_beam_wgs, out, arr); break;
+            case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_beam_wgs, out, arr); break;
+            case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_beam_wgs, out, arr); break;
             default: return ISST_ERR_ARG;
         }
     }
     if (rc != ISST_OK) return rc;
-    if (n_splits == 1) return ISST_OK;  // the attention kernel wrote the output itself
-    if (n_splits <= 4)
-        hipLaunchKernelGGL(llm_attn_combine_kernel<4>, dim3(d.heads, rows), dim3(HD), 0, s, partial, out, d.heads, n_splits);
-    else
-        hipLaunchKernelGGL(llm_attn_combine_kernel<32>, dim3(d.heads, rows), dim3(HD), 0, s, partial, out, d.heads, n_splits);
+    if (defer_combine) *defer_combine = 0;
+    if (n_splits == 1 || inline_combine) return ISST_OK;  // the attention kernel wrote the output itself
+    if (n_splits > ATTN_MERGE_MAX_SPLITS) return ISST_ERR_ARG;  // (<= 2048 slots)
+    if (defer_combine) {  // the caller's o_proj GEMV merges the partials while it stages its A row (gemm.hip AMODE 3): no combine launch
+        *defer_combine = n_splits;
+        return ISST_OK;
+    }
+    hipLaunchKernelGGL(llm_attn_combine_kernel, dim3(d.heads, rows), dim3(64), 0, s, partial, out, d.heads, n_splits);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }

@@ -329,3 +329,40 @@ def test_rotated_key_arena_is_bit_identical_to_rotate_on_read(monkeypatch):
     for (ia, la), (ib, lb) in zip(a, b):
         assert ia == ib
         assert np.array_equal(la, lb)
+
+
+def test_inline_split_kv_combine_is_bit_identical_to_the_combine_launch(monkeypatch):
+    """One-stream decode steps combine their split-KV partials INSIDE the attention launch (last-arriver form: write-through slabs, drained,
+    agent-scope arrival counter per kv head, sc1 reads -- csrc/llm_attn.hip).  Against ISST_INLINE_COMBINE=0 (the combine as its own launch):
+    identical logits bit for bit over 12 chunks x 8 passes x 2 layers x 2 kv heads of hand-offs, with evictions, at a cache long enough for
+    several slot splits.  A stale or torn slab would show up as a differing logit."""
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=8, max_llm_cache_size=500)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=71)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 12, stream_id=5)
+    sys_n = len(synth.system_prompt_ids(cfg))
+
+    def run(flag):
+        monkeypatch.setenv("ISST_INLINE_COMBINE", flag)
+        eng = make_engine(cfg, w, debug_taps=False, max_llm_cache_size=500, max_streams=1)
+        sid = eng.open_stream()
+        outs, logs, ckpts = [], [], []
+        for c in range(12):
+            seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+            o, l = eng.generate(gen, [sid], [seg], [synth.chunk_prompt_ids(cfg, 1, first=(c == 0))], [[]],
+                                system_prompt_size=sys_n if c == 0 else 0, return_logits=True)
+            outs.append(o[0])
+            logs.append(l[0][:len(o[0])].copy())
+            cur = eng.stream_info(sid)["llm_cache_len"]
+            ckpts.append(cur)
+            ev = oag.evict(ckpts, cur, 200, True, sys_n)
+            if ev is not None:
+                ckpts, new_size = ev
+                eng.kv_evict(sid, new_size, sys_n)
+        eng.close()
+        return outs, logs
+
+    (oa, la), (ob, lb) = run("1"), run("0")
+    assert oa == ob
+    for c, (x, y) in enumerate(zip(la, lb)):
+        assert np.array_equal(x, y), f"chunk {c}: logits differ between the in-launch combine and the combine launch"

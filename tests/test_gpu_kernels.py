@@ -338,3 +338,34 @@ def test_gemm_splitk_layernorm(M, N, K, ks):
     close_bf16(x_new, ref_linear(A, W, "bias_res", bias, x), f"splitk-ln x M{M}", ulps=2.5, atol=3.2e-2)
     ref_ln = torch.nn.functional.layer_norm(x_new.float().cpu(), (N,), lw.float(), lb.float(), 1e-5)
     close_bf16(normed, bf(ref_ln), f"splitk-ln norm M{M}", ulps=2.0, atol=4e-3)
+
+
+def test_split_kv_merge_fused_into_oproj_equals_combine_then_gemm():
+    """The flash-decoding merge of the decode attention's split-KV partials exists in three places that must agree bit for bit (one
+    definition: csrc/common.h attn_merge_*): the combine launch, the o_proj GEMV's merge-on-load prologue (gemm.hip AMODE 3) and -- compared
+    end to end in test_gpu_engine -- the attention kernel's own last-arriver combine.  Here: combine + GEMV against the fused GEMV, and the
+    combine against a straightforward fp32 restatement (softmax re-weighting of the partial outputs)."""
+    torch.manual_seed(0)
+    H, S, K, N = 8, 19, 1024, 512
+    part = torch.randn(2, H, S, 132, device="cuda")
+    part[..., 128] *= 3.0                       # running max of each split
+    part[..., 129] = part[..., 129].abs() + 0.5  # sum of each split
+    part[0, 3, 5:, 128] = float("-inf")          # splits without a live key for a row (weight 0)
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    packed = E.op_pack_weight(w)
+    res = torch.randn(2, N, device="cuda").bfloat16()
+    lib = E.load_library()
+    P = E._ptr
+    for M in (1, 2):
+        attn = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+        assert lib.isst_op_attn_combine(P(part), P(attn), H, M, S, E._stream_ptr()) == 0
+        m, l, o = part[:M, :, :, 128].double(), part[:M, :, :, 129].double(), part[:M, :, :, :128].double()
+        wgt = torch.exp(m - m.max(dim=-1, keepdim=True).values)
+        ref = (o * wgt.unsqueeze(-1)).sum(2) / (l * wgt).sum(-1, keepdim=True)
+        d = (attn.view(M, H, 128).double() - ref).abs().max().item()
+        assert d <= 0.01 * ref.abs().max().item() + 1e-3, d
+        sep = E.op_gemm(attn, packed, N, "res", res=res[:M].contiguous())
+        fused = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        assert lib.isst_op_gemm_attn_merge(P(part), S, P(packed), P(res), N, P(fused), N, M, N, K, E._stream_ptr()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(sep, fused), f"M={M}: merge-on-load differs from combine + GEMV"
