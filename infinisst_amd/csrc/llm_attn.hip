@@ -109,8 +109,15 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     bf16_t* vb = vtpool + base;   // [slots][128] row per key, like K
     const int total = (one.enabled ? one.pos0 + nrows - 1 : row_pos[r0 + nrows - 1]) + 1;  // keys visible to the last row of the group
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
-    // this wave's 16-slot tiles: tile_begin + wave, + 4, ... below tile_end
-    int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, slots >> 4);
+    // Tiles are walked in a COMPACT index space that holds only the tiles with a live slot: [pinned prefix tiles | ring tiles from the one that
+    // holds ring_start on, as many as the live span touches].  The arena is sized for max_llm_cache_size + a chunk + slack, the steady-state
+    // cache fills ~85 % of it, and a dead tile costs the same 8 KB of loads as a live one (64 streams: 318 MB per launch instead of 272).
+    // this wave's tiles: compact indices tile_begin + wave, + 4, ... below tile_end
+    const int sys_tiles = (v.sys_len + 15) >> 4, ring_tiles = d.ring_cap >> 4, ring_tile0 = v.ring_start >> 4;
+    const int ring_len = total - v.sys_len;
+    const int ring_live = ring_len > 0 ? min(ring_tiles, ((v.ring_start & 15) + ring_len + 15) >> 4) : 0;
+    const int live_tiles = sys_tiles + ring_live;
+    int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, live_tiles);
     if (tailwg) {  // the (<= 4, host-checked) ring tiles that hold logical positions tail_start .. total-1: wave w takes the w-th
         const int ring_tiles = d.ring_cap >> 4, ring_tile0 = d.sys_cap >> 4;
         const int s_first = (v.ring_start + (v.tail_start - v.sys_len)) % d.ring_cap, s_last = (v.ring_start + (total - 1 - v.sys_len)) % d.ring_cap;
@@ -120,6 +127,14 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         tile_begin = mine - wave;  // t = tile_begin + wave below
         tile_end = wave < n_tail ? mine + 1 : mine;
     }
+    // compact index -> physical 16-slot tile (the per-beam tail workgroups address physical tiles directly)
+    auto phys = [&](int tc) -> int {
+        if (tailwg) return tc;
+        if (tc < sys_tiles) return tc;
+        int r = ring_tile0 + (tc - sys_tiles);
+        if (r >= ring_tiles) r -= ring_tiles;
+        return (d.sys_cap >> 4) + r;
+    };
 
     // ---- rotated query fragments: B[k = dim][n = column c], c = ct*16 + fr -> (row r0 + c / G, head kvh*G + c % G) ----
     u32x4_t qf[CT][4];
@@ -150,7 +165,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 
     // this lane's key of tile t as an A-operand row (slot 16 t + fr): source row (arena, or the qkv rows for keys written by
     // this launch) and logical position
-    auto key_src = [&](int t, int& jk, bool& k_new) -> const bf16_t* {
+    auto key_src = [&](int tp, int& jk, bool& k_new) -> const bf16_t* {  // tp: physical tile
+        const int t = tp;
         jk = llm_logical(v, d, t * 16 + fr, total);
         k_new = jk >= 0 && jk >= v.new_start;
         return k_new ? qkv + (long)(v.row0 + beam + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(t * 16 + fr) * HD;
@@ -180,25 +196,26 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     // MULTI: the next tile's key and value rows go in flight before this tile's arithmetic.  The prefetch is unconditional, clamped
     // to the wave's last tile (slots % 64 == 0 gives every wave the same tile count): a conditional load makes hipcc branch around it
     // and drain vmcnt(0).
-    const int t_last = tailwg ? t : tile_end - 4 + wave;
+    const int n_mine = tile_end > tile_begin + wave ? (tile_end - tile_begin - wave + 3) >> 2 : 0;  // (compact spans need not be multiples of 4)
+    const int t_last = tailwg ? t : tile_begin + wave + 4 * (n_mine - 1);
     u32x4_t vraw_n[4];
     if (t < tile_end) {
-        const bf16_t* src = key_src(t, jk_n, knew_n);
+        const bf16_t* src = key_src(phys(t), jk_n, knew_n);
 #pragma unroll
         for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-        const bf16_t* vs = val_src(t, jk_n, knew_n);
+        const bf16_t* vs = val_src(phys(t), jk_n, knew_n);
 #pragma unroll
         for (int s = 0; s < 4; ++s) vraw_n[s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
     }
     auto tile_body = [&]() {
-        const int t0 = t * 16;
+        const int t0 = phys(t) * 16;
         const int jk = jk_n;
         const bool k_new = knew_n;
         u32x4_t kraw[4], vraw[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { kraw[s] = kraw_n[s]; vraw[s] = vraw_n[s]; }
         if constexpr (MULTI) {
-            const int tn = min(t + 4, t_last);
+            const int tn = phys(min(t + 4, t_last));
             const bf16_t* src = key_src(tn, jk_n, knew_n);
 #pragma unroll
             for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
