@@ -292,9 +292,17 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             l_run[ct] = l_run[ct] * resc + ls;
             m_run[ct] = m_new;
             // O rows are columns 4 fq + r: fetch their factors from the lanes that hold those columns' statistics
-            float rs[4];
+            if constexpr (MULTI) {  // rescale only when some column's running max moved (wave-uniform; x * 1.0f is exact: no bit changes)
+                if (__any(resc != 1.0f)) {
+                    float rs[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rs[r] = __shfl(resc, 4 * fq + r, WAVE);
+                    for (int r = 0; r < 4; ++r) rs[r] = __shfl(resc, 4 * fq + r, WAVE);
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[ct][nt][r] *= rs[r];
+                }
+            }
             // P (bf16) in the C layout == A operand of the 16x16x16 product: A[row = column fr][k = key 4fq + j]
             u32x2_t pp;
             pp.x = pack_bf(p[0], p[1]);
@@ -309,14 +317,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
                                                              (__attribute__((address_space(3))) s16x4_t*)(vimg + vr_off[nt])));
             }
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                f32x4_t acc = o[ct][nt];
-                if constexpr (MULTI) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] *= rs[r];
-                }
-                o[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf[nt]), acc, 0, 0, 0);
-            }
+            for (int nt = 0; nt < 8; ++nt)
+                o[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf[nt]), o[ct][nt], 0, 0, 0);
         }
     };
     if constexpr (MULTI) {
@@ -403,14 +405,19 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 // no cross-wave merge; with a single split it writes the attention output itself.
 // ------------------------------------------------------------------------------------------------------------------------
 #define PREFILL_MAX_WAVES 8
+#define PF_ST 4  // key / value tiles per staged step (2 loader waves each)
 #define LLM_ATTN_PREFILL_TARGET_WGS 512
 template <int G>
-__global__ __launch_bounds__(PREFILL_MAX_WAVES * 64) void llm_attn_prefill_kernel(
+__global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_kernel(  // (2 workgroups per CU: 128 VGPRs, 2 x 64 KB of LDS)
     const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream, const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
     const int2* __restrict__ groups, const int2* __restrict__ units, const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
     bf16_t* kpool, bf16_t* krpool, bf16_t* vpool, float* __restrict__ partial, bf16_t* __restrict__ out_direct, LlmAttnDims d, int layer,
     int n_splits, int tiles_per_split) {
-    __shared__ __attribute__((aligned(16))) unsigned char kimg[2][4096], vimg[2][4096];  // [buffer][16 keys][128 dims], swizzled 16-byte chunks
+    // [buffer][tile of the stage][16 keys][128 dims], swizzled 16-byte chunks.  A STAGE is PF_ST consecutive live tiles: every one of the 8 waves is a
+    // loader (wave w: keys (even w) or values (odd w) of the stage's tile w >> 1), so a workgroup keeps 8 x 4 KB of loads in flight -- with one tile
+    // per barrier (2 loader waves, 8 KB in flight per workgroup) 512 workgroups had 4 MB in flight chip-wide and the kernel sat on the memory
+    // LATENCY: 272 MB in 197 us = 1.4 TB/s at 64 streams (profiles/r02/bench_kernel_stats_prof64.csv)
+    __shared__ __attribute__((aligned(16))) unsigned char kimg[2][PF_ST][4096], vimg[2][PF_ST][4096];
     const int sp = blockIdx.x, kvh = blockIdx.y;
     const int2 unit = units[blockIdx.z];  // (first group, number of groups)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -429,7 +436,17 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64) void llm_attn_prefill_kerne
     bf16_t* vb = vpool + base;
     const bool rot = v.rot_keys != 0;
     const float scale = 0.08838834764831845f;
-    const int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, slots >> 4);
+    // tiles are walked in the compact index space of the tiles that hold a live slot (see llm_attn_partial_kernel)
+    const int sys_tiles = (v.sys_len + 15) >> 4, ring_tiles = d.ring_cap >> 4, ring_tile0 = v.ring_start >> 4;
+    const int ring_len = total_u - v.sys_len;
+    const int ring_live = ring_len > 0 ? min(ring_tiles, ((v.ring_start & 15) + ring_len + 15) >> 4) : 0;
+    const int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, sys_tiles + ring_live);
+    auto phys = [&](int tc) -> int {
+        if (tc < sys_tiles) return tc;
+        int r = ring_tile0 + (tc - sys_tiles);
+        if (r >= ring_tiles) r -= ring_tiles;
+        return (d.sys_cap >> 4) + r;
+    };
     const bool active = wave < unit.y;  // waves beyond the unit's groups only take part in the barriers
     const int2 grp = groups[unit.x + (active ? wave : 0)];
     const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
@@ -461,134 +478,139 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64) void llm_attn_prefill_kerne
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) o[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // ---- loader roles: wave 0 stages keys, wave 1 stages values (the launch always has at least two waves) ----
-    const bool load_k = wave == 0;
-    // staging is split in two so that a tile's global loads are in flight for a whole iteration: fetch(t) issues them into
-    // registers, commit(buf) -- one iteration later -- rotates / appends / writes the LDS images
-    u32x4_t raw[4];
-    int f_t0 = 0, f_jk = -1;
-    bool f_new = false;
-    auto fetch = [&](int t) {
-        f_t0 = t * 16;
-        f_jk = llm_logical(v, d, f_t0 + fr, total_u);
-        f_new = f_jk >= 0 && f_jk >= v.new_start;
-        const int krow = v.row0 + (f_jk - v.new_start);
+    // ---- loader roles (the launch always has 8 waves): wave w stages keys (even) or values (odd) of the stage's tile w >> 1 ----
+    const bool load_k = (wave & 1) == 0;
+    const int my_slot = wave >> 1;
+    // staging is split in two so that a tile's global loads are in flight for a whole stage: fetch issues them into registers, commit -- one
+    // stage later -- rotates / appends / writes the LDS images.  (A second register set, two stages in flight, needs 162 VGPRs: one workgroup
+    // per CU instead of two, 170 us against 137 us per launch at 64 streams; squeezed into 128 VGPRs it spills 72.)
+    struct Fetch { u32x4_t raw[4]; int t0, jk; bool is_new, valid; };
+    Fetch F0;
+    F0.valid = false; F0.t0 = 0; F0.jk = -1; F0.is_new = false;
+    auto fetch = [&](int stage_first, Fetch& f) {  // this wave's tile of the stage that starts at compact index stage_first
+        const int tc = stage_first + my_slot;
+        f.valid = tc < tile_end;
+        f.t0 = phys(f.valid ? tc : tile_begin) * 16;
+        f.jk = llm_logical(v, d, f.t0 + fr, total_u);
+        f.is_new = f.jk >= 0 && f.jk >= v.new_start;
+        const int krow = v.row0 + (f.jk - v.new_start);
         const bf16_t* src;
-        if (load_k) src = f_new ? qkv + (long)krow * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(f_t0 + fr) * HD;
-        else src = f_new ? qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD : vb + (long)(f_t0 + fr) * HD;
+        if (load_k) src = f.is_new ? qkv + (long)krow * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(f.t0 + fr) * HD;
+        else src = f.is_new ? qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD : vb + (long)(f.t0 + fr) * HD;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) raw[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+        for (int s = 0; s < 4; ++s) f.raw[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
     };
-    auto commit = [&](int buf) {
-        const int krow = v.row0 + (f_jk - v.new_start);
-        const bool mine = f_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;  // a key of this unit's own rows: append it
+    auto commit = [&](int buf, const Fetch& f) {
+        if (!f.valid) return;  // (wave-uniform)
+        const int krow = v.row0 + (f.jk - v.new_start);
+        const bool mine = f.is_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;  // a key of this unit's own rows: append it
         if (load_k) {
             u32x4_t kf[4];
-            if (!rot || __any(f_new)) {
-                rope_row_chunks(raw, f_jk >= 0 ? f_jk : 0, fq, rope_cos, rope_sin, kf);
-                if (rot && !f_new) {
+            if (!rot || __any(f.is_new)) {
+                rope_row_chunks(f.raw, f.jk >= 0 ? f.jk : 0, fq, rope_cos, rope_sin, kf);
+                if (rot && !f.is_new) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) kf[s] = raw[s];
+                    for (int s = 0; s < 4; ++s) kf[s] = f.raw[s];
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) kf[s] = raw[s];
+                for (int s = 0; s < 4; ++s) kf[s] = f.raw[s];
             }
             if (mine) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    *reinterpret_cast<u32x4_t*>(kb + (long)(f_t0 + fr) * HD + 32 * s + 8 * fq) = raw[s];
-                    if (rot) *reinterpret_cast<u32x4_t*>(kr + (long)(f_t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
+                    *reinterpret_cast<u32x4_t*>(kb + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = f.raw[s];
+                    if (rot) *reinterpret_cast<u32x4_t*>(kr + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&kimg[buf][rw_off[s]]) = kf[s];
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&kimg[buf][my_slot][rw_off[s]]) = kf[s];
         } else {
             if (mine) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(vb + (long)(f_t0 + fr) * HD + 32 * s + 8 * fq) = raw[s];
+                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(vb + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = f.raw[s];
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&vimg[buf][rw_off[s]]) = raw[s];
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&vimg[buf][my_slot][rw_off[s]]) = f.raw[s];
         }
     };
-    // tiles of the span that hold a key visible to the unit (dead tiles are skipped by everyone alike: total_u is uniform)
-    auto next_live = [&](int t) -> int {
-        while (t < tile_end) {
-            const int j0 = llm_logical(v, d, t * 16 + fr, total_u);
-            if (__any(j0 >= 0)) break;
-            ++t;
-        }
-        return t;
-    };
-    const bool loader = wave < 2;
-    int t = next_live(tile_begin);
-    int tn = t < tile_end ? next_live(t + 1) : tile_end;
-    if (loader && t < tile_end) {
-        fetch(t);
-        commit(0);
-        if (tn < tile_end) fetch(tn);
-    }
-    __syncthreads();
-    int buf = 0;
-    while (t < tile_end) {
-        const int tnn = tn < tile_end ? next_live(tn + 1) : tile_end;
-        if (loader && tn < tile_end) {
-            commit(buf ^ 1);                  // tile tn: requested one iteration ago
-            if (tnn < tile_end) fetch(tnn);   // tile after it: lands during this iteration's arithmetic
+    // one stage: commit the NEXT stage (fetched one step ago into `f`) to the other buffer, re-arm `f` with the stage after it, consume this one
+    auto step = [&](int s0, int b, Fetch& f) {
+        if (s0 + PF_ST < tile_end) {
+            commit(b ^ 1, f);
+            if (s0 + 2 * PF_ST < tile_end) fetch(s0 + 2 * PF_ST, f);
+            else f.valid = false;
         }
         if (active) {
-            const int t0 = t * 16;
-            u32x4_t kf[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const u32x4_t*>(&kimg[buf][rw_off[s]]);
-            f32x4_t st = {0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < PF_ST; ++sl) {
+                if (s0 + sl >= tile_end) break;  // (uniform)
+                const int t0 = phys(s0 + sl) * 16;
+                u32x4_t kf[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[s]), __builtin_bit_cast(bf16x8_t, qf[s]), st, 0, 0, 0);
-            float sc[4], mx = -INFINITY;
+                for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const u32x4_t*>(&kimg[b][sl][rw_off[s]]);
+                f32x4_t st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jc = llm_logical(v, d, t0 + 4 * fq + r, total_u);
-                const bool ok = jc >= 0 && jc <= cpos;
-                sc[r] = ok ? st[r] * scale : -INFINITY;
-                mx = fmaxf(mx, sc[r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
-            const float m_new = fmaxf(m_run, mx);
-            const float resc = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
-            float p[4], ls = 0.f;
+                for (int s = 0; s < 4; ++s)
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[s]), __builtin_bit_cast(bf16x8_t, qf[s]), st, 0, 0, 0);
+                float sc[4], mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = (sc[r] == -INFINITY) ? 0.f : expf(sc[r] - m_new);
-                ls += p[r];
-            }
-            ls += __shfl_xor(ls, 16, WAVE);
-            ls += __shfl_xor(ls, 32, WAVE);
-            l_run = l_run * resc + ls;
-            m_run = m_new;
-            float rs[4];
+                for (int r = 0; r < 4; ++r) {
+                    const int jc = llm_logical(v, d, t0 + 4 * fq + r, total_u);
+                    const bool ok = jc >= 0 && jc <= cpos;
+                    sc[r] = ok ? st[r] * scale : -INFINITY;
+                    mx = fmaxf(mx, sc[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+                const float m_new = fmaxf(m_run, mx);
+                const float resc = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+                float p[4], ls = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rs[r] = __shfl(resc, 4 * fq + r, WAVE);
-            u32x2_t pp;
-            pp.x = pack_bf(p[0], p[1]);
-            pp.y = pack_bf(p[2], p[3]);
-            const s16x4_t pa = __builtin_bit_cast(s16x4_t, pp);
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = (sc[r] == -INFINITY) ? 0.f : expf(sc[r] - m_new);
+                    ls += p[r];
+                }
+                ls += __shfl_xor(ls, 16, WAVE);
+                ls += __shfl_xor(ls, 32, WAVE);
+                l_run = l_run * resc + ls;
+                m_run = m_new;
+                // rescale of O only when some column's running max moved (wave-uniform test; x * 1.0f is exact, so skipping changes no bit):
+                // after the first few tiles of a span the maxima rarely move and the 32 multiplies + 4 shuffles per tile drop out
+                if (__any(resc != 1.0f)) {
+                    float rs[4];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const u32x2_t vf = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                                                   (__attribute__((address_space(3))) s16x4_t*)(&vimg[buf][vr_off[nt]])));
-                f32x4_t acc = o[nt];
+                    for (int r = 0; r < 4; ++r) rs[r] = __shfl(resc, 4 * fq + r, WAVE);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] *= rs[r];
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf), acc, 0, 0, 0);
+                    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[nt][r] *= rs[r];
+                }
+                u32x2_t pp;
+                pp.x = pack_bf(p[0], p[1]);
+                pp.y = pack_bf(p[2], p[3]);
+                const s16x4_t pa = __builtin_bit_cast(s16x4_t, pp);
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    const u32x2_t vf = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                       (__attribute__((address_space(3))) s16x4_t*)(&vimg[b][sl][vr_off[nt]])));
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf), o[nt], 0, 0, 0);
+                }
             }
         }
         __syncthreads();  // the other buffer is staged, this one is free again
-        t = tn;
-        tn = tnn;
-        buf ^= 1;
+    };
+    // ---- software pipeline over stages: stage s+1 is committed to the other buffer and stage s+2 requested while stage s is consumed ----
+    int st0 = tile_begin;  // compact index of the current stage's first tile
+    if (st0 < tile_end) {
+        fetch(st0, F0);
+        commit(0, F0);
+        if (st0 + PF_ST < tile_end) fetch(st0 + PF_ST, F0); else F0.valid = false;
+    }
+    __syncthreads();
+    for (; st0 < tile_end; st0 += 2 * PF_ST) {
+        step(st0, 0, F0);
+        if (st0 + PF_ST < tile_end) step(st0 + PF_ST, 1, F0);
     }
     if (!active) return;
     // ---- output: o[nt][r] = O[column 4fq + r][dim 16nt + fr]; the column's statistics sit in the lanes fr == column ----
@@ -714,7 +736,7 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
         if (n_splits > ATTN_MERGE_MAX_SPLITS) n_splits = ATTN_MERGE_MAX_SPLITS;  // (very long caches: longer spans instead of more slabs)
         const int tiles_per_split = (total_tiles + n_splits - 1) / n_splits;
         n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
-        const int waves = max_unit_groups < 2 ? 2 : max_unit_groups;
+        const int waves = PREFILL_MAX_WAVES;  // every wave is a loader (2 per staged tile); waves beyond the unit's row groups do not consume
         bf16_t* od = n_splits == 1 ? out : nullptr;
         switch (G) {
             case 1: rc = launch_prefill_g<1>(qkv, row_stream, row_pos, sv, groups, units, n_units, waves, rope_cos, rope_sin, kpool, krpool, vtpool, partial, od, d, layer, n_splits, tiles_per_split, s); break;
