@@ -341,3 +341,28 @@ def test_splice_row_map_matches_reference_fixture(golden_dir):
         ref = ollm.splice_speech(cfg, torch.from_numpy(ids), table[ids], feats)
         assert len(m) == ref.shape[0] == len(ids) - max(0, 24 - n_feat)
         assert torch.equal(torch.stack([table[ids[t]] if t >= 0 else feats[-1 - t] for t in m]), ref), n_feat
+
+
+def test_two_utterances_with_stale_checkpoints_never_ask_for_an_impossible_eviction():
+    """`cache_checkpoints` is agent-level and survives `states.reset()` (reference agents/infinisst.py:106): the second utterance starts with
+    the first one's checkpoints still in the list, so the checkpoint loop can return sizes outside [0, cur - pinned].  The library refuses
+    those (the reference's slices would silently duplicate or drop entries); the agent must hand over a size inside the evictable range."""
+    cfg = toy_config()
+
+    class Strict(_FakeEngine):
+        def kv_evict(self, sid, new_size, keep):
+            assert 0 <= new_size <= self.len - keep, (new_size, self.len, keep)
+            super().kv_evict(sid, new_size, keep)
+
+    eng = Strict(np.random.default_rng(11))
+    agent = InfiniSST(default_args(max_llm_cache_size=120, always_cache_system_prompt=True, max_new_tokens=10), engine=eng, model_cfg=cfg)
+    st = agent.states
+    for utt, n_seg in enumerate((9, 14, 6)):
+        st.reset()
+        st.source_sample_rate = 16000
+        for c in range(n_seg):
+            st.source.extend([0.01] * cfg.chunk_samples)
+            st.source_finished = c == n_seg - 1
+            agent.policy(st)
+        assert eng.len <= 120 + agent.system_prompt_size + 40
+    assert len(eng.evictions) >= 6

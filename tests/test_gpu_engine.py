@@ -366,3 +366,29 @@ def test_inline_split_kv_combine_is_bit_identical_to_the_combine_launch(monkeypa
     assert oa == ob
     for c, (x, y) in enumerate(zip(la, lb)):
         assert np.array_equal(x, y), f"chunk {c}: logits differ between the in-launch combine and the combine launch"
+
+
+def test_llm_embed_tap_equals_oracle_splice():
+    """The `llm_embed` tap (decoder input rows after embedding lookup + speech splice, model/llm.py:86-113) against the oracle's splice of the
+    oracle's own speech features: a pure row copy on the device, so token rows are bit-exact and speech rows carry only the encoder's error."""
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=2)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=72)
+    eng = make_engine(cfg, w)
+    sid = eng.open_stream()
+    audio = synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=6)
+    cache, rope_e = oenc.new_cache(cfg), oenc.make_rope(cfg)
+    for c in range(2):
+        seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        x = torch.from_numpy(seg)
+        if c == 0:
+            x = torch.cat([torch.zeros(cfg.first_chunk_offset), x])
+        feats, cache = oenc.encode_speech(w, cfg, x.unsqueeze(0).bfloat16(), cache, 1, rope_e)
+        ids = torch.tensor(prompt)
+        ref = ollm.splice_speech(cfg, ids, torch.nn.functional.embedding(ids, w["model.embed_tokens.weight"]), feats[0])
+        eng.generate(gen, [sid], [seg], [prompt], [[]])
+        got = eng.debug_tap("llm_embed").view(len(prompt), cfg.llm_dim)
+        is_speech = torch.tensor([t == cfg.sp_patch_id for t in prompt])
+        assert torch.equal(got[~is_speech], ref[~is_speech]), f"chunk {c}: token rows of the decoder input differ"
+        assert_close(f"chunk {c} spliced speech rows", got[is_speech], ref[is_speech], 0.06, 0.02)

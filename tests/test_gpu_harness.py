@@ -46,16 +46,20 @@ def test_tokenizer_prompts_and_instances_log(tmp_path):
     st = oa.build_states()
     st.source_sample_rate = 16000
     wav = utts[1][1]
+    margins = []
     for pos in range(0, wav.shape[0], cfg.chunk_samples):
         st.source.extend(wav[pos:pos + cfg.chunk_samples].tolist())
         st.source_finished = pos + cfg.chunk_samples >= wav.shape[0]
         oa.policy(st)
+        for sc in oa.last_output.step_scores[:-1]:  # the steps whose tokens entered target_ids
+            top2 = torch.topk(sc, 2).values
+            margins.append(float(top2[0] - top2[1]))
     got, ref = list(agent.states.target_ids), list(st.target_ids)
     print("harness ids:", got, "oracle ids:", ref)
-    # random toy weights leave near-ties: ids are compared up to the first flip (logit parity itself is test_gpu_engine's job);
-    # the prompt structure is what this test pins: same cache length means same prompts went in
+    # random toy weights leave near-ties: every id before the oracle's first near-tie (top-2 margin within 2 x the logit tolerance) must agree
+    first_tie = next((i for i, m in enumerate(margins) if m <= 0.3), len(margins))
     k = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
-    assert k >= 1 or not ref
+    assert k >= min(first_tie, len(ref)), f"ids part at {k}, before the first near-tie at {first_tie}"
     if got == ref:
         from oracle import llm as ollm
         assert eng.stream_info(agent.states.stream_id)["llm_cache_len"] == ollm.kv_len(st.past_key_values)

@@ -101,7 +101,9 @@ def test_gemm_swiglu(M):
 @pytest.mark.parametrize("M", [1, 2, 5, 8])
 @pytest.mark.parametrize("epi", ["none", "f32", "swiglu"])
 def test_gemm_fused_rmsnorm(M, epi):
-    """RMSNorm applied inside the A-fragment load == rmsnorm kernel / oracle followed by the plain projection."""
+    """RMSNorm applied inside the A-fragment load against the ORACLE end to end -- oracle LlamaRMSNorm (pinned to HF's class,
+    tests/golden/llama_blocks.npz), then the projection in fp32 with the reference's bf16 rounding points -- and against the two-step HIP
+    path (oracle norm, then the plain HIP projection)."""
     g = torch.Generator().manual_seed(M + len(epi))
     K, N = 512, 256
     x = bf(torch.randn(M, K, generator=g) * 2)
@@ -115,6 +117,14 @@ def test_gemm_fused_rmsnorm(M, epi):
     two_step = E.op_gemm(xn.to(DEV), Wp, N, epi)
     torch.cuda.synchronize()
     close_bf16(fused, two_step, f"fused norm {epi} M{M}", ulps=2.5, atol=4e-3)
+    if epi == "swiglu":
+        Wg = W.view(N // 32, 2, 16, K)[:, 0].reshape(N // 2, K)
+        Wu = W.view(N // 32, 2, 16, K)[:, 1].reshape(N // 2, K)
+        ref = torch.nn.functional.silu(bf(xn.float() @ Wg.float().t())) * bf(xn.float() @ Wu.float().t())
+        close_bf16(fused, bf(ref.float()), f"fused norm swiglu vs oracle M{M}", ulps=3, atol=4e-3)
+    else:
+        ref = bf(xn.float() @ W.float().t())
+        close_bf16(fused, ref, f"fused norm {epi} vs oracle M{M}", ulps=2.5, atol=4e-3)
 
 
 @pytest.mark.parametrize("k,stride,T", [(3, 2, 157), (2, 2, 48)])
