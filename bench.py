@@ -389,9 +389,9 @@ def dry_run(args, world, rank):
     exactly the barrier / max-over-ranks / gather path of a real run."""
     if world > 1:
         dist.init_process_group("gloo")
+    tg = S.TimingGroup(None)
     mine = S.assign_streams(args.streams * world, rank, world)
-    if world > 1:
-        dist.barrier()
+    tg.barrier()
     t0 = time.perf_counter()
     lat = []
     for _ in range(args.steps):
@@ -399,14 +399,13 @@ def dry_run(args, world, rank):
         time.sleep(0.002 * (1 + rank))
         lat.append(time.perf_counter() - s0)
     elapsed_local = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    elapsed = S.max_over_ranks(elapsed_local)
-    audio_s = S.sum_over_ranks(0.96 * args.steps * len(mine))
-    all_lat = S.gather_floats(lat)
+    tg.barrier()
+    elapsed = tg.max(elapsed_local)
+    audio_s = tg.sum(0.96 * args.steps * len(mine))
+    all_lat = tg.gather(lat)
     if rank == 0:
         print(json.dumps({"metric": "DRY RUN of the launcher (no compute, not a measurement)", "dry_run": True, "value": round(audio_s / elapsed, 3),
-                          "unit": "audio-seconds per wall-second", "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "unit": "audio-seconds per wall-second", "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "timing_collectives": tg.describe(),
                           "steps": args.steps, "warmup": args.warmup, "streams_of_rank0": mine, "latencies_gathered": len(all_lat),
                           "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak"}), flush=True)
     if world > 1:
@@ -424,9 +423,11 @@ def main():
         return dry_run(args, world, rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or under_launcher:  # (a one-rank launch still forms the group: the RCCL path is then exercised on a one-GPU box too)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
+    tg = S.TimingGroup(device if world > 1 else None)
 
     cfg = (toy_config() if args.toy else full_config()).replace(eos_ids=())  # fixed G: EOS never stops a chunk early
     gen = GenConfig(latency_multiplier=1, max_new_tokens=args.gen_tokens, no_repeat_ngram_size=5, no_repeat_ngram_lookback=100,
@@ -443,8 +444,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        tg.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -464,9 +464,9 @@ def main():
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
     sync_all()
-    elapsed = S.max_over_ranks(elapsed_local, device if world > 1 else None)
-    audio_s = S.sum_over_ranks(0.96 * args.steps * len(mine), device if world > 1 else None)
-    all_lat = S.gather_floats(lat, device if world > 1 else None)
+    elapsed = tg.max(elapsed_local)
+    audio_s = tg.sum(0.96 * args.steps * len(mine))
+    all_lat = tg.gather(lat)
     info = eng.stream_info(loop.sids[0])
     timed_evictions = loop.evictions - ev0
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
@@ -492,8 +492,7 @@ def main():
             except Exception as e:  # report, never hide
                 base = {"value": None, "unit": "xRT (audio-s/wall-s), 1 stream", "cores": os.cpu_count(), "kind": "port",
                         "sample": f"failed: {type(e).__name__}: {e}"}
-    if world > 1:
-        dist.barrier()
+    tg.barrier()
     if rank == 0:
         value = audio_s / elapsed
         line = {
@@ -501,7 +500,8 @@ def main():
             "value": round(value, 3),
             "unit": "audio-seconds per wall-second",
             "n_gpus": world,
-            "ranks_seen": dist.get_world_size() if world > 1 else 1,
+            "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "timing_collectives": tg.describe(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -531,7 +531,7 @@ def main():
             "streams64": s64,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
