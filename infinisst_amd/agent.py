@@ -168,6 +168,8 @@ class InfiniSST(_AgentBase):
         if getattr(args, "do_sample", False):
             raise NotImplementedError("sampling is not part of the hot path (the reference scripts never enable it)")
         self.pseudo_batch_size = getattr(args, "pseudo_batch_size", 1)  # accepted, not used: see add_args
+        self.dpo_sampling = getattr(args, "dpo_sampling", False)         # reference :108-110
+        self.output_file = getattr(args, "output_file", "translations.json")
         self.max_llm_cache_size = args.max_llm_cache_size
         self.always_cache_system_prompt = args.always_cache_system_prompt
         self.cache_checkpoints: List[int] = []  # agent-level, not reset per utterance (reference :106)
@@ -380,6 +382,15 @@ class InfiniSST(_AgentBase):
         output_ids = generated[:-1]  # outputs.sequences[0, len(prompt):-1]  (:363)
         states.target_ids.extend(output_ids)
         translation = self.decode_fn(output_ids).strip().replace("�", "")
+        if self.dpo_sampling:  # reference :369-382: per-chunk translations of an utterance, one bracketed line per utterance
+            states.translations_list.append(f"'{translation}'" if translation else "''")
+            if states.source_finished:
+                try:
+                    with open(self.output_file, "a", encoding="utf-8") as f:
+                        f.write(f"[{', '.join(states.translations_list)}]" + "\n")
+                    states.translations_list = []
+                except Exception as e:  # the reference prints and carries on
+                    print(f"Error writing translations to file: {e}")
         states.segment_idx += 1
         if translation != "" or states.source_finished:  # :389-395
             return WriteAction(content=translation, finished=states.source_finished)

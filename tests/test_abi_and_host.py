@@ -366,3 +366,28 @@ def test_two_utterances_with_stale_checkpoints_never_ask_for_an_impossible_evict
             agent.policy(st)
         assert eng.len <= 120 + agent.system_prompt_size + 40
     assert len(eng.evictions) >= 6
+
+
+def test_dpo_sampling_writes_the_reference_line_format(tmp_path):
+    """`--dpo-sampling` (reference agents/infinisst.py:369-382): every chunk's translation is collected as a quoted string ('' when empty) and the
+    utterance's list is appended to --output-file as one bracketed line when the source finishes."""
+    cfg = toy_config()
+    out = tmp_path / "translations.json"
+    eng = _FakeEngine(np.random.default_rng(2))
+    agent = InfiniSST(default_args(dpo_sampling=True, output_file=str(out)), engine=eng, model_cfg=cfg,
+                      decode_fn=lambda ids: "" if len(ids) % 2 else "w" + str(len(ids)))
+    st = agent.states
+    expect = []
+    for utt in range(2):
+        st.reset()
+        st.source_sample_rate = 16000
+        chunks = []
+        for c in range(3):
+            st.source.extend([0.01] * cfg.chunk_samples)
+            st.source_finished = c == 2
+            agent.policy(st)
+            n = eng.calls[-1]["n_gen"] - 1
+            chunks.append("''" if n % 2 else f"'w{n}'")
+        expect.append(f"[{', '.join(chunks)}]")
+        assert st.translations_list == []
+    assert out.read_text(encoding="utf-8").splitlines() == expect
