@@ -1,5 +1,6 @@
 """Probe: the 64-row decode projections on gemm_mid (A staged through LDS chunk by chunk) against the skinny kernel with 4 / 8 n-tiles per workgroup
-(A fragments straight from L2 into registers, no LDS, no barrier in the k-loop).  Weights rotate over copies."""
+(A fragments straight from L2 into registers, no LDS, no barrier in the k-loop).  Weights rotate over copies.
+NEEDS profiles/r02/gemm_wide_skinny_experiment.patch applied (the 600000+ntb tuning codes exist only there)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
