@@ -85,6 +85,7 @@ struct GemmArgs {
     // the split-KV partials of llm_attn_partial_kernel, [M][K / 128][attn_splits][ATTN_SLAB] fp32 = (unnormalised O[128], running max, sum) per split
     const float* attn_partial;
     int attn_splits;
+    int tune;                                      // experiment switches (gemm_set_tuning 700000 + bits), 0 in production
 };
 #define ATTN_MERGE_MAX_ROWS 2
 #define ATTN_MERGE_MAX_SPLITS 32

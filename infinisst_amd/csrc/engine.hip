@@ -158,7 +158,8 @@ struct isst_handle {
     LlmAttnDims adims{};
 
     // workspace
-    float* pcm_f32 = nullptr;
+    float* pcm_f32 = nullptr;   // [max_streams][n_new_max] samples of the call, then [max_streams] stream ids (ints)
+    float* pcm_host = nullptr;  // pinned twin: one upload per call
     bf16_t *window = nullptr, *act_a = nullptr, *act_b = nullptr;
     bf16_t *ex = nullptr, *exn = nullptr, *eqkv = nullptr, *eattn = nullptr, *effn = nullptr, *speech = nullptr;
     bf16_t *lx = nullptr, *lxn = nullptr, *lqkv = nullptr, *lqrot = nullptr, *lattn = nullptr, *lact = nullptr, *llast = nullptr;
@@ -322,6 +323,7 @@ extern "C" void isst_destroy(isst_handle* h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->meta_host) (void)hipHostFree(h->meta_host);
     if (h->tok_host) (void)hipHostFree(h->tok_host);
+    if (h->pcm_host) (void)hipHostFree(h->pcm_host);
     if (h->top_val_host) (void)hipHostFree(h->top_val_host);
     if (h->top_idx_host) (void)hipHostFree(h->top_idx_host);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
@@ -441,7 +443,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     int cmax = 0;
     for (int i = 0; i < c.n_conv; ++i) cmax = c.conv_dim[i] > cmax ? c.conv_dim[i] : cmax;
     const size_t ER = h->enc_rows_max, LR = h->llm_rows_max;
-    h->pcm_f32 = h->dalloc<float>((size_t)ns * h->n_new_max);
+    h->pcm_f32 = h->dalloc<float>((size_t)ns * h->n_new_max + ns);
     h->window = h->dalloc<bf16_t>((size_t)ns * round_up(win, 8));
     h->act_a = h->dalloc<bf16_t>((size_t)ns * T0 * cmax);
     h->act_b = h->dalloc<bf16_t>((size_t)ns * T0 * cmax);
@@ -486,6 +488,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         if (!p) { h->fail(ISST_ERR_NOMEM, "state/workspace allocation failed"); return die(ISST_ERR_NOMEM); }
     if (hipHostMalloc(reinterpret_cast<void**>(&h->meta_host), h->meta_bytes) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->tok_host), sizeof(int) * NB) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->pcm_host), sizeof(float) * ((size_t)c.max_streams * h->n_new_max + c.max_streams)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->top_val_host), sizeof(float) * NB * BEAM_TOPK) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&h->top_idx_host), sizeof(int) * NB * BEAM_TOPK) != hipSuccess) {
         h->fail(ISST_ERR_NOMEM, "pinned host allocation failed"); return die(ISST_ERR_NOMEM);
@@ -779,11 +782,12 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
     const int hist = h->hist, win = hist + n_samples, winp = round_up(hist + h->n_new_max, 8);
     const int histp = round_up(hist, 8);
     // ---- audio: [history | new samples] per stream, bf16 (agents/infinisst.py:222) ----
-    for (int i = 0; i < n; ++i) {
-        HIPCHK(hipMemcpyAsync(h->pcm_f32 + (size_t)i * h->n_new_max, pcm[i], (size_t)n_samples * sizeof(float), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(h->window + (size_t)i * winp, h->audio_hist + (size_t)sids[i] * histp, (size_t)hist * 2, hipMemcpyDeviceToDevice, st));
-        CHK(launch_cast_f32_bf16(h->pcm_f32 + (size_t)i * h->n_new_max, h->window + (size_t)i * winp + hist, n_samples, st));
-    }
+    // (samples and stream ids go up in ONE copy from a pinned staging block; one kernel builds every stream's window)
+    for (int i = 0; i < n; ++i) std::memcpy(h->pcm_host + (size_t)i * n_samples, pcm[i], (size_t)n_samples * sizeof(float));
+    std::memcpy(h->pcm_host + (size_t)n * n_samples, sids, (size_t)n * sizeof(int));
+    HIPCHK(hipMemcpyAsync(h->pcm_f32, h->pcm_host, ((size_t)n * n_samples + n) * sizeof(float), hipMemcpyHostToDevice, st));
+    const int* sids_dev = reinterpret_cast<const int*>(h->pcm_f32 + (size_t)n * n_samples);
+    CHK(launch_audio_window(h->pcm_f32, sids_dev, h->audio_hist, histp, h->window, winp, hist, n_samples, n, st));
     // ---- conv stack ----
     std::vector<int> T(c.n_conv);
     int len = win;
@@ -806,8 +810,7 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
     const int cdim = h->conv.back().dim, D = c.enc_dim, ER = n * Q;
     CHK(tap(h, "conv_out", cur, (int64_t)ER * cdim, st));
     // history for the next chunk: last `hist` samples of the window
-    for (int i = 0; i < n; ++i)
-        HIPCHK(hipMemcpyAsync(h->audio_hist + (size_t)sids[i] * histp, h->window + (size_t)i * winp + (win - hist), (size_t)hist * 2, hipMemcpyDeviceToDevice, st));
+    CHK(launch_audio_hist_save(h->window, winp, sids_dev, h->audio_hist, histp, hist, win, n, st));
     // ---- LayerNorm + post_extract_proj (patch_speech_encoder.py:268-269,:301) ----
     CHK(launch_layernorm(cur, cdim, h->enc_ln_in.w, h->enc_ln_in.b, nxt, cdim, ER, cdim, 1e-5f, 0, st));
     CHK(gemm(h, nxt, cdim, h->post_proj, EPI_BIAS, nullptr, 0, h->ex, D, ER, st));

@@ -78,6 +78,21 @@ int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int ro
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
+// -DISST_GEMV_TRACE (make trace -> libinfinisst_hip_trace.so, profiles/gemv_trace_probe.py): wave 0 of every workgroup of the skinny kernel
+// stamps the 100 MHz wall clock at entry / rows staged / first weight batch consumed / k-loop done / output stored, plus its XCC and CU id.
+#ifdef ISST_GEMV_TRACE
+#define GEMV_TRACE_SLOTS 8
+__device__ unsigned long long g_gemv_trace[16384 * GEMV_TRACE_SLOTS];
+// (one 2048-workgroup region per Llama decode projection, so that one graph replay leaves the last layer's four launches side by side)
+#define GEMV_REGION (g.N == 6144 ? 0 : g.N == 28672 ? 4096 : g.K == 4096 ? 2048 : 8192)
+#define GEMV_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048) g_gemv_trace[(GEMV_REGION + blockIdx.x) * GEMV_TRACE_SLOTS + (i)] = wall_clock64(); } while (0)
+extern "C" int isst_debug_gemv_trace_read(void* dst, long bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemv_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#else
+#define GEMV_STAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 template <bool NT>
 __device__ __forceinline__ u32x4_t load_w(const u32x4_t* p) {
@@ -103,6 +118,7 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
     // the reduction buffer then REUSES the same bytes (one more barrier) -- kept apart, 4 rows needed 41 KB per workgroup: 3 instead
     // of 4 workgroups per CU and a second round of workgroups for the 896-workgroup gate/up launch (+7 us)
     extern __shared__ __attribute__((aligned(16))) float red[];
+    GEMV_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int W = blockDim.x >> 6;
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
             if constexpr (AMODE == 2) nw0[u] = *reinterpret_cast<const u32x4_t*>(g.norm_w + (c < g.K ? c : cfirst));
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (g.tune & 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
@@ -288,6 +305,15 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
     }
 
     const bool avalid = arow < g.M;  // (AMODE >= 1: one m-tile, m0 = 0)
+#ifdef ISST_GEMV_TRACE
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 2048) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_gemv_trace[(GEMV_REGION + blockIdx.x) * GEMV_TRACE_SLOTS + 5] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    GEMV_STAMP(1);
     const int batches = (KT + W * UNR - 1) / (W * UNR);
     for (int b0 = 0; b0 < batches; b0 += DEPTH) {
 #pragma unroll
@@ -308,11 +334,15 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
                         acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, aring[d][u][AMODE == 0 ? mt : 0]),
                                                                              __builtin_bit_cast(bf16x8_t, wring[d][u][nb]), acc[mt][nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef ISST_GEMV_TRACE
+            if (b0 == 0 && d == 0) { asm volatile("s_nop 0" :: "v"(acc[0][0][0])); GEMV_STAMP(2); }
+#endif
             issue(b0 + d + DEPTH, d);  // past the end: zeros, never used
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    GEMV_STAMP(3);
     // ---- cross-wave reduction through LDS: red[wave][(mt*NTB+nb)*4 + r][lane] ----
     if constexpr (AMODE >= 1) {
         if (overlay) __syncthreads();  // every wave is done reading the staged rows that `red` overlays
@@ -360,12 +390,13 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
             reinterpret_cast<bf16_t*>(g.out)[b * g.out_batch + (long)row * g.ldo + col] = f2bf(v);
         }
     }
+    GEMV_STAMP(4);
 }
 
 // tuning overrides for profiles/gemv_sweep.py (0 = heuristic)
-static int g_tune_w = 0, g_force_skinny = 0, g_tune_merge_w = 0;
+static int g_tune_w = 0, g_force_skinny = 0, g_tune_merge_w = 0, g_tune_flags = 0;
 // w: waves per workgroup of the skinny kernel (0 = heuristic, < 0 = never use the mid / tiled kernels); ntb: passed on to gemm_mid (its width / timing knobs)
-void gemm_set_tuning(int w, int ntb) { if (w >= 300000) { g_tune_merge_w = w - 300000; return; } if (w >= 200000) { gemm_mid_set_min_rows(w - 200000); return; } if (w >= 100000) { gemm_tiled_set_raster(w - 100000); return; } g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
+void gemm_set_tuning(int w, int ntb) { if (w >= 700000) { g_tune_flags = w - 700000; return; } if (w >= 300000) { g_tune_merge_w = w - 300000; return; } if (w >= 200000) { gemm_mid_set_min_rows(w - 200000); return; } if (w >= 100000) { gemm_tiled_set_raster(w - 100000); return; } g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
 
 static inline bool gemm_can_stage(const GemmArgs& g) {
     return g.batch == 1 && g.M <= 16 && (size_t)g.M * g.K * 2 <= 64 * 1024 && g.M <= GEMM_FUSED_NORM_MAX_M;
@@ -396,12 +427,15 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
         lds = g.M > 2 ? (lds > rows ? lds : rows) : lds + rows;
     }
     dim3 grid(blocks_x, blocks_y, g.batch), block(W * 64);
+    GemmArgs gt = g;
+    gt.tune = g_tune_flags;
     auto go = [&](auto kern) {
         if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, g);
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, gt);
         return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
     };
     constexpr int NTB = EPI == EPI_SWIGLU ? 2 : 1;
+    if constexpr (AMODE == 2) { if (g_tune_flags & 2) return go(gemm_skinny_kernel<MT, NTB, EPI, NT, AMODE, 2, MS>); }
     return go(gemm_skinny_kernel<MT, NTB, EPI, NT, AMODE, (AMODE >= 1 ? GEMM_DEPTH_STAGED : GEMM_DEPTH), MS>);
 }
 

@@ -10,6 +10,34 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = f2bf(src[i]);
 }
+// all streams of a call at once: window[i] = [history of stream sids[i] | bf16(pcm[i])]  (one launch instead of a copy + a cast per stream:
+// at 64 streams the per-stream form was 192 dependent operations, ~20 us of queue turnaround each)
+__global__ void audio_window_kernel(const float* __restrict__ pcm, const int* __restrict__ sids, const bf16_t* __restrict__ hist_pool, long histp,
+                                    bf16_t* __restrict__ window, long winp, int hist, int n_samples) {
+    const int i = blockIdx.y;
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= hist + n_samples) return;
+    window[i * winp + j] = j < hist ? hist_pool[sids[i] * histp + j] : f2bf(pcm[(long)i * n_samples + (j - hist)]);
+}
+int launch_audio_window(const float* pcm, const int* sids, const bf16_t* hist_pool, long histp, bf16_t* window, long winp, int hist, int n_samples,
+                        int n, hipStream_t s) {
+    if (n <= 0) return ISST_OK;
+    hipLaunchKernelGGL(audio_window_kernel, dim3((unsigned)((hist + n_samples + 255) / 256), n), dim3(256), 0, s, pcm, sids, hist_pool, histp, window,
+                       winp, hist, n_samples);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+// history for the next chunk: the last `hist` samples of every stream's window (the window is not modified, so no ordering hazard)
+__global__ void audio_hist_save_kernel(const bf16_t* __restrict__ window, long winp, const int* __restrict__ sids, bf16_t* __restrict__ hist_pool,
+                                       long histp, int hist, int win) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < hist) hist_pool[sids[i] * histp + j] = window[i * winp + (win - hist) + j];
+}
+int launch_audio_hist_save(const bf16_t* window, long winp, const int* sids, bf16_t* hist_pool, long histp, int hist, int win, int n, hipStream_t s) {
+    if (n <= 0 || hist <= 0) return ISST_OK;
+    hipLaunchKernelGGL(audio_hist_save_kernel, dim3((unsigned)((hist + 255) / 256), n), dim3(256), 0, s, window, winp, sids, hist_pool, histp, hist, win);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s) {
     if (n <= 0) return ISST_OK;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);

@@ -19,6 +19,11 @@ for i, (s, e, n) in enumerate(rows):
         g = rows[i + 1][0] - e
         gaps.append(g); gap_after[short] += max(g, 0)
 tot_busy = sum(busy.values())
+def _short(n): return re.sub(r"\(.*", "", n).replace("void ", "")[:44]
+top = sorted(range(len(gaps)), key=lambda i: -gaps[i])[:12]
+print("largest gaps, with the kernels either side:")
+for i in top:
+    print(f"  {gaps[i]/1e3:9.1f} us   after {_short(rows[i][2]):44s} before {_short(rows[i + 1][2])}")
 big = sorted(gaps)[-20:]
 print(f"largest gaps (us): {[round(g/1e3) for g in big]}")
 print(f"window {span/1e6:.2f} ms, {len(rows)} kernels, busy {tot_busy/1e6:.2f} ms ({100*tot_busy/span:.1f} %), gaps {sum(max(g,0) for g in gaps)/1e6:.2f} ms, "
