@@ -33,6 +33,7 @@
 // the arena, so every new key is stored exactly once and nobody reads a slot another workgroup writes.
 // The 4 waves' partials meet in LDS; one (m, l, o[128]) slab per (row, head, split) goes to global and a small
 // second kernel combines the splits (a fused last-arriver combine measured slower, see profiles/r01).
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -77,6 +78,11 @@ __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int
 
 // MULTI: a wave may take several tiles (running softmax, next tile's keys prefetched); false: exactly one tile per wave,
 // the lean one-stream form (fewer registers, 3 waves per SIMD)
+// tiles a wave keeps in flight ahead of the one it works on (MULTI form).  Measured, same box, 64 streams x 10 passes: 1 -> 93.4 / 93.7 ms per
+// step, 2 -> 94.2 / 94.5 (256 VGPRs, no spill): more bytes in flight per wave do not raise the rate the launch streams the caches at
+#ifndef ATTN_DECODE_PD
+#define ATTN_DECODE_PD 1
+#endif
 template <int G, int CT, bool MULTI>  // G q-heads per kv head, CT column tiles (16 columns each) per workgroup
 __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
                                                                const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
@@ -186,9 +192,11 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     for (int nt = 0; nt < 8; ++nt) vr_off[nt] = v_off(4 * fq + tq, 2 * nt + (tp >> 1)) + 8 * (tp & 1);
 
     int t = tile_begin + wave;
-    int jk_n = -1;
-    bool knew_n = false;
-    u32x4_t kraw_n[4];
+    // MULTI: PD tiles ahead of the one being worked on are in flight
+    constexpr int PD = MULTI ? ATTN_DECODE_PD : 1;
+    int jk_n[PD];
+    bool knew_n[PD];
+    u32x4_t kraw_n[PD][4];
     // the lane's value row of tile tt: from the arena, or from the qkv row for a key written by this launch
     auto val_src = [&](int tt, int jk, bool k_new) -> const bf16_t* {
         return k_new ? qkv + (long)(v.row0 + beam + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD : vb + (long)(tt * 16 + fr) * HD;
@@ -198,30 +206,40 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     // and drain vmcnt(0).
     const int n_mine = tile_end > tile_begin + wave ? (tile_end - tile_begin - wave + 3) >> 2 : 0;  // (compact spans need not be multiples of 4)
     const int t_last = tailwg ? t : tile_begin + wave + 4 * (n_mine - 1);
-    u32x4_t vraw_n[4];
-    if (t < tile_end) {
-        const bf16_t* src = key_src(phys(t), jk_n, knew_n);
+    u32x4_t vraw_n[PD][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-        const bf16_t* vs = val_src(phys(t), jk_n, knew_n);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) vraw_n[s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
+    for (int st = 0; st < PD; ++st) {
+        jk_n[st] = -1;
+        knew_n[st] = false;
     }
-    auto tile_body = [&]() {
+    if (t < tile_end) {
+#pragma unroll
+        for (int st = 0; st < PD; ++st) {
+            const int tn = phys(MULTI ? min(t + 4 * st, t_last) : t);
+            const bf16_t* src = key_src(tn, jk_n[st], knew_n[st]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kraw_n[st][s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+            const bf16_t* vs = val_src(tn, jk_n[st], knew_n[st]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) vraw_n[st][s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
+        }
+    }
+    auto tile_body = [&](auto stage) {
+        constexpr int ST = decltype(stage)::value;
         const int t0 = phys(t) * 16;
-        const int jk = jk_n;
-        const bool k_new = knew_n;
+        const int jk = jk_n[ST];
+        const bool k_new = knew_n[ST];
         u32x4_t kraw[4], vraw[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { kraw[s] = kraw_n[s]; vraw[s] = vraw_n[s]; }
+        for (int s = 0; s < 4; ++s) { kraw[s] = kraw_n[ST][s]; vraw[s] = vraw_n[ST][s]; }
         if constexpr (MULTI) {
-            const int tn = phys(min(t + 4, t_last));
-            const bf16_t* src = key_src(tn, jk_n, knew_n);
+            const int tn = phys(min(t + 4 * PD, t_last));
+            const bf16_t* src = key_src(tn, jk_n[ST], knew_n[ST]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) kraw_n[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-            const bf16_t* vs = val_src(tn, jk_n, knew_n);
+            for (int s = 0; s < 4; ++s) kraw_n[ST][s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+            const bf16_t* vs = val_src(tn, jk_n[ST], knew_n[ST]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) vraw_n[s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
+            for (int s = 0; s < 4; ++s) vraw_n[ST][s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
         }
         const bool tile_live = __any(jk >= 0);
         if (!tile_live) return;
@@ -322,9 +340,17 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         }
     };
     if constexpr (MULTI) {
-        for (; t < tile_end; t += 4) tile_body();
+        while (t < tile_end) {
+            tile_body(std::integral_constant<int, 0>{});
+            t += 4;
+            if constexpr (PD > 1) {
+                if (t >= tile_end) break;
+                tile_body(std::integral_constant<int, PD - 1>{});
+                t += 4;
+            }
+        }
     } else {
-        if (t < tile_end) tile_body();
+        if (t < tile_end) tile_body(std::integral_constant<int, 0>{});
     }
     // ---- the 4 waves' partials meet in LDS.  o[ct][nt][r] is O[column ct*16 + 4fq + r][dim 16nt + fr] ----
 #pragma unroll
