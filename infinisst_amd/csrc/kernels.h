@@ -27,8 +27,8 @@ struct LlmStreamView {
 };
 
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
-int launch_audio_window(const float* pcm, const int* sids, const bf16_t* hist_pool, long histp, bf16_t* window, long winp, int hist, int n_samples,
-                        int n, hipStream_t s);
+int launch_audio_window(const float* pcm, const float* const* ptrs, const int* sids, const bf16_t* hist_pool, long histp, bf16_t* window, long winp,
+                        int hist, int n_samples, int n, hipStream_t s);
 int launch_audio_hist_save(const bf16_t* window, long winp, const int* sids, bf16_t* hist_pool, long histp, int hist, int win, int n, hipStream_t s);
 int launch_conv0(const bf16_t* audio, long audio_batch, const bf16_t* w, const bf16_t* bias, const bf16_t* ln_w,
                  const bf16_t* ln_b, bf16_t* out, long out_batch, int T, int C, int k, int stride, int batch, hipStream_t s);

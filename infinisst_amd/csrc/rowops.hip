@@ -12,18 +12,20 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
 }
 // all streams of a call at once: window[i] = [history of stream sids[i] | bf16(pcm[i])]  (one launch instead of a copy + a cast per stream:
 // at 64 streams the per-stream form was 192 dependent operations, ~20 us of queue turnaround each)
-__global__ void audio_window_kernel(const float* __restrict__ pcm, const int* __restrict__ sids, const bf16_t* __restrict__ hist_pool, long histp,
-                                    bf16_t* __restrict__ window, long winp, int hist, int n_samples) {
+// (ptrs != null: the samples of stream i are at ptrs[i] -- audio the caller already holds in HBM; else at pcm + i * n_samples)
+__global__ void audio_window_kernel(const float* __restrict__ pcm, const float* const* __restrict__ ptrs, const int* __restrict__ sids,
+                                    const bf16_t* __restrict__ hist_pool, long histp, bf16_t* __restrict__ window, long winp, int hist, int n_samples) {
     const int i = blockIdx.y;
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= hist + n_samples) return;
-    window[i * winp + j] = j < hist ? hist_pool[sids[i] * histp + j] : f2bf(pcm[(long)i * n_samples + (j - hist)]);
+    const float* src = ptrs ? ptrs[i] : pcm + (long)i * n_samples;
+    window[i * winp + j] = j < hist ? hist_pool[sids[i] * histp + j] : f2bf(src[j - hist]);
 }
-int launch_audio_window(const float* pcm, const int* sids, const bf16_t* hist_pool, long histp, bf16_t* window, long winp, int hist, int n_samples,
-                        int n, hipStream_t s) {
+int launch_audio_window(const float* pcm, const float* const* ptrs, const int* sids, const bf16_t* hist_pool, long histp, bf16_t* window, long winp,
+                        int hist, int n_samples, int n, hipStream_t s) {
     if (n <= 0) return ISST_OK;
-    hipLaunchKernelGGL(audio_window_kernel, dim3((unsigned)((hist + n_samples + 255) / 256), n), dim3(256), 0, s, pcm, sids, hist_pool, histp, window,
-                       winp, hist, n_samples);
+    hipLaunchKernelGGL(audio_window_kernel, dim3((unsigned)((hist + n_samples + 255) / 256), n), dim3(256), 0, s, pcm, ptrs, sids, hist_pool, histp,
+                       window, winp, hist, n_samples);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 // history for the next chunk: the last `hist` samples of every stream's window (the window is not modified, so no ordering hazard)

@@ -51,7 +51,7 @@ class _GenParams(C.Structure):
         ("multiplier", C.c_int), ("max_new_tokens", C.c_int), ("no_repeat_ngram_size", C.c_int),
         ("encoder_no_repeat_ngram_size", C.c_int), ("repetition_penalty", C.c_float),
         ("suppress_tokens", C.POINTER(C.c_int)), ("n_suppress", C.c_int), ("system_prompt_size", C.c_int),
-        ("num_beams", C.c_int), ("length_penalty", C.c_float),
+        ("num_beams", C.c_int), ("length_penalty", C.c_float), ("pcm_on_device", C.c_int),
     ]
 
 
@@ -322,13 +322,22 @@ class Engine:
                  system_prompt_size: int = 0, forced_tokens: Optional[Sequence[Optional[Sequence[int]]]] = None,
                  return_logits: bool = False):
         """model.generate(...) of reference agents/infinisst.py:307-332 for len(stream_ids) streams.
+        `pcm`: one fp32 waveform segment per stream -- numpy arrays (host; the library uploads them, reference :222) or, all of them,
+        contiguous fp32 CUDA tensors (audio already resident in HBM: isst_gen_params.pcm_on_device).
         Returns (list of generated id lists, logits or None)."""
         n = len(stream_ids)
-        pcm = [np.ascontiguousarray(p, dtype=np.float32) for p in pcm]
-        n_samples = pcm[0].shape[0]
-        if any(p.shape != (n_samples,) for p in pcm):
+        on_device = len(pcm) > 0 and all(isinstance(x, torch.Tensor) and x.is_cuda for x in pcm)
+        if on_device:
+            if any(x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 1 for x in pcm):
+                raise IsstError("device audio must be contiguous 1-D fp32 tensors")
+            pcm = list(pcm)
+        else:
+            pcm = [np.ascontiguousarray(x, dtype=np.float32) for x in pcm]
+        n_samples = int(pcm[0].shape[0])
+        if any(tuple(x.shape) != (n_samples,) for x in pcm):
             raise IsstError("all streams of one call must bring the same number of samples")
         p = _GenParams()
+        p.pcm_on_device = int(on_device)
         p.multiplier, p.max_new_tokens = gen.latency_multiplier, gen.max_new_tokens
         p.no_repeat_ngram_size = p.encoder_no_repeat_ngram_size = gen.no_repeat_ngram_size
         p.repetition_penalty = gen.repetition_penalty
@@ -353,7 +362,8 @@ class Engine:
 
         out_lens = (C.c_int * n)()
         logits = np.zeros((n, gen.max_new_tokens, self.cfg.vocab), dtype=np.float32) if return_logits else None
-        rc = self.lib.isst_generate(self.h, C.byref(p), n, sid_arr, vp(pcm), n_samples, vp(prompts), lens(prompts),
+        pcm_ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in pcm]) if on_device else vp(pcm)
+        rc = self.lib.isst_generate(self.h, C.byref(p), n, sid_arr, pcm_ptrs, n_samples, vp(prompts), lens(prompts),
                                     vp(prevs), lens(prevs), vp(forced), lens(forced),
                                     (C.c_void_p * n)(*[o.ctypes.data for o in outs]), out_lens,
                                     None if logits is None else logits.ctypes.data, _stream_ptr())

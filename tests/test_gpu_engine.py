@@ -188,6 +188,29 @@ def test_two_streams_batched_equals_single():
             assert d <= 0.07
 
 
+def test_device_resident_audio_is_bit_identical_to_host_audio():
+    """isst_gen_params.pcm_on_device: audio the caller already holds in HBM (bench.py's timed region, a capture pipeline) is read in place;
+    tokens and logits must equal the host-array hand-over (reference agents/infinisst.py:222 moves host tensors itself) bit for bit --
+    3 chunks of 2 streams (history carried between chunks), then a mixed call must be refused."""
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=4, max_llm_cache_size=150)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=29)
+    eng = make_engine(cfg, w, debug_taps=False, max_streams=4)
+    h0, h1, d0, d1 = (eng.open_stream() for _ in range(4))
+    audio = [synth.synthetic_audio(cfg.chunk_samples * 3, stream_id=i) for i in (5, 6)]
+    audio_dev = [torch.from_numpy(x).cuda() for x in audio]
+    for c in range(3):
+        sl = slice(c * cfg.chunk_samples, (c + 1) * cfg.chunk_samples)
+        p = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        oh, lh = eng.generate(gen, [h0, h1], [x[sl] for x in audio], [p, p], [[], []], return_logits=True)
+        od, ld = eng.generate(gen, [d0, d1], [x[sl] for x in audio_dev], [p, p], [[], []], return_logits=True)
+        assert oh == od
+        for i in range(2):
+            assert np.array_equal(lh[i][:len(oh[i])], ld[i][:len(od[i])])
+    with pytest.raises(IsstError):  # non-contiguous device audio
+        eng.generate(gen, [d0], [audio_dev[0][::2][:cfg.chunk_samples]], [p], [[]])
+
+
 def test_agent_policy_matches_oracle_agent():
     """InfiniSST.policy over the engine vs OracleAgent.policy: same READ/WRITE actions, cache lengths and
     checkpoints over an utterance with a ragged tail and evictions (ids compared on decisive steps only)."""
