@@ -20,16 +20,20 @@
 //     anyway (rowops.hip rmsnorm_reduce_kernel), so the split costs no extra launch.
 #include "common.h"
 
-#define MID_KSW 2                 // k-steps per wave and chunk
-#define MID_KS (4 * MID_KSW)      // k-steps per chunk
+#define MID_KS 8                  // k-steps per chunk (KSW per wave: 4 k-step waves x 2, or -- the narrow forms -- 8 k-step waves x 1)
 #define MID_CK (32 * MID_KS)      // K elements per staged chunk (256): one barrier per chunk, 4 * MT MFMAs per wave between barriers
 
 // NP: n-tile pairs per workgroup (1, 2 or 4) -> 32, 64 or 128 columns, 4 * NP waves.  Wave (np, wk) owns the two n-tiles of pair np
 // (for SwiGLU exactly one (gate, up) pair) and k-steps wk*KSW .. of every chunk: per chunk it reads its KSW * MT A fragments from
 // LDS once and feeds 2 MFMAs on independent accumulators from each.
-template <int MT, int NP, int EPI>
-__global__ __launch_bounds__(NP * 256, NP == 2 ? 4 : (NP == 4 ? 4 : 2)) void gemm_mid_kernel(GemmArgs g, int k_chunks, int dbg) {
-    constexpr int NW = NP * 4;                     // waves per workgroup
+// KSW: k-steps per wave and chunk.  2: 4 k-step waves per n-tile pair.  1: 8 of them -- twice the waves on the same tile.  A 32- or 64-column
+// workgroup of the KSW = 2 form is 4 or 8 waves, and the narrow projections give a CU one workgroup: one or two waves per SIMD, whose LDS pass,
+// loads, MFMAs and barrier then run one after the other (q/k/v at 64 rows: 1.4 us per 256-deep chunk = the SUM of its parts).
+template <int MT, int NP, int EPI, int KSW = 2>
+__global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ? 4 : (NP == 4 ? 4 : 2))) void gemm_mid_kernel(GemmArgs g, int k_chunks, int dbg) {
+    constexpr int MID_KSW = KSW;
+    constexpr int KW = MID_KS / KSW;               // k-step waves per n-tile pair
+    constexpr int NW = NP * KW;                    // waves per workgroup
     constexpr int WN = NP * 2;                     // n-tiles per workgroup
     constexpr int UNITS = MT * 2 * MID_KS / 2;     // staging units (8 rows x 128 B = two k-steps) per chunk
     constexpr int AU = (UNITS + NW - 1) / NW;      // ... per wave
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(NP * 256, NP == 2 ? 4 : (NP == 4 ? 4 : 2)) void gem
         }
     }
 
-    // ---- K reduction across the 4 k-step waves through LDS: red[wk][(mt*WN + n)*4 + r][lane], n = 2 np + nb ----
+    // ---- K reduction across the KW k-step waves through LDS: red[wk][(mt*WN + n)*4 + r][lane], n = 2 np + nb ----
     float* red = reinterpret_cast<float*>(smem);
     constexpr int TILES = MT * WN;
 #pragma unroll
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(NP * 256, NP == 2 ? 4 : (NP == 4 ? 4 : 2)) void gem
         else { mt = ot / WN; nb = ot % WN; }
         float s = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < KW; ++w) {
             const float* pr = red + (long)w * (TILES * 256);
             s += pr[((mt * WN + nb) * 4 + r) * 64 + l];
             if constexpr (EPI == EPI_SWIGLU) s2 += pr[((mt * WN + nb + 1) * 4 + r) * 64 + l];
@@ -192,8 +196,8 @@ __global__ __launch_bounds__(NP * 256, NP == 2 ? 4 : (NP == 4 ? 4 : 2)) void gem
 static int g_mid_min_rows = ISST_MID_MIN_ROWS;  // rows from which (exclusive) the kernel takes over from the skinny one (gemm_mid_set_min_rows)
 void gemm_mid_set_min_rows(int rows) { g_mid_min_rows = rows; }
 static int g_mid_max_rows = 64;  // above 64 rows the kernel runs 64-row m-blocks (grid.z) that re-read the weights through L2
-static int g_mid_wn = 0, g_mid_dbg = 0;  // tuning override (profiles/mid_probe.py): 0 = heuristic; bits 4-5: timing-only builds (A / W descriptor emptied)
-void gemm_mid_set_tuning(int wn) { g_mid_wn = wn & 15; g_mid_dbg = (wn >> 4) & 3; if (wn >> 8) g_mid_max_rows = wn >> 8; }
+static int g_mid_wn = 0, g_mid_dbg = 0, g_mid_kw4 = 0;  // tuning override (profiles/mid_probe.py): 0 = heuristic; bits 4-5: timing-only builds (A / W descriptor emptied)
+void gemm_mid_set_tuning(int wn) { g_mid_wn = wn & 15; g_mid_dbg = (wn >> 4) & 3; g_mid_kw4 = (wn >> 6) & 1; if (wn >> 8) g_mid_max_rows = wn >> 8; }
 
 bool gemm_mid_supported(const GemmArgs& g) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
@@ -206,19 +210,20 @@ bool gemm_mid_supported(const GemmArgs& g) {
 // faster on the skinny kernel's many 16-column workgroups (11.2 vs 14.9 us for fc2)
 bool gemm_mid_preferred(const GemmArgs& g) { return g.ksplit > 1 || g.epi == EPI_PARTIAL || (long)g.N * g.K >= (8L << 20) || g_mid_wn != 0; }
 
-template <int MT, int NP, int EPI>
+template <int MT, int NP, int EPI, int KSW = 2>
 static int launch_mid_cfg(const GemmArgs& g, hipStream_t stream) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     const int NTILES = g.N / 16, WN = NP * 2;
-    dim3 grid((NTILES + WN - 1) / WN, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(NP * 256);
-    size_t lds = (size_t)2 * MID_KS * MT * 1024;  // A double buffer 16 MT KiB >= K-reduction buffer 4 * MT * WN KiB (NP <= 2)
-    if ((size_t)4 * MT * WN * 1024 > lds) lds = (size_t)4 * MT * WN * 1024;
+    constexpr int KW = MID_KS / KSW;
+    dim3 grid((NTILES + WN - 1) / WN, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(NP * 64 * KW);
+    size_t lds = (size_t)2 * MID_KS * MT * 1024;  // A double buffer 16 MT KiB >= K-reduction buffer KW * MT * WN KiB (NP <= 2 at KW = 4, NP = 1 at KW = 8)
+    if ((size_t)KW * MT * WN * 1024 > lds) lds = (size_t)KW * MT * WN * 1024;
     if (lds > 64 * 1024) {
         static bool attr = false;
-        if (!attr && hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<MT, NP, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+        if (!attr && hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<MT, NP, EPI, KSW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_mid_kernel<MT, NP, EPI>), grid, block, lds, stream, g, g.K / MID_CK / ks, g_mid_dbg);
+    hipLaunchKernelGGL((gemm_mid_kernel<MT, NP, EPI, KSW>), grid, block, lds, stream, g, g.K / MID_CK / ks, g_mid_dbg);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
@@ -236,6 +241,13 @@ static int launch_mid_wn(const GemmArgs& g, hipStream_t stream) {
     if (ks == 1 && g.N / 128 >= 192) wn = 8;
     if (g_mid_wn == 2 || g_mid_wn == 4 || g_mid_wn == 8) wn = g_mid_wn;
     if (wn == 8) return launch_mid_cfg<MT, 4, EPI>(g, stream);
+    // 32- and 64-column workgroups take the 8-k-step-wave form (profiles/mid_kw8_probe.py, r02/mid_kw8_probe.txt: q/k/v 23.1 -> 21.6 us at 64 rows,
+    // 15.0 -> 13.9 at 22; o_proj + norm 19.6 -> 18.4 / 14.3 -> 13.8; down + norm 33.0 -> 32.6 / 29.0 -> 27.8); gemm_mid_set_tuning bit 6 forces
+    // the 4-wave form back for A/B runs
+    if (!g_mid_kw4) {
+        if (wn >= 4) return launch_mid_cfg<MT, 2, EPI, 1>(g, stream);
+        return launch_mid_cfg<MT, 1, EPI, 1>(g, stream);
+    }
     if (wn >= 4) return launch_mid_cfg<MT, 2, EPI>(g, stream);
     return launch_mid_cfg<MT, 1, EPI>(g, stream);
 }
