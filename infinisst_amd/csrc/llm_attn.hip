@@ -80,6 +80,9 @@ __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int
 // the lean one-stream form (fewer registers, 3 waves per SIMD)
 // tiles a wave keeps in flight ahead of the one it works on (MULTI form).  Measured, same box, 64 streams x 10 passes: 1 -> 93.4 / 93.7 ms per
 // step, 2 -> 94.2 / 94.5 (256 VGPRs, no spill): more bytes in flight per wave do not raise the rate the launch streams the caches at
+#ifndef ATTN_KV_NT
+#define ATTN_KV_NT 0
+#endif
 #ifndef ATTN_DECODE_PD
 #define ATTN_DECODE_PD 1
 #endif
@@ -218,10 +221,10 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             const int tn = phys(MULTI ? min(t + 4 * st, t_last) : t);
             const bf16_t* src = key_src(tn, jk_n[st], knew_n[st]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) kraw_n[st][s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+            for (int s = 0; s < 4; ++s) kraw_n[st][s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
             const bf16_t* vs = val_src(tn, jk_n[st], knew_n[st]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) vraw_n[st][s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
+            for (int s = 0; s < 4; ++s) vraw_n[st][s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
         }
     }
     auto tile_body = [&](auto stage) {
@@ -236,10 +239,10 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             const int tn = phys(min(t + 4 * PD, t_last));
             const bf16_t* src = key_src(tn, jk_n[ST], knew_n[ST]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) kraw_n[ST][s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+            for (int s = 0; s < 4; ++s) kraw_n[ST][s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
             const bf16_t* vs = val_src(tn, jk_n[ST], knew_n[ST]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) vraw_n[ST][s] = *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
+            for (int s = 0; s < 4; ++s) vraw_n[ST][s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
         }
         const bool tile_live = __any(jk >= 0);
         if (!tile_live) return;
