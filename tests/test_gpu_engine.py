@@ -211,6 +211,49 @@ def test_device_resident_audio_is_bit_identical_to_host_audio():
         eng.generate(gen, [d0], [audio_dev[0][::2][:cfg.chunk_samples]], [p], [[]])
 
 
+@pytest.mark.parametrize("n", [3, 17])
+def test_batch_is_deterministic_and_independent_of_stream_order(n):
+    """Size-independent properties of the batched path: (1) the same call sequence on fresh streams gives the same bits twice; (2) a stream's
+    tokens and logits do not depend on WHERE in the batch it sits -- the same streams stepped in reverse order give every stream the same
+    bits (every reduction in the path runs in an order fixed by the stream's own data: K slices, split-KV slabs, k-step waves).  3 streams run the
+    skinny kernels (3 rows), 17 the 13..64-row machinery; three chunks with a pinned system prompt and an eviction."""
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=4, max_llm_cache_size=60)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=31)
+    eng = make_engine(cfg, w, debug_taps=False, max_streams=3 * n, max_llm_cache_size=60)
+    sys_n = len(synth.system_prompt_ids(cfg))
+    audio = [synth.synthetic_audio(cfg.chunk_samples * 3, stream_id=40 + i) for i in range(n)]
+
+    def run(order):
+        sids = [eng.open_stream() for _ in range(n)]
+        logs = [[] for _ in range(n)]
+        toks = [[] for _ in range(n)]
+        for c in range(3):
+            p = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            segs = [audio[i][c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples] for i in order]
+            outs, lg = eng.generate(gen, [sids[i] for i in order], segs, [p] * n, [[]] * n, system_prompt_size=sys_n if c == 0 else 0,
+                                    return_logits=True)
+            for pos, i in enumerate(order):
+                toks[i].append(outs[pos])
+                logs[i].append(lg[pos][:len(outs[pos])].copy())
+                if c == 1:  # whole-chunk eviction between chunks, as the agent would do it
+                    cur = eng.stream_info(sids[i])["llm_cache_len"]
+                    eng.kv_evict(sids[i], cur - sys_n - 20, sys_n)
+        for sid in sids:
+            eng.close_stream(sid)
+        return toks, logs
+
+    fwd = list(range(n))
+    t1, l1 = run(fwd)
+    t2, l2 = run(fwd)
+    t3, l3 = run(fwd[::-1])
+    for i in range(n):
+        assert t1[i] == t2[i] == t3[i], f"stream {i}: tokens differ between runs / batch orders"
+        for c in range(3):
+            assert np.array_equal(l1[i][c], l2[i][c]), f"stream {i} chunk {c}: not deterministic"
+            assert np.array_equal(l1[i][c], l3[i][c]), f"stream {i} chunk {c}: logits depend on the stream's position in the batch"
+
+
 def test_agent_policy_matches_oracle_agent():
     """InfiniSST.policy over the engine vs OracleAgent.policy: same READ/WRITE actions, cache lengths and
     checkpoints over an utterance with a ragged tail and evictions (ids compared on decisive steps only)."""

@@ -267,4 +267,19 @@ def test_full_size_64_streams_steady_state(full, steady):
         assert d.mean() <= 0.15 and d.max() <= 1.0
     for i, sid in enumerate(sids):
         assert eng.stream_info(sid)["llm_cache_len"] == sys_n + N_RING + len(st["prompt"]) + len(outs[i]) - 1
+    # size-independent property at the full configs[2] size: the same 64 streams, same state, stepped in ANOTHER ORDER in the call (stream slots
+    # no longer contiguous: the encoder leaves its batched-ring form) give every stream the same tokens and the same logits bit for bit
+    perm = [int(x) for x in np.random.default_rng(5).permutation(n)]
+    for i, sid in enumerate(sids):
+        eng.reset_stream(sid)
+        _import_state(eng, sid, cfg, sys_n, st["kv0"], st["enc0"], st["src0"], llm_ring_start=(ring_cap - 500 + 37 * i) % ring_cap,
+                      enc_ring_start=(600 + 11 * i) % 640)
+    outs2, logits2 = eng.generate(st["gen"], [sids[i] for i in perm], [segs[i] for i in perm], [st["prompt"]] * n, [[]] * n,
+                                  forced_tokens=[outs[i] for i in perm], return_logits=True)
+    n_diff = 0
+    for pos, i in enumerate(perm):
+        assert outs2[pos] == outs[i], f"stream {i} at batch position {pos}: tokens differ"
+        n_diff += int(not np.array_equal(logits2[pos][:len(outs[i])], logits[i][:len(outs[i])]))
+    print(f"permuted batch order: {n_diff} of {n} streams with any logit bit changed")
+    assert n_diff == 0
     eng.close()
