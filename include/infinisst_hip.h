@@ -204,6 +204,16 @@ int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const u
  * K % (64 * ksplit) == 0. */
 int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, const uint16_t* norm_w,
                                 uint16_t* out, float* slabs, int M, int N, int K, int ksplit, float norm_eps, void* hip_stream);
+/* the same pair WITHOUT a launch between the two projections (13..64 rows, N % 32 == 0, K % 128 == 0 for the consumer):
+ * isst_op_gemm_splitk_fused: slabs as above; the K-slice workgroup of a column block that arrives last sums the slabs and writes
+ *   x = bf16(x + bf16(sum)) in place (the same bits as isst_op_gemm_splitk_rmsnorm's x) plus, per row and 32 columns, the sum of squares of
+ *   the new x into ssq[M][N / 32]; tickets: N / 16 ints, zero before the first call (the kernel re-arms them);
+ * isst_op_gemm_norm_ssq: out = epi(LlamaRMSNorm(norm_w, eps)(x) @ W^T) with the rows normalised while they are staged, 1/rms from ssq[M][K / 32]
+ *   (epi: none, swiglu or f32). */
+int isst_op_gemm_splitk_fused(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, float* slabs, float* ssq, int* tickets,
+                              int M, int N, int K, int ksplit, void* hip_stream);
+int isst_op_gemm_norm_ssq(const uint16_t* x, int64_t ldx, const uint16_t* packed, void* out, int64_t ldo, int M, int N, int K, int n_valid,
+                          int epi, const uint16_t* norm_w, float norm_eps, float* ssq, void* hip_stream);
 /* the encoder twin (wav2vec2 TransformerSentenceEncoderLayer: x = residual + Linear(.) with bias, then LayerNorm):
  * x = bf16(x + bf16(sum of slabs + bias)) in place; ln_w != NULL: out = LayerNorm(ln_w, ln_b, eps)(x). */
 int isst_op_gemm_splitk_layernorm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, uint16_t* x,

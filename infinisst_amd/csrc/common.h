@@ -86,6 +86,12 @@ struct GemmArgs {
     const float* attn_partial;
     int attn_splits;
     int tune;                                      // experiment switches (gemm_set_tuning 700000 + bits), 0 in production
+    // 13..64 rows (gemm_mid.hip), the residual + RMSNorm between two projections WITHOUT a launch of its own:
+    //  producer (EPI_PARTIAL, tickets != null): the K-slice workgroup of a column block that arrives last sums the slabs (slice order), writes
+    //    x = bf16(x + bf16(sum)) in place (x = res, ldres) and, per row and 32-column pair, the sum of squares of the new x -> ssq[row][N / 32];
+    //  consumer (norm_w != null, ssq != null): A = x; rows are RMS-normalised on the way into LDS with 1/rms from the ssq partials (fixed order).
+    float* ssq; int ssq_n;                         // [M][ssq_n] fp32, ssq_n = x columns / 32
+    int* tickets;                                  // [column blocks] arrival counters, zero between launches (the last arriver re-arms its own)
 };
 #define ATTN_MERGE_MAX_ROWS 2
 #define ATTN_MERGE_MAX_SPLITS 32

@@ -109,6 +109,12 @@ struct isst_handle {
                                   // round trips through memory cost what the kernel boundary costs
     bool fuse_combine = false;    // ISST_FUSE_COMBINE=1: the o_proj GEMV merges the partials while it stages its A row (gemm.hip AMODE 3): every one of
                                   // its 256 workgroups re-reads all 316 KB of slabs through L2 -- 33.7 ms per chunk against 32.3
+    bool fuse_reduce = true;      // 13..64 rows -- no rmsnorm_reduce launches: the last K-slice workgroup of o_proj / down_proj sums the slabs and writes x
+                                  // (+ sums of squares per row and 32 columns), the next projection normalises its rows while it stages them (gemm_mid.hip).
+                                  // A/B on one box, ms per step: 16 streams 52.64 -> 51.73, 32: 67.21 -> 66.98, 64: 93.35 -> 92.85, one stream (22-row
+                                  // prefill) equal -- the hand-off costs nearly what the launch costs.  ISST_FUSE_REDUCE=0 restores the reduce launches
+    float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
+    int* ltickets = nullptr;      // [llm_dim / 32] arrival counters (GemmArgs::tickets), zero between launches
     bool use_graphs = false;  // ISST_GRAPH=1 enables.  Measured on MI355X (1 stream): 35.40 ms per chunk replayed vs 35.28 launched one by
                               // one -- the loop is GPU-bound, the host is ~0.6 ms ahead per pass, and a graph does not shorten the
                               // GPU-side kernel boundaries; it only saves host time (230 launches -> 1 per step)
@@ -342,6 +348,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_GRAPH")) h->use_graphs = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_ROT_KEYS")) h->rot_keys = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_COMBINE")) h->fuse_combine = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_FUSE_REDUCE")) h->fuse_reduce = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
     const isst_config& c = h->cfg;
@@ -454,6 +461,8 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->lqrot = h->dalloc<bf16_t>(LR * H * 128); h->lattn = h->dalloc<bf16_t>(LR * H * 128); h->lact = h->dalloc<bf16_t>(LR * c.llm_ffn);
     h->llast = h->dalloc<bf16_t>((size_t)ns * h->max_beams * DL);
     h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * ATTN_SLAB);
+    h->lssq = h->dalloc<float>((size_t)64 * (DL / 32), true);
+    h->ltickets = h->dalloc<int>((size_t)DL / 16 + 16, true);
     h->attn_cnt = h->dalloc<int>(64, true);  // arrival counters of the in-kernel split-KV combine (llm_attn.hip), one per kv head; zero between launches
     h->lslab = h->dalloc<float>((size_t)LLM_SLAB_ROWS * std::max(DL, (H + 2 * KV) * 128));
     const size_t NB = (size_t)ns * h->max_beams;  // decode rows of a beam step
@@ -734,8 +743,9 @@ int tap(isst_handle* h, const std::string& name, const bf16_t* src, int64_t elem
 
 int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int epi, const bf16_t* res, long ldres, void* out, long ldo,
          int M, hipStream_t st, int batch = 1, long a_batch = 0, long out_batch = 0, long res_batch = 0,
-         const bf16_t* norm_w = nullptr, float norm_eps = 0.f) {
+         const bf16_t* norm_w = nullptr, float norm_eps = 0.f, float* ssq = nullptr) {
     GemmArgs g{};
+    g.ssq = ssq; g.ssq_n = ssq ? L.K / 32 : 0;
     g.A = A; g.lda = lda; g.a_batch = a_batch;
     g.Wp = L.wp; g.bias = L.bias;
     g.res = res; g.ldres = ldres; g.res_batch = res_batch;
@@ -767,8 +777,12 @@ int pick_ksplit(int K, int N, int rows) {
     return s;
 }
 // slabs[ksplit][M][N] (fp32) = A @ W^T per K slice; reduced by launch_rmsnorm_reduce
-int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, float* slabs, int M, int ksplit, hipStream_t st) {
+// x != null (13..64 rows): the launch also reduces -- x = bf16(x + bf16(sum of the slabs)) by the last K-slice workgroup of every column block,
+// sums of squares of the new x per row and 32 columns into ssq (GemmArgs::tickets)
+int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, float* slabs, int M, int ksplit, hipStream_t st,
+                 bf16_t* x = nullptr, long ldx = 0, float* ssq = nullptr) {
     GemmArgs g{};
+    if (x) { g.res = x; g.ldres = ldx; g.ssq = ssq; g.ssq_n = L.n_valid / 32; g.tickets = h->ltickets; }
     g.A = A; g.lda = lda; g.Wp = L.wp;
     g.out = slabs; g.ldo = L.n_valid; g.out_batch = (long)M * L.n_valid;
     g.M = M; g.N = L.N; g.K = L.K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = L.n_valid; g.ksplit = ksplit;
@@ -985,7 +999,9 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     const int so = split_rows ? pick_ksplit(H * 128, DL, rows) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL, rows) : 1;
     const int sq = (rows > 128 && rows <= LLM_SPLIT_MAX_ROWS) ? pick_ksplit(DL, (H + 2 * KV) * 128, rows) : 1;  // q/k/v: 65..128 rows run on gemm_mid
     const long slab = (long)rows * DL;
-    bool pending = false;
+    // 13..64 rows: no residual + RMSNorm launches (gemm_mid.hip: the producer reduces, the consumer normalises while staging)
+    const bool fr = h->fuse_reduce && split_rows && rows <= 64 && so > 1 && sd > 1 && DL % 128 == 0;
+    bool pending = false, pending_fused = false;
     for (int l = 0; l < c.llm_layers; ++l) {
         const LlmLayer& L = h->llm[l];
         // decode shapes: RMSNorm is applied inside the projection's A-fragment load (gemm.hip NORM); larger row counts
@@ -994,14 +1010,21 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         if (fuse) {
             CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps));
         } else {
-            if (pending) {
+            bool qkv_done = false;
+            if (pending_fused) {  // lx is complete (the down_proj launch reduced its own slabs); q/k/v normalises it on the way into LDS
+                if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
+                pending_fused = false;
+                CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps, h->lssq));
+                qkv_done = true;
+            } else if (pending) {
                 CHK(launch_rmsnorm_reduce(h->lslab, slab, sd, h->lx, DL, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
                 if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
                 pending = false;
             } else {
                 CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             }
-            if (sq > 1) {  // 129..1024 rows: the 48 column blocks of the dense kernel get K slices; a small pass sums the slabs to bf16
+            if (qkv_done) {
+            } else if (sq > 1) {  // 129..1024 rows: the 48 column blocks of the dense kernel get K slices; a small pass sums the slabs to bf16
                 CHK(gemm_partial(h, h->lxn, DL, L.qkv, h->lslab, rows, sq, st));
                 CHK(launch_slab_reduce(h->lslab, (long)rows * (H + 2 * KV) * 128, sq, h->lqkv, (H + 2 * KV) * 128, rows, (H + 2 * KV) * 128, st));
             } else {
@@ -1014,7 +1037,10 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
                                  max_unit_groups, n_beam_wgs, merge_in_oproj ? &merge_splits : nullptr, h->inline_combine ? h->attn_cnt : nullptr));
-        if (so > 1) {
+        if (so > 1 && fr) {
+            CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st, h->lx, DL, h->lssq));
+            CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps, h->lssq));
+        } else if (so > 1) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
             CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
@@ -1050,7 +1076,10 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
             }
         }
-        if (sd > 1 && l + 1 < c.llm_layers) {
+        if (sd > 1 && l + 1 < c.llm_layers && fr) {
+            CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st, h->lx, DL, h->lssq));
+            pending_fused = true;
+        } else if (sd > 1 && l + 1 < c.llm_layers) {
             CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st));
             pending = true;
         } else {
@@ -1712,6 +1741,26 @@ extern "C" int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const
     const int rc = launch_gemm(g, st);
     if (rc != ISST_OK) return rc;
     return launch_rmsnorm_reduce(slabs, (long)M * N, ksplit, x, N, norm_w, out, N, M, N, norm_eps, st);
+}
+extern "C" int isst_op_gemm_splitk_fused(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, float* slabs, float* ssq, int* tickets,
+                                         int M, int N, int K, int ksplit, void* hip_stream) {
+    if (N % 32 != 0 || !x || !slabs || !tickets) return ISST_ERR_ARG;
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.Wp = packed; g.out = slabs; g.ldo = N; g.out_batch = (long)M * N;
+    g.M = M; g.N = N; g.K = K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = N; g.ksplit = ksplit;
+    g.res = x; g.ldres = N; g.ssq = ssq; g.ssq_n = N / 32; g.tickets = tickets;
+    if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
+    return launch_gemm_mid(g, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_gemm_norm_ssq(const uint16_t* x, int64_t ldx, const uint16_t* packed, void* out, int64_t ldo, int M, int N, int K, int n_valid,
+                                     int epi, const uint16_t* norm_w, float norm_eps, float* ssq, void* hip_stream) {
+    if (!norm_w || !ssq) return ISST_ERR_ARG;
+    GemmArgs g{};
+    g.A = x; g.lda = ldx; g.Wp = packed; g.out = out; g.ldo = ldo;
+    g.M = M; g.N = round_up(N, 16); g.K = K; g.batch = 1; g.epi = epi; g.n_valid = n_valid;
+    g.norm_w = norm_w; g.norm_eps = norm_eps; g.ssq = ssq; g.ssq_n = K / 32;
+    if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
+    return launch_gemm_mid(g, reinterpret_cast<hipStream_t>(hip_stream));
 }
 extern "C" int isst_op_gemm_splitk_layernorm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, uint16_t* x,
                                              const uint16_t* ln_w, const uint16_t* ln_b, uint16_t* out, float* slabs, int M, int N, int K, int ksplit,

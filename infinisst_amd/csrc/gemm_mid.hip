@@ -29,7 +29,8 @@
 // KSW: k-steps per wave and chunk.  2: 4 k-step waves per n-tile pair.  1: 8 of them -- twice the waves on the same tile.  A 32- or 64-column
 // workgroup of the KSW = 2 form is 4 or 8 waves, and the narrow projections give a CU one workgroup: one or two waves per SIMD, whose LDS pass,
 // loads, MFMAs and barrier then run one after the other (q/k/v at 64 rows: 1.4 us per 256-deep chunk = the SUM of its parts).
-template <int MT, int NP, int EPI, int KSW = 2>
+// NORM: A rows are RMS-normalised while they are staged (GemmArgs::ssq, the consumer half of the launch-free residual + RMSNorm).
+template <int MT, int NP, int EPI, int KSW = 2, bool NORM = false>
 __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ? 4 : (NP == 4 ? 4 : 2))) void gemm_mid_kernel(GemmArgs g, int k_chunks, int dbg) {
     constexpr int MID_KSW = KSW;
     constexpr int KW = MID_KS / KSW;               // k-step waves per n-tile pair
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
     constexpr int UNITS = MT * 2 * MID_KS / 2;     // staging units (8 rows x 128 B = two k-steps) per chunk
     constexpr int AU = (UNITS + NW - 1) / NW;      // ... per wave
     constexpr int BUF = MID_KS * MT * 1024;        // bytes of one staged chunk
+    constexpr int LDS_MAIN = (2 * BUF > KW * MT * WN * 1024) ? 2 * BUF : KW * MT * WN * 1024;  // NORM: the norm weight follows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x [MID_KS k-steps][MT][64 lanes][16 B]; later the K-reduction buffer [4][MT*WN][256] fp32
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the buffer descriptors below are built from it
@@ -76,6 +78,39 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) wf[u][j][nb] = load_b(u, j, nb);
 
+    // ---- NORM: 1/rms of every row from the producer's per-pair sums of squares, 4 lanes per row, fixed summation order ----
+    __shared__ float rsS[NORM ? 64 : 1];
+    if constexpr (NORM) {
+        static_assert(MT <= 4, "one 64-row block");
+        const int row = tid >> 2, q = tid & 3;
+        float pq = 0.f;
+        if (row < g.M) {
+            const int per = g.ssq_n >> 2;
+            const float* sp = g.ssq + (long)row * g.ssq_n + q * per;
+            if ((per & 15) == 0) {  // all loads of a 16-float group in flight before the first add (a plain loop waits for every load in turn)
+                for (int i0 = 0; i0 < per; i0 += 16) {
+                    f32x4_t t4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t4[u] = *reinterpret_cast<const f32x4_t*>(sp + i0 + 4 * u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { pq += t4[u].x; pq += t4[u].y; pq += t4[u].z; pq += t4[u].w; }
+                }
+            } else {
+                for (int i = 0; i < per; ++i) pq += sp[i];
+            }
+        }
+        // the norm weight (K bf16) sits in LDS behind the staging / reduction buffers: a 16-byte ds_read at the point of use instead of a
+        // register set travelling with the A registers (the 16-wave forms are at the 128-VGPR cap)
+        for (int i = tid; i < (g.K >> 3); i += NW * 64)
+            *reinterpret_cast<u32x4_t*>(smem + LDS_MAIN + i * 16) = *reinterpret_cast<const u32x4_t*>(g.norm_w + i * 8);
+        const float o1 = __shfl_xor(pq, 1, WAVE);
+        const float s2 = (q & 1) ? o1 + pq : pq + o1;   // (even + odd), the same operand order in both lanes
+        const float o2 = __shfl_xor(s2, 2, WAVE);
+        const float tot = (q & 2) ? o2 + s2 : s2 + o2;
+        if (row < g.M && q == 0) rsS[row] = rsqrtf(tot / g.K + g.norm_eps);
+        __syncthreads();
+    }
+
     // ---- A staging: unit = 8 rows x 128 B (two k-steps); lane -> (row rlo = lane & 7, 16-byte piece p = lane >> 3) ----
     // One register set: chunk c+1 is written to LDS at the START of iteration c (its loads were issued a whole iteration
     // earlier) and the same registers are re-armed with chunk c+2 right away.
@@ -98,12 +133,28 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
         if (unit >= UNITS) adst[a] = -1;
     }
     auto load_a = [&](int c, int a) -> u32x4_t { return __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[a] + c * (MID_CK * 2), 0, 0); };
+    // NORM: every unit of a wave sits at the same k-step pair (NW is a multiple of MID_KS / 2), so ONE 16-byte piece of the norm weight per
+    // chunk serves all of the lane's units; it travels with the A registers (same distance ahead); [3P] HF LlamaRMSNorm rounding points
+    static_assert(NW % (MID_KS / 2) == 0, "units of a wave share their k-step pair");
+    const int nwoff = LDS_MAIN + (chunk0 * MID_CK + (wave % (MID_KS / 2)) * 64 + p * 8) * 2;
+    // (1/rms is re-read from LDS per unit and the eight values go through one dword at a time: the 16-wave forms sit at the 128-VGPR cap)
+    auto staged = [&](const u32x4_t& xv, int c, int a) -> u32x4_t {
+        if constexpr (!NORM) return xv;
+        const u32x4_t nwv = *reinterpret_cast<const u32x4_t*>(smem + nwoff + c * (MID_CK * 2));
+        const float rs = rsS[min(m0 + ((wave + a * NW) / (MID_KS / 2)) * 8 + rlo, g.M - 1)];
+        u32x4_t o;
+        o.x = pack_bf(lo_bf(nwv.x) * bfr(lo_bf(xv.x) * rs), hi_bf(nwv.x) * bfr(hi_bf(xv.x) * rs));
+        o.y = pack_bf(lo_bf(nwv.y) * bfr(lo_bf(xv.y) * rs), hi_bf(nwv.y) * bfr(hi_bf(xv.y) * rs));
+        o.z = pack_bf(lo_bf(nwv.z) * bfr(lo_bf(xv.z) * rs), hi_bf(nwv.z) * bfr(hi_bf(xv.z) * rs));
+        o.w = pack_bf(lo_bf(nwv.w) * bfr(lo_bf(xv.w) * rs), hi_bf(nwv.w) * bfr(hi_bf(xv.w) * rs));
+        return o;
+    };
     u32x4_t areg[AU];
 #pragma unroll
     for (int a = 0; a < AU; ++a) areg[a] = load_a(0, a);
 #pragma unroll
     for (int a = 0; a < AU; ++a)
-        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(smem + adst[a]) = areg[a];
+        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(smem + adst[a]) = staged(areg[a], 0, a);
 #pragma unroll
     for (int a = 0; a < AU; ++a) areg[a] = load_a(1, a);
     __syncthreads();
@@ -125,7 +176,7 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
                     unsigned char* nbuf = smem + ((c + 1) & 1) * BUF;
 #pragma unroll
                     for (int a = 0; a < AU; ++a)
-                        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(nbuf + adst[a]) = areg[a];
+                        if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(nbuf + adst[a]) = staged(areg[a], c + 1, a);
                 }
 #pragma unroll
                 for (int a = 0; a < AU; ++a) areg[a] = load_a(c + 2, a);
@@ -157,6 +208,72 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
     __syncthreads();
 
     const int nt0 = blockIdx.x * WN;
+    if constexpr (EPI == EPI_PARTIAL) {
+        if (g.tickets) {
+            // ---- launch-free residual + RMSNorm, producer half (MI355X_MICROARCH.md "Hand-offs measured with sc1 loads", row 1) ----
+            // 1. this slice's slab goes out write-through (sc1), every storing wave drains its stores
+            float* slab = reinterpret_cast<float*>(g.out);
+            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)((long)gridDim.y * g.out_batch * 4), 0x00020000);
+            for (int e = tid; e < TILES * 256; e += NW * 64) {
+                const int ot = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
+                const int mt = ot / WN, nb = ot % WN;
+                float sacc = 0.f;
+#pragma unroll
+                for (int w = 0; w < KW; ++w) sacc += red[(long)w * (TILES * 256) + ((mt * WN + nb) * 4 + r) * 64 + l];
+                const int row = m0 + mt * 16 + (l >> 4) * 4 + r, col = (nt0 + nb) * 16 + (l & 15);
+                if (row < g.M && col < g.n_valid)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sacc), srs, (unsigned)(((long)blockIdx.y * g.out_batch + (long)row * g.ldo + col) * 4), 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // 2. one agent-scope add per workgroup on the column block's counter; the workgroup that draws the last ticket reduces
+            __shared__ int s_tk;
+            if (tid == 0) s_tk = __hip_atomic_fetch_add(g.tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (s_tk != (int)gridDim.y - 1) return;
+            // 3. x = bf16(x + bf16(sum of the slabs, slice order)) for this block's columns, all rows (rowops.hip rmsnorm_reduce_kernel's arithmetic:
+            //    the same bits); sums of squares per (row, 32-column pair): 8 lanes x 4 columns, fixed tree
+            constexpr int C4 = WN * 4;  // float4 tasks per row
+            bf16_t* x = const_cast<bf16_t*>(g.res);
+            const int tasks = g.M * C4;
+            for (int t0 = 0; t0 < tasks; t0 += NW * 64) {
+                const int t = t0 + tid;
+                const bool tv = t < tasks;
+                const int row = tv ? t / C4 : 0, col = nt0 * 16 + (tv ? t % C4 : 0) * 4;
+                const bool valid = tv && col < g.n_valid;
+                f32x4_t acc4 = {0.f, 0.f, 0.f, 0.f};
+                // (all slices' loads in flight before the first add: they come from memory, ~1.5 us each if taken one by one; slices past gridDim.y
+                //  fall outside the descriptor and read zeros, and adding +0 changes no bit of a partial sum)
+                for (unsigned s0 = 0; s0 < gridDim.y; s0 += 8) {
+                    u32x4_t raw[8];
+#pragma unroll
+                    for (unsigned u = 0; u < 8; ++u)
+                        raw[u] = __builtin_amdgcn_raw_buffer_load_b128(srs, (valid && s0 + u < gridDim.y) ? (unsigned)(((long)(s0 + u) * g.out_batch + (long)row * g.ldo + col) * 4) : 0xffffffffu, 0, 16);
+#pragma unroll
+                    for (unsigned u = 0; u < 8; ++u) {
+                        acc4.x += __uint_as_float(raw[u].x); acc4.y += __uint_as_float(raw[u].y); acc4.z += __uint_as_float(raw[u].z); acc4.w += __uint_as_float(raw[u].w);
+                    }
+                }
+                float sq = 0.f;
+                if (valid) {
+                    u32x2_t* xp = reinterpret_cast<u32x2_t*>(x + (long)row * g.ldres + col);
+                    const u32x2_t xin = *xp;
+                    const float v0 = bfr(lo_bf(xin.x) + bfr(acc4.x)), v1 = bfr(hi_bf(xin.x) + bfr(acc4.y));
+                    const float v2 = bfr(lo_bf(xin.y) + bfr(acc4.z)), v3 = bfr(hi_bf(xin.y) + bfr(acc4.w));
+                    u32x2_t xo;
+                    xo.x = pack_bf(v0, v1); xo.y = pack_bf(v2, v3);
+                    *xp = xo;
+                    sq = (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+                }
+                sq += __shfl_xor(sq, 1, WAVE);
+                sq += __shfl_xor(sq, 2, WAVE);
+                sq += __shfl_xor(sq, 4, WAVE);
+                if (valid && (t & 7) == 0 && g.ssq) g.ssq[(long)row * g.ssq_n + (col >> 5)] = sq;
+            }
+            if (tid == 0) g.tickets[blockIdx.x] = 0;  // re-armed for the next launch (launch boundary = visibility)
+            return;
+        }
+    }
     constexpr int OUT_TILES = (EPI == EPI_SWIGLU) ? TILES / 2 : TILES;
     for (int e = tid; e < OUT_TILES * 256; e += NW * 64) {
         const int ot = e >> 8, rl = e & 255;
@@ -204,26 +321,37 @@ bool gemm_mid_supported(const GemmArgs& g) {
     // up to 64 rows always; 65..128 rows as two 64-row blocks for the short weight streams only (q/k/v at 88 rows: 35 us against 56 us
     // on the 128x128 dense kernel, whose 48 column blocks leave most CUs idle; gate/up is faster there: profiles/rows_probe.py)
     const int max_rows = (g.ksplit <= 1 && (long)g.N * g.K <= (32L << 20) && g_mid_max_rows < 128) ? 128 : g_mid_max_rows;
-    return g.batch == 1 && g.M > g_mid_min_rows && g.M <= max_rows && g.K % (MID_CK * ks) == 0 && g.N % 16 == 0 && g.lda % 8 == 0 && !g.norm_w;
+    return g.batch == 1 && g.M > g_mid_min_rows && g.M <= max_rows && g.K % (MID_CK * ks) == 0 && g.N % 16 == 0 && g.lda % 8 == 0 && (!g.norm_w || (g.ssq && g.M <= 64 && g.ssq_n % 4 == 0 && g.ssq_n * 32 == g.K)) &&
+           (!g.tickets || (g.epi == EPI_PARTIAL && g.M <= 64 && g.res && g.N % 32 == 0));
 }
 // worth it only when the weight stream is long: the encoder's 2-8 MB projections at 48 rows are latency-bound and run
 // faster on the skinny kernel's many 16-column workgroups (11.2 vs 14.9 us for fc2)
-bool gemm_mid_preferred(const GemmArgs& g) { return g.ksplit > 1 || g.epi == EPI_PARTIAL || (long)g.N * g.K >= (8L << 20) || g_mid_wn != 0; }
+bool gemm_mid_preferred(const GemmArgs& g) { return g.ssq || g.tickets || g.ksplit > 1 || g.epi == EPI_PARTIAL || (long)g.N * g.K >= (8L << 20) || g_mid_wn != 0; }
 
+template <int MT, int NP, int EPI, int KSW, bool NORM>
+static int launch_mid_cfg2(const GemmArgs& g, hipStream_t stream);
 template <int MT, int NP, int EPI, int KSW = 2>
 static int launch_mid_cfg(const GemmArgs& g, hipStream_t stream) {
+    if constexpr (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_F32) {
+        if (g.norm_w) return launch_mid_cfg2<MT, NP, EPI, KSW, true>(g, stream);
+    }
+    return launch_mid_cfg2<MT, NP, EPI, KSW, false>(g, stream);
+}
+template <int MT, int NP, int EPI, int KSW, bool NORM>
+static int launch_mid_cfg2(const GemmArgs& g, hipStream_t stream) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     const int NTILES = g.N / 16, WN = NP * 2;
     constexpr int KW = MID_KS / KSW;
     dim3 grid((NTILES + WN - 1) / WN, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(NP * 64 * KW);
     size_t lds = (size_t)2 * MID_KS * MT * 1024;  // A double buffer 16 MT KiB >= K-reduction buffer KW * MT * WN KiB (NP <= 2 at KW = 4, NP = 1 at KW = 8)
     if ((size_t)KW * MT * WN * 1024 > lds) lds = (size_t)KW * MT * WN * 1024;
+    if (NORM) lds += (size_t)g.K * 2;  // the norm weight (gemm_mid_kernel LDS_MAIN)
     if (lds > 64 * 1024) {
-        static bool attr = false;
-        if (!attr && hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<MT, NP, EPI, KSW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
-        attr = true;
+        static size_t attr_lds = 0;  // (NORM: the size depends on K)
+        if (lds > attr_lds && hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mid_kernel<MT, NP, EPI, KSW, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+        if (lds > attr_lds) attr_lds = lds;
     }
-    hipLaunchKernelGGL((gemm_mid_kernel<MT, NP, EPI, KSW>), grid, block, lds, stream, g, g.K / MID_CK / ks, g_mid_dbg);
+    hipLaunchKernelGGL((gemm_mid_kernel<MT, NP, EPI, KSW, NORM>), grid, block, lds, stream, g, g.K / MID_CK / ks, g_mid_dbg);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 

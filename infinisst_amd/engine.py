@@ -68,7 +68,7 @@ EXPORTS = [
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
     "isst_op_attn_combine", "isst_op_gemm_attn_merge", "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_end", "isst_op_pack_weight",
-    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
 ]
 
 
@@ -446,6 +446,36 @@ def op_gemm_splitk_rmsnorm(A: torch.Tensor, packed: torch.Tensor, x: torch.Tenso
     if rc:
         raise IsstError(f"isst_op_gemm_splitk_rmsnorm -> {rc}")
     return x, out
+
+
+def op_gemm_splitk_fused(A: torch.Tensor, packed: torch.Tensor, x: torch.Tensor, ksplit: int, tickets: Optional[torch.Tensor] = None):
+    """The launch-free form of op_gemm_splitk_rmsnorm's first half: returns (x_new, ssq [M][N/32] fp32, tickets) -- 13..64 rows."""
+    lib = load_library()
+    M, K = A.shape
+    N = x.shape[1]
+    x = x.clone()
+    slabs = torch.empty((ksplit, M, N), dtype=torch.float32, device=A.device)
+    ssq = torch.zeros((M, N // 32), dtype=torch.float32, device=A.device)
+    if tickets is None:
+        tickets = torch.zeros(N // 16, dtype=torch.int32, device=A.device)
+    lib.isst_op_gemm_splitk_fused.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = lib.isst_op_gemm_splitk_fused(_ptr(A), A.stride(0), _ptr(packed), _ptr(x), _ptr(slabs), _ptr(ssq), _ptr(tickets), M, N, K, ksplit, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_gemm_splitk_fused -> {rc}")
+    return x, ssq, tickets
+
+
+def op_gemm_norm_ssq(x: torch.Tensor, packed: torch.Tensor, N: int, norm_w: torch.Tensor, ssq: torch.Tensor, epi: str = "none", norm_eps: float = 1e-5):
+    """epi(RMSNorm(x) @ W^T) with the rows normalised while they are staged (1/rms from the producer's sums of squares) -- 13..64 rows."""
+    lib = load_library()
+    M, K = x.shape
+    n_out = N // 2 if epi == "swiglu" else N
+    out = torch.zeros((M, n_out), dtype=torch.float32 if epi == "f32" else torch.bfloat16, device=x.device)
+    lib.isst_op_gemm_norm_ssq.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    rc = lib.isst_op_gemm_norm_ssq(_ptr(x), x.stride(0), _ptr(packed), _ptr(out), out.stride(0), M, N, K, n_out, EPI[epi], _ptr(norm_w), norm_eps, _ptr(ssq), _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_gemm_norm_ssq -> {rc}")
+    return out
 
 
 def op_gemm_splitk_layernorm(A, packed, bias, x, ksplit, ln_w, ln_b, eps=1e-5):

@@ -333,6 +333,43 @@ def test_gemm_splitk_rmsnorm(M, N, K, ks, with_norm):
         assert normed is None
 
 
+@pytest.mark.parametrize("M,N,K,ks,N2,epi2", [(13, 256, 1024, 2, 512, "none"), (22, 4096, 4096, 2, 1024, "swiglu"), (64, 4096, 2048, 4, 768, "none"),
+                                              (64, 512, 2048, 4, 512, "f32"), (48, 1024, 14336, 4, 2048, "swiglu"), (33, 256, 4096, 8, 256, "none")])
+def test_launch_free_residual_rmsnorm_equals_the_reduce_launch(M, N, K, ks, N2, epi2):
+    """13..64 rows without a residual + RMSNorm launch (gemm_mid.hip): the last K-slice workgroup of a column block reduces the slabs, writes x and the
+    per-(row, 32 columns) sums of squares; the next projection normalises its rows while it stages them.  x must carry the SAME BITS as the
+    reduce launch writes (same arithmetic, same slice order); the second projection is held to the oracle's RMSNorm + Linear on that x and to the
+    unfused pair; the counters must be re-armed (second call on the same tickets gives the same bits)."""
+    g = torch.Generator().manual_seed(M + N + K + ks)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    x = bf(torch.randn(M, N, generator=g))
+    nw = bf(1 + 0.2 * torch.randn(N, generator=g))
+    W2 = bf(torch.randn(N2, N, generator=g) * 0.05)
+    Wp, W2p = E.op_pack_weight(W.to(DEV)), E.op_pack_weight(W2.to(DEV))
+    x_ref, normed_ref = E.op_gemm_splitk_rmsnorm(A.to(DEV), Wp, x.to(DEV), ks, nw.to(DEV), 1e-5)
+    x_new, ssq, tickets = E.op_gemm_splitk_fused(A.to(DEV), Wp, x.to(DEV), ks)
+    torch.cuda.synchronize()
+    assert torch.equal(x_new, x_ref), f"x differs from the reduce launch: max |d| {float((x_new.float() - x_ref.float()).abs().max())}"
+    assert int(tickets.abs().sum()) == 0, "arrival counters not re-armed"
+    ssq_ref = (x_new.float() ** 2).reshape(M, N // 32, 32).sum(-1)
+    assert torch.allclose(ssq, ssq_ref, rtol=1e-5, atol=1e-6), float((ssq - ssq_ref).abs().max())
+    x_again, ssq_again, _ = E.op_gemm_splitk_fused(A.to(DEV), Wp, x.to(DEV), ks, tickets=tickets)
+    assert torch.equal(x_again, x_new) and torch.equal(ssq_again, ssq)
+    out = E.op_gemm_norm_ssq(x_new, W2p, N2, nw.to(DEV), ssq, epi2, 1e-5)
+    ref2 = E.op_gemm(normed_ref, W2p, N2, epi2)  # the unfused pair: norm launch output -> plain projection
+    torch.cuda.synchronize()
+    xn = ollm.rmsnorm(x_new.cpu(), nw, 1e-5)
+    if epi2 == "swiglu":  # W2's 16-row tiles alternate gate, up (the engine's packing)
+        Wg = W2.view(N2 // 32, 2, 16, N)[:, 0].reshape(N2 // 2, N)
+        Wu = W2.view(N2 // 32, 2, 16, N)[:, 1].reshape(N2 // 2, N)
+        want = bf((torch.nn.functional.silu(bf(xn.float() @ Wg.float().t())) * bf(xn.float() @ Wu.float().t())).float())
+    else:
+        want = bf(xn.float() @ W2.float().t())
+    close_bf16(out, want, f"norm-on-stage {epi2} M{M} N{N} vs oracle", ulps=3.0, atol=6e-2)
+    close_bf16(out, ref2, f"norm-on-stage {epi2} M{M} N{N} vs the unfused pair", ulps=3.0, atol=6e-2)
+
+
 @pytest.mark.parametrize("M,N,K,ks", [(96, 256, 1024, 2), (384, 1024, 2048, 4), (130, 512, 512, 1)])
 def test_gemm_splitk_layernorm(M, N, K, ks):
     """Encoder out_proj / fc2 at 65..1024 rows: K slices on the dense kernel, summed (+ bias, + residual) by the LayerNorm kernel.
