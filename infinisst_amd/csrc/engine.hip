@@ -111,7 +111,7 @@ struct isst_handle {
                                   // its 256 workgroups re-reads all 316 KB of slabs through L2 -- 33.7 ms per chunk against 32.3
     bool fuse_reduce = true;      // 13..64 rows -- no rmsnorm_reduce launches: the last K-slice workgroup of o_proj / down_proj sums the slabs and writes x
                                   // (+ sums of squares per row and 32 columns), the next projection normalises its rows while it stages them (gemm_mid.hip).
-                                  // A/B on one box, ms per step: 16 streams 52.64 -> 51.73, 32: 67.21 -> 66.98, 64: 93.35 -> 92.85, one stream (22-row
+                                  // A/B on one box, ms per step: 16 streams 52.42 -> 51.28, 32: 66.92 -> 66.04, 64: 92.67 -> 92.49, one stream (22-row
                                   // prefill) equal -- the hand-off costs nearly what the launch costs.  ISST_FUSE_REDUCE=0 restores the reduce launches
     float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
     int* ltickets = nullptr;      // [llm_dim / 32] arrival counters (GemmArgs::tickets), zero between launches

@@ -78,39 +78,7 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) wf[u][j][nb] = load_b(u, j, nb);
 
-    // ---- NORM: 1/rms of every row from the producer's per-pair sums of squares, 4 lanes per row, fixed summation order ----
     __shared__ float rsS[NORM ? 64 : 1];
-    if constexpr (NORM) {
-        static_assert(MT <= 4, "one 64-row block");
-        const int row = tid >> 2, q = tid & 3;
-        float pq = 0.f;
-        if (row < g.M) {
-            const int per = g.ssq_n >> 2;
-            const float* sp = g.ssq + (long)row * g.ssq_n + q * per;
-            if ((per & 15) == 0) {  // all loads of a 16-float group in flight before the first add (a plain loop waits for every load in turn)
-                for (int i0 = 0; i0 < per; i0 += 16) {
-                    f32x4_t t4[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) t4[u] = *reinterpret_cast<const f32x4_t*>(sp + i0 + 4 * u);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { pq += t4[u].x; pq += t4[u].y; pq += t4[u].z; pq += t4[u].w; }
-                }
-            } else {
-                for (int i = 0; i < per; ++i) pq += sp[i];
-            }
-        }
-        // the norm weight (K bf16) sits in LDS behind the staging / reduction buffers: a 16-byte ds_read at the point of use instead of a
-        // register set travelling with the A registers (the 16-wave forms are at the 128-VGPR cap)
-        for (int i = tid; i < (g.K >> 3); i += NW * 64)
-            *reinterpret_cast<u32x4_t*>(smem + LDS_MAIN + i * 16) = *reinterpret_cast<const u32x4_t*>(g.norm_w + i * 8);
-        const float o1 = __shfl_xor(pq, 1, WAVE);
-        const float s2 = (q & 1) ? o1 + pq : pq + o1;   // (even + odd), the same operand order in both lanes
-        const float o2 = __shfl_xor(s2, 2, WAVE);
-        const float tot = (q & 2) ? o2 + s2 : s2 + o2;
-        if (row < g.M && q == 0) rsS[row] = rsqrtf(tot / g.K + g.norm_eps);
-        __syncthreads();
-    }
-
     // ---- A staging: unit = 8 rows x 128 B (two k-steps); lane -> (row rlo = lane & 7, 16-byte piece p = lane >> 3) ----
     // One register set: chunk c+1 is written to LDS at the START of iteration c (its loads were issued a whole iteration
     // earlier) and the same registers are re-armed with chunk c+2 right away.
@@ -149,9 +117,46 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
         o.w = pack_bf(lo_bf(nwv.w) * bfr(lo_bf(xv.w) * rs), hi_bf(nwv.w) * bfr(hi_bf(xv.w) * rs));
         return o;
     };
+    // ---- NORM: 1/rms of every row from the producer's per-pair sums of squares, 4 lanes per row, fixed summation order (behind the first A loads) ----
+    auto norm_prologue = [&]() {
+        static_assert(MT <= 4, "one 64-row block");
+        const int row = tid >> 2, q = tid & 3;
+        float pq = 0.f;
+        if (row < g.M) {
+            const int per = g.ssq_n >> 2;
+            const float* sp = g.ssq + (long)row * g.ssq_n + q * per;
+            if ((per & 15) == 0) {  // all loads of a 16-float group in flight before the first add (a plain loop waits for every load in turn;
+                                    // 32 at a time spills in the 16-wave forms, which sit at the 128-VGPR cap)
+                for (int i0 = 0; i0 < per; i0 += 16) {
+                    f32x4_t t4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t4[u] = *reinterpret_cast<const f32x4_t*>(sp + i0 + 4 * u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { pq += t4[u].x; pq += t4[u].y; pq += t4[u].z; pq += t4[u].w; }
+                }
+            } else if ((per & 3) == 0) {
+                for (int i0 = 0; i0 < per; i0 += 4) { const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(sp + i0); pq += t4.x; pq += t4.y; pq += t4.z; pq += t4.w; }
+            } else {
+                for (int i = 0; i < per; ++i) pq += sp[i];
+            }
+        }
+        // the norm weight (K bf16) sits in LDS behind the staging / reduction buffers: a 16-byte ds_read at the point of use instead of a
+        // register set travelling with the A registers (the 16-wave forms are at the 128-VGPR cap)
+        for (int i = tid; i < (g.K >> 3); i += NW * 64)
+            *reinterpret_cast<u32x4_t*>(smem + LDS_MAIN + i * 16) = *reinterpret_cast<const u32x4_t*>(g.norm_w + i * 8);
+        const float o1 = __shfl_xor(pq, 1, WAVE);
+        const float s2 = (q & 1) ? o1 + pq : pq + o1;   // (even + odd), the same operand order in both lanes
+        const float o2 = __shfl_xor(s2, 2, WAVE);
+        const float tot = (q & 2) ? o2 + s2 : s2 + o2;
+        if (row < g.M && q == 0) rsS[row] = rsqrtf(tot / g.K + g.norm_eps);
+        __syncthreads();
+    };
+    // (the prologue runs behind the first A loads, except in the 16-wave forms: there that order costs two spilled registers at the 128-VGPR cap)
     u32x4_t areg[AU];
+    if constexpr (NORM && NP == 4) norm_prologue();
 #pragma unroll
     for (int a = 0; a < AU; ++a) areg[a] = load_a(0, a);
+    if constexpr (NORM && NP != 4) norm_prologue();
 #pragma unroll
     for (int a = 0; a < AU; ++a)
         if (adst[a] >= 0) *reinterpret_cast<u32x4_t*>(smem + adst[a]) = staged(areg[a], 0, a);
