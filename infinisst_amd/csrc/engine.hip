@@ -1076,9 +1076,10 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
             }
         }
-        if (sd > 1 && l + 1 < c.llm_layers && fr) {
+        if (sd > 1 && fr) {  // (the last layer too: lx is complete when the launch ends, and lm_head can take the sums of squares)
             CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st, h->lx, DL, h->lssq));
-            pending_fused = true;
+            pending_fused = l + 1 < c.llm_layers;
+            if (!pending_fused && tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
         } else if (sd > 1 && l + 1 < c.llm_layers) {
             CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st));
             pending = true;
@@ -1093,6 +1094,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
     } else if (n_last <= LLM_FUSED_NORM_MAX_ROWS_LM_HEAD) {  // decode: rows == last rows, final norm fused into the lm_head projection
         CHK(gemm(h, h->lx, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st, 1, 0, 0, 0, h->final_norm, c.rms_eps));
+    } else if (fr && n_last == rows) {  // 13..64 decode rows: the last down_proj launch left the sums of squares; lm_head normalises while it stages
+        CHK(gemm(h, h->lx, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st, 1, 0, 0, 0, h->final_norm, c.rms_eps, h->lssq));
     } else {
         CHK(launch_rmsnorm(h->lx, DL, nullptr, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
         CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
