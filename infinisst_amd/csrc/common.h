@@ -92,6 +92,7 @@ struct GemmArgs {
     //  consumer (norm_w != null, ssq != null): A = x; rows are RMS-normalised on the way into LDS with 1/rms from the ssq partials (fixed order).
     float* ssq; int ssq_n;                         // [M][ssq_n] fp32, ssq_n = x columns / 32
     int* tickets;                                  // [column blocks] arrival counters, zero between launches (the last arriver re-arms its own)
+    int reduce_plain;                              // producer: no residual -- res[row][col] = bf16(sum of the slabs) (q/k/v in K slices), ssq unused
 };
 #define ATTN_MERGE_MAX_ROWS 2
 #define ATTN_MERGE_MAX_SPLITS 32

@@ -113,6 +113,7 @@ struct isst_handle {
                                   // (+ sums of squares per row and 32 columns), the next projection normalises its rows while it stages them (gemm_mid.hip).
                                   // A/B on one box, ms per step: 16 streams 52.42 -> 51.28, 32: 66.92 -> 66.04, 64: 92.67 -> 92.49, one stream (22-row
                                   // prefill) equal -- the hand-off costs nearly what the launch costs.  ISST_FUSE_REDUCE=0 restores the reduce launches
+    int qkv_slices = 0;           // ISST_QKV_SLICES: K slices of the q/k/v projection at 13..64 rows (in-launch reduction); 0 = by row count
     float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
     int* ltickets = nullptr;      // [llm_dim / 32] arrival counters (GemmArgs::tickets), zero between launches
     bool use_graphs = false;  // ISST_GRAPH=1 enables.  Measured on MI355X (1 stream): 35.40 ms per chunk replayed vs 35.28 launched one by
@@ -349,6 +350,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_ROT_KEYS")) h->rot_keys = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_COMBINE")) h->fuse_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_REDUCE")) h->fuse_reduce = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_QKV_SLICES")) h->qkv_slices = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
     const isst_config& c = h->cfg;
@@ -780,9 +782,14 @@ int pick_ksplit(int K, int N, int rows) {
 // x != null (13..64 rows): the launch also reduces -- x = bf16(x + bf16(sum of the slabs)) by the last K-slice workgroup of every column block,
 // sums of squares of the new x per row and 32 columns into ssq (GemmArgs::tickets)
 int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, float* slabs, int M, int ksplit, hipStream_t st,
-                 bf16_t* x = nullptr, long ldx = 0, float* ssq = nullptr) {
+                 bf16_t* x = nullptr, long ldx = 0, float* ssq = nullptr, bf16_t* plain_out = nullptr, long ld_plain = 0,
+                 const bf16_t* norm_w = nullptr, float norm_eps = 0.f, float* ssq_in = nullptr) {
     GemmArgs g{};
     if (x) { g.res = x; g.ldres = ldx; g.ssq = ssq; g.ssq_n = L.n_valid / 32; g.tickets = h->ltickets; }
+    if (plain_out) {  // q/k/v in K slices: the last slice workgroup writes bf16(sum) to plain_out; A may be normalised while staged (norm_w + ssq_in)
+        g.res = plain_out; g.ldres = ld_plain; g.reduce_plain = 1; g.tickets = h->ltickets;
+        g.norm_w = norm_w; g.norm_eps = norm_eps; g.ssq = ssq_in; g.ssq_n = ssq_in ? L.K / 32 : 0;
+    }
     g.A = A; g.lda = lda; g.Wp = L.wp;
     g.out = slabs; g.ldo = L.n_valid; g.out_batch = (long)M * L.n_valid;
     g.M = M; g.N = L.N; g.K = L.K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = L.n_valid; g.ksplit = ksplit;
@@ -1001,6 +1008,11 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     const long slab = (long)rows * DL;
     // 13..64 rows: no residual + RMSNorm launches (gemm_mid.hip: the producer reduces, the consumer normalises while staging)
     const bool fr = h->fuse_reduce && split_rows && rows <= 64 && so > 1 && sd > 1 && DL % 128 == 0;
+    // ... and q/k/v in K slices with the same in-launch reduction (192 workgroups of 32 columns leave a quarter of the CUs idle and give the others one
+    // workgroup each; ISST_QKV_SLICES=1 forces the unsplit launch)
+    // A/B on one box, ms per step: 64 streams 92.63 (1 slice) / 91.33 (2) / 92.61 (4); 16 streams 51.24 / 51.52 / 50.84 -- two slices from 33 rows
+    const int qs = h->qkv_slices > 0 ? h->qkv_slices : (rows > 32 ? 2 : 1);
+    const int sqf = (fr && qs > 1 && DL % (256 * qs) == 0) ? qs : 1;
     bool pending = false, pending_fused = false;
     for (int l = 0; l < c.llm_layers; ++l) {
         const LlmLayer& L = h->llm[l];
@@ -1014,7 +1026,10 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             if (pending_fused) {  // lx is complete (the down_proj launch reduced its own slabs); q/k/v normalises it on the way into LDS
                 if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
                 pending_fused = false;
-                CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps, h->lssq));
+                if (sqf > 1)
+                    CHK(gemm_partial(h, h->lx, DL, L.qkv, h->lslab, rows, sqf, st, nullptr, 0, nullptr, h->lqkv, (H + 2 * KV) * 128, L.in_norm, c.rms_eps, h->lssq));
+                else
+                    CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps, h->lssq));
                 qkv_done = true;
             } else if (pending) {
                 CHK(launch_rmsnorm_reduce(h->lslab, slab, sd, h->lx, DL, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
@@ -1024,6 +1039,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             }
             if (qkv_done) {
+            } else if (sqf > 1) {  // (first layer: the norm launch ran; the K slices still pay)
+                CHK(gemm_partial(h, h->lxn, DL, L.qkv, h->lslab, rows, sqf, st, nullptr, 0, nullptr, h->lqkv, (H + 2 * KV) * 128));
             } else if (sq > 1) {  // 129..1024 rows: the 48 column blocks of the dense kernel get K slices; a small pass sums the slabs to bf16
                 CHK(gemm_partial(h, h->lxn, DL, L.qkv, h->lslab, rows, sq, st));
                 CHK(launch_slab_reduce(h->lslab, (long)rows * (H + 2 * KV) * 128, sq, h->lqkv, (H + 2 * KV) * 128, rows, (H + 2 * KV) * 128, st));

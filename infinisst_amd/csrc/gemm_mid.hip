@@ -260,7 +260,11 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
                     }
                 }
                 float sq = 0.f;
-                if (valid) {
+                if (valid && g.reduce_plain) {
+                    u32x2_t xo;
+                    xo.x = pack_bf(acc4.x, acc4.y); xo.y = pack_bf(acc4.z, acc4.w);
+                    *reinterpret_cast<u32x2_t*>(x + (long)row * g.ldres + col) = xo;
+                } else if (valid) {
                     u32x2_t* xp = reinterpret_cast<u32x2_t*>(x + (long)row * g.ldres + col);
                     const u32x2_t xin = *xp;
                     const float v0 = bfr(lo_bf(xin.x) + bfr(acc4.x)), v1 = bfr(hi_bf(xin.x) + bfr(acc4.y));
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(NP * 64 * (MID_KS / KSW), KSW == 1 ? 1 : (NP == 2 ?
                 sq += __shfl_xor(sq, 1, WAVE);
                 sq += __shfl_xor(sq, 2, WAVE);
                 sq += __shfl_xor(sq, 4, WAVE);
-                if (valid && (t & 7) == 0 && g.ssq) g.ssq[(long)row * g.ssq_n + (col >> 5)] = sq;
+                if (valid && (t & 7) == 0 && g.ssq && !g.reduce_plain) g.ssq[(long)row * g.ssq_n + (col >> 5)] = sq;  // (plain: ssq, if any, is this launch's INPUT)
             }
             if (tid == 0) g.tickets[blockIdx.x] = 0;  // re-armed for the next launch (launch boundary = visibility)
             return;
@@ -327,7 +331,7 @@ bool gemm_mid_supported(const GemmArgs& g) {
     // on the 128x128 dense kernel, whose 48 column blocks leave most CUs idle; gate/up is faster there: profiles/rows_probe.py)
     const int max_rows = (g.ksplit <= 1 && (long)g.N * g.K <= (32L << 20) && g_mid_max_rows < 128) ? 128 : g_mid_max_rows;
     return g.batch == 1 && g.M > g_mid_min_rows && g.M <= max_rows && g.K % (MID_CK * ks) == 0 && g.N % 16 == 0 && g.lda % 8 == 0 && (!g.norm_w || (g.ssq && g.M <= 64 && g.ssq_n % 4 == 0 && g.ssq_n * 32 == g.K)) &&
-           (!g.tickets || (g.epi == EPI_PARTIAL && g.M <= 64 && g.res && g.N % 32 == 0));
+           (!g.tickets || (g.epi == EPI_PARTIAL && g.M <= 64 && g.res && g.N % 32 == 0 && (g.reduce_plain || !g.norm_w)));
 }
 // worth it only when the weight stream is long: the encoder's 2-8 MB projections at 48 rows are latency-bound and run
 // faster on the skinny kernel's many 16-column workgroups (11.2 vs 14.9 us for fc2)
@@ -337,7 +341,7 @@ template <int MT, int NP, int EPI, int KSW, bool NORM>
 static int launch_mid_cfg2(const GemmArgs& g, hipStream_t stream);
 template <int MT, int NP, int EPI, int KSW = 2>
 static int launch_mid_cfg(const GemmArgs& g, hipStream_t stream) {
-    if constexpr (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_F32) {
+    if constexpr (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_F32 || EPI == EPI_PARTIAL) {
         if (g.norm_w) return launch_mid_cfg2<MT, NP, EPI, KSW, true>(g, stream);
     }
     return launch_mid_cfg2<MT, NP, EPI, KSW, false>(g, stream);
