@@ -212,6 +212,10 @@ int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const uint16_t* 
  *   (epi: none, swiglu or f32). */
 int isst_op_gemm_splitk_fused(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, float* slabs, float* ssq, int* tickets,
                               int M, int N, int K, int ksplit, void* hip_stream);
+/* K slices with the same in-launch reduction and NO residual: out[M][N] = bf16(sum of the slabs) (q/k/v at 33..64 rows); norm_w != NULL: A = x is
+ * normalised while staged as in isst_op_gemm_norm_ssq (ssq_in[M][K / 32]). */
+int isst_op_gemm_splitk_plain(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* out, int64_t ldo, float* slabs, int* tickets,
+                              int M, int N, int K, int ksplit, const uint16_t* norm_w, float norm_eps, float* ssq_in, void* hip_stream);
 int isst_op_gemm_norm_ssq(const uint16_t* x, int64_t ldx, const uint16_t* packed, void* out, int64_t ldo, int M, int N, int K, int n_valid,
                           int epi, const uint16_t* norm_w, float norm_eps, float* ssq, void* hip_stream);
 /* the encoder twin (wav2vec2 TransformerSentenceEncoderLayer: x = residual + Linear(.) with bias, then LayerNorm):

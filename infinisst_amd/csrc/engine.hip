@@ -1772,6 +1772,17 @@ extern "C" int isst_op_gemm_splitk_fused(const uint16_t* A, int64_t lda, const u
     if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
     return launch_gemm_mid(g, reinterpret_cast<hipStream_t>(hip_stream));
 }
+extern "C" int isst_op_gemm_splitk_plain(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* out, int64_t ldo, float* slabs, int* tickets,
+                                         int M, int N, int K, int ksplit, const uint16_t* norm_w, float norm_eps, float* ssq_in, void* hip_stream) {
+    if (N % 32 != 0 || !out || !slabs || !tickets || (norm_w && !ssq_in)) return ISST_ERR_ARG;
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.Wp = packed; g.out = slabs; g.ldo = N; g.out_batch = (long)M * N;
+    g.M = M; g.N = N; g.K = K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = N; g.ksplit = ksplit;
+    g.res = out; g.ldres = ldo; g.reduce_plain = 1; g.tickets = tickets;
+    g.norm_w = norm_w; g.norm_eps = norm_eps; g.ssq = norm_w ? ssq_in : nullptr; g.ssq_n = norm_w ? K / 32 : 0;
+    if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
+    return launch_gemm_mid(g, reinterpret_cast<hipStream_t>(hip_stream));
+}
 extern "C" int isst_op_gemm_norm_ssq(const uint16_t* x, int64_t ldx, const uint16_t* packed, void* out, int64_t ldo, int M, int N, int K, int n_valid,
                                      int epi, const uint16_t* norm_w, float norm_eps, float* ssq, void* hip_stream) {
     if (!norm_w || !ssq) return ISST_ERR_ARG;

@@ -68,7 +68,7 @@ EXPORTS = [
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
     "isst_op_attn_combine", "isst_op_gemm_attn_merge", "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_end", "isst_op_pack_weight",
-    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
 ]
 
 
@@ -463,6 +463,23 @@ def op_gemm_splitk_fused(A: torch.Tensor, packed: torch.Tensor, x: torch.Tensor,
     if rc:
         raise IsstError(f"isst_op_gemm_splitk_fused -> {rc}")
     return x, ssq, tickets
+
+
+def op_gemm_splitk_plain(A: torch.Tensor, packed: torch.Tensor, N: int, ksplit: int, norm_w=None, ssq=None, norm_eps: float = 1e-5):
+    """bf16(A @ W^T) through `ksplit` K slices reduced inside the launch (no residual); norm_w + ssq: A rows RMS-normalised while staged."""
+    lib = load_library()
+    M, K = A.shape
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=A.device)
+    slabs = torch.empty((ksplit, M, N), dtype=torch.float32, device=A.device)
+    tickets = torch.zeros(N // 16, dtype=torch.int32, device=A.device)
+    lib.isst_op_gemm_splitk_plain.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    rc = lib.isst_op_gemm_splitk_plain(_ptr(A), A.stride(0), _ptr(packed), _ptr(out), out.stride(0), _ptr(slabs), _ptr(tickets), M, N, K, ksplit,
+                                       _ptr(norm_w), norm_eps, _ptr(ssq), _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_gemm_splitk_plain -> {rc}")
+    assert int(tickets.abs().sum()) == 0, "arrival counters not re-armed"
+    return out
 
 
 def op_gemm_norm_ssq(x: torch.Tensor, packed: torch.Tensor, N: int, norm_w: torch.Tensor, ssq: torch.Tensor, epi: str = "none", norm_eps: float = 1e-5):

@@ -368,6 +368,11 @@ def test_launch_free_residual_rmsnorm_equals_the_reduce_launch(M, N, K, ks, N2, 
         want = bf(xn.float() @ W2.float().t())
     close_bf16(out, want, f"norm-on-stage {epi2} M{M} N{N} vs oracle", ulps=3.0, atol=6e-2)
     close_bf16(out, ref2, f"norm-on-stage {epi2} M{M} N{N} vs the unfused pair", ulps=3.0, atol=6e-2)
+    if epi2 == "none" and N % 512 == 0:  # the q/k/v form: the second projection itself in two K slices, reduced in the launch, rows normalised while staged
+        out2 = E.op_gemm_splitk_plain(x_new, W2p, N2, 2, nw.to(DEV), ssq, 1e-5)
+        close_bf16(out2, want, f"split-K plain + norm-on-stage M{M} N{N} vs oracle", ulps=3.0, atol=6e-2)
+        out3 = E.op_gemm_splitk_plain(normed_ref, W2p, N2, 2)  # without the norm: bf16(sum of two slices) against the unsplit launch
+        close_bf16(out3, ref2, f"split-K plain M{M} N{N} vs the unsplit launch", ulps=2.0, atol=3e-2)
 
 
 @pytest.mark.parametrize("M,N,K,ks", [(96, 256, 1024, 2), (384, 1024, 2048, 4), (130, 512, 512, 1)])
