@@ -768,7 +768,9 @@ int pick_ksplit(int K, int N, int rows) {
     if (rows <= 64) {
         // (N <= 2048 = the encoder's out_proj / fc2, 16..32 column blocks: fc2 20.1 us as GEMM + LayerNorm, 16.6 / 14.7 / 16.5 us with 2 / 4 / 8 slices
         //  + the reducing LayerNorm; out_proj 14.2 -> 11.5 us with 2: profiles/enc_probe.py)
-        for (int s = (K >= 8192 || (N <= 2048 && K >= 4096)) ? 4 : 2; s > 1; s >>= 1)
+        // (33..64 rows, N = K = 4096 -- o_proj of a many-stream decode pass -- with the in-launch reduction: 2 slices of 32 columns 16.8 us, 4 slices of
+        //  64 columns 15.3; down_proj stays at 4 x 64 columns: 29.2 against 34.7 for 8 and 45.0 for 2; profiles/fused_ks_probe.py)
+        for (int s = (K >= 8192 || (N <= 2048 && K >= 4096) || (rows > 32 && K >= 4096)) ? 4 : 2; s > 1; s >>= 1)
             if (K % (256 * s) == 0 && K / (256 * s) >= 1) return s;
         return 1;
     }

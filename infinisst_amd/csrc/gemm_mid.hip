@@ -370,7 +370,7 @@ static int launch_mid_wn(const GemmArgs& g, hipStream_t stream) {
     // (A is then staged twice as often); up to 32 rows the 4-wave / 32-column form wins except for the widest projection
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     int wn;
-    if (g.M <= 32) wn = g.N >= 16384 ? 4 : 2;
+    if (g.M <= 32) wn = (g.N >= 16384 || (long)(g.N / 64) * ks >= 256) ? 4 : 2;  // (K slices with the in-launch reduction, 22 rows: down_proj 4 x 64 columns 23.1 us, 4 x 32: 24.9)
     else wn = ((long)(g.N / 64) * ks >= 192) ? 4 : 2;
     // the widest projections (gate/up, lm_head: >= 192 workgroups even at 128 columns) take 128 columns and 16 waves: A is staged half as
     // often -- at 64 rows its L2->LDS traffic equals the weight bytes otherwise (gate/up 53.8 -> 44.3 us, the weight-only time; 22 rows
