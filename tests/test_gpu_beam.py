@@ -193,6 +193,49 @@ def test_beam_decisions_follow_oracle():
     assert same + near_tie == 8 and same >= 3
 
 
+def test_beam_many_streams_run_the_mid_row_machinery_and_stay_order_independent():
+    """5 streams x 4 beams = 20 rows per decode pass: the 13..64-row machinery (gemm_mid, K slices with the in-launch reduction, norm while staging)
+    under beam search.  Properties: the same call twice and the streams in reverse order give every stream the same tokens (bit-transparent
+    batching); against each stream searched ALONE (4 rows: the skinny kernels, another summation order) most streams must agree -- a near-tie may
+    legitimately flip a beam decision, so 3 of 5 is the bar, as in test_beam_decisions_follow_oracle."""
+    cfg = toy_config()
+    B, n = 4, 5
+    gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=400)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=44)
+    eng = Engine(cfg, max_streams=n, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
+    eng.load_weights(w)
+    audio = [synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=70 + i) for i in range(n)]
+
+    def run(order):
+        sids = [eng.open_stream() for _ in range(n)]
+        toks = [[] for _ in range(n)]
+        for c in range(2):
+            p = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            outs, _ = eng.generate(gen, [sids[i] for i in order], [audio[i][c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples] for i in order],
+                                   [p] * len(order), [[]] * len(order))
+            for pos, i in enumerate(order):
+                toks[i].append(outs[pos])
+        for sid in sids:
+            eng.close_stream(sid)
+        return toks
+
+    a = run(list(range(n)))
+    assert run(list(range(n))) == a, "beam search over 20 rows is not deterministic"
+    assert run(list(range(n))[::-1]) == a, "a stream's beam search depends on its position in the batch"
+    same = 0
+    for i in range(n):
+        sid = eng.open_stream()
+        alone = []
+        for c in range(2):
+            p = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            outs, _ = eng.generate(gen, [sid], [audio[i][c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]], [p], [[]])
+            alone.append(outs[0])
+        eng.close_stream(sid)
+        same += int(alone == a[i])
+    print(f"beam 4, 5 streams batched vs alone: {same} of {n} identical")
+    assert same >= 3
+
+
 def test_beam_finished_stream_is_frozen_while_batch_mates_continue():
     """the scorer must skip a stream whose search is done (patch_hf.py:83-92) while other streams of the call keep decoding --
     otherwise the finished stream goes on closing hypotheses and its winner / KV tail depend on its batch mates.  Stream A (finishes
