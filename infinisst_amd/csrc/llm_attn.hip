@@ -80,6 +80,9 @@ __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int
 // the lean one-stream form (fewer registers, 3 waves per SIMD)
 // tiles a wave keeps in flight ahead of the one it works on (MULTI form).  Measured, same box, 64 streams x 10 passes: 1 -> 93.4 / 93.7 ms per
 // step, 2 -> 94.2 / 94.5 (256 VGPRs, no spill): more bytes in flight per wave do not raise the rate the launch streams the caches at
+#ifndef ATTN_SLAB_SC1
+#define ATTN_SLAB_SC1 0  // 1: partial slabs always stored write-through (experiment: a cheaper end-of-kernel write-back?)
+#endif
 #ifndef ATTN_KV_NT
 #define ATTN_KV_NT 0
 #endif
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             const u32x4_t ob = __builtin_bit_cast(u32x4_t, O);
             u32x4_t sb;
             sb.x = __float_as_uint(M); sb.y = __float_as_uint(L); sb.z = 0u; sb.w = 0u;
-            if (inline_combine) {  // write-through (sc1): the reducing workgroup may sit on another XCD, whose L2 never sees this one's lines
+            if (inline_combine || ATTN_SLAB_SC1) {  // write-through (sc1): the reducing workgroup may sit on another XCD, whose L2 never sees this one's lines
                 const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc(dst, 0, ATTN_SLAB * 4, 0x00020000);
                 __builtin_amdgcn_raw_buffer_store_b128(ob, ds, (unsigned)d4 * 4u, 0, 16);
                 if (d4 == 0) __builtin_amdgcn_raw_buffer_store_b128(sb, ds, HD * 4u, 0, 16);
