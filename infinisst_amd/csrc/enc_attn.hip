@@ -56,6 +56,18 @@ __device__ __forceinline__ u32x4_t rot_frag(const bf16_t* p, int pos, int dim0, 
     return pack8(y);
 }
 
+// -DISST_ENC_TRACE (make trace): wave 0 of every workgroup stamps the 100 MHz wall clock at entry / queries rotated / scores written / softmax done /
+// P.V done / stored (profiles/enc_attn_trace_probe.py)
+#ifdef ISST_ENC_TRACE
+__device__ unsigned long long g_enc_trace[4096 * 8];
+#define ENC_STAMP(i) do { if (threadIdx.x == 0) { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (wg_ < 4096) g_enc_trace[wg_ * 8 + (i)] = wall_clock64(); } } while (0)
+extern "C" int isst_debug_enc_trace_read(void* dst, long bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_enc_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#else
+#define ENC_STAMP(i) do {} while (0)
+#endif
+
 template <int QT>  // m-tiles of 16 query rows per workgroup
 __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                                                             const EncStreamView* __restrict__ sv,
@@ -63,6 +75,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
                                                             int round_each, bf16_t* __restrict__ out, int Q, int heads, int cap,
                                                             int C, int bs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ENC_STAMP(0);
     bf16_t* S = reinterpret_cast<bf16_t*>(smem);  // [QT*16][cap + ENC_SPAD]
     const int ldS = cap + ENC_SPAD;
     float* Ohalf = reinterpret_cast<float*>(smem + (size_t)QT * 16 * ldS * 2);  // [QT*16][64] partial O of the upper key half
@@ -102,6 +115,10 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
             lo[mt][r] = max(0, qi + P - C) - off;
         }
 
+#ifdef ISST_ENC_TRACE
+    asm volatile("s_nop 0" :: "v"(qf[0][0].x), "v"(qf[0][1].x));
+#endif
+    ENC_STAMP(1);
     // ---- 1. scores ----
     const int n_tiles = cap >> 4;
     for (int nt = wave; nt < n_tiles; nt += ENC_WAVES) {
@@ -137,6 +154,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
         }
     }
     __syncthreads();
+    ENC_STAMP(2);
 
     // ---- 2. softmax per row (fp32), probabilities rounded to bf16 in place ----
     for (int row = wave; row < QT * 16; row += ENC_WAVES) {
@@ -177,6 +195,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
         }
     }
     __syncthreads();
+    ENC_STAMP(3);
 
     // ---- 3. O = P V : wave w owns dims 16(w&3) .. +15 and the key steps of half (w>>2) ----
     const int dt = wave & 3, half = wave >> 2;
@@ -226,6 +245,10 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
             }
         }
     }
+#ifdef ISST_ENC_TRACE
+    asm volatile("s_nop 0" :: "v"(o[0][0]));
+#endif
+    ENC_STAMP(4);
     if (half == 1) {
 #pragma unroll
         for (int mt = 0; mt < QT; ++mt)
@@ -242,6 +265,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
                 out[((long)s * Q + qi) * D + h * ENC_HD + dim] = f2bf(o[mt][r] + Ohalf[(mt * 16 + fq * 4 + r) * ENC_HD + dim]);
             }
     }
+    ENC_STAMP(5);
     // ---- append V^T of the chunk's own keys (query block 0): [dim][slot] <- V[new frame][dim] ----
     if (qb == 0) {
         for (int e = tid; e < Q * ENC_HD; e += ENC_WAVES * 64) {
@@ -251,6 +275,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
             vt[(long)dd * cap + slot] = vnew[(long)i * 3 * D + dd];
         }
     }
+    ENC_STAMP(6);
 }
 
 int launch_enc_attention(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
