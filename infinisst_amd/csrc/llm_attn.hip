@@ -80,6 +80,17 @@ __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int
 // the lean one-stream form (fewer registers, 3 waves per SIMD)
 // tiles a wave keeps in flight ahead of the one it works on (MULTI form).  Measured, same box, 64 streams x 10 passes: 1 -> 93.4 / 93.7 ms per
 // step, 2 -> 94.2 / 94.5 (256 VGPRs, no spill): more bytes in flight per wave do not raise the rate the launch streams the caches at
+// -DISST_ATTN_TRACE (make trace): thread 0 of every workgroup of the decode attention stamps the 100 MHz wall clock: entry / queries rotated /
+// tiles done / slab stored (profiles/attn_trace_probe.py)
+#ifdef ISST_ATTN_TRACE
+__device__ unsigned long long g_attn_trace[8192 * 8];
+#define ATTN_STAMP(i) do { if (threadIdx.x == 0) { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (wg_ < 8192) g_attn_trace[wg_ * 8 + (i)] = wall_clock64(); } } while (0)
+extern "C" int isst_debug_attn_trace_read(void* dst, long bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#else
+#define ATTN_STAMP(i) do {} while (0)
+#endif
 #ifndef ATTN_SLAB_SC1
 #define ATTN_SLAB_SC1 0  // 1: partial slabs always stored write-through (experiment: a cheaper end-of-kernel write-back?)
 #endif
@@ -102,6 +113,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
     __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
     __shared__ int s_ticket;
+    ATTN_STAMP(0);
     const int sp = blockIdx.x, kvh = blockIdx.y;
     const int2 grp = one.enabled ? one.grp : groups[blockIdx.z];
     const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
@@ -164,6 +176,10 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         rope_row_chunks(qraw, cv ? cpos[ct] : 0, fq, rope_cos, rope_sin, qf[ct]);
     }
 
+#ifdef ISST_ATTN_TRACE
+    asm volatile("s_nop 0" :: "v"(qf[0][0].x), "v"(qf[0][3].w));
+#endif
+    ATTN_STAMP(1);
     // running softmax state of this wave (flash-style, fp32): per column fr its max and sum; O in the C layout
     float m_run[CT], l_run[CT];
     f32x4_t o[CT][8];
@@ -358,6 +374,10 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     } else {
         if (t < tile_end) tile_body(std::integral_constant<int, 0>{});
     }
+#ifdef ISST_ATTN_TRACE
+    asm volatile("s_nop 0" :: "v"(o[0][0][0]), "v"(o[0][7][3]));
+#endif
+    ATTN_STAMP(2);
     // ---- the 4 waves' partials meet in LDS.  o[ct][nt][r] is O[column ct*16 + 4fq + r][dim 16nt + fr] ----
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -407,6 +427,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             }
         }
     }
+    ATTN_STAMP(3);
     if (!inline_combine) return;
     // ---- in-launch combine (cdna_hip_programming.md Guideline 16, the counter form; MI355X_MICROARCH.md visibility table, row 1): every slab byte
     //      was stored sc1; every storing wave drains its stores; after the workgroup's barrier ONE lane adds to the (kv head's) arrival counter at
