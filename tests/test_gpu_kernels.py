@@ -375,6 +375,43 @@ def test_launch_free_residual_rmsnorm_equals_the_reduce_launch(M, N, K, ks, N2, 
         close_bf16(out3, ref2, f"split-K plain M{M} N{N} vs the unsplit launch", ulps=2.0, atol=3e-2)
 
 
+def test_in_launch_reduction_under_uneven_load():
+    """The cross-workgroup hand-off of the in-launch reduction (sc1 slabs, drained, one agent-scope ticket per workgroup, the last arriver reads every
+    slice with sc1 loads) checked the way MI355X_MICROARCH.md asks for hand-offs: under UNEVEN load, every word, many times.  A second stream keeps the
+    chip busy with a bandwidth-bound copy and a compute-bound matmul of varying size while 300 fused launches run (o_proj and q/k/v forms at 64 and 22
+    rows, rotating weights so that nothing is L2-warm by accident); every result must carry the bits of the quiet-chip run."""
+    g = torch.Generator().manual_seed(77)
+    cases = []
+    for (M, N, K, ks, plain) in [(64, 4096, 4096, 4, False), (22, 4096, 4096, 2, False), (64, 6144, 4096, 2, True), (48, 4096, 14336, 4, False)]:
+        A = bf(torch.randn(M, K, generator=g)).to(DEV)
+        Ws = [E.op_pack_weight(bf(torch.randn(N, K, generator=g) * 0.05).to(DEV)) for _ in range(3)]
+        x = bf(torch.randn(M, N, generator=g)).to(DEV)
+        quiet = [E.op_gemm_splitk_plain(A, w, N, ks) if plain else E.op_gemm_splitk_fused(A, w, x, ks)[:2] for w in Ws]
+        cases.append((A, Ws, x, N, ks, plain, quiet))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    mm = torch.randn(2048, 2048, device=DEV)
+    bad = 0
+    for it in range(300):
+        with torch.cuda.stream(side):  # uneven background load: alternating copy / matmul bursts of changing size
+            if it % 3 == 0:
+                n_el = (4 << 20) * (1 + it % 7)
+                big[:n_el].copy_(big[n_el:2 * n_el])
+            else:
+                mm = (mm @ mm).clamp_(-1, 1)
+        A, Ws, x, N, ks, plain, quiet = cases[it % len(cases)]
+        w = it % 3
+        if plain:
+            got = E.op_gemm_splitk_plain(A, Ws[w], N, ks)
+            bad += int(not torch.equal(got, quiet[w]))
+        else:
+            xn, ssq, _ = E.op_gemm_splitk_fused(A, Ws[w], x, ks)
+            bad += int(not (torch.equal(xn, quiet[w][0]) and torch.equal(ssq, quiet[w][1])))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 300 fused launches under load differ from the quiet-chip bits"
+
+
 @pytest.mark.parametrize("M,N,K,ks", [(96, 256, 1024, 2), (384, 1024, 2048, 4), (130, 512, 512, 1)])
 def test_gemm_splitk_layernorm(M, N, K, ks):
     """Encoder out_proj / fc2 at 65..1024 rows: K slices on the dense kernel, summed (+ bias, + residual) by the LayerNorm kernel.
