@@ -25,6 +25,7 @@
 #ifndef LLM_SPLIT_TARGET_WGS
 #define LLM_SPLIT_TARGET_WGS 768
 #endif
+#define LT_MIN_ROWS 128  // rows above which the Llama projections of a prefill pass are plain library GEMMs (blaslt.hip)
 #ifndef LLM_SPLIT_MAX_ROWS
 #define LLM_SPLIT_MAX_ROWS 2048  // rows up to which o_proj / down_proj run split-K into slabs (beyond, the dense kernel has the workgroups)
 #endif
@@ -46,6 +47,7 @@ struct PackedLinear {
     int N = 0;        // packed rows (multiple of 16)
     int K = 0;
     int n_valid = 0;  // real output columns
+    bf16_t* w_rm = nullptr;  // row-major [rows][K] copy for the library GEMM of the many-row prefill (blaslt.hip); SwiGLU pairs as [gate rows | up rows]
 };
 struct Norm {
     bf16_t* w = nullptr;
@@ -116,6 +118,9 @@ struct isst_handle {
     int qkv_slices = 0;           // ISST_QKV_SLICES: K slices of the q/k/v projection at 13..64 rows (in-launch reduction); 0 = by row count
     float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
     int* ltickets = nullptr;      // [llm_dim / 32] arrival counters (GemmArgs::tickets), zero between launches
+    bool use_blaslt = true;       // ISST_BLASLT=0: the > LT_MIN_ROWS-row prefill projections stay on gemm_tiled.hip (see blaslt.hip for why they leave it)
+    bf16_t* lgu = nullptr;        // [llm_rows_max][2 x ffn] gate | up outputs of the library GEMM
+    bf16_t* ltmp = nullptr;       // [llm_rows_max][llm_dim] o_proj / down_proj outputs of the library GEMM
     bool rope_side = false;       // ISST_ROPE_SIDE=1: the rotated-key pre-pass of a chunk (pure memory traffic) runs on a low-priority side stream beside the
                                   // speech encoder (MFMA-bound at many streams) and joins before the prefill.  Measured, one box, ms per step: 64 streams
                                   // 90.96 / 90.90 without, 91.17 / 90.69 with; 16 streams 51.11 / 51.21 -- nothing, stays off
@@ -358,6 +363,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_FUSE_COMBINE")) h->fuse_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_REDUCE")) h->fuse_reduce = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_ROPE_SIDE")) h->rope_side = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_BLASLT")) h->use_blaslt = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_QKV_SLICES")) h->qkv_slices = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
@@ -427,6 +433,17 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         ok = ok && L.in_norm && L.post_norm && alloc_linear(h, L.qkv, (H + 2 * KV) * 128, DL, false) && alloc_linear(h, L.o, DL, H * 128, false) &&
              alloc_linear(h, L.gateup, 2 * c.llm_ffn, DL, false) && alloc_linear(h, L.down, DL, c.llm_ffn, false);
         L.gateup.n_valid = c.llm_ffn;
+        if (h->use_blaslt && h->llm_rows_max > LT_MIN_ROWS) {  // only engines that can reach the many-row prefill pay for the second copy
+            for (PackedLinear* pl : {&L.qkv, &L.o, &L.gateup, &L.down}) {
+                pl->w_rm = h->dalloc<bf16_t>((size_t)pl->N * pl->K, true);
+                ok = ok && pl->w_rm;
+            }
+        }
+    }
+    if (h->use_blaslt && h->llm_rows_max > LT_MIN_ROWS) {
+        h->lgu = h->dalloc<bf16_t>((size_t)h->llm_rows_max * 2 * c.llm_ffn);
+        h->ltmp = h->dalloc<bf16_t>((size_t)h->llm_rows_max * DL);
+        ok = ok && h->lgu && h->ltmp;
     }
     h->final_norm = h->dalloc<bf16_t>(DL, true);
     ok = ok && h->final_norm && alloc_linear(h, h->lm_head, c.vocab, DL, false);
@@ -535,6 +552,10 @@ int copy_vec(isst_handle* h, bf16_t* dst, const bf16_t* src, size_t n) {
 }
 int pack_into(isst_handle* h, PackedLinear& L, const bf16_t* src, int n_rows, int row_offset_tiles, int tile_stride, int tile_phase, int conv_k) {
     CHK(launch_pack_weight(src, L.wp, n_rows, L.K, row_offset_tiles, tile_stride, tile_phase, conv_k, 0));
+    if (L.w_rm && conv_k == 0) {  // row-major twin: parts stacked (q | k | v; gate | up -- NOT tile-interleaved like the packed form)
+        const long row0 = tile_stride > 1 ? (long)tile_phase * n_rows : (long)row_offset_tiles * 16;
+        HIPCHK(hipMemcpyAsync(L.w_rm + row0 * L.K, src, (size_t)n_rows * L.K * 2, hipMemcpyDeviceToDevice, 0));
+    }
     return ISST_OK;
 }
 
@@ -1023,7 +1044,11 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     // A/B on one box, ms per step: 64 streams 92.63 (1 slice) / 91.33 (2) / 92.61 (4); 16 streams 51.24 / 51.52 / 50.84 -- two slices from 33 rows
     const int qs = h->qkv_slices > 0 ? h->qkv_slices : (rows > 32 ? 2 : 1);
     const int sqf = (fr && qs > 1 && DL % (256 * qs) == 0) ? qs : 1;
-    bool pending = false, pending_fused = false;
+    // more than LT_MIN_ROWS rows (a many-stream prefill): the four projections are plain library GEMMs on the row-major weight twins, their epilogues two
+    // bandwidth-bound passes (blaslt.hip, rowops.hip)
+    const bool lt = h->use_blaslt && rows > LT_MIN_ROWS && h->lgu && h->llm[0].qkv.w_rm && gemm_lt_available();
+    const int QW = (H + 2 * KV) * 128;
+    bool pending = false, pending_fused = false, pending_lt = false;
     for (int l = 0; l < c.llm_layers; ++l) {
         const LlmLayer& L = h->llm[l];
         // decode shapes: RMSNorm is applied inside the projection's A-fragment load (gemm.hip NORM); larger row counts
@@ -1033,7 +1058,11 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps));
         } else {
             bool qkv_done = false;
-            if (pending_fused) {  // lx is complete (the down_proj launch reduced its own slabs); q/k/v normalises it on the way into LDS
+            if (pending_lt) {  // the previous layer's down_proj output waits in ltmp: residual + this layer's input norm in one pass
+                CHK(launch_residual_rmsnorm(h->ltmp, DL, h->lx, DL, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+                if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
+                pending_lt = false;
+            } else if (pending_fused) {  // lx is complete (the down_proj launch reduced its own slabs); q/k/v normalises it on the way into LDS
                 if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
                 pending_fused = false;
                 if (sqf > 1)
@@ -1049,6 +1078,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             }
             if (qkv_done) {
+            } else if (lt) {
+                CHK(launch_gemm_lt(h->lxn, DL, L.qkv.w_rm, h->lqkv, QW, rows, QW, DL, st));
             } else if (sqf > 1) {  // (first layer: the norm launch ran; the K slices still pay)
                 CHK(gemm_partial(h, h->lxn, DL, L.qkv, h->lslab, rows, sqf, st, nullptr, 0, nullptr, h->lqkv, (H + 2 * KV) * 128));
             } else if (sq > 1) {  // 129..1024 rows: the 48 column blocks of the dense kernel get K slices; a small pass sums the slabs to bf16
@@ -1064,7 +1095,12 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
                                  max_unit_groups, n_beam_wgs, merge_in_oproj ? &merge_splits : nullptr, h->inline_combine ? h->attn_cnt : nullptr));
-        if (so > 1 && fr) {
+        if (lt) {
+            CHK(launch_gemm_lt(h->lattn, H * 128, L.o.w_rm, h->ltmp, DL, rows, DL, H * 128, st));
+            CHK(launch_residual_rmsnorm(h->ltmp, DL, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+            CHK(launch_gemm_lt(h->lxn, DL, L.gateup.w_rm, h->lgu, 2 * c.llm_ffn, rows, 2 * c.llm_ffn, DL, st));
+            CHK(launch_swiglu_pass(h->lgu, 2 * c.llm_ffn, h->lact, c.llm_ffn, rows, c.llm_ffn, st));
+        } else if (so > 1 && fr) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st, h->lx, DL, h->lssq));
             CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps, h->lssq));
         } else if (so > 1) {
@@ -1103,7 +1139,14 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
             }
         }
-        if (sd > 1 && fr) {  // (the last layer too: lx is complete when the launch ends, and lm_head can take the sums of squares)
+        if (lt) {
+            CHK(launch_gemm_lt(h->lact, c.llm_ffn, L.down.w_rm, h->ltmp, DL, rows, DL, c.llm_ffn, st));
+            pending_lt = l + 1 < c.llm_layers;
+            if (!pending_lt) {  // last layer: the residual alone (the final norm runs on the gathered last rows)
+                CHK(launch_residual_rmsnorm(h->ltmp, DL, h->lx, DL, nullptr, nullptr, 0, rows, DL, c.rms_eps, st));
+                if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
+            }
+        } else if (sd > 1 && fr) {  // (the last layer too: lx is complete when the launch ends, and lm_head can take the sums of squares)
             CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st, h->lx, DL, h->lssq));
             pending_fused = l + 1 < c.llm_layers;
             if (!pending_fused && tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
