@@ -25,7 +25,9 @@
 #ifndef LLM_SPLIT_TARGET_WGS
 #define LLM_SPLIT_TARGET_WGS 768
 #endif
-#define LT_MIN_ROWS 128  // rows above which the Llama projections of a prefill pass are plain library GEMMs (blaslt.hip)
+// rows above which the Llama projections of a pass are plain library GEMMs (blaslt.hip).  ms per step with / without the library path, one box:
+// 132 rows (6 streams' prefill) 42.10 / 41.73, 176: 43.80 / 43.99, 220: 46.80 / 46.74, 264: 49.59 / 50.22, 352: 49.97 / 51.21, 1408: 86.2 / 90.5
+#define LT_MIN_ROWS 160
 #ifndef LLM_SPLIT_MAX_ROWS
 #define LLM_SPLIT_MAX_ROWS 2048  // rows up to which o_proj / down_proj run split-K into slabs (beyond, the dense kernel has the workgroups)
 #endif
@@ -118,6 +120,7 @@ struct isst_handle {
     int qkv_slices = 0;           // ISST_QKV_SLICES: K slices of the q/k/v projection at 13..64 rows (in-launch reduction); 0 = by row count
     float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
     int* ltickets = nullptr;      // [llm_dim / 32] arrival counters (GemmArgs::tickets), zero between launches
+    int lt_min_rows = LT_MIN_ROWS; // ISST_BLASLT_MIN_ROWS: rows above which the library GEMM path runs
     bool use_blaslt = true;       // ISST_BLASLT=0: the > LT_MIN_ROWS-row prefill projections stay on gemm_tiled.hip (see blaslt.hip for why they leave it)
     bf16_t* lgu = nullptr;        // [llm_rows_max][2 x ffn] gate | up outputs of the library GEMM
     bf16_t* ltmp = nullptr;       // [llm_rows_max][llm_dim] o_proj / down_proj outputs of the library GEMM
@@ -364,6 +367,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_FUSE_REDUCE")) h->fuse_reduce = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_ROPE_SIDE")) h->rope_side = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BLASLT")) h->use_blaslt = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_BLASLT_MIN_ROWS")) h->lt_min_rows = atoi(e) >= 16 ? atoi(e) : LT_MIN_ROWS;
     if (const char* e = getenv("ISST_QKV_SLICES")) h->qkv_slices = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
@@ -433,14 +437,14 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         ok = ok && L.in_norm && L.post_norm && alloc_linear(h, L.qkv, (H + 2 * KV) * 128, DL, false) && alloc_linear(h, L.o, DL, H * 128, false) &&
              alloc_linear(h, L.gateup, 2 * c.llm_ffn, DL, false) && alloc_linear(h, L.down, DL, c.llm_ffn, false);
         L.gateup.n_valid = c.llm_ffn;
-        if (h->use_blaslt && h->llm_rows_max > LT_MIN_ROWS) {  // only engines that can reach the many-row prefill pay for the second copy
+        if (h->use_blaslt && h->llm_rows_max > h->lt_min_rows) {  // only engines that can reach the many-row prefill pay for the second copy
             for (PackedLinear* pl : {&L.qkv, &L.o, &L.gateup, &L.down}) {
                 pl->w_rm = h->dalloc<bf16_t>((size_t)pl->N * pl->K, true);
                 ok = ok && pl->w_rm;
             }
         }
     }
-    if (h->use_blaslt && h->llm_rows_max > LT_MIN_ROWS) {
+    if (h->use_blaslt && h->llm_rows_max > h->lt_min_rows) {
         h->lgu = h->dalloc<bf16_t>((size_t)h->llm_rows_max * 2 * c.llm_ffn);
         h->ltmp = h->dalloc<bf16_t>((size_t)h->llm_rows_max * DL);
         ok = ok && h->lgu && h->ltmp;
@@ -1046,7 +1050,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     const int sqf = (fr && qs > 1 && DL % (256 * qs) == 0) ? qs : 1;
     // more than LT_MIN_ROWS rows (a many-stream prefill): the four projections are plain library GEMMs on the row-major weight twins, their epilogues two
     // bandwidth-bound passes (blaslt.hip, rowops.hip)
-    const bool lt = h->use_blaslt && rows > LT_MIN_ROWS && h->lgu && h->llm[0].qkv.w_rm && gemm_lt_available();
+    const bool lt = h->use_blaslt && rows > h->lt_min_rows && h->lgu && h->llm[0].qkv.w_rm && gemm_lt_available();
     const int QW = (H + 2 * KV) * 128;
     bool pending = false, pending_fused = false, pending_lt = false;
     for (int l = 0; l < c.llm_layers; ++l) {

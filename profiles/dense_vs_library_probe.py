@@ -14,7 +14,8 @@ def timeit(fn, n=30):
     for i in range(n): fn(i)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1000 / n
-M = 1408
+import sys
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 1408
 for name, N, K, epi in (("q/k/v", 6144, 4096, "none"), ("o_proj", 4096, 4096, "none"), ("gate/up", 28672, 4096, "swiglu"), ("down", 4096, 14336, "none")):
     copies = 3
     Ws = [(torch.randn(N, K, device=dev) * 0.02).bfloat16() for _ in range(copies)]
