@@ -1844,6 +1844,18 @@ extern "C" int isst_op_gemm_splitk_fused(const uint16_t* A, int64_t lda, const u
     if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
     return launch_gemm_mid(g, reinterpret_cast<hipStream_t>(hip_stream));
 }
+// the many-row prefill's library path, piece by piece (blaslt.hip + the two passes of rowops.hip): w_rm row-major [N][K]
+extern "C" int isst_op_gemm_lt(const uint16_t* A, int64_t lda, const uint16_t* w_rm, uint16_t* out, int64_t ldo, int M, int N, int K, void* hip_stream) {
+    if (!gemm_lt_available()) return ISST_ERR_HIP;
+    return launch_gemm_lt(A, lda, w_rm, out, ldo, M, N, K, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_swiglu_pass(const uint16_t* gu, int64_t ldgu, uint16_t* act, int64_t ldact, int rows, int F, void* hip_stream) {
+    return launch_swiglu_pass(gu, ldgu, act, ldact, rows, F, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_residual_rmsnorm(const uint16_t* t, int64_t ldt, uint16_t* x, int64_t ldx, const uint16_t* norm_w, uint16_t* out, int64_t ldo, int rows, int D,
+                                        float eps, void* hip_stream) {
+    return launch_residual_rmsnorm(t, ldt, x, ldx, norm_w, out, ldo, rows, D, eps, reinterpret_cast<hipStream_t>(hip_stream));
+}
 extern "C" int isst_op_gemm_splitk_plain(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* out, int64_t ldo, float* slabs, int* tickets,
                                          int M, int N, int K, int ksplit, const uint16_t* norm_w, float norm_eps, float* ssq_in, void* hip_stream) {
     if (N % 32 != 0 || !out || !slabs || !tickets || (norm_w && !ssq_in)) return ISST_ERR_ARG;

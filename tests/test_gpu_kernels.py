@@ -375,6 +375,32 @@ def test_launch_free_residual_rmsnorm_equals_the_reduce_launch(M, N, K, ks, N2, 
         close_bf16(out3, ref2, f"split-K plain M{M} N{N} vs the unsplit launch", ulps=2.0, atol=3e-2)
 
 
+@pytest.mark.parametrize("M,D,F", [(176, 256, 512), (1408, 1024, 2048), (200, 4096, 1024)])
+def test_library_gemm_path_pieces_match_the_fused_kernels(M, D, F):
+    """The many-row prefill's library path (hipBLASLt GEMM on the row-major weight twin + SwiGLU pass + residual/RMSNorm pass) against the oracle arithmetic
+    and against the packed-weight kernels with fused epilogues it replaces there -- same rounding points (bf16 after the GEMM, after silu, after the product,
+    after the residual add, twice inside the norm), another fp32 summation order."""
+    g = torch.Generator().manual_seed(M + D + F)
+    A = bf(torch.randn(M, D, generator=g))
+    Wg, Wu = bf(torch.randn(F, D, generator=g) * 0.05), bf(torch.randn(F, D, generator=g) * 0.05)
+    Wd = bf(torch.randn(D, F, generator=g) * 0.05)
+    x = bf(torch.randn(M, D, generator=g))
+    nw = bf(1 + 0.2 * torch.randn(D, generator=g))
+    gu = E.op_gemm_lt(A.to(DEV), torch.cat([Wg, Wu]).to(DEV))                       # [gate | up]
+    act = E.op_swiglu_pass(gu)
+    ref_act = torch.nn.functional.silu(bf(A.float() @ Wg.float().t())) * bf(A.float() @ Wu.float().t())
+    close_bf16(act, bf(ref_act.float()), f"library gate/up + SwiGLU pass M{M}", ulps=4.5, atol=4e-3)  # (gate and up each within an ulp: their product within ~2.5 + its own rounding)
+    inter = torch.stack([Wg.view(F // 16, 16, D), Wu.view(F // 16, 16, D)], dim=1).reshape(2 * F, D)   # the packed form interleaves 16-row tiles
+    close_bf16(act, E.op_gemm(A.to(DEV), E.op_pack_weight(inter.to(DEV)), 2 * F, "swiglu"), f"library path vs fused SwiGLU kernel M{M}", ulps=4.5, atol=4e-3)
+    t = E.op_gemm_lt(act, Wd.to(DEV))
+    x_new, normed = E.op_residual_rmsnorm(t, x.to(DEV), nw.to(DEV), 1e-5)
+    close_bf16(t, ref_linear(act.cpu(), Wd, "none"), f"library down_proj M{M}", ulps=2.5, atol=3.2e-2)
+    assert torch.equal(x_new.cpu(), bf(x.float() + t.float().cpu())), "residual pass: x != bf16(x + t)"   # (exact: one add, one rounding)
+    close_bf16(normed, ollm.rmsnorm(x_new.cpu(), nw, 1e-5), f"residual/RMSNorm pass M{M}", ulps=2.0, atol=1e-3)
+    x_only, none = E.op_residual_rmsnorm(t, x.to(DEV), None)
+    assert none is None and torch.equal(x_only, x_new)
+
+
 def test_in_launch_reduction_under_uneven_load():
     """The cross-workgroup hand-off of the in-launch reduction (sc1 slabs, drained, one agent-scope ticket per workgroup, the last arriver reads every
     slice with sc1 loads) checked the way MI355X_MICROARCH.md asks for hand-offs: under UNEVEN load, every word, many times.  A second stream keeps the
