@@ -22,7 +22,7 @@ struct LtPlan {
 hipblasLtHandle_t g_lt = nullptr;
 void* g_ws = nullptr;
 constexpr size_t LT_WS_BYTES = 64u << 20;
-std::map<std::tuple<int, int, int, long, long>, LtPlan> g_plans;
+std::map<std::tuple<int, int, int, long, long, int>, LtPlan> g_plans;
 
 bool lt_init() {
     if (g_lt) return true;
@@ -34,10 +34,11 @@ bool lt_init() {
 
 bool gemm_lt_available() { return lt_init(); }
 
-int launch_gemm_lt(const bf16_t* A, long lda, const bf16_t* W, bf16_t* C, long ldc, int M, int N, int K, hipStream_t stream) {
+// bias != null: C = bf16(acc + bias[n]) (the library's bias epilogue: added in fp32 before the one rounding, as the packed kernels' EPI_BIAS)
+int launch_gemm_lt(const bf16_t* A, long lda, const bf16_t* W, bf16_t* C, long ldc, int M, int N, int K, hipStream_t stream, const bf16_t* bias) {
     if (M <= 0) return ISST_OK;
     if (!lt_init()) return ISST_ERR_HIP;
-    const auto key = std::make_tuple(M, N, K, lda, ldc);
+    const auto key = std::make_tuple(M, N, K, lda, ldc, bias ? 1 : 0);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
         // column-major view of the row-major problem: C^T (N x M, ld = ldc) = W (K x N, ld = K)^T . A^T (K x M, ld = lda)
@@ -47,6 +48,14 @@ int launch_gemm_lt(const bf16_t* A, long lda, const bf16_t* W, bf16_t* C, long l
         if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof opT) != HIPBLAS_STATUS_SUCCESS ||
             hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof opN) != HIPBLAS_STATUS_SUCCESS)
             return ISST_ERR_HIP;
+        if (bias) {
+            const hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
+            const hipDataType bt = HIP_R_16BF;
+            if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof epi) != HIPBLAS_STATUS_SUCCESS ||
+                hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof bt) != HIPBLAS_STATUS_SUCCESS ||
+                hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof bias) != HIPBLAS_STATUS_SUCCESS)
+                return ISST_ERR_HIP;
+        }
         if (hipblasLtMatrixLayoutCreate(&p.lw, HIP_R_16BF, K, N, K) != HIPBLAS_STATUS_SUCCESS ||
             hipblasLtMatrixLayoutCreate(&p.la, HIP_R_16BF, K, M, lda) != HIPBLAS_STATUS_SUCCESS ||
             hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_16BF, N, M, ldc) != HIPBLAS_STATUS_SUCCESS)
@@ -65,6 +74,7 @@ int launch_gemm_lt(const bf16_t* A, long lda, const bf16_t* W, bf16_t* C, long l
         it = g_plans.emplace(key, p).first;
     }
     const LtPlan& p = it->second;
+    if (bias && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof bias) != HIPBLAS_STATUS_SUCCESS) return ISST_ERR_HIP;  // (per call: plans are shared by layers)
     const float alpha = 1.f, beta = 0.f;
     const hipblasStatus_t st = hipblasLtMatmul(g_lt, p.desc, &alpha, W, p.lw, A, p.la, &beta, C, p.lc, C, p.lc, &p.algo, g_ws, p.ws <= LT_WS_BYTES ? p.ws : 0, stream);
     return st == HIPBLAS_STATUS_SUCCESS ? ISST_OK : ISST_ERR_HIP;

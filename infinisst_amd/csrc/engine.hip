@@ -28,6 +28,10 @@
 // rows above which the Llama projections of a pass are plain library GEMMs (blaslt.hip).  ms per step with / without the library path, one box:
 // 132 rows (6 streams' prefill) 42.10 / 41.73, 176: 43.80 / 43.99, 220: 46.80 / 46.74, 264: 49.59 / 50.22, 352: 49.97 / 51.21, 1408: 86.2 / 90.5
 #define LT_MIN_ROWS 160
+// ... and of the speech encoder's layers (K = 1024 / 4096; library 106 us per layer at 3072 rows against 198 for gemm_tiled: enc_vs_library_probe.py).  ms per
+// step with / without, one box each pair: 48 rows (one stream) 32.59 / 32.02, 96: 33.65 / 34.36, 144: 36.60 / 37.56, 192: 37.90 / 39.02, 384: 43.17 / 44.13,
+// 768: 49.34 / 50.40, 3072: 85.77 / 87.20
+#define ENC_LT_MIN_ROWS 64
 #ifndef LLM_SPLIT_MAX_ROWS
 #define LLM_SPLIT_MAX_ROWS 2048  // rows up to which o_proj / down_proj run split-K into slabs (beyond, the dense kernel has the workgroups)
 #endif
@@ -121,6 +125,8 @@ struct isst_handle {
     float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
     int* ltickets = nullptr;      // [llm_dim / 32] arrival counters (GemmArgs::tickets), zero between launches
     int lt_min_rows = LT_MIN_ROWS; // ISST_BLASLT_MIN_ROWS: rows above which the library GEMM path runs
+    int enc_lt_min_rows = ENC_LT_MIN_ROWS;  // ISST_BLASLT_ENC_MIN_ROWS: the same for the speech encoder's four projections per layer
+    bf16_t* etmp = nullptr;       // [enc_rows_max][enc_dim] out_proj / fc2 outputs of the library GEMM
     bool use_blaslt = true;       // ISST_BLASLT=0: the > LT_MIN_ROWS-row prefill projections stay on gemm_tiled.hip (see blaslt.hip for why they leave it)
     bf16_t* lgu = nullptr;        // [llm_rows_max][2 x ffn] gate | up outputs of the library GEMM
     bf16_t* ltmp = nullptr;       // [llm_rows_max][llm_dim] o_proj / down_proj outputs of the library GEMM
@@ -368,6 +374,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_ROPE_SIDE")) h->rope_side = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BLASLT")) h->use_blaslt = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BLASLT_MIN_ROWS")) h->lt_min_rows = atoi(e) >= 16 ? atoi(e) : LT_MIN_ROWS;
+    if (const char* e = getenv("ISST_BLASLT_ENC_MIN_ROWS")) h->enc_lt_min_rows = atoi(e) >= 16 ? atoi(e) : ENC_LT_MIN_ROWS;
     if (const char* e = getenv("ISST_QKV_SLICES")) h->qkv_slices = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
@@ -420,6 +427,15 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         ok = ok && alloc_norm(h, L.ln1, D) && alloc_norm(h, L.ln2, D) && alloc_linear(h, L.qkv, 3 * D, D, true) &&
              alloc_linear(h, L.out, D, D, true) && alloc_linear(h, L.fc1, c.enc_ffn, D, true) && alloc_linear(h, L.fc2, D, c.enc_ffn, true);
     ok = ok && alloc_norm(h, h->enc_ln_out, D);
+    if (h->use_blaslt && h->enc_rows_max > h->enc_lt_min_rows) {  // row-major twins for the library GEMM path of many-stream calls
+        for (auto& L : h->enc)
+            for (PackedLinear* pl : {&L.qkv, &L.out, &L.fc1, &L.fc2}) {
+                pl->w_rm = h->dalloc<bf16_t>((size_t)pl->N * pl->K, true);
+                ok = ok && pl->w_rm;
+            }
+        h->etmp = h->dalloc<bf16_t>((size_t)h->enc_rows_max * D);
+        ok = ok && h->etmp;
+    }
     h->shrink.resize(c.n_shrink);
     for (int i = 0; i < c.n_shrink; ++i) {
         ConvLayer& L = h->shrink[i];
@@ -911,16 +927,24 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
     const int s_out = esplit ? pick_ksplit(D, D, ER) : 1, s_fc2 = esplit ? pick_ksplit(c.enc_ffn, D, ER) : 1;
     const long eslab = (long)ER * D;
     const EncLayer* pend = nullptr;  // layer whose fc2 slabs h->ex still lacks
+    // many rows: the four projections of a layer as library GEMMs with the bias epilogue (blaslt.hip); GELU and residual + LayerNorm as passes
+    const bool elt = h->use_blaslt && ER > h->enc_lt_min_rows && h->etmp && h->enc[0].qkv.w_rm && gemm_lt_available();
+    bool pend_lt = false;            // etmp holds the previous layer's fc2 output (bias included)
     for (int l = 0; l < c.enc_layers; ++l) {
         const EncLayer& L = h->enc[l];
-        if (pend) {
+        if (pend_lt) {
+            CHK(launch_residual_layernorm(h->etmp, D, h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, st));
+            if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l - 1), h->ex, (int64_t)ER * D, st));
+            pend_lt = false;
+        } else if (pend) {
             CHK(launch_layernorm_reduce(h->lslab, eslab, s_fc2, pend->fc2.bias, h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, st));
             if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l - 1), h->ex, (int64_t)ER * D, st));
             pend = nullptr;
         } else {
             CHK(launch_layernorm(h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
         }
-        CHK(gemm(h, h->exn, D, L.qkv, EPI_BIAS, nullptr, 0, h->eqkv, 3 * D, ER, st));
+        if (elt) CHK(launch_gemm_lt(h->exn, D, L.qkv.w_rm, h->eqkv, 3 * D, ER, 3 * D, D, st, L.qkv.bias));
+        else CHK(gemm(h, h->exn, D, L.qkv, EPI_BIAS, nullptr, 0, h->eqkv, 3 * D, ER, st));
         if (contiguous) {
             bf16_t* kb = h->enc_k + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
             bf16_t* vb = h->enc_v + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
@@ -933,6 +957,15 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
                 CHK(launch_enc_attention(h->eqkv + (size_t)i * Q * 3 * D, kb, vb, 0, ev + i, h->enc_cos, h->enc_sin, c.enc_rope_round_each,
                                          h->eattn + (size_t)i * Q * D, 1, Q, c.enc_heads, h->enc_cap, c.max_cache_size, bs, st));
             }
+        }
+        if (elt) {
+            CHK(launch_gemm_lt(h->eattn, D, L.out.w_rm, h->etmp, D, ER, D, D, st, L.out.bias));
+            CHK(launch_residual_layernorm(h->etmp, D, h->ex, D, L.ln2.w, L.ln2.b, h->exn, D, ER, D, c.enc_ln_eps, st));
+            CHK(launch_gemm_lt(h->exn, D, L.fc1.w_rm, h->effn, c.enc_ffn, ER, c.enc_ffn, D, st, L.fc1.bias));
+            CHK(launch_gelu_pass(h->effn, c.enc_ffn, ER, c.enc_ffn, st));
+            CHK(launch_gemm_lt(h->effn, c.enc_ffn, L.fc2.w_rm, h->etmp, D, ER, D, c.enc_ffn, st, L.fc2.bias));
+            pend_lt = true;
+            continue;
         }
         if (s_out > 1) {
             CHK(gemm_partial(h, h->eattn, D, L.out, h->lslab, ER, s_out, st));
@@ -950,7 +983,10 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
             if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l), h->ex, (int64_t)ER * D, st));
         }
     }
-    if (pend) {
+    if (pend_lt) {
+        CHK(launch_residual_layernorm(h->etmp, D, h->ex, D, h->enc_ln_out.w, h->enc_ln_out.b, h->exn, D, ER, D, c.enc_ln_eps, st));
+        if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(c.enc_layers - 1), h->ex, (int64_t)ER * D, st));
+    } else if (pend) {
         CHK(launch_layernorm_reduce(h->lslab, eslab, s_fc2, pend->fc2.bias, h->ex, D, h->enc_ln_out.w, h->enc_ln_out.b, h->exn, D, ER, D, c.enc_ln_eps, st));
         if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(c.enc_layers - 1), h->ex, (int64_t)ER * D, st));
     } else {

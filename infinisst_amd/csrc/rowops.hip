@@ -119,7 +119,8 @@ template <int STEPS>
 __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ b, bf16_t* out, long ldo,
                                                         int rows, int C, float eps, int gelu, const float* __restrict__ slabs, long slab_stride,
-                                                        int n_slabs, const bf16_t* __restrict__ proj_bias) {
+                                                        int n_slabs, const bf16_t* __restrict__ proj_bias, const bf16_t* __restrict__ tin, long ldt) {
+    // (tin != null -- the library-GEMM path: the projection's bf16 output, bias included, waits in tin: x = bf16(x + t) is written back first)
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -142,6 +143,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
                 unpack8(*reinterpret_cast<const u32x4_t*>(proj_bias + c), pb);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + bfr(acc[j] + pb[j]));
+                *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
+            } else if (tin) {
+                float tv[8];
+                unpack8(*reinterpret_cast<const u32x4_t*>(tin + row * ldt + c), tv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + tv[j]);
                 *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
             }
 #pragma unroll
@@ -177,16 +184,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
 }
 
 static int launch_layernorm_impl(bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps,
-                                 int gelu, const float* slabs, long slab_stride, int n_slabs, const bf16_t* proj_bias, hipStream_t s) {
+                                 int gelu, const float* slabs, long slab_stride, int n_slabs, const bf16_t* proj_bias, hipStream_t s,
+                                 const bf16_t* tin = nullptr, long ldt = 0) {
     if (rows <= 0) return ISST_OK;
     if (C % 8 != 0 || C > 4096 || ldx % 8 != 0 || ldo % 8 != 0) return ISST_ERR_ARG;
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 512)
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias);
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias, tin, ldt);
     else if (C <= 1024)
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias);
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias, tin, ldt);
     else
-        hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias);
+        hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias, tin, ldt);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
@@ -195,6 +203,29 @@ int launch_layernorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b
     return launch_layernorm_impl(const_cast<bf16_t*>(x), ldx, w, b, out, ldo, rows, C, eps, gelu, nullptr, 0, 0, nullptr, s);
 }
 
+int launch_residual_layernorm(const bf16_t* t, long ldt, bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps,
+                              hipStream_t s) {
+    if (!t || ldt % 8 != 0) return ISST_ERR_ARG;
+    return launch_layernorm_impl(x, ldx, w, b, out, ldo, rows, C, eps, 0, nullptr, 0, 0, nullptr, s, t, ldt);
+}
+// x = bf16(gelu_erf(x)) in place (the exact-erf GELU of the bf16 value, as EPI_BIAS_GELU applies it after the bias rounding)
+__global__ __launch_bounds__(256) void gelu_pass_kernel(bf16_t* x, long ldx, int C) {
+    const long row = blockIdx.y;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c >= C) return;
+    float v[8];
+    u32x4_t* p = reinterpret_cast<u32x4_t*>(x + row * ldx + c);
+    unpack8(*p, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+    *p = pack8(v);
+}
+int launch_gelu_pass(bf16_t* x, long ldx, int rows, int C, hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    if (C % 8 != 0 || ldx % 8 != 0) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(gelu_pass_kernel, dim3((C / 8 + 255) / 256, rows), dim3(256), 0, s, x, ldx, C);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
 // x[rows][C] (in place) += projection slabs + bias, then out = LayerNorm(x) (w == null: update only)
 int launch_layernorm_reduce(const float* slabs, long slab_stride, int n_slabs, const bf16_t* proj_bias, bf16_t* x, long ldx, const bf16_t* w,
                             const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps, hipStream_t s) {
