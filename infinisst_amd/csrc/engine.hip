@@ -1881,9 +1881,17 @@ extern "C" int isst_op_gemm_splitk_fused(const uint16_t* A, int64_t lda, const u
     return launch_gemm_mid(g, reinterpret_cast<hipStream_t>(hip_stream));
 }
 // the many-row prefill's library path, piece by piece (blaslt.hip + the two passes of rowops.hip): w_rm row-major [N][K]
-extern "C" int isst_op_gemm_lt(const uint16_t* A, int64_t lda, const uint16_t* w_rm, uint16_t* out, int64_t ldo, int M, int N, int K, void* hip_stream) {
+extern "C" int isst_op_gemm_lt(const uint16_t* A, int64_t lda, const uint16_t* w_rm, const uint16_t* bias, uint16_t* out, int64_t ldo, int M, int N, int K,
+                               void* hip_stream) {
     if (!gemm_lt_available()) return ISST_ERR_HIP;
-    return launch_gemm_lt(A, lda, w_rm, out, ldo, M, N, K, reinterpret_cast<hipStream_t>(hip_stream));
+    return launch_gemm_lt(A, lda, w_rm, out, ldo, M, N, K, reinterpret_cast<hipStream_t>(hip_stream), bias);
+}
+extern "C" int isst_op_gelu_pass(uint16_t* x, int64_t ldx, int rows, int C, void* hip_stream) {
+    return launch_gelu_pass(x, ldx, rows, C, reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" int isst_op_residual_layernorm(const uint16_t* t, int64_t ldt, uint16_t* x, int64_t ldx, const uint16_t* ln_w, const uint16_t* ln_b, uint16_t* out,
+                                          int64_t ldo, int rows, int C, float eps, void* hip_stream) {
+    return launch_residual_layernorm(t, ldt, x, ldx, ln_w, ln_b, out, ldo, rows, C, eps, reinterpret_cast<hipStream_t>(hip_stream));
 }
 extern "C" int isst_op_swiglu_pass(const uint16_t* gu, int64_t ldgu, uint16_t* act, int64_t ldact, int rows, int F, void* hip_stream) {
     return launch_swiglu_pass(gu, ldgu, act, ldact, rows, F, reinterpret_cast<hipStream_t>(hip_stream));

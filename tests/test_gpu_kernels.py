@@ -401,6 +401,30 @@ def test_library_gemm_path_pieces_match_the_fused_kernels(M, D, F):
     assert none is None and torch.equal(x_only, x_new)
 
 
+@pytest.mark.parametrize("M,D,F", [(96, 256, 512), (3072, 1024, 4096)])
+def test_library_gemm_path_encoder_pieces(M, D, F):
+    """The speech encoder's library path (more than 64 rows): GEMM with the bias epilogue, exact-erf GELU pass, residual + LayerNorm prologue -- against
+    the fused packed-weight kernels (bias, bias + GELU, bias + residual) and torch's LayerNorm, same rounding points."""
+    g = torch.Generator().manual_seed(M + D)
+    A = bf(torch.randn(M, D, generator=g))
+    W1, b1 = bf(torch.randn(F, D, generator=g) * 0.05), bf(torch.randn(F, generator=g))
+    W2, b2 = bf(torch.randn(D, F, generator=g) * 0.03), bf(torch.randn(D, generator=g))
+    x = bf(torch.randn(M, D, generator=g))
+    lw, lb = bf(1 + 0.2 * torch.randn(D, generator=g)), bf(0.1 * torch.randn(D, generator=g))
+    h1 = E.op_gemm_lt(A.to(DEV), W1.to(DEV), b1.to(DEV))
+    close_bf16(h1, ref_linear(A, W1, "bias", b1), f"library bias epilogue M{M}", ulps=2.0, atol=2e-2)
+    act = E.op_gelu_pass(h1)
+    close_bf16(act, bf(torch.nn.functional.gelu(h1.float().cpu())), f"GELU pass M{M}", ulps=1.0, atol=1e-3)   # (device erff against torch's: a last-bit flip at most)
+    close_bf16(act, E.op_gemm(A.to(DEV), E.op_pack_weight(W1.to(DEV)), F, "bias_gelu", bias=b1.to(DEV)), f"library fc1 + GELU pass vs EPI_BIAS_GELU M{M}", ulps=3.0, atol=2e-2)
+    t = E.op_gemm_lt(act, W2.to(DEV), b2.to(DEV))
+    x_new, normed = E.op_residual_layernorm(t, x.to(DEV), lw.to(DEV), lb.to(DEV), 1e-5)
+    assert torch.equal(x_new.cpu(), bf(x.float() + t.float().cpu())), "residual prologue: x != bf16(x + t)"
+    ref_ln = torch.nn.functional.layer_norm(x_new.float().cpu(), (D,), lw.float(), lb.float(), 1e-5)
+    close_bf16(normed, bf(ref_ln), f"residual + LayerNorm M{M}", ulps=2.0, atol=8e-3)
+    fused = E.op_gemm(act, E.op_pack_weight(W2.to(DEV)), D, "bias_res", bias=b2.to(DEV), res=x.to(DEV))
+    close_bf16(x_new, fused, f"library fc2 + residual vs EPI_BIAS_RES M{M}", ulps=2.5, atol=6e-2)
+
+
 def test_in_launch_reduction_under_uneven_load():
     """The cross-workgroup hand-off of the in-launch reduction (sc1 slabs, drained, one agent-scope ticket per workgroup, the last arriver reads every
     slice with sc1 loads) checked the way MI355X_MICROARCH.md asks for hand-offs: under UNEVEN load, every word, many times.  A second stream keeps the
