@@ -254,6 +254,39 @@ def test_batch_is_deterministic_and_independent_of_stream_order(n):
             assert np.array_equal(l1[i][c], l3[i][c]), f"stream {i} chunk {c}: logits depend on the stream's position in the batch"
 
 
+def test_many_streams_decode_rows_beyond_the_library_threshold():
+    """170 streams in one call at toy width: the DECODE passes have 170 rows (> 160: the library-GEMM path of engine.hip with its SwiGLU and
+    residual + RMSNorm passes, last layer's bare residual included), the prefill 170 x prompt rows, the encoder 170 x block rows.  Streams 0, 85 and 169
+    are held to the same streams stepped alone (the packed-weight kernels at 1 / few rows) within the batched-vs-single tolerance, two chunks."""
+    cfg = toy_config()
+    n = 170
+    gen = GenConfig(max_new_tokens=4, max_llm_cache_size=150)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=33)
+    eng = make_engine(cfg, w, debug_taps=False, max_streams=n + 1, max_multiplier=1)
+    sids = [eng.open_stream() for _ in range(n)]
+    solo = eng.open_stream()
+    audio = [synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=300 + i) for i in range(n)]
+    picks = (0, 85, 169)
+    ref = {i: [] for i in picks}
+    for i in picks:  # the picked streams alone, free-running: their tokens teacher-force the batch
+        eng.reset_stream(solo)
+        for c in range(2):
+            p = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            o, l = eng.generate(gen, [solo], [audio[i][c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]], [p], [[]], return_logits=True)
+            ref[i].append((o[0], l[0]))
+    for c in range(2):
+        p = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        forced = [ref[i][c][0] if i in ref else None for i in range(n)]
+        outs, logits = eng.generate(gen, sids, [a[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples] for a in audio], [p] * n, [[]] * n,
+                                    forced_tokens=forced, return_logits=True)
+        for i in picks:
+            o1, l1 = ref[i][c]
+            k = min(len(o1), len(outs[i]))
+            d = float(np.abs(logits[i][:k] - l1[:k]).max())
+            print(f"chunk {c} stream {i} of {n}: batched (library path) vs alone max |d| = {d:.4f}")
+            assert d <= 0.07
+
+
 def test_agent_policy_matches_oracle_agent():
     """InfiniSST.policy over the engine vs OracleAgent.policy: same READ/WRITE actions, cache lengths and
     checkpoints over an utterance with a ragged tail and evictions (ids compared on decisive steps only)."""
