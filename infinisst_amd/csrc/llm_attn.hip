@@ -91,6 +91,13 @@ extern "C" int isst_debug_attn_trace_read(void* dst, long bytes) {
 #else
 #define ATTN_STAMP(i) do {} while (0)
 #endif
+// exp of the prefill kernel's online softmax: the hardware exp2 on x * log2(e) (two instructions; libm's expf is ~10 with its range handling, and the
+// loop is VALU-issue-bound).  Arguments are <= 0 and results feed a bf16 rounding; PF_EXP_LIBM=1 restores expf for A/B runs.
+#ifndef PF_EXP_LIBM
+#define PF_EXP(x) __builtin_amdgcn_exp2f((x) * 1.44269504088896340736f)
+#else
+#define PF_EXP(x) expf(x)
+#endif
 #ifndef ATTN_SLAB_SC1
 #define ATTN_SLAB_SC1 0  // 1: partial slabs always stored write-through (experiment: a cheaper end-of-kernel write-back?)
 #endif
@@ -606,22 +613,36 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[s]), __builtin_bit_cast(bf16x8_t, qf[s]), st, 0, 0, 0);
+                // logical positions of the lane's four keys (slots t0 + 4 fq + r): the tile's base is wave-uniform, so the ring arithmetic is scalar and a
+                // lane only adds its offset and wraps (llm_logical's arithmetic, once per tile instead of once per key; this loop is VALU-issue-bound:
+                // three waves per SIMD x 65 tiles x ~1000 issue cycles)
                 float sc[4], mx = -INFINITY;
+                const bool sys_tile = t0 < d.sys_cap;
+                int xb = t0 - d.sys_cap - v.ring_start;
+                if (xb < 0) xb += d.ring_cap;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int jc = llm_logical(v, d, t0 + 4 * fq + r, total_u);
-                    const bool ok = jc >= 0 && jc <= cpos;
+                    int jc;
+                    if (sys_tile) {
+                        jc = t0 + 4 * fq + r;
+                        if (jc >= v.sys_len) jc = 0x7fffffff;
+                    } else {
+                        int x = xb + 4 * fq + r;
+                        if (x >= d.ring_cap) x -= d.ring_cap;
+                        jc = v.sys_len + x;
+                    }
+                    const bool ok = jc < total_u && jc <= cpos;
                     sc[r] = ok ? st[r] * scale : -INFINITY;
                     mx = fmaxf(mx, sc[r]);
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
                 const float m_new = fmaxf(m_run, mx);
-                const float resc = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+                const float resc = (m_run == -INFINITY) ? 0.f : PF_EXP(m_run - m_new);
                 float p[4], ls = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    p[r] = (sc[r] == -INFINITY) ? 0.f : expf(sc[r] - m_new);
+                    p[r] = (sc[r] == -INFINITY) ? 0.f : PF_EXP(sc[r] - m_new);
                     ls += p[r];
                 }
                 ls += __shfl_xor(ls, 16, WAVE);
