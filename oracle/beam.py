@@ -12,8 +12,13 @@ Restates the reference's patched HF beam search (the production decoding mode, b
   _expand_inputs_for_generation  :305-342   (inputs and KV cache repeated num_beams times)
 `scorer_process`, `BeamHypotheses.add` and `finalize` are pinned against the reference's own functions, executed from their
 source on a stand-in scorer (tests/golden/gen_golden.py::gen_beam_scorer -> beam_scorer.npz, tests/test_oracle_golden.py).
-transformers 4.47.0 cannot be imported here, so `BeamHypotheses.is_done` (early_stopping=False heuristic) and
-`n_tokens_to_keep = max(2, 1 + n_eos) * num_beams` are restated from that release's published code: parity unpinned.
+The LOOP (`beam_search_loop`: expansion, log-softmax, processors on log-probs, + beam scores, top-k over beams x vocab incl.
+`n_tokens_to_keep`, reorder, stop test, finalize) is pinned the same way: gen_golden.py::gen_beam_loop compiles
+`generation_mixin_beam_search` and `_expand_inputs_for_generation` from patch_hf.py's own text, drives them on a toy model whose
+logits depend on the whole per-beam cache, and stores every step's candidates, chosen (token, parent) pairs, the winning
+sequence and the cache that travels with it (beam_loop.npz, 6 cases incl. EOS-closed hypotheses and a non-empty past cache).
+transformers 4.47.0 cannot be imported here, so `BeamHypotheses.is_done` (early_stopping=False heuristic), `BeamSearchScorer.is_done`
+and DynamicCache (update / reorder_cache) stay restated from that release's published code: parity unpinned for those three.
 
 The model is the batch-1 oracle; every beam carries its own KV list (what `_temporary_reorder_cache` + index_select
 achieve in the reference).
@@ -89,7 +94,7 @@ class BeamOutput:
 
 
 def scorer_process(hyps: BeamHypotheses, done: bool, input_ids: List[List[int]], cand_scores, cand_tokens, cand_beams, kvs,
-                   eos_ids: Sequence[int], num_beams: int, decoder_prompt_len: int):
+                   eos_ids: Sequence[int], num_beams: int, decoder_prompt_len: int, clone=clone_kv):
     """beam_search_process for batch size 1 (patch_hf.py:43-157).  Returns (next_scores, next_tokens, next_parents, done)."""
     cur_len = len(input_ids[0]) + 1
     next_scores, next_tokens, next_parents = [], [], []
@@ -97,7 +102,7 @@ def scorer_process(hyps: BeamHypotheses, done: bool, input_ids: List[List[int]],
         if tok in eos_ids:
             if rank >= num_beams:
                 continue
-            hyps.add(input_ids[b], sc, cur_len - decoder_prompt_len, clone_kv(kvs[b]))
+            hyps.add(input_ids[b], sc, cur_len - decoder_prompt_len, clone(kvs[b]))
         else:
             next_scores.append(sc)
             next_tokens.append(tok)
@@ -126,6 +131,49 @@ def finalize(hyps: BeamHypotheses, done: bool, seqs: List[List[int]], beam_score
     return out, best_kv
 
 
+def beam_search_loop(forward, process, num_beams: int, input_ids: List[int], kv, eos_ids: Sequence[int], max_new_tokens: int,
+                     length_penalty: float = 1.0, clone=clone_kv):
+    """generation_mixin_beam_search for batch size 1 (patch_hf.py:687-967) over a pluggable model.
+
+    `forward(tokens, kv, first) -> logits (V,)` runs one beam's forward pass and appends to that beam's `kv` in place (step 0:
+    the whole prompt, later steps: the last token -- model/llm.py:114-115); `process(log_probs, seq) -> scores` are the logits
+    processors (:839, applied to log-probs).  Returns (sequence, best_kv, steps).  Pinned against the reference's own loop,
+    compiled from patch_hf.py's text and driven on a toy model (tests/golden/gen_golden.py::gen_beam_loop -> beam_loop.npz)."""
+    prompt_len = len(input_ids)
+    max_length = prompt_len + max_new_tokens
+    n_keep = max(2, 1 + len(eos_ids)) * num_beams  # :869-870
+    seqs = [list(input_ids) for _ in range(num_beams)]
+    kvs = [clone(kv) for _ in range(num_beams)]  # _expand_inputs_for_generation :305-342
+    beam_scores = [0.0] + [-1e9] * (num_beams - 1)  # :770-771
+    hyps = BeamHypotheses(num_beams, length_penalty)
+    done = False
+    steps: List[BeamStepRecord] = []
+    step = 0
+    while True:
+        rows = []
+        for b in range(num_beams):
+            logits = forward(seqs[b] if step == 0 else seqs[b][-1:], kvs[b], step == 0)
+            lp = torch.log_softmax(logits.float(), dim=-1)  # :833-837
+            sc = process(lp, seqs[b])  # :839, on log-probs
+            rows.append(sc + torch.tensor(beam_scores[b], dtype=torch.float32))  # :840 (fp32 add, as beam_scores[:, None])
+        V = rows[0].numel()
+        flat = torch.cat(rows)
+        top = torch.topk(flat, n_keep, largest=True, sorted=True)  # :878
+        cand_scores = [float(x) for x in top.values]
+        cand_beams = [int(i) // V for i in top.indices]
+        cand_tokens = [int(i) % V for i in top.indices]
+        ns, nt, npar, done = scorer_process(hyps, done, seqs, cand_scores, cand_tokens, cand_beams, kvs, eos_ids, num_beams, prompt_len, clone)
+        steps.append(BeamStepRecord(rows, cand_scores, cand_tokens, cand_beams, nt, npar, ns, list(beam_scores)))
+        seqs = [seqs[p] + [t] for p, t in zip(npar, nt)]  # :902 input_ids[beam_idx] + token
+        kvs = [clone(kvs[p]) for p in npar]  # :910-913 _temporary_reorder_cache
+        beam_scores = ns
+        step += 1
+        if done or len(seqs[0]) >= max_length:  # :921
+            break
+    out, best_kv = finalize(hyps, done, seqs, beam_scores, kvs, prompt_len, max_length, eos_ids[0] if eos_ids else 0)
+    return out, best_kv, steps
+
+
 def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batch: torch.Tensor, kv, speech_cache, rope_llm,
                   rope_enc, encoder_input_ids: Sequence[int], length_penalty: float = 1.0) -> BeamOutput:
     """One chunk with beam search.  `kv` (the stream's cache before this chunk) is not modified; the winning
@@ -133,41 +181,13 @@ def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batc
     m = gen.latency_multiplier
     feats, _ = oenc.encode_speech(w, cfg, speech_batch, speech_cache, m, rope_enc)
     feats = feats[0]
-    prompt_len = len(input_ids)
-    max_length = prompt_len + gen.max_new_tokens
-    n_keep = max(2, 1 + len(cfg.eos_ids)) * num_beams
-    seqs = [list(input_ids) for _ in range(num_beams)]
-    kvs = [clone_kv(kv) for _ in range(num_beams)]  # _expand_inputs_for_generation
-    beam_scores = [0.0] + [-1e9] * (num_beams - 1)
-    hyps = BeamHypotheses(num_beams, length_penalty)
-    done = False
-    steps: List[BeamStepRecord] = []
-    step = 0
-    V = None
-    while True:
-        rows = []
-        for b in range(num_beams):
-            if step == 0:
-                logits = ollm.model_forward(w, cfg, torch.tensor(seqs[b]), kvs[b], rope_llm, speech=feats)
-            else:
-                logits = ollm.model_forward(w, cfg, torch.tensor(seqs[b][-1:]), kvs[b], rope_llm)
-            lp = torch.log_softmax(logits.float(), dim=-1)  # :833-837
-            sc = ogen.process_logits(lp, seqs[b], encoder_input_ids, gen.repetition_penalty, gen.no_repeat_ngram_size,
-                                     gen.no_repeat_ngram_size, gen.suppress_tokens)  # :839, on log-probs
-            rows.append(sc + beam_scores[b])
-        V = rows[0].numel()
-        flat = torch.cat(rows)
-        top = torch.topk(flat, n_keep, largest=True, sorted=True)  # :878
-        cand_scores = [float(x) for x in top.values]
-        cand_beams = [int(i) // V for i in top.indices]
-        cand_tokens = [int(i) % V for i in top.indices]
-        ns, nt, npar, done = scorer_process(hyps, done, seqs, cand_scores, cand_tokens, cand_beams, kvs, cfg.eos_ids, num_beams, prompt_len)
-        steps.append(BeamStepRecord(rows, cand_scores, cand_tokens, cand_beams, nt, npar, ns, list(beam_scores)))
-        seqs = [seqs[p] + [t] for p, t in zip(npar, nt)]  # input_ids[beam_idx] + token
-        kvs = [clone_kv(kvs[p]) for p in npar]  # _temporary_reorder_cache
-        beam_scores = ns
-        step += 1
-        if done or len(seqs[0]) >= max_length:  # :920
-            break
-    out, best_kv = finalize(hyps, done, seqs, beam_scores, kvs, prompt_len, max_length, cfg.eos_ids[0] if cfg.eos_ids else 0)
+
+    def forward(tokens, beam_kv, first):
+        return ollm.model_forward(w, cfg, torch.tensor(tokens), beam_kv, rope_llm, speech=feats if first else None)
+
+    def process(lp, seq):
+        return ogen.process_logits(lp, seq, encoder_input_ids, gen.repetition_penalty, gen.no_repeat_ngram_size,
+                                   gen.no_repeat_ngram_size, gen.suppress_tokens)
+
+    out, best_kv, steps = beam_search_loop(forward, process, num_beams, input_ids, kv, cfg.eos_ids, gen.max_new_tokens, length_penalty)
     return BeamOutput(sequences=out, kv=best_kv, steps=steps, speech_features=feats)

@@ -652,6 +652,220 @@ def gen_beam_scorer():
 
 
 # --------------------------------------------------------------------------------------------
+# beam-search LOOP: the reference's own generation_mixin_beam_search (+ _expand_inputs_for_generation and the three scorer
+# functions), model/patches/patch_hf.py:43-342,687-967, executed from their source text on a toy model
+# --------------------------------------------------------------------------------------------
+def gen_beam_loop():
+    """patch_hf.py cannot be imported under transformers 5.15, so the function DEFINITIONS are compiled from the reference file's
+    own AST (as gen_beam_scorer does) into a namespace that supplies the names they use.  `self` is a stand-in model: toy forward
+    (toy_beam_forward), `prepare_inputs_for_generation` always handing over the full input_ids with the model embedding the whole
+    prompt on the first call and the last token afterwards (model/llm.py:69,114-115,272-295), a 4.47-style DynamicCache restated
+    below ([3P]: key_cache / value_cache lists, iteration yields (k, v), update() concatenates on dim -2, reorder_cache =
+    index_select on dim 0 -- `_temporary_reorder_cache`), stopping criteria and logits processors from the image's transformers
+    5.15 built by ITS `_get_logits_processor` from the agent's generate kwargs (agents/infinisst.py:307-332) -- whose class ORDER
+    is stored as a secondary pin of oracle/generate.py::process_logits (patch_hf.py:586-600; 4.47 itself is absent)."""
+    import ast
+    from collections import UserDict
+    from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+    import transformers
+    from transformers import GenerationConfig, LlamaConfig, LlamaForCausalLM
+    from transformers.generation.logits_process import LogitsProcessorList
+    from transformers.generation.stopping_criteria import MaxLengthCriteria, StoppingCriteriaList
+    from transformers.generation.utils import (GenerateBeamDecoderOnlyOutput, GenerateBeamEncoderDecoderOutput, GenerateBeamOutput)
+    sys.path.insert(0, os.path.abspath(os.path.join(OUT, "..")))
+    from toy_beam_model import toy_beam_forward
+    path = os.path.join(REF, "model", "patches", "patch_hf.py")
+    tree = ast.parse(open(path).read())
+    want = {"beam_search_process", "beam_search_finalize", "beam_hypotheses_add", "generation_mixin_beam_search",
+            "generation_mixin_expand_inputs_for_generation"}
+
+    class Cache447:  # [3P] transformers 4.47 DynamicCache, the subset the reference touches
+        def __init__(self, n=None):
+            self.key_cache, self.value_cache = [], []
+
+        def __len__(self):
+            return len(self.key_cache)
+
+        def __iter__(self):
+            for i in range(len(self)):
+                yield self.key_cache[i], self.value_cache[i]
+
+        def __getitem__(self, i):
+            return self.key_cache[i], self.value_cache[i]
+
+        def update(self, k, v, layer_idx, cache_kwargs=None):
+            if len(self.key_cache) <= layer_idx:
+                self.key_cache.append(k)
+                self.value_cache.append(v)
+            else:
+                self.key_cache[layer_idx] = torch.cat([self.key_cache[layer_idx], k], dim=-2)
+                self.value_cache[layer_idx] = torch.cat([self.value_cache[layer_idx], v], dim=-2)
+            return self.key_cache[layer_idx], self.value_cache[layer_idx]
+
+        def reorder_cache(self, beam_idx):
+            for i in range(len(self)):
+                self.key_cache[i] = self.key_cache[i].index_select(0, beam_idx)
+                self.value_cache[i] = self.value_cache[i].index_select(0, beam_idx)
+
+    ns = {"torch": torch, "nn": nn, "UserDict": UserDict, "Optional": Optional, "Union": Union, "List": List, "Dict": Dict,
+          "Tuple": Tuple, "Any": Any, "Callable": Callable, "DynamicCache": Cache447, "BeamScorer": object,
+          "LogitsProcessorList": LogitsProcessorList, "StoppingCriteriaList": StoppingCriteriaList, "GenerationConfig": GenerationConfig,
+          "GenerateBeamOutput": GenerateBeamOutput, "GenerateBeamDecoderOnlyOutput": GenerateBeamDecoderOnlyOutput,
+          "GenerateBeamEncoderDecoderOutput": GenerateBeamEncoderDecoderOutput}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in want:
+            node.decorator_list = []  # @staticmethod / @torch.no_grad: bound below
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+
+    class Hyps:
+        def __init__(self, num_beams, length_penalty):
+            self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, False
+            self.beams, self.worst_score = [], 1e9
+
+        def __len__(self):
+            return len(self.beams)
+
+        add = ns["beam_hypotheses_add"]
+
+        def is_done(self, best_sum_logprobs, cur_len, decoder_prompt_len=0):  # [3P transformers 4.47, restated]
+            if len(self) < self.num_beams:
+                return False
+            highest_attainable = best_sum_logprobs / (cur_len - decoder_prompt_len) ** self.length_penalty
+            return self.worst_score >= highest_attainable
+
+    trace = {}
+
+    class Scorer:
+        finalize = ns["beam_search_finalize"]
+
+        def __init__(self, B, length_penalty):
+            self.num_beams = self.group_size = B
+            self.num_beam_groups, self.num_beam_hyps_to_keep = 1, 1
+            self.device = torch.device("cpu")
+            self._beam_hyps = [Hyps(B, length_penalty)]
+            self._done = torch.tensor([False])
+
+        @property
+        def is_done(self):  # [3P] BeamSearchScorer.is_done
+            return bool(self._done.all())
+
+        def process(self, input_ids, next_scores, next_tokens, next_indices, **kw):
+            res = ns["beam_search_process"](self, input_ids, next_scores, next_tokens, next_indices, **kw)
+            st = trace["n"]
+            pre = trace["pre"]
+            out[pre + f"s{st}_in_ids"] = input_ids.numpy().copy()
+            out[pre + f"s{st}_cand_scores"] = next_scores[0].numpy().copy()
+            out[pre + f"s{st}_cand_tokens"] = next_tokens[0].numpy().copy()
+            out[pre + f"s{st}_cand_beams"] = next_indices[0].numpy().copy()
+            out[pre + f"s{st}_next_scores"] = res["next_beam_scores"].numpy().copy()
+            out[pre + f"s{st}_next_tokens"] = res["next_beam_tokens"].numpy().copy()
+            out[pre + f"s{st}_next_beams"] = res["next_beam_indices"].numpy().copy()
+            out[pre + f"s{st}_done"] = np.array(bool(self._done[0]))
+            trace["n"] = st + 1
+            return res
+
+    # the processors of the agent's generate() call, built by transformers 5.15's own _get_logits_processor
+    V, D = 61, 12
+    tiny = LlamaForCausalLM(LlamaConfig(hidden_size=16, intermediate_size=32, num_hidden_layers=1, num_attention_heads=2,
+                                        num_key_value_heads=1, vocab_size=V))
+    out = {"transformers_version": np.array(transformers.__version__)}
+    cases = [(4, 1.0, 9, 10, 0.0, 101), (4, 1.0, 14, 10, 2.5, 102), (2, 1.0, 7, 12, 1.5, 103), (3, 0.6, 11, 9, 2.0, 104),
+             (4, 1.0, 22, 20, 1.0, 105), (4, 1.0, 8, 6, 4.0, 106)]
+    eos = [57, 58, 59]
+    for ci, (B, lp, prompt_len, max_new, eos_bias, seed) in enumerate(cases):
+        g = torch.Generator().manual_seed(seed)
+        E = torch.randn(V, D, generator=g)
+        O = torch.randn(D, V, generator=g) * 1.5
+        bias = torch.randn(V, generator=g) * 0.3
+        bias[eos] += eos_bias - 2.0  # EOS candidates show up among the top ranks in the biased cases
+        decay = 0.8
+        fwd = toy_beam_forward(E, O, bias, decay)
+        small = 9 if ci in (1, 4) else V - 4  # a small alphabet makes repeated n-grams (banned tokens) likely
+        prompt = torch.randint(3, small, (1, prompt_len), generator=g)
+        enc_ids = torch.randint(3, small, (1, 30), generator=g)
+        suppress = [5, 40]
+        ngram = 3 if ci in (1, 4) else 5
+        gc = GenerationConfig(repetition_penalty=1.2, no_repeat_ngram_size=ngram, encoder_no_repeat_ngram_size=ngram,
+                              suppress_tokens=suppress, num_beams=B, max_new_tokens=max_new, pad_token_id=60, eos_token_id=eos)
+        procs = tiny._get_logits_processor(generation_config=gc, input_ids_seq_length=prompt_len, encoder_input_ids=enc_ids,
+                                           prefix_allowed_tokens_fn=None, logits_processor=LogitsProcessorList(), device="cpu",
+                                           model_kwargs={})
+        out[f"c{ci}_processor_order"] = np.array([type(p).__name__ for p in procs])
+
+        class Model:
+            config = types.SimpleNamespace(is_encoder_decoder=False)
+
+            def __init__(self):
+                self.first = True  # model.model.speech_features_extracted = False (agents/infinisst.py:306)
+
+            def _get_initial_cache_position(self, input_ids, model_kwargs):
+                return model_kwargs
+
+            def _has_unfinished_sequences(self, this_peer_finished, synced_gpus, device=None):
+                return not this_peer_finished
+
+            def prepare_inputs_for_generation(self, input_ids, past_key_values=None, **kw):  # model/llm.py:272-295
+                return {"input_ids": input_ids, "past_key_values": past_key_values}
+
+            def __call__(self, input_ids=None, past_key_values=None, return_dict=True):
+                toks = input_ids if self.first else input_ids[:, -1:]  # model/llm.py:69 vs :114-115
+                self.first = False
+                rows = []
+                k_new = E[toks]  # (beams, T, D): the toy cache holds the embedding rows of every consumed token
+                k_all, _ = past_key_values.update(k_new.unsqueeze(1), k_new.unsqueeze(1) + 0.5, 0)
+                for b in range(input_ids.shape[0]):
+                    kv = [k_all[b, 0, i] for i in range(k_all.shape[2])]
+                    n = len(kv)
+                    wts = decay ** torch.arange(n - 1, -1, -1, dtype=torch.float32)
+                    h = (torch.stack(kv) * wts[:, None]).sum(0)
+                    rows.append(torch.tanh(h) @ O + bias)
+                logits = torch.stack(rows).unsqueeze(1)  # (beams, 1, V): only [:, -1] is read (:833)
+                return types.SimpleNamespace(logits=logits, past_key_values=past_key_values)
+
+            def _update_model_kwargs_for_generation(self, outputs, model_kwargs, is_encoder_decoder=False):
+                model_kwargs["past_key_values"] = outputs.past_key_values
+                return model_kwargs
+
+            def _temporary_reorder_cache(self, past_key_values, beam_idx):  # [3P] 4.47: DynamicCache.reorder_cache
+                past_key_values.reorder_cache(beam_idx)
+                return past_key_values
+
+        # the stream's cache before this chunk: `n_past` tokens already consumed (batch 1), expanded by the reference's own function
+        n_past = [0, 6, 3, 0, 17, 5][ci]
+        past_tokens = torch.randint(3, V - 4, (n_past,), generator=g)
+        past = Cache447()
+        if n_past:
+            past.update(E[past_tokens][None, None], E[past_tokens][None, None] + 0.5, 0)
+        else:
+            past.update(torch.zeros(1, 1, 0, D), torch.zeros(1, 1, 0, D), 0)
+        ids_x, kw_x = ns["generation_mixin_expand_inputs_for_generation"](expand_size=B, is_encoder_decoder=False, input_ids=prompt,
+                                                                          past_key_values=past)
+        gcfg = types.SimpleNamespace(_pad_token_tensor=torch.tensor(60), _eos_token_tensor=torch.tensor(eos), output_attentions=False,
+                                     output_hidden_states=False, output_scores=False, output_logits=False,
+                                     return_dict_in_generate=True, low_memory=False, do_sample=False)
+        trace.update(n=0, pre=f"c{ci}_")
+        scorer = Scorer(B, lp)
+        res = ns["generation_mixin_beam_search"](Model(), ids_x, scorer, logits_processor=procs,
+                                                 stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(prompt_len + max_new)]),
+                                                 generation_config=gcfg, synced_gpus=False, **kw_x)
+        out[f"c{ci}_cfg"] = np.array([B, prompt_len, max_new, trace["n"], ngram], dtype=np.int64)
+        out[f"c{ci}_lp"] = np.array(lp)
+        out[f"c{ci}_E"], out[f"c{ci}_O"], out[f"c{ci}_bias"], out[f"c{ci}_decay"] = E.numpy(), O.numpy(), bias.numpy(), np.array(decay)
+        out[f"c{ci}_prompt"] = prompt[0].numpy()
+        out[f"c{ci}_enc_ids"] = enc_ids[0].numpy()
+        out[f"c{ci}_past_tokens"] = past_tokens.numpy()
+        out[f"c{ci}_suppress"] = np.array(suppress)
+        out[f"c{ci}_sequence"] = res.sequences[0].numpy()
+        out[f"c{ci}_hyp_scores"] = np.array(sorted(h[0] for h in scorer._beam_hyps[0].beams), dtype=np.float64)  # :937-939 drops sequences_scores
+        out[f"c{ci}_winner_kv"] = res.past_key_values[0].key_cache[0][0, 0].numpy()  # (T, D): the cache that travels with the winner
+        print(f"  beam loop case {ci}: {trace['n']} steps, sequence {res.sequences[0].tolist()[prompt_len:]}, order {list(out[f'c{ci}_processor_order'])}")
+    out["n_cases"] = np.array(len(cases))
+    out["eos"] = np.array(eos)
+    np.savez_compressed(os.path.join(OUT, "beam_loop.npz"), **out)
+    print("beam_loop.npz:", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------------------------
 # logits processors: HF transformers' own classes (the image has 5.15.0; the reference pins 4.47.0 -- the four processors
 # used by agents/infinisst.py:307-332 have had the same semantics since 4.2x)
 # --------------------------------------------------------------------------------------------
@@ -874,6 +1088,7 @@ def main():
     gen_agent()
     gen_splice()
     gen_beam_scorer()
+    gen_beam_loop()
     gen_logits_processors()
     gen_llama_blocks()
     gen_prompts()

@@ -1,6 +1,7 @@
 """Pin the oracle against the golden vectors produced by the reference's own functions
 (tests/golden/gen_golden.py ran them in the build container)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -189,6 +190,47 @@ def test_beam_scorer_matches_reference(golden_dir):
         out, best_kv = obeam.finalize(hyps, done, seqs, [float(x) for x in g[f"c{ci}_final_scores"]], kvs, prompt_len, max_length, eos[0])
         assert out == [int(t) for t in g[f"c{ci}_sequence"]], f"case {ci} winning sequence"
         assert float(best_kv[0][0]) == float(g[f"c{ci}_kv_marker"][0]), f"case {ci}: the winner must carry its own KV cache"
+
+
+def test_beam_loop_matches_reference(golden_dir):
+    """oracle/beam.py::beam_search_loop against the reference's own generation_mixin_beam_search + _expand_inputs_for_generation
+    (patch_hf.py:305-342,687-967) compiled from the file's text and run on the toy model of tests/toy_beam_model.py
+    (gen_golden.gen_beam_loop): per step the top-2B..4B candidates (score, token, beam), the chosen (token, parent) pairs and
+    beam scores, the done flag; then the winning sequence and the KV cache that travels with it.  Also the processor ORDER that
+    transformers 5.15's `_get_logits_processor` builds from the agent's kwargs (secondary pin of oracle.generate.process_logits)."""
+    from oracle import beam as obeam
+    from oracle import generate as ogen
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from toy_beam_model import toy_beam_forward
+    g = load(golden_dir, "beam_loop.npz")
+    eos = [int(e) for e in g["eos"]]
+    n_eos_hyps = 0
+    for ci in range(int(g["n_cases"])):
+        B, prompt_len, max_new, n_steps, ngram = (int(v) for v in g[f"c{ci}_cfg"])
+        assert [str(x) for x in g[f"c{ci}_processor_order"]] == ["RepetitionPenaltyLogitsProcessor", "NoRepeatNGramLogitsProcessor",
+                                                                  "EncoderNoRepeatNGramLogitsProcessor", "SuppressTokensLogitsProcessor"]
+        E, O, bias = (torch.from_numpy(g[f"c{ci}_{k}"]) for k in ("E", "O", "bias"))
+        fwd = toy_beam_forward(E, O, bias, float(g[f"c{ci}_decay"]))
+        enc_ids = [int(t) for t in g[f"c{ci}_enc_ids"]]
+        suppress = [int(t) for t in g[f"c{ci}_suppress"]]
+        process = lambda lp, seq: ogen.process_logits(lp, seq, enc_ids, 1.2, ngram, ngram, suppress)
+        past = [E[int(t)].clone() for t in g[f"c{ci}_past_tokens"]]
+        out, best_kv, steps = obeam.beam_search_loop(fwd, process, B, [int(t) for t in g[f"c{ci}_prompt"]], past, eos, max_new,
+                                                     float(g[f"c{ci}_lp"]), clone=lambda kv: [t.clone() for t in kv])
+        assert len(steps) == n_steps, f"case {ci}: {len(steps)} steps, reference {n_steps}"
+        for st, rec in enumerate(steps):
+            pre = f"c{ci}_s{st}_"
+            assert rec.cand_tokens == [int(x) for x in g[pre + "cand_tokens"]], f"case {ci} step {st}: candidate tokens"
+            assert rec.cand_beams == [int(x) for x in g[pre + "cand_beams"]], f"case {ci} step {st}: candidate beams"
+            np.testing.assert_allclose(rec.cand_scores, g[pre + "cand_scores"], rtol=0, atol=2e-5)
+            assert rec.next_tokens == [int(x) for x in g[pre + "next_tokens"]], f"case {ci} step {st}: next tokens"
+            assert rec.next_parents == [int(x) for x in g[pre + "next_beams"]], f"case {ci} step {st}: parents"
+            np.testing.assert_allclose(rec.next_scores, g[pre + "next_scores"], rtol=0, atol=2e-5)
+            n_eos_hyps += sum(1 for t in rec.cand_tokens[:B] if t in eos)
+        assert out == [int(t) for t in g[f"c{ci}_sequence"]], f"case {ci}: winning sequence"
+        np.testing.assert_allclose(torch.stack(best_kv).numpy(), g[f"c{ci}_winner_kv"], rtol=0, atol=0,
+                                   err_msg=f"case {ci}: the winner must carry its own cache")
+    assert n_eos_hyps >= 3, "the fixture must exercise EOS-closed hypotheses"
 
 
 def test_logits_processors_match_transformers(golden_dir):
