@@ -56,6 +56,9 @@ def parse():
                     "rate); default: the audio is resident in HBM before the timed region")
     ap.add_argument("--no-streams64", action="store_true", help="skip the 64-streams-per-GPU leg (configs[2]) that follows the timed region at N=1")
     ap.add_argument("--streams64-steps", type=int, default=16)
+    ap.add_argument("--no-beam4", action="store_true", help="skip the num_beams = 4 leg (the reference's production decoding) that follows the timed region at N=1")
+    ap.add_argument("--beam4-steps", type=int, default=16)
+    ap.add_argument("--host-audio-steps", type=int, default=16, help="steps of the PCIe-inclusive leg (chunks handed over as host arrays) after the timed region")
     ap.add_argument("--cold-start", action="store_true", help="do NOT import the steady state: streams start empty (first-chunk behaviour; then use --warmup >= 40)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
     ap.add_argument("--cpu-chunks", type=int, default=4, help="steady-state chunks the CPU baseline runs")
@@ -130,23 +133,32 @@ STEADY_CHUNKS = 31  # chunks' worth of LLM KV behind the system prompt in the im
 
 
 class ChunkLoop:
-    """The per-chunk control logic of policy() for the streams of one rank (generate + whole-chunk eviction)."""
+    """The streams of one rank over `streams.StreamBatch` (the product's multi-stream driver: one isst_generate per tick, per-stream
+    target ids / checkpoints / whole-chunk eviction); this class only adds the synthetic audio and the imported steady state."""
 
     def __init__(self, eng, cfg, gen, stream_ids, sys_n, host_audio=False):
         """`stream_ids`: GLOBAL stream ids of this rank (streams.assign_streams); they seed the audio.
         The audio of every stream is resident in HBM before the timed region (isst_gen_params.pcm_on_device) unless `host_audio`:
         then every chunk's samples are handed over as host arrays and uploaded inside the step, as the reference agent does."""
         self.eng, self.cfg, self.gen, self.sys_n = eng, cfg, gen, sys_n
-        self.sids = [eng.open_stream() for _ in stream_ids]
+        self.batch = S.StreamBatch(eng, gen, sys_n, lambda first, m: synth.chunk_prompt_ids(cfg, m, first=first))
+        self.idx = [self.batch.open() for _ in stream_ids]
+        self.sids = [self.batch.stream_id(i) for i in self.idx]
         n_chunks = 64
         self.audio = [synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=g) for g in stream_ids]
-        self.audio_dev = None if host_audio else [torch.from_numpy(a).to("cuda") for a in self.audio]
+        self.audio_dev = None
+        self.set_host_audio(host_audio)
         self.n_chunks = n_chunks
-        self.ckpts = [[] for _ in stream_ids]
-        self.targets = [[] for _ in stream_ids]
-        self.first = True
         self.c = 0
-        self.evictions = 0
+
+    def set_host_audio(self, host_audio: bool):
+        self.host_audio = host_audio
+        if not host_audio and self.audio_dev is None:
+            self.audio_dev = [torch.from_numpy(a).to("cuda") for a in self.audio]
+
+    @property
+    def evictions(self):
+        return self.batch.evictions
 
     def import_steady_state(self, device):
         """Every stream starts where a long-running stream is ("warm up >= 40 chunks (or pre-fill)"): LLM KV = system prompt +
@@ -169,35 +181,15 @@ class ChunkLoop:
             tail = torch.from_numpy(self.audio[i][-cfg.first_chunk_offset:].copy())
             eng.import_speech_cache(sid, enc, n_steps=cfg.block_size * 40, audio_tail=tail, ring_start=(enc_cap - 100 + 7 * i) % enc_cap)
             first_ck = self.sys_n + per_chunk  # cache length after the first chunk (system prompt + its turn), then one more turn each
-            self.ckpts[i] = [first_ck + k * per_chunk for k in range(STEADY_CHUNKS)]
-            assert self.ckpts[i][-1] == total
-        self.first = False
+            ckpts = [first_ck + k * per_chunk for k in range(STEADY_CHUNKS)]
+            assert ckpts[-1] == total
+            self.batch.adopt_state(self.idx[i], ckpts)
 
     def step(self):
-        cfg, gen = self.cfg, self.gen
+        cfg = self.cfg
         k = self.c % self.n_chunks
-        segs = [a[k * cfg.chunk_samples:(k + 1) * cfg.chunk_samples] for a in (self.audio if self.audio_dev is None else self.audio_dev)]
-        prompt = synth.chunk_prompt_ids(cfg, 1, first=self.first)
-        prev = [t[-gen.no_repeat_ngram_lookback:] for t in self.targets]
-        outs, _ = self.eng.generate(gen, self.sids, segs, [prompt] * len(self.sids), prev,
-                                    system_prompt_size=self.sys_n if self.first else 0)
-        for i, sid in enumerate(self.sids):
-            self.targets[i].extend(outs[i][:-1])
-            self.targets[i] = self.targets[i][-256:]
-            cur = self.eng.stream_info(sid)["llm_cache_len"]
-            ck = self.ckpts[i]
-            ck.append(cur)
-            if cur > gen.max_llm_cache_size:  # reference agents/infinisst.py:340-361
-                new_size = 0
-                for j, c in enumerate(ck):
-                    new_size = cur - c
-                    if new_size <= gen.max_llm_cache_size:
-                        trimmed = c - self.sys_n
-                        self.ckpts[i] = [x - trimmed for x in ck[j + 1:]]
-                        break
-                self.eng.kv_evict(sid, new_size, self.sys_n)
-                self.evictions += 1
-        self.first = False
+        segs = [a[k * cfg.chunk_samples:(k + 1) * cfg.chunk_samples] for a in (self.audio if self.host_audio else self.audio_dev)]
+        self.batch.step(segs)
         self.c += 1
 
 
@@ -212,38 +204,132 @@ def chunk_algorithmic_bytes(cfg, n_streams, passes, kv_len):
     return passes * (llm_w + n_streams * kv_per_entry * kv_len) + enc_w + n_streams * enc_kv
 
 
-def run_streams64(cfg, gen, weights, device, args):
-    """BASELINE.json configs[2] in the same process: 64 concurrent streams on this GPU (shared weights, per-stream KV), steady state
-    imported, a few warm-up steps, `--streams64-steps` timed.  Reported next to the one-stream line."""
-    n = 64
-    eng, _, sys_n = build_engine(cfg, n, args.gen_tokens, device, 1, weights)
-    loop = ChunkLoop(eng, cfg, gen, list(range(n)), sys_n, host_audio=args.host_audio)
+def timed_steps(loop, steps):
+    """`steps` chunks of every stream of `loop`, bracketed by device synchronisation; returns (seconds, per-step latencies, host seconds)."""
+    torch.cuda.synchronize()
+    loop.batch.reset_timers()
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s0 = time.perf_counter()
+        loop.step()  # returns after the last token id is on the host (isst_generate synchronises the stream)
+        lat.append(time.perf_counter() - s0)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, lat, loop.batch.host_seconds
+
+
+def whole_step_roofline(cfg, n_streams, passes, kv_len, ms):
+    algo = chunk_algorithmic_bytes(cfg, n_streams, passes, kv_len)
+    achieved = algo / (ms * 1e-3) / 1e9
+    return {"kernel": f"whole chunk (all kernels of one {n_streams}-stream step)", "bound": "hbm", "algorithmic_bytes_per_step": algo,
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+
+
+def host_audio_leg(loop, steps, n_streams):
+    """The same loop with every chunk handed over as host arrays (61 KB per stream, uploaded inside the step like the reference's
+    `_prepare_speech`, agents/infinisst.py:222): the PCIe-inclusive rate, reported beside `value` (which has the audio resident)."""
+    loop.set_host_audio(True)
+    for _ in range(2):
+        loop.step()
+    dt, lat, _ = timed_steps(loop, steps)
+    loop.set_host_audio(False)
+    return {"what": "chunks handed over as host arrays, H2D inside the step (SURVEY 8(d) latency definition)", "steps": steps,
+            "ms_per_step": round(1e3 * dt / steps, 3), "xrt": round(0.96 * n_streams * steps / dt, 3),
+            "p50_chunk_latency_ms": round(1e3 * float(np.percentile(lat, 50)), 3)}
+
+
+def run_leg(cfg, gen, weights, device, args, n_streams, steps, workload, extra_env=None):
+    """One more configuration in the same process: `n_streams` concurrent streams on this GPU (shared weights, per-stream KV),
+    steady state imported, a few warm-up steps, `steps` timed.  Reported next to the one-stream line."""
+    saved = {k: os.environ.get(k) for k in (extra_env or {})}
+    os.environ.update(extra_env or {})
+    try:
+        eng, _, sys_n = build_engine(cfg, n_streams, args.gen_tokens, device, gen.beam, weights)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    loop = ChunkLoop(eng, cfg, gen, list(range(n_streams)), sys_n, host_audio=False)
     loop.import_steady_state(device)
     for _ in range(3):
         loop.step()
-    torch.cuda.synchronize()
-    lat = []
-    t0 = time.perf_counter()
-    for _ in range(args.streams64_steps):
-        s0 = time.perf_counter()
-        loop.step()
-        lat.append(time.perf_counter() - s0)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, lat, host_s = timed_steps(loop, steps)
     info = eng.stream_info(loop.sids[0])
-    ms = 1e3 * dt / args.streams64_steps
-    algo = chunk_algorithmic_bytes(cfg, n, args.gen_tokens, info["llm_cache_len"])
-    achieved = algo / (ms * 1e-3) / 1e9
-    out = {"workload": "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 64 streams on 1 MI355X (BASELINE.json configs[2])",
-           "streams": n, "steps": args.streams64_steps, "ms_per_step": round(ms, 3), "xrt": round(0.96 * n * args.streams64_steps / dt, 2),
+    ms = 1e3 * dt / steps
+    out = {"workload": workload, "streams": n_streams, "num_beams": gen.beam, "steps": steps, "ms_per_step": round(ms, 3),
+           "xrt": round(0.96 * n_streams * steps / dt, 2),
            "p50_chunk_latency_ms": round(1e3 * float(np.percentile(lat, 50)), 3), "p95_chunk_latency_ms": round(1e3 * float(np.percentile(lat, 95)), 3),
-           "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "evictions_per_stream": loop.evictions // n,
-           "roofline": {"kernel": "whole chunk (all kernels of one 64-stream step)", "bound": "hbm", "algorithmic_bytes_per_step": algo,
-                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "note": "the 1408-row prefill GEMMs and the encoder are MFMA-bound, so the HBM fraction of the whole step understates them; "
-                                "per-kernel figures: profiles/"}}
+           "host_ms_per_step": round(1e3 * host_s / steps, 3),
+           "host_ms_per_step_is": "wall time of a step spent in Python / ctypes outside isst_generate (prompt lists, argument marshalling, "
+                                  "per-stream checkpoint walk and isst_kv_evict)",
+           "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "evictions_per_stream": loop.evictions // n_streams,
+           "roofline": whole_step_roofline(cfg, n_streams, args.gen_tokens, info["llm_cache_len"], ms)}
+    return out, loop, eng
+
+
+def run_streams64(cfg, gen, weights, device, args):
+    """BASELINE.json configs[2]: 64 concurrent streams on this GPU."""
+    out, loop, eng = run_leg(cfg, gen, weights, device, args, 64, args.streams64_steps,
+                             "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 64 streams on 1 MI355X (BASELINE.json configs[2])")
+    out["roofline"]["note"] = ("the 1408-row prefill GEMMs and the encoder are MFMA-bound, so the HBM fraction of the whole step understates them: "
+                               "see `mfma`; per-kernel figures: profiles/")
+    out["host_audio"] = host_audio_leg(loop, max(4, args.streams64_steps // 2), 64)
+    eng.close()
+    del loop, eng
+    try:
+        out["mfma"] = mfma_probe(cfg, device, rows=64 * len(synth.chunk_prompt_ids(cfg, 1, first=False)))
+    except Exception as e:  # report, never hide
+        out["mfma"] = {"failed": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def run_beam4(cfg, gen, weights, device, args):
+    """The reference's production decoding mode (`--beam 4`, scripts/infer/infinisst.sh:48) -- the only setting it publishes a number for
+    (RTF 0.382 = 2.6 xRT on an L40S, plots/plot.ipynb:528-531): one stream, 4 beams, steady state imported."""
+    import dataclasses
+    g4 = dataclasses.replace(gen, beam=4)
+    out, loop, eng = run_leg(cfg, g4, weights, device, args, 1, args.beam4_steps,
+                             "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 1 stream, num_beams 4 (the reference's production decoding)")
+    out["reference_published"] = {"rtf": 0.382, "xrt": 2.62, "hardware": "1x L40S (inferred)", "source": "plots/plot.ipynb:528-531"}
     eng.close()
     return out
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 (the 5 PF headline includes 2:1 sparsity)
+
+
+def mfma_probe(cfg, device, rows, iters=20):
+    """MFMA utilisation of the widest dense contraction of a 64-stream step: the prefill gate/up projection (rows x 2*ffn x dim,
+    SwiGLU epilogue) on the hand-written dense kernel, HIP events around `iters` back-to-back launches on random operands, weights
+    rotating over copies (no launch finds its weights in the Infinity Cache)."""
+    from infinisst_amd import engine as E
+    N, K = 2 * cfg.llm_ffn, cfg.llm_dim
+    g = torch.Generator(device=device)
+    g.manual_seed(2)
+    packs = []
+    for _ in range(3):
+        w = torch.empty((N, K), device=device, dtype=torch.float32).normal_(0, 0.02, generator=g).bfloat16()
+        packs.append(E.op_pack_weight(w))
+        del w
+    x = torch.randn(rows, K, device=device, generator=g).bfloat16()
+    for p in packs:
+        E.op_gemm(x, p, N, "swiglu")
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for i in range(iters):
+        E.op_gemm(x, packs[i % 3], N, "swiglu")
+    ev1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * ev0.elapsed_time(ev1) / iters
+    flop = 2.0 * rows * N * K
+    tf = flop / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": E.dense_kernel_name(), "shape": f"M={rows} N={N} K={K} (prefill gate/up of one layer, 64 streams x 22 rows)",
+            "launch_us": round(us, 2), "flop_per_launch": flop, "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+            "source": "HIP events in this run (op_gemm allocates its output per call: the figure includes that); rocprofv3 per-kernel durations: profiles/r03/"}
 
 
 def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
@@ -390,29 +476,63 @@ def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=32, n_c
             "chunk_seconds": round(dt, 3), "p50_chunk_seconds": round(float(np.percentile(per_chunk_s, 50)), 3), "chunks": n_chunks}
 
 
+class DryEngine:
+    """`--dry-run` stand-in for the library (no GPU, no compute): a call sleeps, caches grow and shrink as the real ones would, so the
+    product's StreamBatch (prompts, checkpoint walk, evictions) and the launcher / barrier / reduction path run unchanged."""
+
+    def __init__(self, rank, gen_tokens):
+        self.rank, self.gen_tokens, self.lens, self.last_call_seconds = rank, gen_tokens, [], 0.0
+
+    def open_stream(self):
+        self.lens.append(0)
+        return len(self.lens) - 1
+
+    def generate(self, gen, sids, pcm, prompts, prevs, system_prompt_size=0, forced_tokens=None, return_logits=False):
+        t0 = time.perf_counter()
+        time.sleep(0.002 * (1 + self.rank))
+        for sid, pr in zip(sids, prompts):
+            self.lens[sid] += len(pr) + self.gen_tokens - 1
+        self.last_call_seconds = time.perf_counter() - t0
+        return [[7] * self.gen_tokens for _ in sids], None
+
+    def stream_cache_lens(self, sids):
+        return [self.lens[s] for s in sids]
+
+    def kv_evict(self, sid, new_size, keep):
+        self.lens[sid] = new_size + keep
+
+
 def dry_run(args, world, rank):
-    """Launcher self-test (no GPU, no compute): the ranks meet over gloo, deal the global stream ids, "step" by sleeping, and go through
-    exactly the barrier / max-over-ranks / gather path of a real run."""
+    """Launcher self-test (no GPU, no compute): the ranks meet over gloo, deal the global stream ids, step their streams through the
+    product's StreamBatch over a sleeping stand-in engine, and go through exactly the barrier / max-over-ranks / gather path of a real run."""
     if world > 1:
         dist.init_process_group("gloo")
     tg = S.TimingGroup(None)
     mine = S.assign_streams(args.streams * world, rank, world)
+    cfg = toy_config()
+    gen = GenConfig(latency_multiplier=1, max_new_tokens=args.gen_tokens, max_llm_cache_size=200, always_cache_system_prompt=True)
+    sys_n = len(synth.system_prompt_ids(cfg))
+    batch = S.StreamBatch(DryEngine(rank, args.gen_tokens), gen, sys_n, lambda first, m: synth.chunk_prompt_ids(cfg, m, first=first))
+    idx = [batch.open() for _ in mine]
+    seg = np.zeros(cfg.chunk_samples, dtype=np.float32)
     tg.barrier()
     t0 = time.perf_counter()
     lat = []
     for _ in range(args.steps):
         s0 = time.perf_counter()
-        time.sleep(0.002 * (1 + rank))
+        batch.step([seg] * len(idx))
         lat.append(time.perf_counter() - s0)
     elapsed_local = time.perf_counter() - t0
     tg.barrier()
     elapsed = tg.max(elapsed_local)
     audio_s = tg.sum(0.96 * args.steps * len(mine))
     all_lat = tg.gather(lat)
+    evictions = tg.sum(batch.evictions)
     if rank == 0:
         print(json.dumps({"metric": "DRY RUN of the launcher (no compute, not a measurement)", "dry_run": True, "value": round(audio_s / elapsed, 3),
                           "unit": "audio-seconds per wall-second", "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "timing_collectives": tg.describe(),
                           "steps": args.steps, "warmup": args.warmup, "streams_of_rank0": mine, "latencies_gathered": len(all_lat),
+                          "evictions_all_ranks": int(evictions), "host_ms_per_step": round(1e3 * batch.host_seconds / max(1, batch.ticks), 3),
                           "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak"}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -465,14 +585,7 @@ def main():
     ev0 = loop.evictions
     kv_min = eng.stream_info(loop.sids[0])["llm_cache_len"]
     log(f"warm-up done ({args.warmup} chunks, KV {kv_min} entries)")
-    lat = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s0 = time.perf_counter()
-        loop.step()  # returns after the last token id is on the host (generate synchronises the stream)
-        lat.append(time.perf_counter() - s0)
-    torch.cuda.synchronize()
-    elapsed_local = time.perf_counter() - t0
+    elapsed_local, lat, _ = timed_steps(loop, args.steps)  # EXACTLY K steps between device synchronisations
     sync_all()
     elapsed = tg.max(elapsed_local)
     audio_s = tg.sum(0.96 * args.steps * len(mine))
@@ -484,17 +597,31 @@ def main():
     roof = None
     base = None
     s64 = None
+    b4 = None
+    host_leg = None
+    host_ms = 1e3 * loop.batch.host_seconds / max(1, loop.batch.ticks)
     if rank == 0:
+        if not args.host_audio and args.host_audio_steps > 0:
+            host_leg = host_audio_leg(loop, args.host_audio_steps, len(mine))
+            log(f"host-audio leg done: {host_leg['ms_per_step']} ms per step")
         if not args.no_roofline:
             in_situ = args.streams == 1 and args.beam == 1
             roof = gemm_roofline(cfg, device, loop if in_situ else None, eng if in_situ else None)
+            roof["whole_step"] = whole_step_roofline(cfg, args.streams, args.gen_tokens, info["llm_cache_len"], 1e3 * elapsed / args.steps)
             log(f"roofline probe done: {roof['achieved']} GB/s, in-situ bracket {roof['in_situ_event_bracket_us']} us")
-        if world == 1 and args.streams == 1 and args.beam == 1 and not args.toy and not args.no_streams64:
+        legs = world == 1 and args.streams == 1 and args.beam == 1 and not args.toy
+        if legs and not args.no_streams64:
             try:
                 s64 = run_streams64(cfg, gen, weights, device, args)
                 log(f"64-stream leg done: {s64['xrt']} xRT, {s64['ms_per_step']} ms per step")
             except Exception as e:  # report, never hide
                 s64 = {"failed": f"{type(e).__name__}: {e}"}
+        if legs and not args.no_beam4:
+            try:
+                b4 = run_beam4(cfg, gen, weights, device, args)
+                log(f"beam-4 leg done: {b4['xrt']} xRT, {b4['ms_per_step']} ms per step")
+            except Exception as e:  # report, never hide
+                b4 = {"failed": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 base = cpu_baseline(cfg, gen, weights, sys_n, args.cpu_threads, args.cpu_layers, args.cpu_chunks)
@@ -538,9 +665,12 @@ def main():
             "p50_chunk_latency_ms": round(1e3 * float(np.percentile(all_lat, 50)), 3),
             "p95_chunk_latency_ms": round(1e3 * float(np.percentile(all_lat, 95)), 3),
             "xrt_per_gpu": round(value / world, 3),
+            "host_ms_per_step": round(host_ms, 3),
+            "host_audio": host_leg,
             "roofline": roof,
             "cpu_baseline": base,
             "streams64": s64,
+            "beam4": b4,
         }
         print(json.dumps(line), flush=True)
     if dist.is_initialized():

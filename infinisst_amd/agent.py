@@ -29,6 +29,7 @@ import os
 from . import synth
 from .config import GenConfig, ModelConfig, full_config
 from .engine import Engine
+from .streams import effective_new_cache_size, evict_whole_chunks  # noqa: F401  (effective_new_cache_size: re-exported for tests)
 
 logger = logging.getLogger(__name__)
 
@@ -362,22 +363,12 @@ class InfiniSST(_AgentBase):
         states.started = True
         generated = outs[0]
 
-        # LLM-KV eviction by whole chunks (:337-361)
+        # LLM-KV eviction by whole chunks (:337-361); the walk itself is shared with the multi-stream driver (streams.StreamBatch)
         cur = self.engine.stream_info(states.stream_id)["llm_cache_len"]
-        self.cache_checkpoints.append(cur)
-        if cur > self.max_llm_cache_size:
-            new_size = 0
-            for i, ckpt in enumerate(self.cache_checkpoints):
-                new_size = cur - ckpt
-                if new_size <= self.max_llm_cache_size:
-                    self.cache_checkpoints = self.cache_checkpoints[i + 1:]
-                    n_trimmed = ckpt
-                    if self.always_cache_system_prompt:
-                        n_trimmed -= self.system_prompt_size
-                    self.cache_checkpoints = [c - n_trimmed for c in self.cache_checkpoints]
-                    break
-            keep = self.system_prompt_size if self.always_cache_system_prompt else 0
-            self.engine.kv_evict(states.stream_id, effective_new_cache_size(new_size, cur, keep), keep)
+        keep = self.system_prompt_size if self.always_cache_system_prompt else 0
+        self.cache_checkpoints, new_size = evict_whole_chunks(self.cache_checkpoints, cur, self.max_llm_cache_size, keep)
+        if new_size is not None:
+            self.engine.kv_evict(states.stream_id, new_size, keep)
 
         output_ids = generated[:-1]  # outputs.sequences[0, len(prompt):-1]  (:363)
         states.target_ids.extend(output_ids)
@@ -395,22 +386,6 @@ class InfiniSST(_AgentBase):
         if translation != "" or states.source_finished:  # :389-395
             return WriteAction(content=translation, finished=states.source_finished)
         return ReadAction()
-
-
-def effective_new_cache_size(new_size: int, cur: int, keep_prefix: int) -> int:
-    """Entries of the tail that survive `k[:, :, -new_size:]` (reference agents/infinisst.py:354-361) for ANY integer the checkpoint
-    loop can produce.  `cache_checkpoints` is agent-level and never reset (:106), so after a new utterance starts the list holds
-    stale, possibly larger-than-`cur` entries and `new_size` can leave [0, cur - keep_prefix]:
-      * 0 < new_size <= cur - keep_prefix: the ordinary case;
-      * new_size < 0: Python slicing `-new_size:` = `[|new_size|:]` keeps the last cur - |new_size| entries;
-      * a tail that would overlap the pinned prefix (the reference then DUPLICATES prefix entries behind the prefix -- the cache
-        grows with repeated keys) is clamped to the evictable range: nothing is evicted, nothing is duplicated (deliberate);
-      * new_size == 0 (one chunk longer than the whole budget): `-0:` keeps everything in the reference, again duplicating the
-        prefix; here the tail is dropped, as the budget asks (deliberate; same as oracle/agent.py)."""
-    evictable = max(0, cur - keep_prefix)
-    if new_size < 0:
-        new_size = max(0, cur + new_size)
-    return min(new_size, evictable)
 
 
 def default_args(**overrides) -> argparse.Namespace:

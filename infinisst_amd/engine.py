@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -190,6 +191,7 @@ class Engine:
         self.c_cfg = make_c_config(cfg, max_streams, max_multiplier, max_prompt_len, max_new_tokens,
                                    max_llm_cache_size, max_system_prompt, debug_taps, max_beams)
         self.max_new_tokens = max_new_tokens
+        self.last_call_seconds = 0.0
         r64 = lambda x: (x + 63) // 64 * 64
         # rows the library wants from isst_set_rope_tables (engine.hip isst_create: sys_cap + ring_cap, enc_cap)
         self._llm_rope_rows = r64(max_system_prompt) + r64(max_llm_cache_size + max_prompt_len + max_new_tokens + 8)
@@ -259,6 +261,16 @@ class Engine:
         info = _StreamInfo()
         self._check(self.lib.isst_stream_info_get(self.h, sid, C.byref(info)), "isst_stream_info_get")
         return {k: getattr(info, k) for k, _ in _StreamInfo._fields_}
+
+    def stream_cache_lens(self, sids: Sequence[int]) -> list:
+        """llm_cache_len of several streams (what the agent reads as past_key_values[0][0].size(2), agents/infinisst.py:337)."""
+        info = _StreamInfo()
+        ref = C.byref(info)
+        out = []
+        for sid in sids:
+            self._check(self.lib.isst_stream_info_get(self.h, sid, ref), "isst_stream_info_get")
+            out.append(info.llm_cache_len)
+        return out
 
     def kv_evict(self, sid: int, new_cache_size: int, keep_prefix: int):
         self._check(self.lib.isst_kv_evict(self.h, sid, new_cache_size, keep_prefix), "isst_kv_evict")
@@ -363,10 +375,11 @@ class Engine:
         out_lens = (C.c_int * n)()
         logits = np.zeros((n, gen.max_new_tokens, self.cfg.vocab), dtype=np.float32) if return_logits else None
         pcm_ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in pcm]) if on_device else vp(pcm)
-        rc = self.lib.isst_generate(self.h, C.byref(p), n, sid_arr, pcm_ptrs, n_samples, vp(prompts), lens(prompts),
-                                    vp(prevs), lens(prevs), vp(forced), lens(forced),
-                                    (C.c_void_p * n)(*[o.ctypes.data for o in outs]), out_lens,
-                                    None if logits is None else logits.ctypes.data, _stream_ptr())
+        args = (self.h, C.byref(p), n, sid_arr, pcm_ptrs, n_samples, vp(prompts), lens(prompts), vp(prevs), lens(prevs), vp(forced), lens(forced),
+                (C.c_void_p * n)(*[o.ctypes.data for o in outs]), out_lens, None if logits is None else logits.ctypes.data, _stream_ptr())
+        t0 = time.perf_counter()
+        rc = self.lib.isst_generate(*args)
+        self.last_call_seconds = time.perf_counter() - t0  # wall time inside the library (it returns once the last token id is on the host)
         self._check(rc, "isst_generate")
         return [outs[i][: out_lens[i]].tolist() for i in range(n)], logits
 
@@ -431,6 +444,11 @@ def op_gemm(A: torch.Tensor, packed: torch.Tensor, N: int, epi: str = "none", bi
     if rc:
         raise IsstError(f"isst_op_gemm -> {rc}")
     return out
+
+
+def dense_kernel_name() -> str:
+    """The kernel isst_op_gemm dispatches to above 64 rows (bench.py's `mfma` block names it)."""
+    return "gemm_tiled_kernel<EPI> (128 x 128 tile, 4 waves, gemm_tiled.hip)"
 
 
 def op_gemm_splitk_rmsnorm(A: torch.Tensor, packed: torch.Tensor, x: torch.Tensor, ksplit: int, norm_w=None, norm_eps: float = 1e-5):

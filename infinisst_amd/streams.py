@@ -1,12 +1,21 @@
-"""Stream-parallel partitioning across the GPUs of one node (replicas only).
+"""Many concurrent streams: the batch driver of one GPU (`StreamBatch`) and the stream-parallel partitioning across the GPUs of
+one node (replicas only).
 
 Audio streams are independent; nothing inside one stream shards, so there is no data-path collective: every rank
 holds a full weight replica and steps its own streams.  `torch.distributed` is used for rendezvous, the timing
 barrier and the max-over-ranks reduction of the elapsed time only.
+
+`StreamBatch` is what BASELINE.json configs[2] / [3] run: the per-chunk body of the reference's `policy()`
+(agents/infinisst.py:287-367) for MANY independent streams with ONE `isst_generate` call per tick.  The reference has no such
+thing -- its only "batching" replicates one stream N times (`pseudo_batch_size`, :291-301) -- so the class restates, per stream,
+exactly the state one single-stream agent keeps: `speech_cache` / `past_key_values` (inside the library, by stream id),
+`target_ids`, the `cache_checkpoints` list and the whole-chunk eviction (:337-361).
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+import time
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -15,6 +24,158 @@ import torch.distributed as dist
 def assign_streams(n_streams: int, rank: int, world_size: int) -> List[int]:
     """gpu = stream_id mod n_gpu."""
     return [s for s in range(n_streams) if s % world_size == rank]
+
+
+@dataclass
+class _Slot:
+    sid: int
+    started: bool = False  # reference: states.speech_cache is not None
+    target_ids: List[int] = field(default_factory=list)
+    ckpts: List[int] = field(default_factory=list)  # cache_checkpoints of this stream's agent (:106, never reset per utterance)
+    chunks: int = 0
+    evictions: int = 0
+
+
+class StreamBatch:
+    """One GPU's concurrent streams, stepped together.
+
+        batch = StreamBatch(engine, gen, system_prompt_size, prompt_fn)
+        a = batch.open(); b = batch.open()                 # one library stream + one agent-side state each
+        outs = batch.step([seg_a, None])                   # stream b brought no new chunk this tick: it is skipped
+        outs[0] -> output_ids of stream a (generated[:-1], agents/infinisst.py:363); outs[1] is None
+
+    * ONE `isst_generate` call per tick for every stream that brought a chunk (ragged prompts: a stream's first chunk carries the
+      system prompt, later chunks the 22-token turn; the system prompt is pinned for fresh streams only);
+    * per stream: `target_ids` (the last `no_repeat_ngram_lookback` feed the encoder-n-gram processor, :298-300), the
+      checkpoint list and the whole-chunk eviction -- the same code path as `agent.InfiniSST.policy` (`evict_whole_chunks`);
+    * all streams of a tick must bring the same number of samples (one latency multiplier per batch: `gen.latency_multiplier`);
+    * `host_seconds` / `device_call_seconds`: wall time spent outside / inside the library call since `reset_timers()`."""
+
+    def __init__(self, engine, gen, system_prompt_size: int, prompt_fn: Callable[[bool, int], List[int]]):
+        self.engine, self.gen = engine, gen
+        self.system_prompt_size = system_prompt_size
+        self.prompt_fn = prompt_fn
+        self.slots: List[Optional[_Slot]] = []
+        self.reset_timers()
+
+    def reset_timers(self):
+        self.host_seconds = 0.0
+        self.device_call_seconds = 0.0
+        self.ticks = 0
+
+    # ------------------------------------------------------------------ stream lifetime
+    def open(self) -> int:
+        slot = _Slot(sid=self.engine.open_stream())
+        for i, s in enumerate(self.slots):
+            if s is None:
+                self.slots[i] = slot
+                return i
+        self.slots.append(slot)
+        return len(self.slots) - 1
+
+    def close(self, idx: int):
+        self.engine.close_stream(self._slot(idx).sid)
+        self.slots[idx] = None
+
+    def new_utterance(self, idx: int):
+        """S2TAgentStates.reset (:60-67): fresh speech cache / KV cache / target ids; the checkpoint list is agent-level and stays."""
+        s = self._slot(idx)
+        self.engine.reset_stream(s.sid)
+        s.started, s.target_ids = False, []
+
+    def _slot(self, idx: int) -> _Slot:
+        if idx < 0 or idx >= len(self.slots) or self.slots[idx] is None:
+            raise KeyError(f"no open stream {idx}")
+        return self.slots[idx]
+
+    def stream_id(self, idx: int) -> int:
+        return self._slot(idx).sid
+
+    def cache_len(self, idx: int) -> int:
+        return self.engine.stream_info(self._slot(idx).sid)["llm_cache_len"]
+
+    @property
+    def evictions(self) -> int:
+        return sum(s.evictions for s in self.slots if s is not None)
+
+    def adopt_state(self, idx: int, ckpts: Sequence[int], started: bool = True):
+        """A stream whose caches were imported (isst_stream_import_*: resume, steady-state set-up) also needs the agent-side half."""
+        s = self._slot(idx)
+        s.ckpts, s.started = list(ckpts), started
+
+    # ------------------------------------------------------------------ one tick
+    def step(self, audio: Sequence, forced_tokens=None, return_logits: bool = False):
+        """`audio[i]`: the new samples of open stream i (fp32 numpy array, or a contiguous fp32 CUDA tensor: resident audio), already
+        padded to whole chunks (`agent._prepare_speech`), or None when stream i has nothing new.  Returns a list with, per stream,
+        the output ids of this chunk (`sequences[0, len(prompt):-1]`) or None; with `return_logits` a pair (that list, logits of the
+        active streams in call order)."""
+        t0 = time.perf_counter()
+        if len(audio) != len(self.slots):
+            raise ValueError(f"{len(audio)} audio entries for {len(self.slots)} stream slots")
+        active = [i for i, a in enumerate(audio) if a is not None and self.slots[i] is not None]
+        outs: List[Optional[List[int]]] = [None] * len(self.slots)
+        if not active:
+            self.host_seconds += time.perf_counter() - t0
+            return (outs, None) if return_logits else outs
+        gen = self.gen
+        slots = [self.slots[i] for i in active]
+        prompts = [self.prompt_fn(not s.started, gen.latency_multiplier) for s in slots]
+        prevs = [s.target_ids[-gen.no_repeat_ngram_lookback:] for s in slots]
+        pin = self.system_prompt_size if gen.always_cache_system_prompt else 0
+        forced = None if forced_tokens is None else [forced_tokens[i] for i in active]
+        gens, logits = self.engine.generate(gen, [s.sid for s in slots], [audio[i] for i in active], prompts, prevs,
+                                            system_prompt_size=pin, forced_tokens=forced, return_logits=return_logits)
+        self.device_call_seconds += self.engine.last_call_seconds
+        lens = self.engine.stream_cache_lens([s.sid for s in slots])
+        keep = self.system_prompt_size if gen.always_cache_system_prompt else 0
+        for i, s, g, cur in zip(active, slots, gens, lens):
+            s.started = True
+            s.chunks += 1
+            s.ckpts, new_size = evict_whole_chunks(s.ckpts, cur, gen.max_llm_cache_size, keep)
+            if new_size is not None:
+                self.engine.kv_evict(s.sid, new_size, keep)
+                s.evictions += 1
+            out = g[:-1]
+            s.target_ids.extend(out)
+            if len(s.target_ids) > 4 * max(1, gen.no_repeat_ngram_lookback):  # only the last `lookback` ids are ever read
+                s.target_ids = s.target_ids[-gen.no_repeat_ngram_lookback:]
+            outs[i] = out
+        self.ticks += 1
+        self.host_seconds += time.perf_counter() - t0 - self.engine.last_call_seconds
+        return (outs, logits) if return_logits else outs
+
+
+def evict_whole_chunks(ckpts: List[int], cur: int, max_llm_cache_size: int, keep_prefix: int):
+    """The checkpoint walk of agents/infinisst.py:337-352 for one stream: append the cache length after this chunk; when it exceeds
+    the budget find the first checkpoint c with cur - c <= budget, drop the checkpoints up to it and rebase the rest (the pinned
+    system prompt is not counted as trimmed).  Returns (new checkpoint list, tail size for isst_kv_evict or None)."""
+    ckpts = list(ckpts) + [cur]
+    if cur <= max_llm_cache_size:
+        return ckpts, None
+    new_size = 0
+    for i, c in enumerate(ckpts):
+        new_size = cur - c
+        if new_size <= max_llm_cache_size:
+            n_trimmed = c - keep_prefix
+            ckpts = [x - n_trimmed for x in ckpts[i + 1:]]
+            break
+    return ckpts, effective_new_cache_size(new_size, cur, keep_prefix)
+
+
+def effective_new_cache_size(new_size: int, cur: int, keep_prefix: int) -> int:
+    """Entries of the tail that survive `k[:, :, -new_size:]` (reference agents/infinisst.py:354-361) for ANY integer the checkpoint
+    loop can produce.  `cache_checkpoints` is agent-level and never reset (:106), so after a new utterance starts the list holds
+    stale, possibly larger-than-`cur` entries and `new_size` can leave [0, cur - keep_prefix]:
+      * 0 < new_size <= cur - keep_prefix: the ordinary case;
+      * new_size < 0: Python slicing `-new_size:` = `[|new_size|:]` keeps the last cur - |new_size| entries;
+      * a tail that would overlap the pinned prefix (the reference then DUPLICATES prefix entries behind the prefix -- the cache
+        grows with repeated keys) is clamped to the evictable range: nothing is evicted, nothing is duplicated (deliberate);
+      * new_size == 0 (one chunk longer than the whole budget): `-0:` keeps everything in the reference, again duplicating the
+        prefix; here the tail is dropped, as the budget asks (deliberate; same as oracle/agent.py)."""
+    evictable = max(0, cur - keep_prefix)
+    if new_size < 0:
+        new_size = max(0, cur + new_size)
+    return min(new_size, evictable)
 
 
 class TimingGroup:

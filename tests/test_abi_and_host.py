@@ -391,3 +391,101 @@ def test_dpo_sampling_writes_the_reference_line_format(tmp_path):
         expect.append(f"[{', '.join(chunks)}]")
         assert st.translations_list == []
     assert out.read_text(encoding="utf-8").splitlines() == expect
+
+
+class _FakeMultiEngine:
+    """Many-stream stand-in for the library: cache growth per stream, generated ids a pure function of (stream key, chunk index)."""
+
+    def __init__(self, key_offset=0):
+        self.key_offset, self.state, self.calls, self.evicted = key_offset, {}, [], []
+        self.last_call_seconds = 0.0
+
+    def open_stream(self):
+        sid = len(self.state)
+        self.state[sid] = dict(len=0, sys=0, chunk=0)
+        return sid
+
+    def reset_stream(self, sid):
+        self.state[sid].update(len=0, sys=0)
+
+    def close_stream(self, sid):
+        self.state[sid] = None
+
+    def generate(self, gen, sids, pcm, prompts, prevs, system_prompt_size=0, forced_tokens=None, return_logits=False):
+        assert len({len(x) for x in pcm}) == 1, "one isst_generate call takes equally long segments"
+        outs = []
+        for sid, a, pr, pv in zip(sids, pcm, prompts, prevs):
+            st = self.state[sid]
+            rng = np.random.default_rng(1000 * (sid + self.key_offset) + st["chunk"])
+            n_gen = int(rng.integers(2, gen.max_new_tokens + 1))
+            if st["len"] == 0:
+                st["sys"] = system_prompt_size
+            st["len"] += len(pr) + n_gen - 1
+            st["chunk"] += 1
+            outs.append([int(x) for x in rng.integers(10, 900, size=n_gen)])
+            self.calls.append(dict(key=sid + self.key_offset, n=len(sids), prompt_len=len(pr), prev=list(pv), samples=len(a)))
+        return outs, None
+
+    def stream_info(self, sid):
+        return {"llm_cache_len": self.state[sid]["len"]}
+
+    def stream_cache_lens(self, sids):
+        return [self.state[s]["len"] for s in sids]
+
+    def kv_evict(self, sid, new_size, keep):
+        assert keep == self.state[sid]["sys"] and 0 <= new_size <= self.state[sid]["len"] - keep
+        self.evicted.append((sid + self.key_offset, new_size, keep))
+        self.state[sid]["len"] = new_size + keep
+
+
+@pytest.mark.parametrize("keep_sys", [True, False])
+def test_stream_batch_equals_one_agent_per_stream(keep_sys):
+    """streams.StreamBatch (one library call per tick for every stream that brought a chunk; ragged first / later prompts; streams
+    without a new chunk skip the tick; per-stream target ids, checkpoints and eviction) against N independent single-stream agents
+    (agent.InfiniSST.policy = the reference's policy(), pinned by agent.npz): same prompts, same encoder_input_ids windows, same
+    evictions, same output ids for every stream."""
+    from infinisst_amd import synth
+    from infinisst_amd.streams import StreamBatch
+    cfg = toy_config().replace(block_size=48)
+    N, ticks = 5, 30
+    args = default_args(max_llm_cache_size=120, always_cache_system_prompt=keep_sys, max_new_tokens=10)
+    sys_n = len(synth.system_prompt_ids(cfg, 1))
+    eng = _FakeMultiEngine()
+    gen = GenConfig(max_new_tokens=10, max_llm_cache_size=120, always_cache_system_prompt=keep_sys)
+    batch = StreamBatch(eng, gen, sys_n, lambda first, m: synth.chunk_prompt_ids(cfg, m, first))
+    idx = [batch.open() for _ in range(N)]
+    agents, states, engines = [], [], []
+    for k in range(N):
+        e = _FakeMultiEngine(key_offset=k)
+        a = InfiniSST(args, engine=e, model_cfg=cfg)
+        st = a.states  # the constructor built the agent's states (= opened library stream 0)
+        st.source_sample_rate = 16000
+        agents.append(a), states.append(st), engines.append(e)
+    rng = np.random.default_rng(5)
+    seg = cfg.chunk_samples
+    for t in range(ticks):
+        present = [bool(rng.random() < 0.7) or t == 0 for _ in range(N)]
+        present[2] = present[2] and t >= 4  # stream 2 joins late: its FIRST chunk (system prompt) shares a call with later chunks
+        audio = [(0.1 * rng.standard_normal(seg)).astype(np.float32) if p else None for p in present]
+        outs = batch.step(audio)
+        for k in range(N):
+            if not present[k]:
+                assert outs[k] is None
+                continue
+            states[k].source.extend(audio[k].tolist())
+            before = len(states[k].target_ids)
+            agents[k].policy(states[k])
+            assert outs[k] == states[k].target_ids[before:], f"tick {t} stream {k}"
+            assert batch.slots[idx[k]].ckpts == agents[k].cache_checkpoints, f"tick {t} stream {k}: checkpoints"
+            assert eng.state[batch.stream_id(idx[k])]["len"] == engines[k].state[0]["len"]
+    assert sorted(eng.evicted) == sorted(ev for e in engines for ev in e.evicted) and len(eng.evicted) > N
+    per_key = lambda calls, key: [(c["prompt_len"], c["prev"]) for c in calls if c["key"] == key]
+    for k in range(N):
+        assert per_key(eng.calls, k) == per_key(engines[k].calls, k)
+    assert any(c["n"] > 1 for c in eng.calls) and {c["prompt_len"] for c in eng.calls if c["n"] > 1} >= {len(synth.chunk_prompt_ids(cfg, 1, True)), len(synth.chunk_prompt_ids(cfg, 1, False))}
+    # a new utterance on one slot: caches reset, checkpoints stay (reference agents/infinisst.py:60-67,106)
+    ck = list(batch.slots[idx[0]].ckpts)
+    batch.new_utterance(idx[0])
+    assert batch.cache_len(idx[0]) == 0 and batch.slots[idx[0]].ckpts == ck and batch.slots[idx[0]].target_ids == []
+    batch.close(idx[1])
+    assert batch.open() == idx[1]

@@ -53,15 +53,16 @@ def test_bench_starts_its_own_ranks_and_relays_rank0_json():
     """`python bench.py --gpus 2` typed as is (no launcher): the parent starts torch.distributed.run as a child, the ranks rendezvous
     on 127.0.0.1, deal the global stream ids (stream_id mod n_gpu), time their steps behind barriers, reduce max/sum over ranks,
     and rank 0's JSON line arrives on the parent's stdout.  --dry-run replaces the GPU work by a sleep and RCCL by gloo -- the
-    launcher, partition and reduction code is the code of a real run."""
+    launcher, partition, StreamBatch and reduction code is the code of a real run."""
     import json
-    r = _run_bench("--dry-run", "--gpus", "2", "--steps", "3", "--streams", "3")
+    r = _run_bench("--dry-run", "--gpus", "2", "--steps", "12", "--streams", "3")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["dry_run"] is True and j["n_gpus"] == 2 and j["ranks_seen"] == 2
-    assert j["streams_of_rank0"] == [0, 2, 4] and j["latencies_gathered"] == 6
+    assert j["streams_of_rank0"] == [0, 2, 4] and j["latencies_gathered"] == 24
+    assert j["evictions_all_ranks"] >= 6  # the product's StreamBatch ran on every rank: all 6 streams outgrew the 200-entry budget
     assert j["ms_per_step"] >= 4.0  # the slower rank (4 ms per step) sets the time
 
 
