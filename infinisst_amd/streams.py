@@ -34,6 +34,7 @@ class _Slot:
     ckpts: List[int] = field(default_factory=list)  # cache_checkpoints of this stream's agent (:106, never reset per utterance)
     chunks: int = 0
     evictions: int = 0
+    last_generated: List[int] = field(default_factory=list)  # every id sampled in the last chunk, the never-fed final one included
 
 
 class StreamBatch:
@@ -131,6 +132,7 @@ class StreamBatch:
         for i, s, g, cur in zip(active, slots, gens, lens):
             s.started = True
             s.chunks += 1
+            s.last_generated = list(g)
             s.ckpts, new_size = evict_whole_chunks(s.ckpts, cur, gen.max_llm_cache_size, keep)
             if new_size is not None:
                 self.engine.kv_evict(s.sid, new_size, keep)

@@ -83,7 +83,7 @@ def test_load_checkpoint_on_the_gpu(tmp_path):
 
 def test_agent_from_simuleval_args_runs_an_utterance_like_the_oracle(tmp_path):
     cfg = toy_config()
-    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=62)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=62, recipe="peaked")  # decisive greedy steps: synth.apply_recipe
     model_dir = build_tokenizer_dir(tmp_path, cfg)
     ckpt = _checkpoint(tmp_path, cfg, w, None, "model.")
     parser = argparse.ArgumentParser()
@@ -124,6 +124,7 @@ def test_agent_from_simuleval_args_runs_an_utterance_like_the_oracle(tmp_path):
     # identical up to the first step whose oracle margin is within bf16 noise (2 x the logit tolerance); everything before it must agree
     first_tie = next((i for i, m in enumerate(margins) if m <= 0.3), len(margins))
     k = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
+    assert first_tie >= min(12, len(ref)), f"the peaked recipe must give decisive steps (first near-tie at {first_tie} of {len(ref)})"
     assert k >= min(first_tie, len(ref)), f"ids part at {k}, before the first near-tie at {first_tie}"
     if got == ref:
         assert agent.engine.stream_info(agent.states.stream_id)["llm_cache_len"] == ollm.kv_len(st.past_key_values)

@@ -171,7 +171,7 @@ def test_agent_multiplier_2_with_a_short_last_segment_matches_oracle_agent():
     from infinisst_amd.agent import InfiniSST, WriteAction, default_args
     from oracle import agent as oag
     cfg = toy_config()
-    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=36)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=36, recipe="peaked")  # decisive greedy steps: synth.apply_recipe
     m = 2
     args = default_args(latency_multiplier=m, max_latency_multiplier=2, max_new_tokens=6, max_llm_cache_size=400)
     eng = Engine(cfg, max_streams=1, max_multiplier=2, max_prompt_len=160, max_new_tokens=16, max_llm_cache_size=400, max_system_prompt=64)
@@ -200,6 +200,7 @@ def test_agent_multiplier_2_with_a_short_last_segment_matches_oracle_agent():
     print("agent ids:", got, "oracle ids:", ref)
     first_tie = next((i for i, mg in enumerate(margins) if mg <= 0.3), len(margins))
     k = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
+    assert first_tie >= min(8, len(ref)), f"the peaked recipe must give decisive steps (first near-tie at {first_tie} of {len(ref)})"
     assert k >= min(first_tie, len(ref))
     if got == ref:
         assert eng.stream_info(st.stream_id)["llm_cache_len"] == ollm.kv_len(so.past_key_values)

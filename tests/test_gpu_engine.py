@@ -138,24 +138,28 @@ def test_generate_teacher_forced_logits(sys_pin):
 
 
 def test_generate_free_running_tokens():
-    """Free-running greedy decode: ids identical to the oracle's wherever the oracle's top-2 margin exceeds
-    2*LOGIT_TOL (near-ties may legitimately flip under bf16); streams re-synchronise per chunk via forced prompts."""
+    """Free-running greedy decode over 5 chunks with evictions: ids identical to the oracle's wherever the oracle's top-2 margin exceeds
+    2*LOGIT_TOL (near-ties may legitimately flip under bf16).  Weights: the "peaked" recipe (synth.apply_recipe), under which all but the
+    steps whose structured continuations are banned by the n-gram processors are decisive -- the test FAILS when fewer than 24 of
+    the 40 steps are (round 2 ran it on the plain init: 3 decisive steps)."""
     cfg = toy_config()
     gen = GenConfig(max_new_tokens=8, max_llm_cache_size=150)
-    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=22)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=22, recipe="peaked")
     eng = make_engine(cfg, w, debug_taps=False)
     sid = eng.open_stream()
-    recs = run_chunks(cfg, gen, w, eng, sid, 2, forced=False, evict=False, sys_pin=True)
-    decisive = mismatch = 0
+    recs = run_chunks(cfg, gen, w, eng, sid, 5, forced=False, evict=True, sys_pin=True)
+    decisive = mismatch = steps = 0
     for c, s, rl, gl, sc, rt, gt in recs:
+        steps += 1
         top2 = np.sort(sc[np.isfinite(sc)])[-2:]
         if top2[1] - top2[0] > 2 * LOGIT_TOL:
             decisive += 1
             mismatch += int(rt != gt)
         if rt != gt:
             break  # contexts diverge after the first flip
-    print(f"free-running: {decisive} decisive steps, {mismatch} mismatches")
+    print(f"free-running: {steps} steps compared, {decisive} decisive, {mismatch} mismatches")
     assert mismatch == 0
+    assert decisive >= 24, f"only {decisive} decisive steps"
 
 
 def test_two_streams_batched_equals_single():

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def test_tokenizer_prompts_and_instances_log(tmp_path):
     cfg = toy_config()
-    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=77)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=77, recipe="peaked")  # decisive greedy steps: synth.apply_recipe
     tok = StubTokenizer(cfg)
     args = default_args(max_llm_cache_size=150, max_new_tokens=6, max_latency_multiplier=1)
     eng = Engine(cfg, max_streams=1, max_multiplier=1, max_prompt_len=128, max_new_tokens=16, max_llm_cache_size=150, max_system_prompt=80)
@@ -59,6 +59,7 @@ def test_tokenizer_prompts_and_instances_log(tmp_path):
     # random toy weights leave near-ties: every id before the oracle's first near-tie (top-2 margin within 2 x the logit tolerance) must agree
     first_tie = next((i for i, m in enumerate(margins) if m <= 0.3), len(margins))
     k = next((i for i, (a, b) in enumerate(zip(got, ref)) if a != b), min(len(got), len(ref)))
+    assert first_tie >= min(8, len(ref)), f"the peaked recipe must give decisive steps (first near-tie at {first_tie} of {len(ref)})"
     assert k >= min(first_tie, len(ref)), f"ids part at {k}, before the first near-tie at {first_tie}"
     if got == ref:
         from oracle import llm as ollm
