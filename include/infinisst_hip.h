@@ -248,9 +248,11 @@ int isst_op_conv0(const uint16_t* audio, const uint16_t* w, const uint16_t* bias
 int isst_op_sample(float* logits, int vocab, const int* ids, int n_ids, const int* enc_ids, int n_enc, const int* suppress,
                    int n_suppress, float repetition_penalty, int ngram, int enc_ngram, int* out_token, void* hip_stream);
 
-/* Merge of the decode attention's split-KV partials [rows][heads][n_splits][2 + 128] fp32 = (running max, sum, unnormalised O[128]) per slot
- * split (the flash-decoding reduction behind patch_llm.py:320-329's single softmax): as a pass of its own (-> out [rows][heads * 128] bf16) and
+/* Merge of the decode attention's split-KV partials [rows][heads][n_splits][ISST_ATTN_SLAB] fp32, one slab per slot split:
+ * floats 0..127 = unnormalised O, 128 = running max, 129 = sum, 130..131 = padding (528 B: 33 whole 16-byte stores)
+ * (the flash-decoding reduction behind patch_llm.py:320-329's single softmax): as a pass of its own (-> out [rows][heads * 128] bf16) and
  * fused into the o_proj projection that follows (patch_llm.py:334): out = (res +) merged @ W_o^T for M <= 2 rows, K = heads * 128. */
+#define ISST_ATTN_SLAB 132
 int isst_op_attn_combine(const float* partial, uint16_t* out, int heads, int rows, int n_splits, void* hip_stream);
 int isst_op_gemm_attn_merge(const float* partial, int n_splits, const uint16_t* packed, const uint16_t* res, int64_t ldres, uint16_t* out,
                             int64_t ldo, int M, int N, int K, void* hip_stream);

@@ -209,7 +209,8 @@ class InfiniSST(_AgentBase):
     @staticmethod
     def _llama_side_config(model_name: str) -> dict:
         """EOS ids / rotary parameters from `<model_name>/generation_config.json` and `config.json` when `--model-name` is a local
-        directory (the reference reads them through from_pretrained, :150-154); Llama-3.1 values otherwise."""
+        directory (the reference reads them through from_pretrained, :150-154); otherwise `load_model` keeps the Llama-3.1 values for a
+        Llama-3.1 model name and falls back to the tokenizer's EOS for anything else."""
         out = {}
         if model_name and os.path.isdir(model_name):
             gpath, cpath = os.path.join(model_name, "generation_config.json"), os.path.join(model_name, "config.json")
@@ -260,7 +261,9 @@ class InfiniSST(_AgentBase):
 
         state = checkpoint.load_state_dict_file(args.state_dict_path)  # :179
         side = self._llama_side_config(args.model_name)
-        if "eos_ids" not in side and getattr(tokenizer, "eos_token_id", None) is not None:
+        if "eos_ids" not in side and "3.1" not in str(args.model_name) and getattr(tokenizer, "eos_token_id", None) is not None:
+            # no generation_config.json / config.json at hand (a hub id): Llama-3.1 keeps ModelConfig's three stop ids (what from_pretrained reads
+            # from its generation_config.json, agents/infinisst.py:150-154); any other model falls back to the tokenizer's EOS
             side["eos_ids"] = (int(tokenizer.eos_token_id),)
         shrink = parse_length_shrink_cfg(getattr(args, "length_shrink_cfg", None))
         cfg = checkpoint.infer_config(state, block_size=args.block_size, max_cache_size=args.max_cache_size,

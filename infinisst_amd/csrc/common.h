@@ -99,7 +99,7 @@ struct GemmArgs {
 #define ATTN_SLAB 132  // floats per (row, head, split) slab: O[0..127], max, sum, 2 x pad -- 528 B, so that a slab is 33 whole 16-byte stores
 // Merge of the split-KV attention partials of one (row, head) for the two output dims a lane owns: the ONE definition of this arithmetic
 // (llm_attn_combine_kernel and the o_proj GEMV's merge-on-load prologue both call it, so a row gives the same bits through either).
-// src: [n_splits][2 + 128] fp32; every load is issued before the first use.  Returns bf16(O / L) of dims 2 lane, 2 lane + 1, packed.
+// src: [n_splits][ATTN_SLAB] fp32 (O[0..127], max, sum, 2 x pad); every load is issued before the first use.  Returns bf16(O / L) of dims 2 lane, 2 lane + 1, packed.
 // (split into a load half and a math half so that a caller can put several heads' loads -- and other loads -- in flight before the first use;
 //  MAXS >= n_splits is the unroll bound: slabs past n_splits fall outside the descriptor's extent and read zeros at no traffic)
 template <int MAXS>

@@ -123,7 +123,8 @@ struct isst_handle {
                                   // prefill) equal -- the hand-off costs nearly what the launch costs.  ISST_FUSE_REDUCE=0 restores the reduce launches
     int qkv_slices = 0;           // ISST_QKV_SLICES: K slices of the q/k/v projection at 13..64 rows (in-launch reduction); 0 = by row count
     float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
-    int* ltickets = nullptr;      // [llm_dim / 32] arrival counters (GemmArgs::tickets), zero between launches
+    int* ltickets = nullptr;      // [ltickets_n] arrival counters (GemmArgs::tickets), one per 32-column block of the widest ticketed launch; zero between launches
+    int ltickets_n = 0;
     int lt_min_rows = LT_MIN_ROWS; // ISST_BLASLT_MIN_ROWS: rows above which the library GEMM path runs
     int enc_lt_min_rows = ENC_LT_MIN_ROWS;  // ISST_BLASLT_ENC_MIN_ROWS: the same for the speech encoder's four projections per layer
     bf16_t* etmp = nullptr;       // [enc_rows_max][enc_dim] out_proj / fc2 outputs of the library GEMM
@@ -509,7 +510,8 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->llast = h->dalloc<bf16_t>((size_t)ns * h->max_beams * DL);
     h->lpartial = h->dalloc<float>(LR * H * ((h->sys_cap + h->ring_cap) / 64) * ATTN_SLAB);
     h->lssq = h->dalloc<float>((size_t)64 * (DL / 32), true);
-    h->ltickets = h->dalloc<int>((size_t)DL / 16 + 16, true);
+    h->ltickets_n = std::max(DL, (H + 2 * KV) * 128) / 32 + 16;  // a ticketed launch indexes tickets[blockIdx.x]; its narrowest workgroup spans 32 columns (gemm_mid NP = 1)
+    h->ltickets = h->dalloc<int>((size_t)h->ltickets_n, true);
     h->attn_cnt = h->dalloc<int>(64, true);  // arrival counters of the in-kernel split-KV combine (llm_attn.hip), one per kv head; zero between launches
     h->lslab = h->dalloc<float>((size_t)LLM_SLAB_ROWS * std::max(DL, (H + 2 * KV) * 128));
     const size_t NB = (size_t)ns * h->max_beams;  // decode rows of a beam step
@@ -844,6 +846,7 @@ int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& 
     g.A = A; g.lda = lda; g.Wp = L.wp;
     g.out = slabs; g.ldo = L.n_valid; g.out_batch = (long)M * L.n_valid;
     g.M = M; g.N = L.N; g.K = L.K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = L.n_valid; g.ksplit = ksplit;
+    if (g.tickets && (L.N + 31) / 32 > h->ltickets_n) return h->fail(ISST_ERR_STATE, "ticketed split-K launch over %d columns needs %d arrival counters, %d allocated", L.N, (L.N + 31) / 32, h->ltickets_n);
     CHK(launch_gemm(g, st));
     return ISST_OK;
 }

@@ -182,19 +182,38 @@ def effective_new_cache_size(new_size: int, cur: int, keep_prefix: int) -> int:
 
 class TimingGroup:
     """The only cross-rank traffic of a run: the barrier around the timed region and the max / sum / gather of python floats.
-    RCCL (backend "nccl") on device tensors is the normal form; if an RCCL call fails on a node (IPC / topology trouble has nothing to do with
-    the stream-parallel data path, which has no collective), the same reductions go over a gloo group on CPU tensors and the failure is REPORTED
-    (`describe()`), not hidden."""
+    RCCL (backend "nccl") on device tensors is the normal form.  Whether it works on this node is decided ONCE, COLLECTIVELY, at
+    construction: every rank tries one RCCL all-reduce, the ranks then agree over a gloo side group (MIN of their "it worked" flags),
+    and if any rank failed ALL ranks use gloo on CPU tensors from then on -- the ranks can never sit in different collectives -- and the
+    failure is REPORTED (`describe()`), not hidden.  (IPC / topology trouble has nothing to do with the stream-parallel data path, which
+    has no collective.)  Without a gloo side group RCCL stays the only path and an error propagates."""
 
     def __init__(self, device=None):
         self.device = device
         self.gloo = None
+        self.gloo_error = None
         self.rccl_error = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and device is not None:
+        self.use_rccl = device is not None
+        if self._active() and device is not None:
             try:
                 self.gloo = dist.new_group(backend="gloo")
             except Exception as e:  # pragma: no cover
-                self.rccl_error = None if self.gloo else f"gloo side group unavailable: {e}"
+                self.gloo_error = f"{type(e).__name__}: {e}"
+            ok = 1.0
+            try:
+                t = torch.ones(1, dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                ok = 1.0 if float(t.item()) == float(dist.get_world_size()) else 0.0
+            except Exception as e:
+                if self.gloo is None:
+                    raise
+                ok, self.rccl_error = 0.0, f"{type(e).__name__}: {e}"
+            if self.gloo is not None:
+                flag = torch.tensor([ok], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.gloo)
+                if float(flag.item()) < 1.0:
+                    self.use_rccl = False
+                    self.rccl_error = self.rccl_error or "an RCCL all-reduce failed on another rank"
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -202,17 +221,12 @@ class TimingGroup:
     def _reduce(self, values: Sequence[float], op) -> List[float]:
         if not self._active():
             return [float(v) for v in values]
-        if self.device is not None and self.rccl_error is None:
-            try:
-                t = torch.tensor(list(values), dtype=torch.float64, device=self.device)
-                dist.all_reduce(t, op=op)
-                return [float(x) for x in t.tolist()]
-            except Exception as e:
-                if self.gloo is None:
-                    raise
-                self.rccl_error = f"{type(e).__name__}: {e}"
+        if self.use_rccl:
+            t = torch.tensor(list(values), dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=op)
+            return [float(x) for x in t.tolist()]
         t = torch.tensor(list(values), dtype=torch.float64)
-        dist.all_reduce(t, op=op, group=self.gloo)
+        dist.all_reduce(t, op=op, group=self.gloo)  # (device None: the default group is the CPU one)
         return [float(x) for x in t.tolist()]
 
     def barrier(self):
@@ -238,7 +252,9 @@ class TimingGroup:
             return "single rank"
         if self.device is None:
             return "gloo"
-        return "rccl" if self.rccl_error is None else f"gloo (an RCCL call failed: {self.rccl_error})"
+        if self.use_rccl:
+            return "rccl" + (f" (no gloo side group: {self.gloo_error})" if self.gloo_error else "")
+        return f"gloo (RCCL unusable on this node: {self.rccl_error})"
 
 
 def max_over_ranks(value: float, device=None) -> float:
