@@ -331,6 +331,7 @@ def test_full_size_free_running_ids_with_peaked_logits():
     rope_e, rope_l = oenc.make_rope(cfg), ollm.llm_rope_tables(cfg, 2048, torch.bfloat16)
     audio = synth.synthetic_audio(cfg.chunk_samples * PEAKED_CHUNKS, stream_id=31337)
     ckpts, targets = list(ckpts0), []
+    perms = synth.peaked_permutations(cfg)
     n_steps = n_decisive = n_mismatch = n_first = n_second = 0
     worst = 0.0
     margins = []
@@ -351,7 +352,7 @@ def test_full_size_free_running_ids_with_peaked_logits():
             top = torch.topk(ref.step_scores[s], 2)
             margin = float(top.values[0] - top.values[1])
             margins.append(margin)
-            s1, s2 = synth.peaked_successors(cfg, seq[-1])
+            s1, s2 = synth.peaked_successors(cfg, seq[-1], perms)[:2]
             n_first += int(tok == s1)
             n_second += int(tok == s2)
             n_steps += 1

@@ -23,7 +23,9 @@ class _Recording:
         return getattr(self.eng, name)
 
     def generate(self, gen, sids, pcm, prompts, prevs, system_prompt_size=0, **kw):
-        outs, logits = self.eng.generate(gen, sids, pcm, prompts, prevs, system_prompt_size=system_prompt_size, return_logits=True)
+        outs, logits = self.eng.generate(gen, sids, pcm, prompts, prevs, system_prompt_size=system_prompt_size,
+                                         forced_tokens=kw.get("forced_tokens"), return_logits=True)
+        self.last_call_seconds = self.eng.last_call_seconds
         for i, sid in enumerate(sids):
             self.last[sid] = (list(outs[i]), logits[i].copy(), list(prompts[i]), list(prevs[i]))
         return outs, None
