@@ -151,6 +151,10 @@ void gemm_set_tuning(int waves_per_block, int ntiles_per_block);  // 0 = heurist
 bool gemm_tiled_supported(const GemmArgs& g);                      // gemm_tiled.hip: dense shapes (M > 64 or batched)
 int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream);
 void gemm_tiled_set_raster(int on);                                // profiling aid: 0 = plain (column block, row block) grid
+bool gemm_dense_supported(const GemmArgs& g);                     // gemm_dense.hip: 256 x 256 tiles, 8-wave ping-pong, LDS-DMA (many-row prefill / encoder)
+bool gemm_dense_preferred(const GemmArgs& g);
+int launch_gemm_dense(const GemmArgs& g, hipStream_t stream);
+void gemm_dense_set(int mode);                                     // profiling aid: 0 never, 1 heuristic, 2 wherever supported
 bool gemm_mid_supported(const GemmArgs& g);                        // gemm_mid.hip: 17..64 rows, A staged through LDS
 bool gemm_mid_preferred(const GemmArgs& g);                       // ... and long enough a weight stream to pay for the staging
 int launch_gemm_mid(const GemmArgs& g, hipStream_t stream);

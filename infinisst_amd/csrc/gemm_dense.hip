@@ -1,0 +1,346 @@
+// 256 x 256-tile MFMA GEMM for the many-row (dense) shapes of the InfiniSST path on gfx950:
+//   out[M,N] = epi(A[M,K] @ W[N,K]^T): the Llama prefill of many streams (64 streams x 22 prompt rows = 1408 rows against q/k/v, o_proj,
+//   gate/up, down_proj -- reference patch_llm.py:260-262,334 and HF LlamaMLP [3P]), the speech encoder's projections at many streams
+//   (patch_speech_encoder.py:741-743,923,586-589) and the conv stack as implicit GEMM.  Below 65 rows the weight-streaming kernels run
+//   (gemm.hip, gemm_mid.hip); gemm_tiled.hip (128 x 128) keeps the shapes this kernel does not fit (K not a multiple of 64, batched).
+//
+// Structure (cdna_hip_programming.md section 5, "the 256^2 8-phase template", re-derived for the fragment-major packed weights):
+//   * 8 waves = 2 (M) x 4 (N); wave (wr, wc) owns 128 rows x 64 columns of the tile = 2 x 2 QUADRANTS of 64 x 32 (4 m-tiles x 2 n-tiles of
+//     v_mfma_f32_16x16x32_bf16), 32 accumulators = 128 VGPRs;
+//   * a K-TILE is 64 deep; both operands of a K-tile go through LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write
+//     pass), 2 K-tile buffers x 4 HALF-TILE slots of 16 KiB = 128 KiB, one workgroup per CU:
+//       A0 / A1 = rows {wr*128 + mh*64 + 0..63} of both wave rows: 16 units of 8 rows x 128 B (full lines), the 16-byte chunk index XORed with
+//                 ((row >> 1) & 7) on the SOURCE side (the DMA destination is lane-linear) and on the read side: conflict-free ds_read_b128;
+//       B0 / B1 = n-tiles {wc*4 + nh*2 + 0..1} of all four wave columns x 2 k-steps: 16 fragments of 1 KiB exactly as the packed weights lie
+//                 in memory ([n-tile][k-tile][lane] x 16 B): lane-linear reads, conflict-free by construction;
+//   * a PHASE = one quadrant x one K-tile = 16 MFMAs (256 matrix-pipe cycles).  Quadrant walk (0,0) (0,1) (1,1) (1,0): phase 1 reads A0 + B0
+//     (12 ds_read_b128), phase 2 B1 (4), phase 3 A1 (8), phase 4 nothing -- B0 stays in registers for its second use, so every half-tile slot
+//     is read in exactly one phase and each of the 24 fragment reads of a K-tile happens once;
+//   * every phase issues ONE half-tile of DMA (2 instructions per wave) into the slot whose last read lies two phases back:
+//       phase 1 of K-tile t: B1 of t+1, phase 2: A1 of t+1, phase 3: A0 of t+2, phase 4: B0 of t+2  (needed 5-6 phases later),
+//     then s_waitcnt vmcnt(8): all but the four youngest half-tiles of this wave have landed -- never a drain; the barrier that follows makes
+//     them visible to the other waves, and a slot is read one phase or more after the wait that retired it;
+//   * the two wave rows run the phases half a phase apart (wr = 1 passes one extra barrier before the loop): between two consecutive
+//     barriers one wave of every SIMD issues its 16 MFMAs while its partner issues its reads and DMAs ("ping-pong"), so the matrix pipe of a
+//     SIMD always has exactly one wave feeding it; s_setprio(1) around the MFMA cluster keeps hipcc from moving MFMAs across the barriers;
+//   * K order per accumulator: ascending, two k-steps per K-tile -- the same order as gemm_tiled.hip, so results are bit-identical to it.
+// Scheduling: one workgroup per tile in an XCD-aware order (as gemm_tiled.hip); narrow outputs split K over blockIdx.z into fp32 slabs
+// (EPI_PARTIAL) that the residual + RMSNorm kernel sums.
+#include "common.h"
+
+#define DT_M 256
+#define DT_NT 16          // n-tiles per tile (256 columns)
+#define DT_K 64
+#define DT_HALF 16384     // bytes per half-tile slot
+#define DT_BUF 65536      // bytes per K-tile buffer: A0 | A1 | B0 | B1
+
+typedef __attribute__((address_space(3))) void* dlds_ptr;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int raster) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x DT_BUF (all LDS of the kernel: a second object would make hipcc drain the DMAs)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int KT = g.K >> 5, NTILES = g.N >> 4;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (raster) {  // XCD-aware tile order: the workgroups an XCD runs at a time form a patch of 8 column blocks x all row blocks (gemm_tiled.hip)
+        const int X = (NTILES + DT_NT - 1) / DT_NT, Y = (g.M + DT_M - 1) / DT_M;
+        const int n_per = gridDim.x >> 3;
+        const int S = (blockIdx.x & 7) * n_per + (blockIdx.x >> 3);
+        if (S >= X * Y) return;
+        const int patch = S / (8 * Y), r = S - patch * (8 * Y);
+        const int pw = min(8, X - patch * 8);
+        by = r / pw;
+        bx = patch * 8 + r % pw;
+    }
+    const int m0 = by * DT_M, nt0 = bx * DT_NT;
+    const int ks = (EPI == EPI_PARTIAL && g.ksplit > 1) ? g.ksplit : 1;
+    const int slice = (EPI == EPI_PARTIAL) ? blockIdx.z : 0;
+    const int T = (g.K / DT_K) / ks;          // K-tiles of this workgroup
+    const long k0 = (long)slice * T * DT_K;   // first K element
+
+    // ---- DMA sources of this wave.  A half mh: units 2*wave, 2*wave + 1 of the slot = m-tile (wave & 3) of wave row (wave >> 2);
+    //      lane -> (row of the 8-row unit = lane >> 3, destination chunk = lane & 7), source chunk = destination chunk ^ ((row in m-tile >> 1) & 7) ----
+    const bf16_t* asrc[2][2];  // [mh][unit]
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rim = u * 8 + (lane >> 3);                                   // row inside the 16-row m-tile
+            const int row = min(m0 + (wave >> 2) * 128 + mh * 64 + (wave & 3) * 16 + rim, g.M - 1);  // rows past M repeat the last row (never stored)
+            const int chunk = (lane & 7) ^ ((rim >> 1) & 7);
+            asrc[mh][u] = g.A + (long)row * g.lda + k0 + chunk * 8;
+        }
+    //      B half nh: fragments 2*wave, 2*wave + 1 of the slot = n-tile (wave >> 1) * 4 + nh * 2 + (wave & 1), k-steps 0 and 1
+    const bf16_t* bsrc[2];     // [nh], k-step 0 of K-tile 0; k-step 1 is 512 elements further
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        const int nt = min(nt0 + (wave >> 1) * 4 + nh * 2 + (wave & 1), NTILES - 1);
+        bsrc[nh] = g.Wp + ((long)nt * KT + (k0 >> 5)) * 512 + lane * 8;
+    }
+    // (past the last K-tile the DMAs re-read K-tile T - 1 into the slot the running index names -- a slot nobody reads any more: the issue
+    //  and wait counts then stay the same in every phase)
+    auto dma_a = [&](int t, int mh) {  // A half mh of K-tile t -> buffer t & 1
+        unsigned char* dst = smem + (t & 1) * DT_BUF + mh * DT_HALF + (2 * wave) * 1024;
+        const long ko = (long)(t < T ? t : T - 1) * DT_K;
+        __builtin_amdgcn_global_load_lds((const void*)(asrc[mh][0] + ko), (dlds_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(asrc[mh][1] + ko), (dlds_ptr)(dst + 1024), 16, 0, 0);
+    };
+    auto dma_b = [&](int t, int nh) {
+        unsigned char* dst = smem + (t & 1) * DT_BUF + (2 + nh) * DT_HALF + (2 * wave) * 1024;
+        const long ko = (long)(t < T ? t : T - 1) * 1024;
+        __builtin_amdgcn_global_load_lds((const void*)(bsrc[nh] + ko), (dlds_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(bsrc[nh] + ko + 512), (dlds_ptr)(dst + 1024), 16, 0, 0);
+    };
+
+    // ---- fragment reads ----
+    const int a_rd = wr * 8192 + (fr >> 3) * 1024 + (fr & 7) * 128;     // + mt * 2048 + (((ks * 4 + fq) ^ ((fr >> 1) & 7)) << 4)
+    const int a_sw = (fr >> 1) & 7;
+    const int b_rd = wc * 4096 + lane * 16;                              // + (nb * 2 + ks) * 1024
+    u32x4_t fa[4][2], fb0[2][2], fb1[2][2];                              // [m-tile][k-step], [n-tile][k-step]
+    auto read_a = [&](int t, int mh) {
+        const unsigned char* base = smem + (t & 1) * DT_BUF + mh * DT_HALF + a_rd;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) fa[mt][k] = *reinterpret_cast<const u32x4_t*>(base + mt * 2048 + (((k * 4 + fq) ^ a_sw) << 4));
+    };
+    auto read_b = [&](int t, int nh, u32x4_t (&fb)[2][2]) {
+        const unsigned char* base = smem + (t & 1) * DT_BUF + (2 + nh) * DT_HALF + b_rd;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) fb[nb][k] = *reinterpret_cast<const u32x4_t*>(base + (nb * 2 + k) * 1024);
+    };
+
+    f32x4_t acc[2][2][4][2];  // [mh][nh][m-tile][n-tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[a][b][mt][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    auto quadrant = [&](f32x4_t (&c)[4][2], const u32x4_t (&fb)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    c[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[mt][k]), __builtin_bit_cast(bf16x8_t, fb[nb][k]), c[mt][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define DT_WAIT_BARRIER()                                   \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    __builtin_amdgcn_s_barrier();                           \
+    __builtin_amdgcn_sched_barrier(0)
+#define DT_END_PHASE()                                      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    __builtin_amdgcn_s_barrier();                           \
+    __builtin_amdgcn_sched_barrier(0)
+
+    // ---- prologue: K-tile 0 whole, then A0 / B0 of K-tile 1 (the order the phases below continue: B1(t+1), A1(t+1), A0(t+2), B0(t+2)) ----
+    dma_a(0, 0); dma_b(0, 0); dma_b(0, 1); dma_a(0, 1);
+    dma_a(1, 0); dma_b(1, 0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-tile 0 has landed (the two youngest half-tiles may fly)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs half a phase behind
+
+    for (int t = 0; t < T; ++t) {
+        // phase 1: quadrant (0, 0)
+        read_a(t, 0);
+        read_b(t, 0, fb0);
+        dma_b(t + 1, 1);
+        DT_WAIT_BARRIER();
+        quadrant(acc[0][0], fb0);
+        DT_END_PHASE();
+        // phase 2: quadrant (0, 1)
+        read_b(t, 1, fb1);
+        dma_a(t + 1, 1);
+        DT_WAIT_BARRIER();
+        quadrant(acc[0][1], fb1);
+        DT_END_PHASE();
+        // phase 3: quadrant (1, 1)
+        read_a(t, 1);
+        dma_a(t + 2, 0);
+        DT_WAIT_BARRIER();
+        quadrant(acc[1][1], fb1);
+        DT_END_PHASE();
+        // phase 4: quadrant (1, 0) -- B0 is still in registers
+        dma_b(t + 2, 0);
+        DT_WAIT_BARRIER();
+        quadrant(acc[1][0], fb0);
+        DT_END_PHASE();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // balances wave row 1's extra barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued DMAs must not land in LDS after the workgroup has gone
+#undef DT_WAIT_BARRIER
+#undef DT_END_PHASE
+
+    // ---- epilogue.  acc[mh][nh][mt][nb][r] = C[m0 + wr*128 + mh*64 + mt*16 + 4 fq + r][(nt0 + wc*4 + nh*2 + nb)*16 + fr] ----
+    // bf16 outputs go through the wave's own 16 KiB of the (now idle) LDS: each value is written once as bf16 -- after the bias / GELU / SwiGLU
+    // arithmetic, i.e. at the reference's rounding point in front of the residual add -- and read back as 16 bytes per lane, so that a store
+    // instruction covers 8 rows x 128 contiguous bytes instead of 4 rows x 32 (the accumulator layout) and the residual is read the same way.
+    constexpr bool BF16_OUT = EPI != EPI_PARTIAL && EPI != EPI_F32;
+    constexpr int WCOLS = EPI == EPI_SWIGLU ? 32 : 64;   // output columns of a wave
+    constexpr int RSTRIDE = WCOLS * 2 + 16;              // LDS row stride in bytes (padded: the four fq row groups of a store spread over the banks)
+    const int col0 = EPI == EPI_SWIGLU ? (nt0 + wc * 4) * 8 : (nt0 + wc * 4) * 16;  // first output column of the wave
+    const bool fast = BF16_OUT && (g.n_valid & 7) == 0 && (g.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0 &&
+                      (!g.res || ((g.ldres & 7) == 0 && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0));
+    if constexpr (BF16_OUT) {
+        if (fast) {
+            __builtin_amdgcn_s_barrier();  // every wave has finished its last fragment reads (and all DMAs have landed): LDS is free
+            unsigned char* mine = smem + wave * 16384;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float bv[2] = {0.f, 0.f};
+                    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) {
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const int col = (nt0 + wc * 4 + nh * 2 + nb) * 16 + fr;
+                            bv[nb] = col < g.n_valid ? bf2f(g.bias[col]) : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int lrow = mh * 64 + mt * 16 + fq * 4 + r;
+                            if constexpr (EPI == EPI_SWIGLU) {
+                                const float v = bfr(silu(bfr(acc[mh][nh][mt][0][r]))) * bfr(acc[mh][nh][mt][1][r]);
+                                *reinterpret_cast<bf16_t*>(mine + lrow * RSTRIDE + (nh * 16 + fr) * 2) = f2bf(v);
+                            } else {
+#pragma unroll
+                                for (int nb = 0; nb < 2; ++nb) {
+                                    const float sacc = acc[mh][nh][mt][nb][r];
+                                    float v;
+                                    if constexpr (EPI == EPI_NONE || EPI == EPI_RES) v = sacc;
+                                    else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RES) v = sacc + bv[nb];
+                                    else v = gelu_erf(bfr(sacc + bv[nb]));
+                                    *reinterpret_cast<bf16_t*>(mine + lrow * RSTRIDE + (nh * 32 + nb * 16 + fr) * 2) = f2bf(v);
+                                }
+                            }
+                        }
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own writes (no other wave touches this region)
+            constexpr int CH = WCOLS / 8;        // 16-byte chunks per row
+            constexpr int RPI = 64 / CH;         // rows per store instruction
+            const int lr = lane / CH, lc = lane % CH;
+            const int gcol = col0 + lc * 8;
+            const bool cvalid = gcol < g.n_valid;
+#pragma unroll
+            for (int it = 0; it < 128 / RPI; ++it) {
+                const int lrow = it * RPI + lr;
+                const int row = m0 + wr * 128 + lrow;
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(mine + lrow * RSTRIDE + lc * 16);
+                if (row < g.M && cvalid) {
+                    if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
+                        const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(g.res + (long)row * g.ldres + gcol);
+                        v.x = pack_bf(lo_bf(rv.x) + lo_bf(v.x), hi_bf(rv.x) + hi_bf(v.x));
+                        v.y = pack_bf(lo_bf(rv.y) + lo_bf(v.y), hi_bf(rv.y) + hi_bf(v.y));
+                        v.z = pack_bf(lo_bf(rv.z) + lo_bf(v.z), hi_bf(rv.z) + hi_bf(v.z));
+                        v.w = pack_bf(lo_bf(rv.w) + lo_bf(v.w), hi_bf(rv.w) + hi_bf(v.w));
+                    }
+                    *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(g.out) + (long)row * g.ldo + gcol) = v;
+                }
+            }
+            return;
+        }
+    }
+    // general form (fp32 outputs, ragged n_valid / unaligned rows): straight from the accumulators
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 128 + mh * 64 + mt * 16 + fq * 4 + r;
+                if (row >= g.M) continue;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const int nt = nt0 + wc * 4 + nh * 2;
+                    if constexpr (EPI == EPI_SWIGLU) {  // (gate, up) = the quadrant's two n-tiles
+                        const int col = (nt >> 1) * 16 + fr;
+                        if (nt < NTILES && col < g.n_valid)
+                            reinterpret_cast<bf16_t*>(g.out)[(long)row * g.ldo + col] = f2bf(bfr(silu(bfr(acc[mh][nh][mt][0][r]))) * bfr(acc[mh][nh][mt][1][r]));
+                    } else {
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const int col = (nt + nb) * 16 + fr;
+                            if (nt + nb >= NTILES || col >= g.n_valid) continue;
+                            const float s = acc[mh][nh][mt][nb][r];
+                            if constexpr (EPI == EPI_PARTIAL) {
+                                reinterpret_cast<float*>(g.out)[(long)slice * g.out_batch + (long)row * g.ldo + col] = s;
+                            } else if constexpr (EPI == EPI_F32) {
+                                reinterpret_cast<float*>(g.out)[(long)row * g.ldo + col] = bfr(s);
+                            } else {
+                                float v;
+                                if constexpr (EPI == EPI_NONE) v = s;
+                                else if constexpr (EPI == EPI_BIAS) v = s + bf2f(g.bias[col]);
+                                else if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(bfr(s + bf2f(g.bias[col])));
+                                else if constexpr (EPI == EPI_RES) v = bf2f(g.res[(long)row * g.ldres + col]) + bfr(s);
+                                else v = bf2f(g.res[(long)row * g.ldres + col]) + bfr(s + bf2f(g.bias[col]));
+                                reinterpret_cast<bf16_t*>(g.out)[(long)row * g.ldo + col] = f2bf(v);
+                            }
+                        }
+                    }
+                }
+            }
+}
+
+static int g_dense_mode = 1;  // tuning hook (gemm_dense_set): 0 = never, 1 = heuristic, 2 = wherever supported
+void gemm_dense_set(int mode) { g_dense_mode = mode; }
+
+bool gemm_dense_supported(const GemmArgs& g) {
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    return g.batch == 1 && g.K % (DT_K * ks) == 0 && g.K / (DT_K * ks) >= 2 && g.lda % 8 == 0 && !g.norm_w && !g.attn_partial && g.M > 64 &&
+           (g.epi != EPI_SWIGLU || g.N % 32 == 0);
+}
+bool gemm_dense_preferred(const GemmArgs& g) {
+    if (g_dense_mode == 0) return false;
+    if (g_dense_mode == 2) return true;
+    return g.M > 128;
+}
+
+int launch_gemm_dense(const GemmArgs& g, hipStream_t stream) {
+    const int NTILES = g.N / 16;
+    const int ks = g.epi == EPI_PARTIAL ? (g.ksplit > 1 ? g.ksplit : 1) : 1;
+    dim3 grid((NTILES + DT_NT - 1) / DT_NT, (g.M + DT_M - 1) / DT_M, ks), block(512);
+    const int raster = (grid.x * grid.y > 256 && grid.y > 1) ? 1 : 0;
+    if (raster) {
+        const unsigned tiles = grid.x * grid.y;
+        grid.x = ((tiles + 7) / 8) * 8;
+        grid.y = 1;
+    }
+    const size_t lds = 2 * DT_BUF;
+#define LAUNCH_D(E)                                                                                                                                  \
+    do {                                                                                                                                             \
+        static bool attr = false;                                                                                                                    \
+        if (!attr) {                                                                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dense_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP; \
+            attr = true;                                                                                                                             \
+        }                                                                                                                                            \
+        hipLaunchKernelGGL(gemm_dense_kernel<E>, grid, block, lds, stream, g, raster);                                                               \
+    } while (0)
+    switch (g.epi) {
+        case EPI_NONE: LAUNCH_D(EPI_NONE); break;
+        case EPI_BIAS: LAUNCH_D(EPI_BIAS); break;
+        case EPI_BIAS_GELU: LAUNCH_D(EPI_BIAS_GELU); break;
+        case EPI_RES: LAUNCH_D(EPI_RES); break;
+        case EPI_BIAS_RES: LAUNCH_D(EPI_BIAS_RES); break;
+        case EPI_SWIGLU: LAUNCH_D(EPI_SWIGLU); break;
+        case EPI_F32: LAUNCH_D(EPI_F32); break;
+        case EPI_PARTIAL: LAUNCH_D(EPI_PARTIAL); break;
+        default: return ISST_ERR_ARG;
+    }
+#undef LAUNCH_D
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
