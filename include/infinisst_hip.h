@@ -212,18 +212,6 @@ int isst_op_gemm_splitk_rmsnorm(const uint16_t* A, int64_t lda, const uint16_t* 
  *   (epi: none, swiglu or f32). */
 int isst_op_gemm_splitk_fused(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* x, float* slabs, float* ssq, int* tickets,
                               int M, int N, int K, int ksplit, void* hip_stream);
-/* the library path of the many-row prefill (more than 160 rows), piece by piece: out[M][N] = bf16(A[M][K] @ w_rm[N][K]^T) through hipBLASLt (row-major
- * operands, fp32 accumulation); act = bf16(bf16(silu(g)) * u) over gu[rows][2F] = [gate | up]; x = bf16(x + t) in place, out = LlamaRMSNorm(norm_w)(x)
- * (norm_w == NULL: the residual alone). */
-int isst_op_gemm_lt(const uint16_t* A, int64_t lda, const uint16_t* w_rm, const uint16_t* bias /* may be NULL: out = bf16(acc + bias) */, uint16_t* out,
-                    int64_t ldo, int M, int N, int K, void* hip_stream);
-/* the speech encoder's twins of the passes (more than 64 rows): x = bf16(gelu_erf(x)) in place; x = bf16(x + t) in place, out = LayerNorm(ln_w, ln_b)(x) */
-int isst_op_gelu_pass(uint16_t* x, int64_t ldx, int rows, int C, void* hip_stream);
-int isst_op_residual_layernorm(const uint16_t* t, int64_t ldt, uint16_t* x, int64_t ldx, const uint16_t* ln_w, const uint16_t* ln_b, uint16_t* out, int64_t ldo,
-                               int rows, int C, float eps, void* hip_stream);
-int isst_op_swiglu_pass(const uint16_t* gu, int64_t ldgu, uint16_t* act, int64_t ldact, int rows, int F, void* hip_stream);
-int isst_op_residual_rmsnorm(const uint16_t* t, int64_t ldt, uint16_t* x, int64_t ldx, const uint16_t* norm_w, uint16_t* out, int64_t ldo, int rows, int D,
-                             float eps, void* hip_stream);
 /* K slices with the same in-launch reduction and NO residual: out[M][N] = bf16(sum of the slabs) (q/k/v at 33..64 rows); norm_w != NULL: A = x is
  * normalised while staged as in isst_op_gemm_norm_ssq (ssq_in[M][K / 32]). */
 int isst_op_gemm_splitk_plain(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* out, int64_t ldo, float* slabs, int* tickets,

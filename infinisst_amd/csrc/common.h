@@ -153,6 +153,7 @@ int launch_gemm_tiled(const GemmArgs& g, hipStream_t stream);
 void gemm_tiled_set_raster(int on);                                // profiling aid: 0 = plain (column block, row block) grid
 bool gemm_dense_supported(const GemmArgs& g);                     // gemm_dense.hip: 256 x 256 tiles, 8-wave ping-pong, LDS-DMA (many-row prefill / encoder)
 bool gemm_dense_preferred(const GemmArgs& g);
+bool gemm_dense_would_run(int M, int N, int K);                   // ... as a function of the shape alone (the engine picks its K slices by it)
 int launch_gemm_dense(const GemmArgs& g, hipStream_t stream);
 void gemm_dense_set(int mode);                                     // profiling aid: 0 never, 1 heuristic, 2 wherever supported
 bool gemm_mid_supported(const GemmArgs& g);                        // gemm_mid.hip: 17..64 rows, A staged through LDS

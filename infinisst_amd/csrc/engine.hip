@@ -25,16 +25,10 @@
 #ifndef LLM_SPLIT_TARGET_WGS
 #define LLM_SPLIT_TARGET_WGS 768
 #endif
-// rows above which the Llama projections of a pass are plain library GEMMs (blaslt.hip).  ms per step with / without the library path, one box:
-// 132 rows (6 streams' prefill) 42.10 / 41.73, 176: 43.80 / 43.99, 220: 46.80 / 46.74, 264: 49.59 / 50.22, 352: 49.97 / 51.21, 1408: 86.2 / 90.5
-#define LT_MIN_ROWS 160
-// ... and of the speech encoder's layers (K = 1024 / 4096; library 106 us per layer at 3072 rows against 198 for gemm_tiled: enc_vs_library_probe.py).  ms per
-// step with / without, one box each pair: 48 rows (one stream) 32.59 / 32.02, 96: 33.65 / 34.36, 144: 36.60 / 37.56, 192: 37.90 / 39.02, 384: 43.17 / 44.13,
-// 768: 49.34 / 50.40, 3072: 85.77 / 87.20
-#define ENC_LT_MIN_ROWS 64
 #ifndef LLM_SPLIT_MAX_ROWS
 #define LLM_SPLIT_MAX_ROWS 2048  // rows up to which o_proj / down_proj run split-K into slabs (beyond, the dense kernel has the workgroups)
 #endif
+#define ENC_SPLIT_MAX_ROWS 8192  // ... and the encoder's out_proj / fc2 (1024 columns: 4 column blocks of the dense kernel; the slab capacity bounds the slices)
 #ifndef LLM_SLAB_ROWS
 #define LLM_SLAB_ROWS 4096       // slices x rows the slab buffer holds
 #endif
@@ -53,7 +47,6 @@ struct PackedLinear {
     int N = 0;        // packed rows (multiple of 16)
     int K = 0;
     int n_valid = 0;  // real output columns
-    bf16_t* w_rm = nullptr;  // row-major [rows][K] copy for the library GEMM of the many-row prefill (blaslt.hip); SwiGLU pairs as [gate rows | up rows]
 };
 struct Norm {
     bf16_t* w = nullptr;
@@ -125,12 +118,6 @@ struct isst_handle {
     float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
     int* ltickets = nullptr;      // [ltickets_n] arrival counters (GemmArgs::tickets), one per 32-column block of the widest ticketed launch; zero between launches
     int ltickets_n = 0;
-    int lt_min_rows = LT_MIN_ROWS; // ISST_BLASLT_MIN_ROWS: rows above which the library GEMM path runs
-    int enc_lt_min_rows = ENC_LT_MIN_ROWS;  // ISST_BLASLT_ENC_MIN_ROWS: the same for the speech encoder's four projections per layer
-    bf16_t* etmp = nullptr;       // [enc_rows_max][enc_dim] out_proj / fc2 outputs of the library GEMM
-    bool use_blaslt = true;       // ISST_BLASLT=0: the > LT_MIN_ROWS-row prefill projections stay on gemm_tiled.hip (see blaslt.hip for why they leave it)
-    bf16_t* lgu = nullptr;        // [llm_rows_max][2 x ffn] gate | up outputs of the library GEMM
-    bf16_t* ltmp = nullptr;       // [llm_rows_max][llm_dim] o_proj / down_proj outputs of the library GEMM
     bool rope_side = false;       // ISST_ROPE_SIDE=1: the rotated-key pre-pass of a chunk (pure memory traffic) runs on a low-priority side stream beside the
                                   // speech encoder (MFMA-bound at many streams) and joins before the prefill.  Measured, one box, ms per step: 64 streams
                                   // 90.96 / 90.90 without, 91.17 / 90.69 with; 16 streams 51.11 / 51.21 -- nothing, stays off
@@ -373,9 +360,6 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_FUSE_COMBINE")) h->fuse_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_REDUCE")) h->fuse_reduce = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_ROPE_SIDE")) h->rope_side = e[0] && e[0] != '0';
-    if (const char* e = getenv("ISST_BLASLT")) h->use_blaslt = e[0] && e[0] != '0';
-    if (const char* e = getenv("ISST_BLASLT_MIN_ROWS")) h->lt_min_rows = atoi(e) >= 16 ? atoi(e) : LT_MIN_ROWS;
-    if (const char* e = getenv("ISST_BLASLT_ENC_MIN_ROWS")) h->enc_lt_min_rows = atoi(e) >= 16 ? atoi(e) : ENC_LT_MIN_ROWS;
     if (const char* e = getenv("ISST_QKV_SLICES")) h->qkv_slices = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
@@ -428,15 +412,6 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         ok = ok && alloc_norm(h, L.ln1, D) && alloc_norm(h, L.ln2, D) && alloc_linear(h, L.qkv, 3 * D, D, true) &&
              alloc_linear(h, L.out, D, D, true) && alloc_linear(h, L.fc1, c.enc_ffn, D, true) && alloc_linear(h, L.fc2, D, c.enc_ffn, true);
     ok = ok && alloc_norm(h, h->enc_ln_out, D);
-    if (h->use_blaslt && h->enc_rows_max > h->enc_lt_min_rows) {  // row-major twins for the library GEMM path of many-stream calls
-        for (auto& L : h->enc)
-            for (PackedLinear* pl : {&L.qkv, &L.out, &L.fc1, &L.fc2}) {
-                pl->w_rm = h->dalloc<bf16_t>((size_t)pl->N * pl->K, true);
-                ok = ok && pl->w_rm;
-            }
-        h->etmp = h->dalloc<bf16_t>((size_t)h->enc_rows_max * D);
-        ok = ok && h->etmp;
-    }
     h->shrink.resize(c.n_shrink);
     for (int i = 0; i < c.n_shrink; ++i) {
         ConvLayer& L = h->shrink[i];
@@ -454,17 +429,6 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         ok = ok && L.in_norm && L.post_norm && alloc_linear(h, L.qkv, (H + 2 * KV) * 128, DL, false) && alloc_linear(h, L.o, DL, H * 128, false) &&
              alloc_linear(h, L.gateup, 2 * c.llm_ffn, DL, false) && alloc_linear(h, L.down, DL, c.llm_ffn, false);
         L.gateup.n_valid = c.llm_ffn;
-        if (h->use_blaslt && h->llm_rows_max > h->lt_min_rows) {  // only engines that can reach the many-row prefill pay for the second copy
-            for (PackedLinear* pl : {&L.qkv, &L.o, &L.gateup, &L.down}) {
-                pl->w_rm = h->dalloc<bf16_t>((size_t)pl->N * pl->K, true);
-                ok = ok && pl->w_rm;
-            }
-        }
-    }
-    if (h->use_blaslt && h->llm_rows_max > h->lt_min_rows) {
-        h->lgu = h->dalloc<bf16_t>((size_t)h->llm_rows_max * 2 * c.llm_ffn);
-        h->ltmp = h->dalloc<bf16_t>((size_t)h->llm_rows_max * DL);
-        ok = ok && h->lgu && h->ltmp;
     }
     h->final_norm = h->dalloc<bf16_t>(DL, true);
     ok = ok && h->final_norm && alloc_linear(h, h->lm_head, c.vocab, DL, false);
@@ -574,10 +538,6 @@ int copy_vec(isst_handle* h, bf16_t* dst, const bf16_t* src, size_t n) {
 }
 int pack_into(isst_handle* h, PackedLinear& L, const bf16_t* src, int n_rows, int row_offset_tiles, int tile_stride, int tile_phase, int conv_k) {
     CHK(launch_pack_weight(src, L.wp, n_rows, L.K, row_offset_tiles, tile_stride, tile_phase, conv_k, 0));
-    if (L.w_rm && conv_k == 0) {  // row-major twin: parts stacked (q | k | v; gate | up -- NOT tile-interleaved like the packed form)
-        const long row0 = tile_stride > 1 ? (long)tile_phase * n_rows : (long)row_offset_tiles * 16;
-        HIPCHK(hipMemcpyAsync(L.w_rm + row0 * L.K, src, (size_t)n_rows * L.K * 2, hipMemcpyDeviceToDevice, 0));
-    }
     return ISST_OK;
 }
 
@@ -825,10 +785,24 @@ int pick_ksplit(int K, int N, int rows) {
             if (K % (256 * s) == 0 && K / (256 * s) >= 1) return s;
         return 1;
     }
+    const long slab_cap = (long)LLM_SLAB_ROWS * 4096;  // fp32 elements the slab buffer always holds (isst_create: LLM_SLAB_ROWS x max(llm_dim, q/k/v width))
+    if (gemm_dense_would_run(rows, N, K)) {
+        // 256 x 256 tiles, one workgroup per CU (gemm_dense.hip): rounds of 1/s-length tiles + the slab traffic each further slice adds (write + read of
+        // rows x N fp32: about 4 % of a round per slice at these shapes).  profiles/dense_split_probe.py, GEMM + reducing norm, us:
+        //   1408 rows  o_proj 82.7 / 62.4 / 79.9 / 102.0 for 1 / 2 / 4 / 8 slices, down_proj 241 / 161 / 178 / 183;   704 rows  o_proj 79 / 52 / 43 / 59, down 248 / 139 / 94 / 116
+        const long tiles = (long)((N + 255) / 256) * ((rows + 255) / 256);
+        int best = 1;
+        double best_cost = 1e30;
+        for (int s = 1; s <= LLM_KSPLIT_MAX; s *= 2) {
+            if (K % (64 * s) != 0 || K / (64 * s) < 4 || (s > 1 && (long)s * rows * N > slab_cap)) break;
+            const double cost = (double)((tiles * s + 255) / 256) / s + 0.04 * s;
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+        }
+        return best;
+    }
     const int blocks = ((N + 127) / 128) * ((rows + 127) / 128);
     int s = 1;
-    while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= LLM_SPLIT_TARGET_WGS && s * 2 * rows <= LLM_SLAB_ROWS && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
-    // (the slab buffer holds LLM_SLAB_ROWS rows of the widest projection, so slices x rows <= LLM_SLAB_ROWS fits any N)
+    while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= LLM_SPLIT_TARGET_WGS && (long)s * 2 * rows * N <= slab_cap && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
     return s;
 }
 // slabs[ksplit][M][N] (fp32) = A @ W^T per K slice; reduced by launch_rmsnorm_reduce
@@ -926,28 +900,20 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
 #ifndef ISST_ESPLIT_MIN_ROWS
 #define ISST_ESPLIT_MIN_ROWS 16
 #endif
-    const bool esplit = ER > ISST_ESPLIT_MIN_ROWS && ER <= LLM_SPLIT_MAX_ROWS;
+    const bool esplit = ER > ISST_ESPLIT_MIN_ROWS && ER <= ENC_SPLIT_MAX_ROWS;
     const int s_out = esplit ? pick_ksplit(D, D, ER) : 1, s_fc2 = esplit ? pick_ksplit(c.enc_ffn, D, ER) : 1;
     const long eslab = (long)ER * D;
     const EncLayer* pend = nullptr;  // layer whose fc2 slabs h->ex still lacks
-    // many rows: the four projections of a layer as library GEMMs with the bias epilogue (blaslt.hip); GELU and residual + LayerNorm as passes
-    const bool elt = h->use_blaslt && ER > h->enc_lt_min_rows && h->etmp && h->enc[0].qkv.w_rm && gemm_lt_available();
-    bool pend_lt = false;            // etmp holds the previous layer's fc2 output (bias included)
     for (int l = 0; l < c.enc_layers; ++l) {
         const EncLayer& L = h->enc[l];
-        if (pend_lt) {
-            CHK(launch_residual_layernorm(h->etmp, D, h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, st));
-            if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l - 1), h->ex, (int64_t)ER * D, st));
-            pend_lt = false;
-        } else if (pend) {
+        if (pend) {
             CHK(launch_layernorm_reduce(h->lslab, eslab, s_fc2, pend->fc2.bias, h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, st));
             if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l - 1), h->ex, (int64_t)ER * D, st));
             pend = nullptr;
         } else {
             CHK(launch_layernorm(h->ex, D, L.ln1.w, L.ln1.b, h->exn, D, ER, D, c.enc_ln_eps, 0, st));
         }
-        if (elt) CHK(launch_gemm_lt(h->exn, D, L.qkv.w_rm, h->eqkv, 3 * D, ER, 3 * D, D, st, L.qkv.bias));
-        else CHK(gemm(h, h->exn, D, L.qkv, EPI_BIAS, nullptr, 0, h->eqkv, 3 * D, ER, st));
+        CHK(gemm(h, h->exn, D, L.qkv, EPI_BIAS, nullptr, 0, h->eqkv, 3 * D, ER, st));
         if (contiguous) {
             bf16_t* kb = h->enc_k + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
             bf16_t* vb = h->enc_v + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
@@ -960,15 +926,6 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
                 CHK(launch_enc_attention(h->eqkv + (size_t)i * Q * 3 * D, kb, vb, 0, ev + i, h->enc_cos, h->enc_sin, c.enc_rope_round_each,
                                          h->eattn + (size_t)i * Q * D, 1, Q, c.enc_heads, h->enc_cap, c.max_cache_size, bs, st));
             }
-        }
-        if (elt) {
-            CHK(launch_gemm_lt(h->eattn, D, L.out.w_rm, h->etmp, D, ER, D, D, st, L.out.bias));
-            CHK(launch_residual_layernorm(h->etmp, D, h->ex, D, L.ln2.w, L.ln2.b, h->exn, D, ER, D, c.enc_ln_eps, st));
-            CHK(launch_gemm_lt(h->exn, D, L.fc1.w_rm, h->effn, c.enc_ffn, ER, c.enc_ffn, D, st, L.fc1.bias));
-            CHK(launch_gelu_pass(h->effn, c.enc_ffn, ER, c.enc_ffn, st));
-            CHK(launch_gemm_lt(h->effn, c.enc_ffn, L.fc2.w_rm, h->etmp, D, ER, D, c.enc_ffn, st, L.fc2.bias));
-            pend_lt = true;
-            continue;
         }
         if (s_out > 1) {
             CHK(gemm_partial(h, h->eattn, D, L.out, h->lslab, ER, s_out, st));
@@ -986,10 +943,7 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
             if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(l), h->ex, (int64_t)ER * D, st));
         }
     }
-    if (pend_lt) {
-        CHK(launch_residual_layernorm(h->etmp, D, h->ex, D, h->enc_ln_out.w, h->enc_ln_out.b, h->exn, D, ER, D, c.enc_ln_eps, st));
-        if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(c.enc_layers - 1), h->ex, (int64_t)ER * D, st));
-    } else if (pend) {
+    if (pend) {
         CHK(launch_layernorm_reduce(h->lslab, eslab, s_fc2, pend->fc2.bias, h->ex, D, h->enc_ln_out.w, h->enc_ln_out.b, h->exn, D, ER, D, c.enc_ln_eps, st));
         if (h->cfg.debug_taps) CHK(tap(h, "enc_layer_" + std::to_string(c.enc_layers - 1), h->ex, (int64_t)ER * D, st));
     } else {
@@ -1087,11 +1041,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     // A/B on one box, ms per step: 64 streams 92.63 (1 slice) / 91.33 (2) / 92.61 (4); 16 streams 51.24 / 51.52 / 50.84 -- two slices from 33 rows
     const int qs = h->qkv_slices > 0 ? h->qkv_slices : (rows > 32 ? 2 : 1);
     const int sqf = (fr && qs > 1 && DL % (256 * qs) == 0) ? qs : 1;
-    // more than LT_MIN_ROWS rows (a many-stream prefill): the four projections are plain library GEMMs on the row-major weight twins, their epilogues two
-    // bandwidth-bound passes (blaslt.hip, rowops.hip)
-    const bool lt = h->use_blaslt && rows > h->lt_min_rows && h->lgu && h->llm[0].qkv.w_rm && gemm_lt_available();
-    const int QW = (H + 2 * KV) * 128;
-    bool pending = false, pending_fused = false, pending_lt = false;
+    bool pending = false, pending_fused = false;
     for (int l = 0; l < c.llm_layers; ++l) {
         const LlmLayer& L = h->llm[l];
         // decode shapes: RMSNorm is applied inside the projection's A-fragment load (gemm.hip NORM); larger row counts
@@ -1101,11 +1051,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps));
         } else {
             bool qkv_done = false;
-            if (pending_lt) {  // the previous layer's down_proj output waits in ltmp: residual + this layer's input norm in one pass
-                CHK(launch_residual_rmsnorm(h->ltmp, DL, h->lx, DL, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
-                if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
-                pending_lt = false;
-            } else if (pending_fused) {  // lx is complete (the down_proj launch reduced its own slabs); q/k/v normalises it on the way into LDS
+            if (pending_fused) {  // lx is complete (the down_proj launch reduced its own slabs); q/k/v normalises it on the way into LDS
                 if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
                 pending_fused = false;
                 if (sqf > 1)
@@ -1121,8 +1067,6 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
             }
             if (qkv_done) {
-            } else if (lt) {
-                CHK(launch_gemm_lt(h->lxn, DL, L.qkv.w_rm, h->lqkv, QW, rows, QW, DL, st));
             } else if (sqf > 1) {  // (first layer: the norm launch ran; the K slices still pay)
                 CHK(gemm_partial(h, h->lxn, DL, L.qkv, h->lslab, rows, sqf, st, nullptr, 0, nullptr, h->lqkv, (H + 2 * KV) * 128));
             } else if (sq > 1) {  // 129..1024 rows: the 48 column blocks of the dense kernel get K slices; a small pass sums the slabs to bf16
@@ -1138,12 +1082,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
                                  max_unit_groups, n_beam_wgs, merge_in_oproj ? &merge_splits : nullptr, h->inline_combine ? h->attn_cnt : nullptr));
-        if (lt) {
-            CHK(launch_gemm_lt(h->lattn, H * 128, L.o.w_rm, h->ltmp, DL, rows, DL, H * 128, st));
-            CHK(launch_residual_rmsnorm(h->ltmp, DL, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
-            CHK(launch_gemm_lt(h->lxn, DL, L.gateup.w_rm, h->lgu, 2 * c.llm_ffn, rows, 2 * c.llm_ffn, DL, st));
-            CHK(launch_swiglu_pass(h->lgu, 2 * c.llm_ffn, h->lact, c.llm_ffn, rows, c.llm_ffn, st));
-        } else if (so > 1 && fr) {
+        if (so > 1 && fr) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st, h->lx, DL, h->lssq));
             CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps, h->lssq));
         } else if (so > 1) {
@@ -1182,14 +1121,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
             }
         }
-        if (lt) {
-            CHK(launch_gemm_lt(h->lact, c.llm_ffn, L.down.w_rm, h->ltmp, DL, rows, DL, c.llm_ffn, st));
-            pending_lt = l + 1 < c.llm_layers;
-            if (!pending_lt) {  // last layer: the residual alone (the final norm runs on the gathered last rows)
-                CHK(launch_residual_rmsnorm(h->ltmp, DL, h->lx, DL, nullptr, nullptr, 0, rows, DL, c.rms_eps, st));
-                if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
-            }
-        } else if (sd > 1 && fr) {  // (the last layer too: lx is complete when the launch ends, and lm_head can take the sums of squares)
+        if (sd > 1 && fr) {  // (the last layer too: lx is complete when the launch ends, and lm_head can take the sums of squares)
             CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st, h->lx, DL, h->lssq));
             pending_fused = l + 1 < c.llm_layers;
             if (!pending_fused && tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
@@ -1882,26 +1814,6 @@ extern "C" int isst_op_gemm_splitk_fused(const uint16_t* A, int64_t lda, const u
     g.res = x; g.ldres = N; g.ssq = ssq; g.ssq_n = N / 32; g.tickets = tickets;
     if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
     return launch_gemm_mid(g, reinterpret_cast<hipStream_t>(hip_stream));
-}
-// the many-row prefill's library path, piece by piece (blaslt.hip + the two passes of rowops.hip): w_rm row-major [N][K]
-extern "C" int isst_op_gemm_lt(const uint16_t* A, int64_t lda, const uint16_t* w_rm, const uint16_t* bias, uint16_t* out, int64_t ldo, int M, int N, int K,
-                               void* hip_stream) {
-    if (!gemm_lt_available()) return ISST_ERR_HIP;
-    return launch_gemm_lt(A, lda, w_rm, out, ldo, M, N, K, reinterpret_cast<hipStream_t>(hip_stream), bias);
-}
-extern "C" int isst_op_gelu_pass(uint16_t* x, int64_t ldx, int rows, int C, void* hip_stream) {
-    return launch_gelu_pass(x, ldx, rows, C, reinterpret_cast<hipStream_t>(hip_stream));
-}
-extern "C" int isst_op_residual_layernorm(const uint16_t* t, int64_t ldt, uint16_t* x, int64_t ldx, const uint16_t* ln_w, const uint16_t* ln_b, uint16_t* out,
-                                          int64_t ldo, int rows, int C, float eps, void* hip_stream) {
-    return launch_residual_layernorm(t, ldt, x, ldx, ln_w, ln_b, out, ldo, rows, C, eps, reinterpret_cast<hipStream_t>(hip_stream));
-}
-extern "C" int isst_op_swiglu_pass(const uint16_t* gu, int64_t ldgu, uint16_t* act, int64_t ldact, int rows, int F, void* hip_stream) {
-    return launch_swiglu_pass(gu, ldgu, act, ldact, rows, F, reinterpret_cast<hipStream_t>(hip_stream));
-}
-extern "C" int isst_op_residual_rmsnorm(const uint16_t* t, int64_t ldt, uint16_t* x, int64_t ldx, const uint16_t* norm_w, uint16_t* out, int64_t ldo, int rows, int D,
-                                        float eps, void* hip_stream) {
-    return launch_residual_rmsnorm(t, ldt, x, ldx, norm_w, out, ldo, rows, D, eps, reinterpret_cast<hipStream_t>(hip_stream));
 }
 extern "C" int isst_op_gemm_splitk_plain(const uint16_t* A, int64_t lda, const uint16_t* packed, uint16_t* out, int64_t ldo, float* slabs, int* tickets,
                                          int M, int N, int K, int ksplit, const uint16_t* norm_w, float norm_eps, float* ssq_in, void* hip_stream) {

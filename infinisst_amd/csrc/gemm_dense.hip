@@ -189,7 +189,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
     // instruction covers 8 rows x 128 contiguous bytes instead of 4 rows x 32 (the accumulator layout) and the residual is read the same way.
     constexpr bool BF16_OUT = EPI != EPI_PARTIAL && EPI != EPI_F32;
     constexpr int WCOLS = EPI == EPI_SWIGLU ? 32 : 64;   // output columns of a wave
-    constexpr int RSTRIDE = WCOLS * 2 + 16;              // LDS row stride in bytes (padded: the four fq row groups of a store spread over the banks)
+    constexpr int RSTRIDE = WCOLS * 2;                   // LDS row stride in bytes: 128 rows x 128 B = the wave's 16 KiB exactly; the 16-byte chunk index of a
+                                                         // row is XORed with its fq (rows 4 apart alias on the banks: the four fq groups of a write then spread)
+    constexpr int SWS = WCOLS / 32 - 1;                  // chunk XOR = fq << SWS (8 chunks per row: fq * 2, 4 chunks: fq)
     const int col0 = EPI == EPI_SWIGLU ? (nt0 + wc * 4) * 8 : (nt0 + wc * 4) * 16;  // first output column of the wave
     const bool fast = BF16_OUT && (g.n_valid & 7) == 0 && (g.ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(g.out) & 15) == 0 &&
                       (!g.res || ((g.ldres & 7) == 0 && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0));
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
                             const int lrow = mh * 64 + mt * 16 + fq * 4 + r;
                             if constexpr (EPI == EPI_SWIGLU) {
                                 const float v = bfr(silu(bfr(acc[mh][nh][mt][0][r]))) * bfr(acc[mh][nh][mt][1][r]);
-                                *reinterpret_cast<bf16_t*>(mine + lrow * RSTRIDE + (nh * 16 + fr) * 2) = f2bf(v);
+                                *reinterpret_cast<bf16_t*>(mine + lrow * RSTRIDE + (((nh * 2 + (fr >> 3)) ^ (fq << SWS)) << 4) + (fr & 7) * 2) = f2bf(v);
                             } else {
 #pragma unroll
                                 for (int nb = 0; nb < 2; ++nb) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
                                     if constexpr (EPI == EPI_NONE || EPI == EPI_RES) v = sacc;
                                     else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RES) v = sacc + bv[nb];
                                     else v = gelu_erf(bfr(sacc + bv[nb]));
-                                    *reinterpret_cast<bf16_t*>(mine + lrow * RSTRIDE + (nh * 32 + nb * 16 + fr) * 2) = f2bf(v);
+                                    *reinterpret_cast<bf16_t*>(mine + lrow * RSTRIDE + (((nh * 4 + nb * 2 + (fr >> 3)) ^ (fq << SWS)) << 4) + (fr & 7) * 2) = f2bf(v);
                                 }
                             }
                         }
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
             for (int it = 0; it < 128 / RPI; ++it) {
                 const int lrow = it * RPI + lr;
                 const int row = m0 + wr * 128 + lrow;
-                u32x4_t v = *reinterpret_cast<const u32x4_t*>(mine + lrow * RSTRIDE + lc * 16);
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(mine + lrow * RSTRIDE + ((lc ^ (((lrow >> 2) & 3) << SWS)) << 4));
                 if (row < g.M && cvalid) {
                     if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
                         const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(g.res + (long)row * g.ldres + gcol);
@@ -304,11 +306,15 @@ bool gemm_dense_supported(const GemmArgs& g) {
     return g.batch == 1 && g.K % (DT_K * ks) == 0 && g.K / (DT_K * ks) >= 2 && g.lda % 8 == 0 && !g.norm_w && !g.attn_partial && g.M > 64 &&
            (g.epi != EPI_SWIGLU || g.N % 32 == 0);
 }
-bool gemm_dense_preferred(const GemmArgs& g) {
-    if (g_dense_mode == 0) return false;
-    if (g_dense_mode == 2) return true;
-    return g.M > 128;
+// where the 256-row tiles pay (profiles/dense_probe.py, dense_split_probe.py; gemm_tiled's 128 x 128 tiles keep the rest): from 640 rows on everything
+// (704 rows: o_proj + norm 42.8 against 44.6 us, down_proj 94 / 120; 1408: 62 / 82, 161 / 202, gate/up 286 / 372, q/k/v 86 / 100), from 320 rows the
+// widest and the deepest projection (352 rows: gate/up 109 / 119, down_proj 60 / 75; o_proj 35 / 31 and q/k/v 70 / 55 stay)
+bool gemm_dense_would_run(int M, int N, int K) {
+    if (g_dense_mode == 0 || K % 64 != 0 || K < 128) return false;
+    if (g_dense_mode == 2) return M > 64;
+    return M >= 640 || (M >= 320 && (N >= 16384 || K >= 8192));
 }
+bool gemm_dense_preferred(const GemmArgs& g) { return gemm_dense_would_run(g.M, g.N, g.K); }
 
 int launch_gemm_dense(const GemmArgs& g, hipStream_t stream) {
     const int NTILES = g.N / 16;

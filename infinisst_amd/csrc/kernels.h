@@ -42,15 +42,6 @@ int launch_rmsnorm(const bf16_t* x, long ldx, const int* rows_idx, const bf16_t*
 // split-K slabs (gemm_mid.hip EPI_PARTIAL) -> x += sum, then RMSNorm of the updated rows (w == null: update only)
 // out = bf16(sum of fp32 slabs [n_slabs][rows][N])
 int launch_slab_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* out, long ldo, int rows, int N, hipStream_t s);
-// blaslt.hip: plain library GEMM C[M][N] = A[M][K] @ W[N][K]^T (row-major bf16, fp32 accumulation) for the many-row prefill projections
-bool gemm_lt_available();
-int launch_gemm_lt(const bf16_t* A, long lda, const bf16_t* W, bf16_t* C, long ldc, int M, int N, int K, hipStream_t stream, const bf16_t* bias = nullptr);
-// encoder twins of the passes: x = bf16(gelu_erf(x)) in place; x = bf16(x + t) in place, out = LayerNorm(w, b)(x)
-int launch_gelu_pass(bf16_t* x, long ldx, int rows, int C, hipStream_t s);
-int launch_residual_layernorm(const bf16_t* t, long ldt, bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps, hipStream_t s);
-// the epilogues of that path as passes: act = bf16(bf16(silu(g)) * u) over gu[rows][2F] = [gate | up]; x = bf16(x + t), out = RMSNorm(x) (w == null: no norm)
-int launch_swiglu_pass(const bf16_t* gu, long ldgu, bf16_t* act, long ldact, int rows, int F, hipStream_t s);
-int launch_residual_rmsnorm(const bf16_t* t, long ldt, bf16_t* x, long ldx, const bf16_t* w, bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t s);
 int launch_rmsnorm_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* x, long ldx, const bf16_t* w, bf16_t* out, long ldo,
                           int rows, int D, float eps, hipStream_t s);
 int launch_embed_splice(const int* ids, const int* speech_row, const bf16_t* table, const bf16_t* speech, bf16_t* out,

@@ -203,29 +203,6 @@ int launch_layernorm(const bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b
     return launch_layernorm_impl(const_cast<bf16_t*>(x), ldx, w, b, out, ldo, rows, C, eps, gelu, nullptr, 0, 0, nullptr, s);
 }
 
-int launch_residual_layernorm(const bf16_t* t, long ldt, bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps,
-                              hipStream_t s) {
-    if (!t || ldt % 8 != 0) return ISST_ERR_ARG;
-    return launch_layernorm_impl(x, ldx, w, b, out, ldo, rows, C, eps, 0, nullptr, 0, 0, nullptr, s, t, ldt);
-}
-// x = bf16(gelu_erf(x)) in place (the exact-erf GELU of the bf16 value, as EPI_BIAS_GELU applies it after the bias rounding)
-__global__ __launch_bounds__(256) void gelu_pass_kernel(bf16_t* x, long ldx, int C) {
-    const long row = blockIdx.y;
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (c >= C) return;
-    float v[8];
-    u32x4_t* p = reinterpret_cast<u32x4_t*>(x + row * ldx + c);
-    unpack8(*p, v);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-    *p = pack8(v);
-}
-int launch_gelu_pass(bf16_t* x, long ldx, int rows, int C, hipStream_t s) {
-    if (rows <= 0) return ISST_OK;
-    if (C % 8 != 0 || ldx % 8 != 0) return ISST_ERR_ARG;
-    hipLaunchKernelGGL(gelu_pass_kernel, dim3((C / 8 + 255) / 256, rows), dim3(256), 0, s, x, ldx, C);
-    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
-}
 // x[rows][C] (in place) += projection slabs + bias, then out = LayerNorm(x) (w == null: update only)
 int launch_layernorm_reduce(const float* slabs, long slab_stride, int n_slabs, const bf16_t* proj_bias, bf16_t* x, long ldx, const bf16_t* w,
                             const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps, hipStream_t s) {
@@ -336,75 +313,6 @@ __global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(const float* __rest
             *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
         }
     }
-}
-
-// ---- epilogues of the library-GEMM prefill path (blaslt.hip) as bandwidth-bound passes ----
-// act[row][j] = bf16(bf16(silu(g)) * u), g = gu[row][j], u = gu[row][F + j]  (HF LlamaMLP: act_fn(gate_proj(x)) * up_proj(x), bf16 after every op)
-__global__ __launch_bounds__(256) void swiglu_pass_kernel(const bf16_t* __restrict__ gu, long ldgu, bf16_t* __restrict__ act, long ldact, int F) {
-    const long row = blockIdx.y;
-    const int j = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (j >= F) return;
-    float g[8], u[8];
-    unpack8(*reinterpret_cast<const u32x4_t*>(gu + row * ldgu + j), g);
-    unpack8(*reinterpret_cast<const u32x4_t*>(gu + row * ldgu + F + j), u);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = bfr(silu(g[e])) * u[e];
-    *reinterpret_cast<u32x4_t*>(act + row * ldact + j) = pack8(g);
-}
-int launch_swiglu_pass(const bf16_t* gu, long ldgu, bf16_t* act, long ldact, int rows, int F, hipStream_t s) {
-    if (rows <= 0) return ISST_OK;
-    if (F % 8 != 0 || ldgu % 8 != 0 || ldact % 8 != 0) return ISST_ERR_ARG;
-    hipLaunchKernelGGL(swiglu_pass_kernel, dim3((F / 8 + 255) / 256, rows), dim3(256), 0, s, gu, ldgu, act, ldact, F);
-    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
-}
-// x = bf16(x + t) in place (t = bf16 projection output), then out = LlamaRMSNorm(w)(x) -- rmsnorm_reduce_kernel's arithmetic with one bf16 "slab"
-template <int STEPS>
-__global__ __launch_bounds__(256) void residual_rmsnorm_kernel(const bf16_t* __restrict__ t, long ldt, bf16_t* x, long ldx, const bf16_t* __restrict__ w,
-                                                               bf16_t* __restrict__ out, long ldo, int D, float eps) {
-    __shared__ float part[4];
-    const long row = blockIdx.x;
-    bf16_t* xr = x + row * ldx;
-    float v[STEPS][8];
-    float sq = 0.f;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        const int c = (threadIdx.x + 256 * s) * 8;
-        if (c < D) {
-            float tv[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(t + row * ldt + c), tv);
-            unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + tv[j]);
-            *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sq += v[s][j] * v[s][j];
-        }
-    }
-    if (!w) return;
-    sq = wave_sum(sq);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
-    __syncthreads();
-    const float r = rsqrtf((part[0] + part[1] + part[2] + part[3]) / D + eps);
-    bf16_t* orow = out + row * ldo;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        const int c = (threadIdx.x + 256 * s) * 8;
-        if (c < D) {
-            float wv[8], y[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(w + c), wv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] = wv[j] * bfr(v[s][j] * r);
-            *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
-        }
-    }
-}
-int launch_residual_rmsnorm(const bf16_t* t, long ldt, bf16_t* x, long ldx, const bf16_t* w, bf16_t* out, long ldo, int rows, int D, float eps, hipStream_t s) {
-    if (rows <= 0) return ISST_OK;
-    if (D % 8 != 0 || D > 8192 || ldt % 8 != 0 || ldx % 8 != 0 || (w && ldo % 8 != 0)) return ISST_ERR_ARG;
-    if (D <= 2048) hipLaunchKernelGGL(residual_rmsnorm_kernel<1>, dim3(rows), dim3(256), 0, s, t, ldt, x, ldx, w, out, ldo, D, eps);
-    else if (D <= 4096) hipLaunchKernelGGL(residual_rmsnorm_kernel<2>, dim3(rows), dim3(256), 0, s, t, ldt, x, ldx, w, out, ldo, D, eps);
-    else hipLaunchKernelGGL(residual_rmsnorm_kernel<4>, dim3(rows), dim3(256), 0, s, t, ldt, x, ldx, w, out, ldo, D, eps);
-    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
 // slabs: fp32 [n_slabs][rows][D] (dense rows); x: residual stream, updated in place; w == null: no norm output

@@ -69,7 +69,7 @@ EXPORTS = [
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
     "isst_op_attn_combine", "isst_op_gemm_attn_merge", "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_end", "isst_op_pack_weight",
-    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_lt", "isst_op_swiglu_pass", "isst_op_residual_rmsnorm", "isst_op_gelu_pass", "isst_op_residual_layernorm", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
 ]
 
 
@@ -448,7 +448,7 @@ def op_gemm(A: torch.Tensor, packed: torch.Tensor, N: int, epi: str = "none", bi
 
 def dense_kernel_name() -> str:
     """The kernel isst_op_gemm dispatches to above 64 rows (bench.py's `mfma` block names it)."""
-    return "gemm_tiled_kernel<EPI> (128 x 128 tile, 4 waves, gemm_tiled.hip)"
+    return "gemm_dense_kernel<EPI> (256 x 256 tile, 8-wave ping-pong, LDS-DMA; gemm_dense.hip)"
 
 
 def op_gemm_splitk_rmsnorm(A: torch.Tensor, packed: torch.Tensor, x: torch.Tensor, ksplit: int, norm_w=None, norm_eps: float = 1e-5):
@@ -481,66 +481,6 @@ def op_gemm_splitk_fused(A: torch.Tensor, packed: torch.Tensor, x: torch.Tensor,
     if rc:
         raise IsstError(f"isst_op_gemm_splitk_fused -> {rc}")
     return x, ssq, tickets
-
-
-def op_gemm_lt(A: torch.Tensor, w_rm: torch.Tensor, bias=None) -> torch.Tensor:
-    """bf16(A @ w_rm^T (+ bias)) through hipBLASLt (the many-row path's plain GEMM)."""
-    lib = load_library()
-    M, K = A.shape
-    N = w_rm.shape[0]
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
-    lib.isst_op_gemm_lt.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    rc = lib.isst_op_gemm_lt(_ptr(A), A.stride(0), _ptr(w_rm), _ptr(bias), _ptr(out), N, M, N, K, _stream_ptr())
-    if rc:
-        raise IsstError(f"isst_op_gemm_lt -> {rc}")
-    return out
-
-
-def op_swiglu_pass(gu: torch.Tensor) -> torch.Tensor:
-    lib = load_library()
-    rows, F2 = gu.shape
-    act = torch.empty((rows, F2 // 2), dtype=torch.bfloat16, device=gu.device)
-    lib.isst_op_swiglu_pass.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
-    rc = lib.isst_op_swiglu_pass(_ptr(gu), gu.stride(0), _ptr(act), act.stride(0), rows, F2 // 2, _stream_ptr())
-    if rc:
-        raise IsstError(f"isst_op_swiglu_pass -> {rc}")
-    return act
-
-
-def op_residual_rmsnorm(t: torch.Tensor, x: torch.Tensor, norm_w=None, eps: float = 1e-5):
-    """x_new = bf16(x + t); returns (x_new, RMSNorm(x_new) or None)."""
-    lib = load_library()
-    rows, D = x.shape
-    x = x.clone()
-    out = torch.empty_like(x) if norm_w is not None else None
-    lib.isst_op_residual_rmsnorm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p]
-    rc = lib.isst_op_residual_rmsnorm(_ptr(t), t.stride(0), _ptr(x), x.stride(0), _ptr(norm_w), _ptr(out), D, rows, D, eps, _stream_ptr())
-    if rc:
-        raise IsstError(f"isst_op_residual_rmsnorm -> {rc}")
-    return x, out
-
-
-def op_gelu_pass(x: torch.Tensor) -> torch.Tensor:
-    lib = load_library()
-    x = x.clone()
-    lib.isst_op_gelu_pass.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
-    rc = lib.isst_op_gelu_pass(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _stream_ptr())
-    if rc:
-        raise IsstError(f"isst_op_gelu_pass -> {rc}")
-    return x
-
-
-def op_residual_layernorm(t: torch.Tensor, x: torch.Tensor, ln_w, ln_b, eps: float = 1e-5):
-    """x_new = bf16(x + t); returns (x_new, LayerNorm(x_new))."""
-    lib = load_library()
-    rows, D = x.shape
-    x = x.clone()
-    out = torch.empty_like(x)
-    lib.isst_op_residual_layernorm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p]
-    rc = lib.isst_op_residual_layernorm(_ptr(t), t.stride(0), _ptr(x), x.stride(0), _ptr(ln_w), _ptr(ln_b), _ptr(out), D, rows, D, eps, _stream_ptr())
-    if rc:
-        raise IsstError(f"isst_op_residual_layernorm -> {rc}")
-    return x, out
 
 
 def op_gemm_splitk_plain(A: torch.Tensor, packed: torch.Tensor, N: int, ksplit: int, norm_w=None, ssq=None, norm_eps: float = 1e-5):

@@ -375,54 +375,64 @@ def test_launch_free_residual_rmsnorm_equals_the_reduce_launch(M, N, K, ks, N2, 
         close_bf16(out3, ref2, f"split-K plain M{M} N{N} vs the unsplit launch", ulps=2.0, atol=3e-2)
 
 
-@pytest.mark.parametrize("M,D,F", [(176, 256, 512), (1408, 1024, 2048), (200, 4096, 1024)])
-def test_library_gemm_path_pieces_match_the_fused_kernels(M, D, F):
-    """The many-row prefill's library path (hipBLASLt GEMM on the row-major weight twin + SwiGLU pass + residual/RMSNorm pass) against the oracle arithmetic
-    and against the packed-weight kernels with fused epilogues it replaces there -- same rounding points (bf16 after the GEMM, after silu, after the product,
-    after the residual add, twice inside the norm), another fp32 summation order."""
-    g = torch.Generator().manual_seed(M + D + F)
-    A = bf(torch.randn(M, D, generator=g))
-    Wg, Wu = bf(torch.randn(F, D, generator=g) * 0.05), bf(torch.randn(F, D, generator=g) * 0.05)
-    Wd = bf(torch.randn(D, F, generator=g) * 0.05)
-    x = bf(torch.randn(M, D, generator=g))
-    nw = bf(1 + 0.2 * torch.randn(D, generator=g))
-    gu = E.op_gemm_lt(A.to(DEV), torch.cat([Wg, Wu]).to(DEV))                       # [gate | up]
-    act = E.op_swiglu_pass(gu)
-    ref_act = torch.nn.functional.silu(bf(A.float() @ Wg.float().t())) * bf(A.float() @ Wu.float().t())
-    close_bf16(act, bf(ref_act.float()), f"library gate/up + SwiGLU pass M{M}", ulps=4.5, atol=4e-3)  # (gate and up each within an ulp: their product within ~2.5 + its own rounding)
-    inter = torch.stack([Wg.view(F // 16, 16, D), Wu.view(F // 16, 16, D)], dim=1).reshape(2 * F, D)   # the packed form interleaves 16-row tiles
-    close_bf16(act, E.op_gemm(A.to(DEV), E.op_pack_weight(inter.to(DEV)), 2 * F, "swiglu"), f"library path vs fused SwiGLU kernel M{M}", ulps=4.5, atol=4e-3)
-    t = E.op_gemm_lt(act, Wd.to(DEV))
-    x_new, normed = E.op_residual_rmsnorm(t, x.to(DEV), nw.to(DEV), 1e-5)
-    close_bf16(t, ref_linear(act.cpu(), Wd, "none"), f"library down_proj M{M}", ulps=2.5, atol=3.2e-2)
-    assert torch.equal(x_new.cpu(), bf(x.float() + t.float().cpu())), "residual pass: x != bf16(x + t)"   # (exact: one add, one rounding)
-    close_bf16(normed, ollm.rmsnorm(x_new.cpu(), nw, 1e-5), f"residual/RMSNorm pass M{M}", ulps=2.0, atol=1e-3)
-    x_only, none = E.op_residual_rmsnorm(t, x.to(DEV), None)
-    assert none is None and torch.equal(x_only, x_new)
+def _dense_mode(m):
+    E.load_library().isst_op_set_gemm_tuning(800000 + m, 0)  # gemm_dense.hip: 0 never, 1 heuristic, 2 wherever it can run
 
 
-@pytest.mark.parametrize("M,D,F", [(96, 256, 512), (3072, 1024, 4096)])
-def test_library_gemm_path_encoder_pieces(M, D, F):
-    """The speech encoder's library path (more than 64 rows): GEMM with the bias epilogue, exact-erf GELU pass, residual + LayerNorm prologue -- against
-    the fused packed-weight kernels (bias, bias + GELU, bias + residual) and torch's LayerNorm, same rounding points."""
-    g = torch.Generator().manual_seed(M + D)
-    A = bf(torch.randn(M, D, generator=g))
-    W1, b1 = bf(torch.randn(F, D, generator=g) * 0.05), bf(torch.randn(F, generator=g))
-    W2, b2 = bf(torch.randn(D, F, generator=g) * 0.03), bf(torch.randn(D, generator=g))
-    x = bf(torch.randn(M, D, generator=g))
-    lw, lb = bf(1 + 0.2 * torch.randn(D, generator=g)), bf(0.1 * torch.randn(D, generator=g))
-    h1 = E.op_gemm_lt(A.to(DEV), W1.to(DEV), b1.to(DEV))
-    close_bf16(h1, ref_linear(A, W1, "bias", b1), f"library bias epilogue M{M}", ulps=2.0, atol=2e-2)
-    act = E.op_gelu_pass(h1)
-    close_bf16(act, bf(torch.nn.functional.gelu(h1.float().cpu())), f"GELU pass M{M}", ulps=1.0, atol=1e-3)   # (device erff against torch's: a last-bit flip at most)
-    close_bf16(act, E.op_gemm(A.to(DEV), E.op_pack_weight(W1.to(DEV)), F, "bias_gelu", bias=b1.to(DEV)), f"library fc1 + GELU pass vs EPI_BIAS_GELU M{M}", ulps=3.0, atol=2e-2)
-    t = E.op_gemm_lt(act, W2.to(DEV), b2.to(DEV))
-    x_new, normed = E.op_residual_layernorm(t, x.to(DEV), lw.to(DEV), lb.to(DEV), 1e-5)
-    assert torch.equal(x_new.cpu(), bf(x.float() + t.float().cpu())), "residual prologue: x != bf16(x + t)"
-    ref_ln = torch.nn.functional.layer_norm(x_new.float().cpu(), (D,), lw.float(), lb.float(), 1e-5)
-    close_bf16(normed, bf(ref_ln), f"residual + LayerNorm M{M}", ulps=2.0, atol=8e-3)
-    fused = E.op_gemm(act, E.op_pack_weight(W2.to(DEV)), D, "bias_res", bias=b2.to(DEV), res=x.to(DEV))
-    close_bf16(x_new, fused, f"library fc2 + residual vs EPI_BIAS_RES M{M}", ulps=2.5, atol=6e-2)
+@pytest.mark.parametrize("M,N,K", [(65, 256, 128), (130, 256, 256), (257, 512, 1536), (700, 1040, 512), (1408, 1024, 2048), (300, 96, 192), (513, 272, 4096)])
+def test_gemm_dense_is_bit_identical_to_gemm_tiled(M, N, K):
+    """gemm_dense.hip (256 x 256 tile, 8-wave ping-pong, LDS-DMA staging, LDS-staged bf16 epilogue) against gemm_tiled.hip (128 x 128) -- the kernel
+    every dense shape ran on before -- on ragged row / column counts (rows past M, n-tiles past N, partial last tiles), 2 .. 64 K-tiles, every
+    epilogue: the same MFMA shape and the same ascending K order per accumulator, so every output bit must agree; and both against the oracle
+    arithmetic (reference call sites: patch_llm.py:260-262,334, HF LlamaMLP, patch_speech_encoder.py:741-743,923,586-589)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf(torch.randn(N, generator=g))
+    res = bf(torch.randn(M, N, generator=g))
+    Wp = E.op_pack_weight(W.to(DEV))
+    try:
+        for epi in ("none", "bias", "bias_gelu", "res", "bias_res", "f32"):
+            kw = dict(bias=bias.to(DEV) if "bias" in epi else None, res=res.to(DEV) if "res" in epi else None)
+            _dense_mode(0)
+            want = E.op_gemm(A.to(DEV), Wp, N, epi, **kw)
+            _dense_mode(2)
+            got = E.op_gemm(A.to(DEV), Wp, N, epi, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), f"{epi} M{M} N{N} K{K}: {int((got != want).sum())} elements differ from gemm_tiled"
+            atol = 2e-3 if epi in ("none", "bias", "f32") else 3.2e-2
+            close_bf16(got, ref_linear(A, W, epi, bias, res), f"dense {epi} M{M} N{N} K{K}", ulps=2.5, atol=atol)
+        if N % 32 == 0:
+            _dense_mode(0)
+            want = E.op_gemm(A.to(DEV), Wp, N, "swiglu")
+            _dense_mode(2)
+            got = E.op_gemm(A.to(DEV), Wp, N, "swiglu")
+            assert torch.equal(got, want), f"swiglu M{M} N{N} K{K}"
+    finally:
+        _dense_mode(1)
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(384, 1024, 2048, 4), (1408, 512, 4096, 2), (130, 512, 512, 2), (700, 256, 1024, 8)])
+def test_gemm_dense_split_k_slabs(M, N, K, ks):
+    """K slices of the dense kernel (EPI_PARTIAL: fp32 slabs) + the reducing residual / RMSNorm kernel, against the same pair on gemm_tiled (bit-identical:
+    the slices cut K at the same places) and against the oracle arithmetic x = bf16(x + bf16(A @ W^T)), LlamaRMSNorm(x)."""
+    g = torch.Generator().manual_seed(M + N + K + ks)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    x = bf(torch.randn(M, N, generator=g))
+    nw = bf(1 + 0.2 * torch.randn(N, generator=g))
+    Wp = E.op_pack_weight(W.to(DEV))
+    try:
+        _dense_mode(0)
+        x0, n0 = E.op_gemm_splitk_rmsnorm(A.to(DEV), Wp, x.to(DEV), ks, nw.to(DEV))
+        _dense_mode(2)
+        x1, n1 = E.op_gemm_splitk_rmsnorm(A.to(DEV), Wp, x.to(DEV), ks, nw.to(DEV))
+        assert torch.equal(x0, x1) and torch.equal(n0, n1)
+    finally:
+        _dense_mode(1)
+    want = bf(x.float() + bf(A.float() @ W.float().t()).float())
+    close_bf16(x1, want, f"dense split-K M{M} N{N} K{K} ks{ks}", ulps=2.5, atol=3.2e-2)
+    close_bf16(n1, ollm.rmsnorm(x1.cpu(), nw, 1e-5), "norm of the updated rows", ulps=2.0, atol=1e-3)
 
 
 def test_in_launch_reduction_under_uneven_load():
