@@ -383,3 +383,58 @@ def test_full_size_free_running_ids_with_peaked_logits():
     assert worst <= LOGIT_TOLERANCE
     assert batch.evictions == PEAKED_CHUNKS
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: an unbounded stream at FULL size -- rolling whole-chunk eviction for hundreds of chunks.
+# ------------------------------------------------------------------------------------------------------------------------
+LONG_CHUNKS = 640
+
+
+def test_full_size_long_stream_is_bounded_and_flat(full):
+    """640 consecutive chunks (10.2 minutes of audio; 1875 = 30 minutes run the same loop in bench.py --steps 1875) of one stream at full size through
+    streams.StreamBatch from the imported steady state: an eviction after every chunk (agents/infinisst.py:340-361), the LLM ring wrapping ~17 times and the
+    encoder ring every 13 chunks (patch_speech_encoder.py:516-520, 259-262).  Size-independent properties: the caches stay bounded (LLM <= budget + one
+    chunk, encoder window == 576 before / 624 inside a chunk), the logits of sampled chunks are finite, per-chunk latency is flat (p95 / p50 <= 1.03 over the
+    last 500 chunks: O(1) cost in stream length) and device memory does not grow."""
+    import time
+    from infinisst_amd.streams import StreamBatch
+    cfg, w_dev, _, sys_n = full
+    cfg = cfg.replace(eos_ids=())  # every chunk runs the worst case of 10 passes
+    eng = Engine(cfg, max_streams=1, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n)
+    eng.load_weights(w_dev)
+    gen = GenConfig(max_new_tokens=10, max_llm_cache_size=1000, always_cache_system_prompt=True)
+    batch = StreamBatch(eng, gen, sys_n, lambda first, m: synth.chunk_prompt_ids(cfg, m, first=first))
+    slot = batch.open()
+    sid = batch.stream_id(slot)
+    kv0, enc0, src0 = _random_state(cfg, sys_n, seed=21)
+    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
+    _import_state(eng, sid, cfg, sys_n, kv0, enc0, src0, llm_ring_start=ring_cap - 100, enc_ring_start=630)
+    per_chunk = len(synth.chunk_prompt_ids(cfg, 1, first=False)) + 9
+    batch.adopt_state(slot, [sys_n + N_RING - k * per_chunk for k in range(30, -1, -1)])
+    audio = torch.from_numpy(synth.synthetic_audio(cfg.chunk_samples * 64, stream_id=555)).cuda()
+    free0 = None
+    lat, lens = [], []
+    for c in range(LONG_CHUNKS):
+        seg = audio[(c % 64) * cfg.chunk_samples:(c % 64 + 1) * cfg.chunk_samples]
+        check = c % 80 == 79
+        t0 = time.perf_counter()
+        out = batch.step([seg], return_logits=check)
+        lat.append(time.perf_counter() - t0)
+        if check:
+            outs, logits = out
+            assert np.isfinite(logits[0][:len(batch.slots[slot].last_generated)]).all(), f"chunk {c}: non-finite logits"
+        info = eng.stream_info(sid)
+        lens.append(info["llm_cache_len"])
+        assert info["llm_cache_len"] <= sys_n + 1000 and info["enc_cache_len"] == cfg.max_cache_size + cfg.block_size and info["enc_n_steps"] == 48 * 20 + 48 * (c + 1)
+        if c == 40:
+            free0 = torch.cuda.mem_get_info()[0]
+    free1 = torch.cuda.mem_get_info()[0]
+    tail = np.array(lat[-500:])
+    p50, p95 = float(np.percentile(tail, 50)), float(np.percentile(tail, 95))
+    print(f"long stream: {LONG_CHUNKS} chunks, {batch.evictions} evictions, KV {min(lens)}..{max(lens)} entries, p50 {1e3 * p50:.2f} ms, p95 {1e3 * p95:.2f} ms, "
+          f"free memory {free0 / 2**30:.2f} -> {free1 / 2**30:.2f} GiB")
+    assert batch.evictions == LONG_CHUNKS
+    assert p95 / p50 <= 1.03, f"per-chunk latency not flat: p50 {p50}, p95 {p95}"
+    assert abs(free1 - free0) <= 64 << 20, "device memory moved"
+    eng.close()
