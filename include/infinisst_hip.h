@@ -79,6 +79,13 @@ typedef struct isst_gen_params {
     float length_penalty;              /* BeamSearchScorer length_penalty (HF default 1.0; 0 is read as 1.0) */
     int pcm_on_device;                 /* nonzero: pcm[i] are DEVICE pointers (fp32, n_samples each): the caller already holds the audio in
                                         * HBM.  0: host pointers, moved by the library as agents/infinisst.py:222 `.to(device)` does */
+    /* the sample branch (agents/infinisst.py:311-315 -> patch_hf.py:606-624 -> HF _sample [3P]); num_beams must be <= 1 with it */
+    int do_sample;                     /* do_sample= ; 0: greedy argmax */
+    float temperature;                 /* temperature= (1.0 or <= 0: off) */
+    int top_k;                         /* top_k= (0: off) */
+    float top_p;                       /* top_p= (>= 1.0: off) */
+    float epsilon_cutoff;              /* epsilon_cutoff= (0: off) */
+    unsigned long long seed;           /* the draw of (stream, chunk, step) is isst_op_sample_uniform(seed, stream id, chunks so far, step) */
 } isst_gen_params;
 
 typedef struct isst_stream_info {
@@ -232,6 +239,10 @@ int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, u
 int isst_op_rmsnorm(const uint16_t* x, const uint16_t* w, uint16_t* out, int rows, int D, float eps, void* hip_stream);
 int isst_op_conv0(const uint16_t* audio, const uint16_t* w, const uint16_t* bias, const uint16_t* ln_w, const uint16_t* ln_b,
                   uint16_t* out, int T, int C, int k, int stride, void* hip_stream);
+/* the sample branch's host half, piece by piece (no GPU needed): HF's warpers Temperature -> TopK -> TopP -> Epsilon on one row of processed fp32
+ * scores (warped in place, -inf = removed) and the inverse-CDF draw at u in [0, 1); the uniform of a (stream, chunk, step) */
+int isst_op_warp_sample(float* scores, int vocab, float temperature, int top_k, float top_p, float epsilon_cutoff, double u, int* token);
+double isst_op_sample_uniform(unsigned long long seed, int stream, int chunk, int step);
 /* logits [vocab] fp32 (modified in place) -> *out_token (device int) */
 int isst_op_sample(float* logits, int vocab, const int* ids, int n_ids, const int* enc_ids, int n_enc, const int* suppress,
                    int n_suppress, float repetition_penalty, int ngram, int enc_ngram, int* out_token, void* hip_stream);

@@ -166,8 +166,13 @@ class InfiniSST(_AgentBase):
         self.repetition_penalty = args.repetition_penalty
         self.suppress_non_language = getattr(args, "suppress_non_language", False)
         self.max_new_tokens = args.max_new_tokens
-        if getattr(args, "do_sample", False):
-            raise NotImplementedError("sampling is not part of the hot path (the reference scripts never enable it)")
+        # the sample branch (reference :311-315): warpers + draw in the library (csrc/warp.hip); the draws come from a counter-based generator, so they
+        # are reproducible but not torch.multinomial's
+        self.do_sample = bool(getattr(args, "do_sample", False))
+        self.top_p, self.top_k = float(getattr(args, "top_p", 1.0)), int(getattr(args, "top_k", 0))
+        self.epsilon_cutoff, self.temperature = float(getattr(args, "epsilon_cutoff", 0.0)), float(getattr(args, "temperature", 1.0))
+        if self.do_sample and self.beam > 1:
+            raise NotImplementedError("--do-sample with --beam > 1 (beam sample) is not implemented")
         self.pseudo_batch_size = getattr(args, "pseudo_batch_size", 1)  # accepted, not used: see add_args
         self.dpo_sampling = getattr(args, "dpo_sampling", False)         # reference :108-110
         self.output_file = getattr(args, "output_file", "translations.json")
@@ -330,7 +335,8 @@ class InfiniSST(_AgentBase):
                          no_repeat_ngram_lookback=self.no_repeat_ngram_lookback,
                          repetition_penalty=self.repetition_penalty, max_llm_cache_size=self.max_llm_cache_size,
                          always_cache_system_prompt=self.always_cache_system_prompt,
-                         suppress_tokens=tuple(self.bad_words_ids))
+                         suppress_tokens=tuple(self.bad_words_ids), do_sample=self.do_sample, temperature=self.temperature, top_k=self.top_k,
+                         top_p=self.top_p, epsilon_cutoff=self.epsilon_cutoff)
 
     def policy(self, states: Optional[S2TAgentStates] = None):
         if states is None:

@@ -157,3 +157,10 @@ class GenConfig:
     max_llm_cache_size: int = 1000
     always_cache_system_prompt: bool = True
     suppress_tokens: Tuple[int, ...] = ()
+    # the sample branch (agents/options.py:43-108 --do-sample / --top-p / --top-k / --epsilon-cutoff / --temperature; greedy when do_sample is off)
+    do_sample: bool = False
+    temperature: float = 1.0
+    top_k: int = 0
+    top_p: float = 1.0
+    epsilon_cutoff: float = 0.0
+    seed: int = 998244353  # reference agents/infinisst.py:74

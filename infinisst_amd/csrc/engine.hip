@@ -187,6 +187,8 @@ struct isst_handle {
     unsigned char* meta_host = nullptr;  // pinned
     size_t meta_bytes = 0;
     int* tok_host = nullptr;  // pinned
+    float* samp_host = nullptr;  // pinned [rows][vocab_pad]: processed scores of a sampling step (allocated on the first do_sample call)
+    size_t samp_host_rows = 0;
 
     // beam search (max_beams > 1): one KV arena per (stream, beam), tail buffers, scoring scratch
     int max_beams = 1, tcap = 0, nbuf = 0;
@@ -337,6 +339,7 @@ extern "C" void isst_destroy(isst_handle* h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->meta_host) (void)hipHostFree(h->meta_host);
     if (h->tok_host) (void)hipHostFree(h->tok_host);
+    if (h->samp_host) (void)hipHostFree(h->samp_host);
     if (h->pcm_host) (void)hipHostFree(h->pcm_host);
     if (h->top_val_host) (void)hipHostFree(h->top_val_host);
     if (h->top_idx_host) (void)hipHostFree(h->top_idx_host);
@@ -1557,6 +1560,16 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     if (forced_tokens && n_forced)
         for (int i = 0; i < n; ++i) any_forced = any_forced || (forced_tokens[i] != nullptr && n_forced[i] > 0);
     if (B > 1 && (any_forced || logits_out)) return h->fail(ISST_ERR_ARG, "forced_tokens / logits_out are greedy-only test aids");
+    if (p->do_sample && B > 1) return h->fail(ISST_ERR_ARG, "do_sample with num_beams > 1 (beam sample) is not implemented");
+    if (p->do_sample && (p->top_k < 0 || !(p->top_p > 0.f) || p->epsilon_cutoff < 0.f || p->epsilon_cutoff >= 1.f))
+        return h->fail(ISST_ERR_ARG, "sampling arguments out of range (top_k >= 0, top_p > 0, 0 <= epsilon_cutoff < 1)");
+    if (p->do_sample && h->samp_host_rows < (size_t)n) {
+        if (h->samp_host) (void)hipHostFree(h->samp_host);
+        h->samp_host = nullptr;
+        h->samp_host_rows = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->samp_host), (size_t)n * h->vocab_pad * sizeof(float)) != hipSuccess) return h->fail(ISST_ERR_NOMEM, "pinned score buffer");
+        h->samp_host_rows = (size_t)n;
+    }
     for (int i = 0; i < n; ++i) {
         const int id = stream_ids[i];
         if (id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", id);
@@ -1686,6 +1699,12 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             for (int r = 0; r < na; ++r)
                 HIPCHK(hipMemcpyAsync(logits_out + ((size_t)active[r] * p->max_new_tokens + gen_count[active[r]]) * c.vocab,
                                       h->logits + (size_t)r * h->vocab_pad, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (p->do_sample) {  // processors on the device, the processed rows to the host: warpers + draw happen there (warp.hip) after the synchronisation
+            CHK(launch_sample_process(h->logits, h->vocab_pad, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
+                                      p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, na, st));
+            HIPCHK(hipMemcpyAsync(h->samp_host, h->logits, (size_t)na * h->vocab_pad * sizeof(float), hipMemcpyDeviceToHost, st));
+            return ISST_OK;
+        }
         CHK(launch_sample(h->logits, h->vocab_pad, c.vocab, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
                           p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->out_tok, h->samp_val, h->samp_idx, na, st));
         HIPCHK(hipMemcpyAsync(h->tok_host, h->out_tok, sizeof(int) * na, hipMemcpyDeviceToHost, st));
@@ -1695,7 +1714,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     // the same from step to step (the per-step values live in the metadata block), so it is captured once per row count and
     // replayed: ~230 launches become one graph launch
     auto decode_step = [&](int nr) -> int {
-        const bool graph_ok = h->use_graphs && st != nullptr && !logits_out && !c.debug_taps && !h->prof_on;  // (the NULL stream cannot be captured)
+        const bool graph_ok = h->use_graphs && st != nullptr && !logits_out && !c.debug_taps && !h->prof_on && !p->do_sample;  // (the NULL stream cannot be captured)
         if (!graph_ok) {
             HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
             CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st, &mh));
@@ -1730,6 +1749,10 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     while (true) {
         const int na = (int)active.size();
         HIPCHK(hipStreamSynchronize(st));
+        if (p->do_sample)  // HF _sample with do_sample: warpers, softmax, one draw per row (patch_hf.py:606-624)
+            for (int r = 0; r < na; ++r)
+                h->tok_host[r] = warp_and_sample(h->samp_host + (size_t)r * h->vocab_pad, c.vocab, p->temperature, p->top_k, p->top_p, p->epsilon_cutoff,
+                                                 sample_uniform(p->seed, stream_ids[active[r]], h->streams[stream_ids[active[r]]].chunks, gen_count[active[r]]));
         std::vector<int> next_active;
         for (int r = 0; r < na; ++r) {
             const int i = active[r];

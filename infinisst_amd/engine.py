@@ -53,6 +53,8 @@ class _GenParams(C.Structure):
         ("encoder_no_repeat_ngram_size", C.c_int), ("repetition_penalty", C.c_float),
         ("suppress_tokens", C.POINTER(C.c_int)), ("n_suppress", C.c_int), ("system_prompt_size", C.c_int),
         ("num_beams", C.c_int), ("length_penalty", C.c_float), ("pcm_on_device", C.c_int),
+        ("do_sample", C.c_int), ("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_float), ("epsilon_cutoff", C.c_float),
+        ("seed", C.c_ulonglong),
     ]
 
 
@@ -69,7 +71,7 @@ EXPORTS = [
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
     "isst_op_attn_combine", "isst_op_gemm_attn_merge", "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_end", "isst_op_pack_weight",
-    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample", "isst_op_warp_sample", "isst_op_sample_uniform",
 ]
 
 
@@ -135,6 +137,9 @@ def load_library(path: Optional[str] = None):
     lib.isst_op_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
     lib.isst_op_conv0.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.isst_op_warp_sample.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_double, C.POINTER(C.c_int)]
+    lib.isst_op_sample_uniform.argtypes = [C.c_ulonglong, C.c_int, C.c_int, C.c_int]
+    lib.isst_op_sample_uniform.restype = C.c_double
     lib.isst_op_sample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                    C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     if path is None:
@@ -359,6 +364,8 @@ class Engine:
         p.system_prompt_size = system_prompt_size
         p.num_beams = gen.beam
         p.length_penalty = 1.0
+        p.do_sample, p.temperature, p.top_k = int(gen.do_sample), float(gen.temperature), int(gen.top_k)
+        p.top_p, p.epsilon_cutoff, p.seed = float(gen.top_p), float(gen.epsilon_cutoff), int(gen.seed)
         sid_arr = (C.c_int * n)(*stream_ids)
         prompts = [np.asarray(x, dtype=np.int32) for x in prompt_ids]
         prevs = [np.asarray(x, dtype=np.int32) for x in prev_target_ids]
@@ -572,6 +579,22 @@ def op_sample(logits: torch.Tensor, ids, enc_ids, suppress, penalty, ngram, enc_
     if rc:
         raise IsstError(f"isst_op_sample -> {rc}")
     return int(out.item())
+
+
+def op_warp_sample(scores: np.ndarray, temperature: float, top_k: int, top_p: float, epsilon_cutoff: float, u: float):
+    """HF's warpers Temperature -> TopK -> TopP -> Epsilon on one row of processed scores + the inverse-CDF draw (host code: no GPU needed).
+    Returns (warped scores, token)."""
+    lib = load_library()
+    s = np.ascontiguousarray(scores, dtype=np.float32).copy()
+    tok = C.c_int(-1)
+    rc = lib.isst_op_warp_sample(s.ctypes.data, s.size, temperature, top_k, top_p, epsilon_cutoff, u, C.byref(tok))
+    if rc:
+        raise IsstError(f"isst_op_warp_sample -> {rc}")
+    return s, tok.value
+
+
+def op_sample_uniform(seed: int, stream: int, chunk: int, step: int) -> float:
+    return float(load_library().isst_op_sample_uniform(seed, stream, chunk, step))
 
 
 def op_splice_map(ids: Sequence[int], user_id: int, assistant_id: int, start_header_id: int, n_features: int) -> list:

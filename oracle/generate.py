@@ -69,6 +69,57 @@ def process_logits(scores: torch.Tensor, input_ids: Sequence[int], encoder_input
     return s
 
 
+def warp_logits(scores: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, epsilon_cutoff: float = 0.0) -> torch.Tensor:
+    """[3P transformers] the warpers `_get_logits_processor` appends for do_sample, in its order: TemperatureLogitsWarper -> TopKLogitsWarper ->
+    TopPLogitsWarper -> EpsilonLogitsWarper (min_tokens_to_keep = 1, filter value -inf), restated from that library's published code and pinned to the
+    image's transformers 5.15 classes (tests/golden/sampling_warpers.npz).  scores (V,) fp32, processed -> warped copy."""
+    s = scores.clone()
+    ninf = float("-inf")
+    if temperature > 0 and temperature != 1.0:
+        s = s / temperature
+    if top_k > 0:
+        k = min(top_k, s.numel())
+        s = s.masked_fill(s < torch.topk(s, k)[0][-1], ninf)
+    if top_p < 1.0:
+        sorted_logits, sorted_idx = torch.sort(s, descending=False)
+        cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1 - top_p)
+        remove[-1:] = False
+        s = s.masked_fill(remove.scatter(0, sorted_idx, remove), ninf)
+    if 0 < epsilon_cutoff < 1:
+        probs = s.softmax(dim=-1)
+        s = s.masked_fill((probs < epsilon_cutoff) & (s < torch.topk(s, 1)[0][-1]), ninf)
+    return s
+
+
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def sample_uniform(seed: int, stream: int, chunk: int, step: int) -> float:
+    """The uniform in [0, 1) of one draw: counter-based, keyed by (seed, stream, chunk, step) -- csrc/warp.hip's generator, restated."""
+    x = _splitmix64(seed & _M64)
+    x = _splitmix64(x ^ (stream & 0xFFFFFFFF))
+    x = _splitmix64(x ^ ((chunk & 0xFFFFFFFF) << 20))
+    x = _splitmix64(x ^ (step & 0xFFFFFFFF))
+    return (x >> 11) / 9007199254740992.0
+
+
+def draw(warped: torch.Tensor, u: float) -> int:
+    """softmax + ONE multinomial draw (HF _sample: probs = softmax(scores); torch.multinomial(probs, 1)) as the inverse CDF in vocabulary order at u.
+    (torch.multinomial's own random stream is not reproducible across libraries; the DISTRIBUTION is the reference's.)"""
+    p = warped.softmax(dim=-1).double()
+    cum = torch.cumsum(p, dim=0)
+    idx = int(torch.searchsorted(cum, torch.tensor(u * float(cum[-1]), dtype=torch.float64), right=True))  # first index whose running sum exceeds the target
+    return idx if idx < p.numel() else int(torch.nonzero(p > 0).flatten()[-1])
+
+
 @dataclass
 class GenerateOutput:
     sequences: List[int]  # prompt + generated (the last generated token is never fed to the model)
@@ -80,8 +131,9 @@ class GenerateOutput:
 def generate(w: Dict[str, torch.Tensor], cfg, gen, input_ids: List[int], speech_batch: torch.Tensor, kv,
              speech_cache, rope_llm, rope_enc, encoder_input_ids: Sequence[int],
              forced_tokens: Optional[Sequence[int]] = None,
-             keep_logits: bool = True) -> GenerateOutput:
-    """One chunk: encoder (step 0) + prefill + greedy decode.  Mutates `kv` and `speech_cache`.
+             keep_logits: bool = True, stream: int = 0, chunk: int = 0) -> GenerateOutput:
+    """One chunk: encoder (step 0) + prefill + greedy decode (or, gen.do_sample, the sample branch: warpers + one draw per step at
+    sample_uniform(gen.seed, stream, chunk, step)).  Mutates `kv` and `speech_cache`.
 
     `forced_tokens` (teacher forcing, test aid): token j of the list is appended instead of the argmax at step j;
     the loop then runs exactly len(forced_tokens) steps unless EOS/max length stops it first."""
@@ -105,6 +157,11 @@ def generate(w: Dict[str, torch.Tensor], cfg, gen, input_ids: List[int], speech_
             out.step_scores.append(scores)
         if forced_tokens is not None and step < len(forced_tokens):
             tok = int(forced_tokens[step])
+        elif getattr(gen, "do_sample", False):  # patch_hf.py:606-624 -> HF _sample with do_sample
+            warped = warp_logits(scores, gen.temperature, gen.top_k, gen.top_p, gen.epsilon_cutoff)
+            if keep_logits:
+                out.step_scores[-1] = warped
+            tok = draw(warped, sample_uniform(gen.seed, stream, chunk, step))
         else:
             tok = int(torch.argmax(scores))
         seq.append(tok)

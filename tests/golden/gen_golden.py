@@ -909,6 +909,40 @@ def gen_logits_processors():
 
 
 # --------------------------------------------------------------------------------------------
+# the sample branch's warpers: transformers' own classes, built by ITS _get_logits_processor from the agent's kwargs with do_sample=True
+# (agents/infinisst.py:311-315 -> patch_hf.py:586-600; 4.47 is absent, the image has 5.15)
+# --------------------------------------------------------------------------------------------
+def gen_sampling_warpers():
+    import transformers
+    from transformers import GenerationConfig, LlamaConfig, LlamaForCausalLM
+    from transformers.generation.logits_process import LogitsProcessorList
+    V = 400
+    tiny = LlamaForCausalLM(LlamaConfig(hidden_size=16, intermediate_size=32, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1, vocab_size=V))
+    out = {"transformers_version": np.array(transformers.__version__)}
+    g = torch.Generator().manual_seed(99)
+    cases = [(0.7, 50, 0.9, 0.0), (1.0, 0, 0.8, 0.0), (1.3, 10, 1.0, 0.0), (1.0, 0, 1.0, 0.004), (0.5, 40, 0.95, 0.002), (1.0, 1, 1.0, 0.0), (2.0, 0, 0.3, 0.0),
+             (0.8, 400, 0.99, 0.0005)]
+    for ci, (temp, top_k, top_p, eps) in enumerate(cases):
+        kw = dict(do_sample=True, temperature=temp, top_k=top_k, top_p=top_p, pad_token_id=0)
+        if eps > 0:
+            kw["epsilon_cutoff"] = eps
+        gc = GenerationConfig(**kw)
+        procs = tiny._get_logits_processor(generation_config=gc, input_ids_seq_length=3, encoder_input_ids=None, prefix_allowed_tokens_fn=None,
+                                           logits_processor=LogitsProcessorList(), device="cpu", model_kwargs={})
+        scores = torch.randn(1, V, generator=g) * (3.0 if ci % 2 else 1.5)
+        scores[0, torch.randint(0, V, (7,), generator=g)] = float("-inf")  # tokens the processors banned
+        ids = torch.zeros(1, 3, dtype=torch.long)
+        outp = procs(ids, scores.clone())
+        out[f"c{ci}_order"] = np.array([type(p).__name__ for p in procs])
+        out[f"c{ci}_cfg"] = np.array([temp, top_k, top_p, eps], dtype=np.float64)
+        out[f"c{ci}_scores"] = scores[0].numpy()
+        out[f"c{ci}_out"] = outp[0].numpy()
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "sampling_warpers.npz"), **out)
+    print("sampling_warpers.npz:", len(out), "arrays, transformers", transformers.__version__)
+
+
+# --------------------------------------------------------------------------------------------
 # HF Llama building blocks (LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP, repeat_kv) of the image's transformers 5.15.0
 # --------------------------------------------------------------------------------------------
 @torch.no_grad()
@@ -1090,6 +1124,7 @@ def main():
     gen_beam_scorer()
     gen_beam_loop()
     gen_logits_processors()
+    gen_sampling_warpers()
     gen_llama_blocks()
     gen_prompts()
     gen_hf_conv_extractor()

@@ -489,3 +489,34 @@ def test_stream_batch_equals_one_agent_per_stream(keep_sys):
     assert batch.cache_len(idx[0]) == 0 and batch.slots[idx[0]].ckpts == ck and batch.slots[idx[0]].target_ids == []
     batch.close(idx[1])
     assert batch.open() == idx[1]
+
+
+def test_host_warpers_and_draw_match_the_oracle(golden_dir):
+    """csrc/warp.hip (the sample branch's host half, callable without a GPU): on the fixture's scores and on 200 random rows the same tokens survive as in
+    oracle.generate.warp_logits (pinned to transformers' warpers), the surviving scores agree to an fp32 ulp of the temperature division, the draw is the
+    oracle's for the same uniform, and the uniforms are the oracle's generator bit for bit."""
+    from infinisst_amd import engine as E
+    from oracle import generate as ogen
+    g = np.load(os.path.join(golden_dir, "sampling_warpers.npz"))
+    rng = np.random.default_rng(11)
+    rows = [(g[f"c{ci}_scores"], tuple(float(x) for x in g[f"c{ci}_cfg"])) for ci in range(int(g["n_cases"]))]
+    for _ in range(200):
+        sc = (rng.standard_normal(700) * rng.choice([1.0, 3.0, 6.0])).astype(np.float32)
+        sc[rng.integers(0, 700, size=5)] = -np.inf
+        rows.append((sc, (float(rng.choice([1.0, 0.7, 1.5])), float(rng.choice([0, 1, 20, 700])), float(rng.choice([1.0, 0.9, 0.5])), float(rng.choice([0.0, 0.003])))))
+    n_draws = 0
+    for sc, (temp, top_k, top_p, eps) in rows:
+        want = ogen.warp_logits(torch.from_numpy(sc), temp, int(top_k), top_p, eps)
+        u = float(rng.random())
+        got, tok = E.op_warp_sample(sc, temp, int(top_k), top_p, eps, u)
+        assert np.array_equal(np.isinf(got), np.isinf(want.numpy())), "kept sets differ"
+        fin = ~np.isinf(got)
+        np.testing.assert_allclose(got[fin], want.numpy()[fin], rtol=2e-7, atol=0)
+        p = want.softmax(-1).double()
+        cum = torch.cumsum(p, 0)
+        if float((cum - u * float(cum[-1])).abs().min()) > 1e-6:  # (a uniform within 1e-6 of a CDF step may fall either way in fp32)
+            assert tok == ogen.draw(want, u)
+            n_draws += 1
+    assert n_draws > 150
+    for key in [(998244353, 0, 0, 0), (998244353, 63, 1874, 39), (7, 5, 3, 1)]:
+        assert E.op_sample_uniform(*key) == ogen.sample_uniform(*key)

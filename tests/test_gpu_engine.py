@@ -495,3 +495,57 @@ def test_llm_embed_tap_equals_oracle_splice():
         is_speech = torch.tensor([t == cfg.sp_patch_id for t in prompt])
         assert torch.equal(got[~is_speech], ref[~is_speech]), f"chunk {c}: token rows of the decoder input differ"
         assert_close(f"chunk {c} spliced speech rows", got[is_speech], ref[is_speech], 0.06, 0.02)
+
+
+def test_sample_branch_draws_from_the_oracle_distribution():
+    """--do-sample (reference agents/infinisst.py:311-315 -> patch_hf.py:606-624 -> HF _sample): processors on the device, the warpers Temperature -> TopK ->
+    TopP -> Epsilon and the draw on the host (csrc/warp.hip).  The engine runs FREE over 4 chunks; the oracle follows its tokens (teacher-forced) and
+    supplies, per step, the reference's warped distribution and the uniform of (seed, stream, chunk, step): the engine's token must be the inverse-CDF
+    draw of that distribution to within the probability mass bf16 logit noise can move (0.04), and must never be a token the oracle's warpers removed
+    with a margin.  Same call again, and the same stream next to another one in a batch: identical tokens (counter-based generator)."""
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=8, max_llm_cache_size=150, do_sample=True, temperature=0.8, top_k=50, top_p=0.9, epsilon_cutoff=0.001)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=91)
+    eng = make_engine(cfg, w, debug_taps=False, max_streams=3)
+    sid, sid2, sid3 = eng.open_stream(), eng.open_stream(), eng.open_stream()
+    audio = synth.synthetic_audio(cfg.chunk_samples * 4, stream_id=9)
+    other = synth.synthetic_audio(cfg.chunk_samples * 4, stream_id=10)
+    kv, sc = ollm.new_kv(cfg), oenc.new_cache(cfg)
+    rope_l, rope_e = ollm.llm_rope_tables(cfg, 2048, torch.bfloat16), oenc.make_rope(cfg)
+    sys_n = len(synth.system_prompt_ids(cfg))
+    prev, steps, distinct = [], 0, set()
+    for c in range(4):
+        seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        outs, _ = eng.generate(gen, [sid], [seg], [prompt], [prev[-100:]], system_prompt_size=sys_n if c == 0 else 0)
+        again, _ = eng.generate(gen, [sid2, sid3], [seg, other[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]], [prompt, prompt], [prev[-100:], []],
+                                system_prompt_size=sys_n if c == 0 else 0, forced_tokens=[outs[0], None])
+        assert again[0] == outs[0]
+        x = torch.from_numpy(seg)
+        if c == 0:
+            x = torch.cat([torch.zeros(cfg.first_chunk_offset), x])
+        ref = ogen.generate(w, cfg, gen, prompt, x.unsqueeze(0).bfloat16(), kv, sc, rope_l, rope_e, prev[-100:], forced_tokens=outs[0], stream=sid, chunk=c)
+        for s, tok in enumerate(outs[0]):
+            warped = ogen.warp_logits(ref.step_scores[s], gen.temperature, gen.top_k, gen.top_p, gen.epsilon_cutoff)
+            p = warped.softmax(-1).double()
+            cum = torch.cumsum(p, 0)
+            u = ogen.sample_uniform(gen.seed, sid, c, s) * float(cum[-1])
+            lo, hi = (float(cum[tok - 1]) if tok > 0 else 0.0), float(cum[tok])
+            assert lo - 0.04 <= u < hi + 0.04, f"chunk {c} step {s}: token {tok} covers [{lo:.4f}, {hi:.4f}) of the oracle's CDF, the uniform is {u:.4f}"
+            steps += 1
+            distinct.add(tok)
+        prev.extend(outs[0][:-1])
+        assert eng.stream_info(sid)["llm_cache_len"] == ollm.kv_len(kv)
+    # a fresh stream with the same id, audio and seed draws the same tokens; another seed draws others
+    eng.reset_stream(sid2)
+    gen_b = GenConfig(max_new_tokens=8, max_llm_cache_size=150, do_sample=True, temperature=0.8, top_k=50, top_p=0.9, epsilon_cutoff=0.001, seed=12345)
+    prompt = synth.chunk_prompt_ids(cfg, 1, first=True)
+    a1, _ = eng.generate(gen_b, [sid2], [audio[:cfg.chunk_samples]], [prompt], [[]], system_prompt_size=sys_n)
+    eng.reset_stream(sid2)
+    a2, _ = eng.generate(gen_b, [sid2], [audio[:cfg.chunk_samples]], [prompt], [[]], system_prompt_size=sys_n)
+    assert a1 == a2
+    print(f"sample branch: {steps} steps, {len(distinct)} distinct tokens drawn; another seed: {a1[0]}")
+    assert steps >= 16 and len(distinct) >= 8, "the draws must actually vary (top_k 50 at temperature 0.8 over near-flat toy logits)"
+    # beam sample is refused
+    with pytest.raises(IsstError):
+        eng.generate(GenConfig(max_new_tokens=4, beam=2, do_sample=True), [sid3], [other[:cfg.chunk_samples]], [prompt], [[]])

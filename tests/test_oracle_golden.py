@@ -249,6 +249,29 @@ def test_logits_processors_match_transformers(golden_dir):
         assert np.array_equal(got[fin], ref[fin]), f"case {ci}: penalised scores differ"
 
 
+def test_sampling_warpers_match_transformers(golden_dir):
+    """oracle.generate.warp_logits (the sample branch, agents/infinisst.py:311-315 -> patch_hf.py:606-624) against the warpers transformers 5.15's own
+    `_get_logits_processor` builds for do_sample -- Temperature -> TopK -> TopP -> Epsilon, the order is part of the fixture -- on 8 parameter sets:
+    the same tokens removed, the same surviving scores bit for bit."""
+    from oracle import generate as ogen
+    g = load(golden_dir, "sampling_warpers.npz")
+    for ci in range(int(g["n_cases"])):
+        temp, top_k, top_p, eps = (float(x) for x in g[f"c{ci}_cfg"])
+        want_order = [n for n, on in (("TemperatureLogitsWarper", temp != 1.0), ("TopKLogitsWarper", top_k > 0), ("TopPLogitsWarper", top_p < 1.0),
+                                      ("EpsilonLogitsWarper", eps > 0)) if on]
+        assert [str(x) for x in g[f"c{ci}_order"]] == want_order, f"case {ci}: warper order"
+        got = ogen.warp_logits(torch.from_numpy(g[f"c{ci}_scores"]), temp, int(top_k), top_p, eps).numpy()
+        ref = g[f"c{ci}_out"]
+        assert np.array_equal(np.isinf(got), np.isinf(ref)), f"case {ci}: kept sets differ"
+        assert np.array_equal(got[~np.isinf(ref)], ref[~np.isinf(ref)]), f"case {ci}: warped scores differ"
+    # the draw: inverse CDF in vocabulary order; the uniforms are a pure function of (seed, stream, chunk, step)
+    w = torch.tensor([0.0, float("-inf"), 1.0, float("-inf"), 0.5])
+    p = w.softmax(-1).double()
+    assert ogen.draw(w, 0.0) == 0 and ogen.draw(w, float(p[0]) - 1e-6) == 0 and ogen.draw(w, float(p[0]) + 1e-6) == 2 and ogen.draw(w, 0.999999) == 4
+    us = [ogen.sample_uniform(998244353, s, c, t) for s in range(3) for c in range(3) for t in range(3)]
+    assert len(set(us)) == 27 and all(0.0 <= u < 1.0 for u in us) and ogen.sample_uniform(1, 2, 3, 4) == ogen.sample_uniform(1, 2, 3, 4)
+
+
 @pytest.mark.parametrize("dt_name,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
 def test_llama_blocks_match_transformers(golden_dir, dt_name, dt):
     """oracle.llm's restated HF blocks (LlamaRMSNorm, apply_rotary_pos_emb, LlamaMLP) against the classes of the image's
