@@ -278,6 +278,13 @@ class InfiniSST(_AgentBase):
             raise ValueError(f"--length-shrink-cfg {shrink} does not match the checkpoint's length_shrink convs {cfg.shrink_layers}")
         if cfg.vocab != ids["vocab"]:  # load_state_dict would fail on the embedding shape (:180)
             raise ValueError(f"checkpoint vocabulary {cfg.vocab} != tokenizer + speech/latency tokens {ids['vocab']}")
+        # the one restated third-party switch that changes every encoder output (DESIGN.md section 4 "parity unpinned": rotary_embedding_torch after
+        # `.to(bf16)`): say which reading is in use, and let a maintainer with the real checkpoint flip it without touching code
+        mode = os.environ.get("INFINISST_ENC_ROPE_MODE")
+        if mode:
+            cfg = cfg.replace(enc_rope_mode=mode)
+        logger.warning("speech-encoder rotary arithmetic: enc_rope_mode=%s (INFINISST_ENC_ROPE_MODE=bf16|fp32 switches it; how to decide: DESIGN.md section 4)",
+                       cfg.enc_rope_mode)
         self.cfg = cfg
         self.llama31 = "3.1" in str(args.model_name)  # :183
         self.decode_fn = self.prompt_fn = None
