@@ -21,10 +21,16 @@ window (K = 624 per step); both rings start close to their physical end so they 
 N ranks = N independent replicas (stream-parallel, no collective: SURVEY 8(e)); global stream ids are dealt to the ranks
 by streams.assign_streams; the barrier and the max/sum reductions of the timing are the only cross-rank traffic.
 
-Rank 0 prints ONE JSON line.  Extra objects: `roofline` for the dominant kernel (the packed-weight skinny GEMM
-streaming Llama weights, HBM-bound) measured live with HIP events on the launch stream; `cpu_baseline` (the CPU oracle
-timed on this box's host cores over 4 steady-state chunks, N=1 only); `streams64` (N=1 only): the same loop re-run in this
-process with 64 concurrent streams on the GPU = BASELINE.json configs[2].
+The streams of a rank are stepped by the PRODUCT's multi-stream driver (infinisst_amd/streams.py::StreamBatch: one isst_generate per tick, per-stream
+target ids / checkpoints / whole-chunk eviction); this file only adds the synthetic audio, the imported steady state and the clock.
+
+Rank 0 prints ONE JSON line.  `value` has the chunks' audio resident in HBM before the timed region (the task's contract); `host_audio` is the same loop
+with every chunk handed over as host arrays (H2D inside the step: SURVEY 8(d)'s latency definition) measured right after it.  Extra objects: `roofline`
+for the dominant kernel (the packed-weight skinny GEMM streaming Llama weights, HBM-bound) measured live with HIP events on the launch stream, with
+`roofline.whole_step` = the whole chunk's algorithmic bytes over the step time; `host_ms_per_step` (wall time outside isst_generate); `cpu_baseline`
+(the CPU oracle timed on this box's host cores over 4 steady-state chunks, N=1 only); and, N=1 only, two more configurations run in this process after the
+timed region: `streams64` = 64 concurrent streams on the GPU (BASELINE.json configs[2]) with its own `host_audio`, `host_ms_per_step` and an `mfma` block
+(the prefill's widest dense GEMM against the 2.5 PFLOP/s dense bf16 peak), and `beam4` = the reference's production decoding (`--beam 4`).
 """
 from __future__ import annotations
 
@@ -302,9 +308,10 @@ MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 (the 5
 
 def mfma_probe(cfg, device, rows, iters=20):
     """MFMA utilisation of the widest dense contraction of a 64-stream step: the prefill gate/up projection (rows x 2*ffn x dim,
-    SwiGLU epilogue) on the hand-written dense kernel, HIP events around `iters` back-to-back launches on random operands, weights
-    rotating over copies (no launch finds its weights in the Infinity Cache)."""
+    SwiGLU epilogue) on the hand-written dense kernel (gemm_dense.hip), HIP events on the launch stream around `iters` back-to-back launches on
+    random operands, weights rotating over copies (no launch finds its weights in the Infinity Cache), output preallocated."""
     from infinisst_amd import engine as E
+    lib = E.load_library()
     N, K = 2 * cfg.llm_ffn, cfg.llm_dim
     g = torch.Generator(device=device)
     g.manual_seed(2)
@@ -314,13 +321,19 @@ def mfma_probe(cfg, device, rows, iters=20):
         packs.append(E.op_pack_weight(w))
         del w
     x = torch.randn(rows, K, device=device, generator=g).bfloat16()
-    for p in packs:
-        E.op_gemm(x, p, N, "swiglu")
+    out = torch.empty((rows, N // 2), device=device, dtype=torch.bfloat16)
+
+    def launch(i):
+        rc = lib.isst_op_gemm(E._ptr(x), K, E._ptr(packs[i % 3]), None, None, 0, E._ptr(out), N // 2, rows, N, K, N // 2, E.EPI["swiglu"], None, 0.0, E._stream_ptr())
+        if rc:
+            raise RuntimeError(f"isst_op_gemm -> {rc}")
+    for i in range(3):
+        launch(i)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for i in range(iters):
-        E.op_gemm(x, packs[i % 3], N, "swiglu")
+        launch(i)
     ev1.record()
     torch.cuda.synchronize()
     us = 1e3 * ev0.elapsed_time(ev1) / iters
@@ -329,7 +342,7 @@ def mfma_probe(cfg, device, rows, iters=20):
     return {"bound": "mfma", "kernel": E.dense_kernel_name(), "shape": f"M={rows} N={N} K={K} (prefill gate/up of one layer, 64 streams x 22 rows)",
             "launch_us": round(us, 2), "flop_per_launch": flop, "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-            "source": "HIP events in this run (op_gemm allocates its output per call: the figure includes that); rocprofv3 per-kernel durations: profiles/r03/"}
+            "source": "HIP events in this run; rocprofv3 per-kernel durations and the MFMA-busy counters of the same kernel: profiles/r03/"}
 
 
 def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
