@@ -160,10 +160,6 @@ bool gemm_mid_supported(const GemmArgs& g);                        // gemm_mid.h
 bool gemm_mid_preferred(const GemmArgs& g);                       // ... and long enough a weight stream to pay for the staging
 int launch_gemm_mid(const GemmArgs& g, hipStream_t stream);
 void gemm_mid_set_tuning(int wn);
-bool gemm_ring_supported(const GemmArgs& g);                       // gemm_ring.hip: 33..64 rows (launch_gemm_mid routes to it)
-int launch_gemm_ring(const GemmArgs& g, hipStream_t stream);
-void gemm_ring_set(int mode);                                      // profiling aid: 0 = gemm_mid.hip keeps 33..64 rows
-void gemm_ring_set_np(int np);
 void gemm_mid_set_min_rows(int rows);                              // rows above which gemm_mid replaces the skinny kernel (default 16)
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,
                        int tile_phase, int conv_k, hipStream_t stream);

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
 // tuning overrides for profiles/gemv_sweep.py (0 = heuristic)
 static int g_tune_w = 0, g_force_skinny = 0, g_tune_merge_w = 0, g_tune_flags = 0;
 // w: waves per workgroup of the skinny kernel (0 = heuristic, < 0 = never use the mid / tiled kernels); ntb: passed on to gemm_mid (its width / timing knobs)
-void gemm_set_tuning(int w, int ntb) { if (w >= 910000) { gemm_ring_set_np(w - 910000); return; } if (w >= 900000) { gemm_ring_set(w - 900000); return; } if (w >= 800000) { gemm_dense_set(w - 800000); return; } if (w >= 700000) { g_tune_flags = w - 700000; return; } if (w >= 300000) { g_tune_merge_w = w - 300000; return; } if (w >= 200000) { gemm_mid_set_min_rows(w - 200000); return; } if (w >= 100000) { gemm_tiled_set_raster(w - 100000); return; } g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
+void gemm_set_tuning(int w, int ntb) { if (w >= 800000) { gemm_dense_set(w - 800000); return; } if (w >= 700000) { g_tune_flags = w - 700000; return; } if (w >= 300000) { g_tune_merge_w = w - 300000; return; } if (w >= 200000) { gemm_mid_set_min_rows(w - 200000); return; } if (w >= 100000) { gemm_tiled_set_raster(w - 100000); return; } g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
 
 static inline bool gemm_can_stage(const GemmArgs& g) {
     return g.batch == 1 && g.M <= 16 && (size_t)g.M * g.K * 2 <= 64 * 1024 && g.M <= GEMM_FUSED_NORM_MAX_M;
