@@ -159,6 +159,9 @@ int isst_debug_tap(isst_handle* h, const char* name, uint16_t* dst, int64_t max_
  * of isst_generate is bracketed by a HIP event pair on the caller's stream; _end synchronises `hip_stream` and returns the
  * average bracket in microseconds (kernel execution + the dispatch latency of that launch) and the number of launches. */
 int isst_profile_begin(isst_handle* h);
+/* the same bracket around the gate/up launch of every Llama pass of rows_lo..rows_hi rows (isst_profile_begin = 1..1): the prefill pass of a many-stream
+ * step is the widest dense contraction of the path, and back-to-back launches of it alone run at lower clocks than it does inside a step */
+int isst_profile_begin_rows(isst_handle* h, int rows_lo, int rows_hi);
 int isst_profile_end(isst_handle* h, void* hip_stream, double* avg_us, int64_t* launches);
 
 /* unrotated K and V (128 bf16 each) of logical position `pos`, kv head `kv_head`, layer `layer` in the arena of beam

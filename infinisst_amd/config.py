@@ -32,6 +32,9 @@ class ModelConfig:
     # (reference agents/infinisst.py:173): "bf16" = positions, inv_freq, angles, cos/sin and
     # every product rounded to bf16; "fp32" = fp32 tables, one rounding at the end.
     enc_rope_mode: str = "bf16"
+    # --rope (reference agents/options.py:37-41, patch_speech_encoder.py:488-493, :823): False = no rotation of q / k, the bf16
+    # sinusoid of each frame's stream position is added to the encoder input instead
+    enc_rope: bool = True
     # --- length shrink + projector (reference model/speech_encoder.py:117-121)
     shrink_layers: List[Tuple[int, int, int]] = field(default_factory=lambda: [(1024, 2, 2)] * 2)
     # --- Llama decoder

@@ -129,6 +129,7 @@ struct isst_handle {
 
     // in-situ timing of the dominant kernel (isst_profile_begin / _end): HIP event pairs around every decode-pass gate/up GEMV
     bool prof_on = false;
+    int prof_rows_lo = 1, prof_rows_hi = 1;  // passes whose gate/up launch is bracketed (1..1: the decode GEMV, the roofline kernel)
     std::vector<hipEvent_t> prof_ev;  // pairs (start, stop)
     size_t prof_used = 0;
 
@@ -1045,8 +1046,26 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     const int qs = h->qkv_slices > 0 ? h->qkv_slices : (rows > 32 ? 2 : 1);
     const int sqf = (fr && qs > 1 && DL % (256 * qs) == 0) ? qs : 1;
     bool pending = false, pending_fused = false;
+    // in-situ timing (isst_profile_begin / _begin_rows): an event pair around the gate/up launch of every layer of a pass whose row count is in the
+    // profiled range -- opens the bracket and hands back the event that closes it
+    auto prof_open = [&](hipEvent_t* close) -> int {
+        *close = nullptr;
+        if (!h->prof_on || rows < h->prof_rows_lo || rows > h->prof_rows_hi) return ISST_OK;
+        if (h->prof_used + 2 > h->prof_ev.size()) {
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                h->prof_ev.push_back(e);
+            }
+        }
+        HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], st));
+        *close = h->prof_ev[h->prof_used + 1];
+        h->prof_used += 2;
+        return ISST_OK;
+    };
     for (int l = 0; l < c.llm_layers; ++l) {
         const LlmLayer& L = h->llm[l];
+        hipEvent_t pe = nullptr;
         // decode shapes: RMSNorm is applied inside the projection's A-fragment load (gemm.hip NORM); larger row counts
         // (prefill, many streams) run the norm kernel once instead of once per workgroup
         const bool fuse = rows <= LLM_FUSED_NORM_MAX_ROWS;
@@ -1087,11 +1106,15 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                                  max_unit_groups, n_beam_wgs, merge_in_oproj ? &merge_splits : nullptr, h->inline_combine ? h->attn_cnt : nullptr));
         if (so > 1 && fr) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st, h->lx, DL, h->lssq));
+            CHK(prof_open(&pe));
             CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps, h->lssq));
+            if (pe) HIPCHK(hipEventRecord(pe, st));
         } else if (so > 1) {
             CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
             CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+            CHK(prof_open(&pe));
             CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+            if (pe) HIPCHK(hipEventRecord(pe, st));
         } else {
             if (merge_splits > 0) {
                 GemmArgs g{};
@@ -1103,25 +1126,14 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
             }
             if (fuse) {
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (h->prof_on && rows == 1) {  // the roofline kernel: one-token gate/up GEMV with the fused RMSNorm
-                    if (h->prof_used + 2 > h->prof_ev.size()) {
-                        for (int k = 0; k < 2; ++k) {
-                            hipEvent_t e;
-                            HIPCHK(hipEventCreate(&e));
-                            h->prof_ev.push_back(e);
-                        }
-                    }
-                    e0 = h->prof_ev[h->prof_used];
-                    e1 = h->prof_ev[h->prof_used + 1];
-                    h->prof_used += 2;
-                    HIPCHK(hipEventRecord(e0, st));
-                }
+                CHK(prof_open(&pe));
                 CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
-                if (e1) HIPCHK(hipEventRecord(e1, st));
+                if (pe) HIPCHK(hipEventRecord(pe, st));
             } else {
                 CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+                CHK(prof_open(&pe));
                 CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+                if (pe) HIPCHK(hipEventRecord(pe, st));
             }
         }
         if (sd > 1 && fr) {  // (the last layer too: lx is complete when the launch ends, and lm_head can take the sums of squares)
@@ -1876,12 +1888,15 @@ extern "C" int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block
     gemm_set_tuning(waves_per_block, ntiles_per_block);
     return ISST_OK;
 }
-extern "C" int isst_profile_begin(isst_handle* h) {
-    if (!h) return ISST_ERR_ARG;
+extern "C" int isst_profile_begin_rows(isst_handle* h, int rows_lo, int rows_hi) {
+    if (!h || rows_lo < 1 || rows_hi < rows_lo) return h ? h->fail(ISST_ERR_ARG, "isst_profile_begin_rows: bad row range %d..%d", rows_lo, rows_hi) : ISST_ERR_ARG;
     h->prof_on = true;
     h->prof_used = 0;
+    h->prof_rows_lo = rows_lo;
+    h->prof_rows_hi = rows_hi;
     return ISST_OK;
 }
+extern "C" int isst_profile_begin(isst_handle* h) { return isst_profile_begin_rows(h, 1, 1); }
 extern "C" int isst_profile_end(isst_handle* h, void* hip_stream, double* avg_us, int64_t* launches) {
     if (!h || !avg_us || !launches) return ISST_ERR_ARG;
     h->prof_on = false;

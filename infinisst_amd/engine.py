@@ -70,7 +70,7 @@ EXPORTS = [
     "isst_stream_import_llm_kv", "isst_stream_import_enc_kv", "isst_stream_import_audio_history",
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
     "isst_op_attn_combine", "isst_op_gemm_attn_merge", "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
-    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_end", "isst_op_pack_weight",
+    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_begin_rows", "isst_profile_end", "isst_op_pack_weight",
     "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample", "isst_op_warp_sample", "isst_op_sample_uniform",
 ]
 
@@ -121,6 +121,7 @@ def load_library(path: Optional[str] = None):
     lib.isst_debug_tap.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     lib.isst_debug_read_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.isst_profile_begin.argtypes = [C.c_void_p]
+    lib.isst_profile_begin_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.isst_profile_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.isst_op_pack_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.isst_op_packed_elems.argtypes = [C.c_int, C.c_int]
@@ -407,11 +408,12 @@ class Engine:
         self._check(self.lib.isst_debug_read_kv(self.h, sid, beam, layer, kv_head, pos, k.data_ptr(), v.data_ptr()), "isst_debug_read_kv")
         return k, v
 
-    def profile_begin(self):
-        self._check(self.lib.isst_profile_begin(self.h), "isst_profile_begin")
+    def profile_begin(self, rows_lo: int = 1, rows_hi: int = 1):
+        """Bracket the gate/up launch of every Llama pass of rows_lo..rows_hi rows (default: the one-token decode GEMV)."""
+        self._check(self.lib.isst_profile_begin_rows(self.h, rows_lo, rows_hi), "isst_profile_begin_rows")
 
     def profile_end(self):
-        """(average event bracket in us around the one-token gate/up GEMV, launches timed) since profile_begin."""
+        """(average event bracket in us around the profiled gate/up launches, launches timed) since profile_begin."""
         avg, n = C.c_double(0.0), C.c_int64(0)
         self._check(self.lib.isst_profile_end(self.h, _stream_ptr(), C.byref(avg), C.byref(n)), "isst_profile_end")
         return avg.value, n.value

@@ -15,11 +15,14 @@ fairseq 0.12.2 ConvFeatureExtractionModel(mode=layer_norm, conv_bias) and rotary
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
 import torch
 import torch.nn.functional as F
+
+NO_ROPE = "no-rope"  # the `rope` argument of the functions below under --rope 0 (cfg.enc_rope False)
 
 ENC = "model.speech_encoder.speech_encoder."
 SHR = "model.speech_encoder.length_shrink."
@@ -125,6 +128,24 @@ def rotate_queries_with_cached_keys(q, k, cos_tab, sin_tab, mode: str):
 
 
 # --------------------------------------------------------------------------------------------
+# absolute positions (--rope 0)  (patch_speech_encoder.py:448-461, :488-493)
+# --------------------------------------------------------------------------------------------
+def sinusoidal_positional_embedding(offset: int, length: int, d_model: int) -> torch.Tensor:
+    """(length, d_model) bf16, rows offset .. offset+length-1: [sin(p * f_j) | cos(p * f_j)], f_j = exp(-j ln(1e4) / (d/2 - 1)).
+    Everything is bf16 in the reference, whatever the model dtype: the index j, the frequencies, the positions themselves
+    (integers above 256 round to the bf16 grid: 257 -> 256, 1001 -> 1000, ...), their product and sin / cos."""
+    half = d_model // 2
+    step = math.log(10000) / (half - 1)
+    freq = torch.exp(torch.arange(half, dtype=torch.bfloat16) * -step)
+    pos = torch.arange(offset, offset + length, dtype=torch.bfloat16)
+    ang = pos.unsqueeze(1) * freq.unsqueeze(0)
+    emb = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1).view(length, -1)
+    if d_model % 2 == 1:
+        emb = torch.cat([emb, torch.zeros(length, 1)], dim=1)
+    return emb
+
+
+# --------------------------------------------------------------------------------------------
 # conv feature extractor  [3P fairseq ConvFeatureExtractionModel(mode="layer_norm"), restated]
 # call sites: patch_speech_encoder.py:245-251
 # --------------------------------------------------------------------------------------------
@@ -182,8 +203,9 @@ def mha_forward(w, cfg, prefix: str, x: torch.Tensor, attn_mask: torch.Tensor, c
         k, v = cache.k, cache.v
     else:
         cache.k, cache.v = k, v
-    cos_tab, sin_tab, mode = rope
-    q, k = rotate_queries_with_cached_keys(q, k, cos_tab, sin_tab, mode)  # :824
+    if rope is not NO_ROPE:  # :823
+        cos_tab, sin_tab, mode = rope
+        q, k = rotate_queries_with_cached_keys(q, k, cos_tab, sin_tab, mode)  # :824
     attn = torch.bmm(q, k.transpose(1, 2))  # :853, output in x.dtype
     attn += attn_mask.unsqueeze(0)  # :858-862 (in place, keeps dtype)
     attn_f = F.softmax(attn.float(), dim=-1)  # :887-889 utils.softmax -> fp32
@@ -211,7 +233,10 @@ def encoder_layer(w, cfg, i: int, x, attn_mask, cache: LayerCache, rope):
 def transformer_encoder(w, cfg, x: torch.Tensor, cache: W2V2RoPECache, blocksize: int, rope,
                         return_layers: bool = False):
     """uni_transformer_encoder_extract_features + _forward (patch_speech_encoder.py:464-554, :440-446).
-    x: (1, T, C).  No positional conv (ROPE path, :488-498)."""
+    x: (1, T, C).  No positional conv; `rope is NO_ROPE` (--rope 0) adds the absolute sinusoid of the frames' stream positions
+    instead of rotating q / k (:488-493)."""
+    if rope is NO_ROPE:
+        x = x + sinusoidal_positional_embedding(cache.n_steps, x.size(1), x.size(2))
     x = x.transpose(0, 1)  # T x B x C (:501)
     prefix_len, seq_len = cache.n_steps, x.size(0)
     if prefix_len > 0:  # :506-509
@@ -270,6 +295,8 @@ def new_cache(cfg) -> W2V2RoPECache:
 
 
 def make_rope(cfg, max_pos: Optional[int] = None, inv_freq: Optional[torch.Tensor] = None):
+    if not getattr(cfg, "enc_rope", True):
+        return NO_ROPE
     n = max_pos or (cfg.max_cache_size + 8 * cfg.block_size * 4)
     cos, sin = enc_rope_tables(n, cfg.enc_head_dim, cfg.enc_rope_theta, cfg.enc_rope_mode, inv_freq)
     return cos, sin, cfg.enc_rope_mode

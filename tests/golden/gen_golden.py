@@ -266,6 +266,45 @@ def gen_encoder(pse, msp):
     print("encoder.npz", len(out))
 
 
+# ------------------------------------------------------------------ 2b. encoder stack, --rope 0 --
+def gen_encoder_abs_pos(pse, msp):
+    """The reference's own absolute-position branch (patch_w2v2(xpos, rope=0): patch_speech_encoder.py:448-461, :488-493, :823):
+    the sinusoid function at offsets on both sides of the bf16 integer grid, and the streaming encoder with it."""
+    from infinisst_amd.config import toy_config
+    from infinisst_amd import synth
+    cfg = toy_config().replace(block_size=16, max_cache_size=40, enc_rope=False)
+    out = {"block_size": np.array(cfg.block_size), "max_cache_size": np.array(cfg.max_cache_size)}
+    cases = [(0, 16, 64), (16, 16, 64), (250, 16, 64), (1000, 48, 64), (22491, 48, 1024), (65000, 7, 33)]
+    for n, (off, length, d) in enumerate(cases):
+        out[f"pos_{n}_args"] = np.array([off, length, d])
+        out[f"pos_{n}"] = pse.sinusoidal_positional_embedding(off, length, d, "cpu").float().numpy()
+    out["n_pos"] = np.array(len(cases))
+    pse.patch_w2v2(1, 0)
+    try:
+        for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            w = synth.random_weights(cfg, dtype=dtype, std=0.08, norm_jitter=0.1, seed=4321)
+            model = build_ref_encoder(pse, cfg, w, dtype)
+            cache = msp.W2V2RoPECache(max_steps=cfg.max_cache_size, layers=[msp.LayerCache() for _ in range(cfg.enc_layers)])
+            n_chunks = 20  # 16 frames each: positions cross 256, where bf16 stops holding every integer
+            audio = synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=5)
+            for c in range(n_chunks):
+                seg = torch.from_numpy(audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples])
+                if c == 0:
+                    seg = torch.cat([torch.zeros(cfg.first_chunk_offset), seg])
+                with torch.no_grad():
+                    res = model.forward(seg.unsqueeze(0).to(dtype), padding_mask=None, mask=False, features_only=True, cache=cache)
+                if c < 3 or c >= n_chunks - 4:
+                    out[f"{tag}_x_{c}"] = res["x"].float().numpy()
+                    out[f"{tag}_k0_{c}"] = cache.layers[0].k.float().numpy()
+                    out[f"{tag}_state_{c}"] = np.array([cache.src.size(1), cache.src_len, cache.n_steps])
+        out["audio"] = audio
+        out["n_chunks"] = np.array(n_chunks)
+    finally:
+        pse.patch_w2v2(0, 1)
+    np.savez_compressed(os.path.join(OUT, "encoder_abs_pos.npz"), **out)
+    print("encoder_abs_pos.npz", len(out))
+
+
 # ------------------------------------------------------------------ 3. length shrink -------------
 def gen_shrink(msp):
     torch.manual_seed(7)
@@ -1117,6 +1156,7 @@ def main():
     msp = importlib.import_module("model.speech_encoder")
     gen_masks(pse)
     gen_encoder(pse, msp)
+    gen_encoder_abs_pos(pse, msp)
     gen_shrink(msp)
     gen_llm_attention()
     gen_agent()
