@@ -63,6 +63,8 @@ typedef struct isst_config {
     int max_system_prompt;   /* pinned system-prompt capacity (--always-cache-system-prompt) */
     int debug_taps;          /* keep copies of intermediate activations for isst_debug_tap */
     int max_beams;           /* largest num_beams of a generate call (1 = greedy only); KV arenas are allocated per beam */
+    int enc_abs_pos;         /* --rope 0 (agents/options.py:37-41): q / k are not rotated (hand isst_set_rope_tables cos = 1, sin = 0), the bf16 sinusoid
+                                of each frame's stream position is added to the encoder input instead (isst_set_enc_position_table) */
 } isst_config;
 
 /* generation arguments of one call; mirrors the keyword arguments at agents/infinisst.py:307-332 */
@@ -109,7 +111,13 @@ int isst_load_weight(isst_handle* h, const char* name, const void* data, int ndi
  * LLM (HF LlamaRotaryEmbedding llama3, patch_llm.py:290-299): bf16 cos/sin [llm_rows][64] (first half of the dims). */
 int isst_set_rope_tables(isst_handle* h, const float* enc_cos, const float* enc_sin, int enc_rows, const uint16_t* llm_cos,
                          const uint16_t* llm_sin, int llm_rows);
-int isst_finalize_weights(isst_handle* h); /* fails listing the first missing tensor */
+/* cfg.enc_abs_pos only (--rope 0): the sinusoid the reference adds to the encoder input (sinusoidal_positional_embedding,
+ * patch_speech_encoder.py:448-461), bf16 bits [rows][enc_dim].  The reference holds the positions themselves in bf16, so the table has one row per
+ * bf16 integer: rows 0..255 = positions 0..255; row 256 + i = the position whose bf16 bit pattern is 0x4380 + i (256, 258, ..., 512, 516, ...).
+ * ISST_ENC_POS_ROWS rows reach position 2^24 (93 hours of audio); a stream that runs past the last row given fails loudly. */
+#define ISST_ENC_POS_ROWS 2305
+int isst_set_enc_position_table(isst_handle* h, const uint16_t* table, int rows);
+int isst_finalize_weights(isst_handle* h); /* fails listing the first missing tensor; needs the tables above */
 
 /* ---- per-utterance state (replaces S2TAgentStates.reset / build_states, agents/infinisst.py:50-67,115-123) ---- */
 int isst_stream_open(isst_handle* h, int* stream_id);

@@ -246,14 +246,18 @@ class InfiniSST(_AgentBase):
         """reference agents/infinisst.py:130-183 on the MI355X engine: tokenizer (+ the speech / latency tokens `preprocess` adds),
         the `--suppress-non-language` scan, model geometry, engine, `--state-dict-path`, chat-template prompts.
 
-        * `--xpos` must be 0 and `--rope` 1 (the production setting, scripts/infer/infinisst.sh:74; the xpos / absolute-position
-          variants of patch_w2v2 are not part of the hot path), `--w2v2-type` must be w2v2 (:168-171).
+        * `--rope 1 --xpos 0` is the production setting (scripts/infer/infinisst.sh:74); `--rope 0` (absolute sinusoid positions, the reference's own
+          arithmetic: patch_speech_encoder.py:448-461, :488-493) runs too, whatever `--xpos` says (the rotary module is built and never called, :823);
+          `--rope 1 --xpos 1` is refused: the xpos scaling lives in the un-vendored rotary_embedding_torch and cannot be pinned here.
+          `--w2v2-type` must be w2v2 (:168-171).
         * `--w2v2-path` / `--ctc-finetuned` only decide the fairseq architecture the reference instantiates before
           `load_state_dict` overwrites every weight (:155-180); here the geometry is read from the state dict itself
           (`checkpoint.infer_config`), so they are accepted and unused."""
         from . import checkpoint, harness
-        if int(getattr(args, "xpos", 0)) != 0 or int(getattr(args, "rope", 1)) != 1:
-            raise NotImplementedError("only --xpos 0 --rope 1 (rotary streaming encoder, the production setting) is implemented")
+        rotary = bool(int(getattr(args, "rope", 1)))
+        if rotary and int(getattr(args, "xpos", 0)) != 0:
+            raise NotImplementedError("--rope 1 --xpos 1 is not implemented (xpos scaling of the un-vendored rotary_embedding_torch); "
+                                      "--xpos 0 (the production setting) and --rope 0 are")
         if getattr(args, "w2v2_type", None) not in (None, "w2v2"):
             raise ValueError(f"Unsupported type: {args.w2v2_type}")  # reference :171
         if not getattr(args, "state_dict_path", None):
@@ -283,8 +287,12 @@ class InfiniSST(_AgentBase):
         mode = os.environ.get("INFINISST_ENC_ROPE_MODE")
         if mode:
             cfg = cfg.replace(enc_rope_mode=mode)
-        logger.warning("speech-encoder rotary arithmetic: enc_rope_mode=%s (INFINISST_ENC_ROPE_MODE=bf16|fp32 switches it; how to decide: DESIGN.md section 4)",
-                       cfg.enc_rope_mode)
+        cfg = cfg.replace(enc_rope=rotary)
+        if rotary:
+            logger.warning("speech-encoder rotary arithmetic: enc_rope_mode=%s (INFINISST_ENC_ROPE_MODE=bf16|fp32 switches it; how to decide: "
+                           "DESIGN.md section 4)", cfg.enc_rope_mode)
+        else:
+            logger.warning("speech encoder without rotary positions (--rope 0): bf16 sinusoid of the stream position added to the encoder input")
         self.cfg = cfg
         self.llama31 = "3.1" in str(args.model_name)  # :183
         self.decode_fn = self.prompt_fn = None

@@ -159,6 +159,8 @@ struct isst_handle {
     float *enc_cos = nullptr, *enc_sin = nullptr;
     bf16_t *llm_cos = nullptr, *llm_sin = nullptr;
     int enc_rope_rows = 0, llm_rope_rows = 0;
+    bf16_t* enc_pos = nullptr;  // cfg.enc_abs_pos (--rope 0): sinusoid rows [enc_pos_rows][enc_dim], one per bf16 integer position (isst_set_enc_position_table)
+    int enc_pos_rows = 0;
     bf16_t* stage = nullptr;
     size_t stage_bytes = 0;
 
@@ -672,11 +674,33 @@ extern "C" int isst_set_rope_tables(isst_handle* h, const float* enc_cos, const 
     return ISST_OK;
 }
 
+// position held by row `row` of the --rope 0 table (rows above 255 are consecutive bf16 bit patterns from 256.0 = 0x4380)
+static float enc_pos_row_value(int row) {
+    if (row < 256) return (float)row;
+    const uint32_t bits = (uint32_t)(0x4380 + row - 256) << 16;
+    float f;
+    std::memcpy(&f, &bits, sizeof f);
+    return f;
+}
+extern "C" int isst_set_enc_position_table(isst_handle* h, const uint16_t* table, int rows) {
+    if (!h || !table) return h ? h->fail(ISST_ERR_ARG, "isst_set_enc_position_table: null table") : ISST_ERR_ARG;
+    if (!h->cfg.enc_abs_pos) return h->fail(ISST_ERR_STATE, "isst_set_enc_position_table: the handle was created with rotary positions (enc_abs_pos 0)");
+    if (rows < 257 || rows > ISST_ENC_POS_ROWS) return h->fail(ISST_ERR_ARG, "isst_set_enc_position_table: %d rows, expected 257..%d", rows, ISST_ENC_POS_ROWS);
+    if (!h->enc_pos) {
+        h->enc_pos = h->dalloc<bf16_t>((size_t)ISST_ENC_POS_ROWS * h->cfg.enc_dim, true);
+        if (!h->enc_pos) return h->fail(ISST_ERR_NOMEM, "isst_set_enc_position_table: device allocation failed");
+    }
+    HIPCHK(hipMemcpy(h->enc_pos, table, (size_t)rows * h->cfg.enc_dim * sizeof(bf16_t), hipMemcpyHostToDevice));
+    h->enc_pos_rows = rows;
+    return ISST_OK;
+}
+
 extern "C" int isst_finalize_weights(isst_handle* h) {
     if (!h) return ISST_ERR_ARG;
     for (const auto& n : h->expected)
         if (!h->loaded.count(n)) return h->fail(ISST_ERR_STATE, "missing tensor %s", n.c_str());
     if (!h->rope_set) return h->fail(ISST_ERR_STATE, "rotary tables not set (isst_set_rope_tables)");
+    if (h->cfg.enc_abs_pos && !h->enc_pos_rows) return h->fail(ISST_ERR_STATE, "enc_abs_pos is set and the position table is not (isst_set_enc_position_table)");
     HIPCHK(hipDeviceSynchronize());
     if (h->stage) { (void)hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
     h->finalized = true;
@@ -893,6 +917,14 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
     }
     EncStreamView* ev = reinterpret_cast<EncStreamView*>(h->meta_dev);
     HIPCHK(hipMemcpyAsync(ev, ev_host, sizeof(EncStreamView) * n, hipMemcpyHostToDevice, st));
+    if (c.enc_abs_pos) {  // --rope 0: the frames' stream positions go into the input instead of into q / k (patch_speech_encoder.py:488-493)
+        for (int i = 0; i < n; ++i) {
+            const long last = (long)h->streams[sids[i]].enc_steps + Q - 1;
+            const long covered = h->enc_pos_rows <= 256 ? h->enc_pos_rows - 1 : (long)enc_pos_row_value(h->enc_pos_rows - 1);
+            if (last > covered) return h->fail(ISST_ERR_STATE, "stream %d is at frame %ld, the position table ends at %ld", sids[i], last, covered);
+        }
+        CHK(launch_enc_add_position(h->ex, ev, h->enc_pos, h->enc_pos_rows, n, Q, D, st));
+    }
     const int bs = c.block_size * multiplier;
     // the n streams of a call must be laid out with ONE stream stride between ring bases: use per-stream pointers
     // via a base + sid * stride scheme -> requires contiguous slots; general case: launch per stream

@@ -26,6 +26,7 @@ struct LlmStreamView {
     long beam_stride;
 };
 
+int launch_enc_add_position(bf16_t* x, const EncStreamView* ev, const bf16_t* table, int table_rows, int n, int Q, int D, hipStream_t s);
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
 int launch_audio_window(const float* pcm, const float* const* ptrs, const int* sids, const bf16_t* hist_pool, long histp, bf16_t* window, long winp,
                         int hist, int n_samples, int n, hipStream_t s);

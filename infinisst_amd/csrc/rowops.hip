@@ -40,6 +40,37 @@ int launch_audio_hist_save(const bf16_t* window, long winp, const int* sids, bf1
     hipLaunchKernelGGL(audio_hist_save_kernel, dim3((unsigned)((hist + 255) / 256), n), dim3(256), 0, s, window, winp, sids, hist_pool, histp, hist, win);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
+// --rope 0 (patch_speech_encoder.py:448-461, :488-493): x[s][t][:] += sinusoid(prefix_s + t), bf16 + bf16 -> bf16.  The reference keeps the positions
+// themselves in bf16, so above 256 several frames share one row: the table holds one row per bf16 integer -- rows 0..255 = positions 0..255, row
+// 256 + i = the bf16 value with bits 0x4380 + i (256, 258, ..., 512, 516, ...) -- built on the host with the reference's own arithmetic (rope.py)
+__global__ void __launch_bounds__(128) enc_add_position_kernel(bf16_t* __restrict__ x, const EncStreamView* __restrict__ ev, const bf16_t* __restrict__ table,
+                                                                int table_rows, int Q, int D) {
+    const int t = blockIdx.x, s = blockIdx.y;
+    const int p = ev[s].prefix + t;
+    int row = p;
+    if (p >= 256) row = 256 + ((int)f2bf((float)p) - 0x4380);
+    row = row < table_rows ? row : table_rows - 1;
+    bf16_t* xr = x + ((size_t)s * Q + t) * D;
+    const bf16_t* tr = table + (size_t)row * D;
+    for (int c = threadIdx.x * 8; c < D; c += 128 * 8) {
+        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(xr + c), b = *reinterpret_cast<const u32x4_t*>(tr + c);
+        float fa[8], fb[8];
+        unpack8(a, fa);
+        unpack8(b, fb);
+        u32x4_t o;
+        o.x = pack_bf(fa[0] + fb[0], fa[1] + fb[1]);
+        o.y = pack_bf(fa[2] + fb[2], fa[3] + fb[3]);
+        o.z = pack_bf(fa[4] + fb[4], fa[5] + fb[5]);
+        o.w = pack_bf(fa[6] + fb[6], fa[7] + fb[7]);
+        *reinterpret_cast<u32x4_t*>(xr + c) = o;
+    }
+}
+int launch_enc_add_position(bf16_t* x, const EncStreamView* ev, const bf16_t* table, int table_rows, int n, int Q, int D, hipStream_t s) {
+    if (n <= 0 || Q <= 0) return ISST_OK;
+    if (D % 8 || !table || table_rows < 257) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(enc_add_position_kernel, dim3((unsigned)Q, (unsigned)n), dim3(128), 0, s, x, ev, table, table_rows, Q, D);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
 int launch_cast_f32_bf16(const float* src, bf16_t* dst, long n, hipStream_t s) {
     if (n <= 0) return ISST_OK;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);

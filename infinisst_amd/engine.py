@@ -43,7 +43,7 @@ class _Config(C.Structure):
         ("n_eos", C.c_int), ("eos_ids", C.c_int * ISST_MAX_EOS),
         ("max_streams", C.c_int), ("max_multiplier", C.c_int), ("max_prompt_len", C.c_int),
         ("max_new_tokens", C.c_int), ("max_llm_cache_size", C.c_int), ("max_system_prompt", C.c_int),
-        ("debug_taps", C.c_int), ("max_beams", C.c_int),
+        ("debug_taps", C.c_int), ("max_beams", C.c_int), ("enc_abs_pos", C.c_int),
     ]
 
 
@@ -65,7 +65,7 @@ class _StreamInfo(C.Structure):
 
 # every symbol include/infinisst_hip.h declares
 EXPORTS = [
-    "isst_create", "isst_destroy", "isst_last_error", "isst_load_weight", "isst_set_rope_tables",
+    "isst_create", "isst_destroy", "isst_last_error", "isst_load_weight", "isst_set_rope_tables", "isst_set_enc_position_table",
     "isst_finalize_weights", "isst_stream_open", "isst_stream_reset", "isst_stream_close", "isst_stream_info_get",
     "isst_stream_import_llm_kv", "isst_stream_import_enc_kv", "isst_stream_import_audio_history",
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
@@ -92,6 +92,7 @@ def load_library(path: Optional[str] = None):
     lib.isst_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
     lib.isst_load_weight.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
     lib.isst_set_rope_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.isst_set_enc_position_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.isst_finalize_weights.argtypes = [C.c_void_p]
     lib.isst_stream_open.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     lib.isst_stream_reset.argtypes = [C.c_void_p, C.c_int]
@@ -181,6 +182,7 @@ def make_c_config(cfg: ModelConfig, max_streams: int, max_multiplier: int, max_p
     c.max_new_tokens, c.max_llm_cache_size, c.max_system_prompt = max_new_tokens, max_llm_cache_size, max_system_prompt
     c.debug_taps = int(debug_taps)
     c.max_beams = max_beams
+    c.enc_abs_pos = int(not cfg.enc_rope)
     return c
 
 
@@ -248,6 +250,9 @@ class Engine:
         self._check(self.lib.isst_set_rope_tables(self.h, C.c_void_p(ec.data_ptr()), C.c_void_p(es.data_ptr()), rows_e,
                                                   C.c_void_p(lc.data_ptr()), C.c_void_p(ls.data_ptr()), rows_l),
                     "isst_set_rope_tables")
+        if not self.cfg.enc_rope:
+            table = rope.encoder_position_table(self.cfg)
+            self._check(self.lib.isst_set_enc_position_table(self.h, C.c_void_p(table.data_ptr()), table.shape[0]), "isst_set_enc_position_table")
         self._check(self.lib.isst_finalize_weights(self.h), "isst_finalize_weights")
         torch.cuda.synchronize()
 

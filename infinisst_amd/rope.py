@@ -22,6 +22,8 @@ def encoder_tables(cfg: ModelConfig, rows: int, inv_freq=None):
     """fp32 cos, sin of shape (rows, head_dim // 2).  `inv_freq`: the `rotary_emb.freqs` parameter of a checkpoint
     (strict load_state_dict overwrites the module's initial value with it), default: the module's initial value."""
     hd = cfg.enc_head_dim
+    if not cfg.enc_rope:  # --rope 0 (patch_speech_encoder.py:823): the kernel's rotation becomes the identity, exactly
+        return torch.ones(rows, hd // 2), torch.zeros(rows, hd // 2)
     inv = 1.0 / (cfg.enc_rope_theta ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd))
     if inv_freq is not None:
         if tuple(inv_freq.shape) != tuple(inv.shape):
@@ -35,6 +37,33 @@ def encoder_tables(cfg: ModelConfig, rows: int, inv_freq=None):
         raise ValueError(f"enc_rope_mode {cfg.enc_rope_mode!r}")
     ang = pos.unsqueeze(1) * inv.unsqueeze(0)
     return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+ENC_POS_ROWS = 2305  # = ISST_ENC_POS_ROWS (include/infinisst_hip.h)
+
+
+def encoder_position_values(rows: int = ENC_POS_ROWS) -> torch.Tensor:
+    """The positions a bf16 `arange` can hold, in table order: 0..255, then the bf16 bit patterns from 0x4380 (= 256.0) on."""
+    small = torch.arange(min(rows, 256), dtype=torch.float32)
+    if rows <= 256:
+        return small
+    bits = (torch.arange(rows - 256, dtype=torch.int32) + 0x4380) << 16
+    return torch.cat([small, bits.view(torch.float32)])
+
+
+def encoder_position_table(cfg: ModelConfig, rows: int = ENC_POS_ROWS) -> torch.Tensor:
+    """--rope 0: bf16 (rows, enc_dim) = [sin(p f_j) | cos(p f_j)] for every position p of `encoder_position_values`, with the arithmetic of the
+    reference's sinusoidal_positional_embedding (model/patches/patch_speech_encoder.py:448-461): index, frequency, position, product and
+    sin / cos all bf16.  handed to isst_set_enc_position_table; the kernel looks a frame's row up by the bf16 rounding of its position."""
+    d = cfg.enc_dim
+    if d % 2:
+        raise ValueError("enc_dim must be even")
+    half = d // 2
+    step = math.log(10000) / (half - 1)
+    freq = torch.exp(torch.arange(half, dtype=torch.bfloat16) * -step)
+    pos = encoder_position_values(rows).bfloat16()  # exact: every value is a bf16 integer
+    ang = pos.unsqueeze(1) * freq.unsqueeze(0)
+    return torch.cat([torch.sin(ang), torch.cos(ang)], dim=1).contiguous()
 
 
 def llama3_inv_freq(cfg: ModelConfig) -> torch.Tensor:

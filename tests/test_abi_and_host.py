@@ -296,12 +296,41 @@ def test_agent_constructs_from_args_alone(tmp_path, monkeypatch):
     assert eng.calls[0]["pin"] == agent.system_prompt_size and eng.calls[0]["prompt_len"] == len(first)
     assert type(acts[-1]).__name__ == "WriteAction" and acts[-1].finished
     assert all(isinstance(a.content, str) for a in acts if hasattr(a, "content"))
+    assert got.enc_rope
     with pytest.raises(NotImplementedError):
         A.InfiniSST(parser.parse_args(["--model-name", model_dir, "--state-dict-path", str(ckpt), "--xpos", "1", "--block-size", "48"]))
+    # --rope 0 runs (absolute sinusoid positions), with either --xpos: the rotary module is built and never called (patch_speech_encoder.py:823)
+    A.InfiniSST(parser.parse_args(["--model-name", model_dir, "--state-dict-path", str(ckpt), "--rope", "0", "--block-size", "48"]))
+    assert not _RecordingEngine.instances[-1].cfg.enc_rope
     with pytest.raises(ValueError, match="length-shrink-cfg"):
         bad = parser.parse_args(["--model-name", model_dir, "--state-dict-path", str(ckpt), "--xpos", "0", "--block-size", "48",
                                  "--length-shrink-cfg", "[(128,2,2)] * 3"])
         A.InfiniSST(bad)
+
+
+def test_position_table_rows_are_the_oracle_sinusoid():
+    """rope.encoder_position_table (what --rope 0 hands the library): row lookup by the bf16 rounding of the position reproduces
+    oracle.sinusoidal_positional_embedding at any offset, and the identity rotary tables leave q / k alone."""
+    from infinisst_amd import rope
+    from oracle import speech_encoder as oenc
+    cfg = toy_config().replace(enc_rope=False)
+    table = rope.encoder_position_table(cfg)
+    assert table.shape == (rope.ENC_POS_ROWS, cfg.enc_dim) and table.dtype == torch.bfloat16
+    vals = rope.encoder_position_values()
+    assert vals[255] == 255 and vals[256] == 256 and vals[257] == 258 and vals[-1] == 2 ** 24
+    assert torch.equal(vals, vals.bfloat16().float()) and bool((vals[1:] > vals[:-1]).all())
+
+    def row_of(p):  # the kernel's lookup (rowops.hip enc_add_position_kernel)
+        if p < 256:
+            return p
+        bits = torch.tensor([float(p)]).bfloat16().view(torch.int16).item() & 0xFFFF
+        return 256 + bits - 0x4380
+    for off in (0, 250, 1000, 22491, 65000, 2 ** 24 - 48):
+        want = oenc.sinusoidal_positional_embedding(off, 48, cfg.enc_dim)
+        got = torch.stack([table[row_of(off + t)] for t in range(48)])
+        assert torch.equal(got, want), off
+    cos, sin = rope.encoder_tables(cfg, 64)
+    assert bool((cos == 1).all()) and bool((sin == 0).all())
 
 
 def test_policy_closes_the_instance_when_the_last_step_brings_no_audio():

@@ -65,6 +65,46 @@ def test_encoder_streaming_equals_oneshot(golden_dir):
     assert np.abs(stream - g["fp32_oneshot"]).max() < 5e-5
 
 
+def test_sinusoid_positions_match_reference_bit_for_bit(golden_dir):
+    """sinusoidal_positional_embedding run unchanged (patch_speech_encoder.py:448-461) at offsets on both sides of 256, where
+    the bf16 position grid stops holding every integer."""
+    g = load(golden_dir, "encoder_abs_pos.npz")
+    for n in range(int(g["n_pos"])):
+        off, length, d = (int(v) for v in g[f"pos_{n}_args"])
+        got = oenc.sinusoidal_positional_embedding(off, length, d).float().numpy()
+        assert np.array_equal(got, g[f"pos_{n}"]), f"case {n}: offset {off}, {length} rows of {d}"
+    a = oenc.sinusoidal_positional_embedding(1000, 4, 64)
+    assert torch.equal(a[0], a[1]) and torch.equal(a[1], a[2]) and not torch.equal(a[2], a[3])  # 1000, 1001, 1002 are one bf16 position, 1003 -> 1004
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("fp32", torch.float32, 2e-5), ("bf16", torch.bfloat16, 6e-2)])
+def test_encoder_streaming_without_rope_matches_reference(golden_dir, tag, dtype, tol):
+    """The reference patched with rope=0 (patch_w2v2(1, 0): :488-493 adds the sinusoid, :823 skips the rotation), 20 chunks, vs
+    oracle.w2v2_forward with cfg.enc_rope False."""
+    g = load(golden_dir, "encoder_abs_pos.npz")
+    cfg = toy_config().replace(block_size=int(g["block_size"]), max_cache_size=int(g["max_cache_size"]), enc_rope=False)
+    w = synth.random_weights(cfg, dtype=dtype, std=0.08, norm_jitter=0.1, seed=4321)
+    rope = oenc.make_rope(cfg)
+    assert rope is oenc.NO_ROPE
+    cache = oenc.new_cache(cfg)
+    audio, n_chunks, seen = g["audio"], int(g["n_chunks"]), 0
+    for c in range(n_chunks):
+        seg = torch.from_numpy(audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples])
+        if c == 0:
+            seg = torch.cat([torch.zeros(cfg.first_chunk_offset), seg])
+        x = oenc.w2v2_forward(w, cfg, seg.unsqueeze(0).to(dtype), cache, cfg.block_size, rope)
+        if f"{tag}_x_{c}" not in g:
+            continue
+        seen += 1
+        ref = g[f"{tag}_x_{c}"]
+        assert x.shape == ref.shape
+        err = np.abs(x.float().numpy() - ref).max()
+        assert err <= tol, f"chunk {c}: max|d|={err}"
+        assert np.abs(cache.layers[0].k.float().numpy() - g[f"{tag}_k0_{c}"]).max() <= tol
+        assert [cache.src.size(1), cache.src_len, cache.n_steps] == [int(v) for v in g[f"{tag}_state_{c}"]]
+    assert seen == 7 and cache.n_steps > 256
+
+
 def test_shrink_block_matches_reference(golden_dir):
     """ConvFeatureExtractionModel (reference model/speech_encoder.py:18-78) vs oracle.shrink_block."""
     g = load(golden_dir, "shrink.npz")
