@@ -6,6 +6,7 @@ PyTorch is used here for plumbing only (device tensors handed over as raw pointe
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import os
 import time
 from typing import Dict, Optional, Sequence
@@ -184,6 +185,28 @@ def make_c_config(cfg: ModelConfig, max_streams: int, max_multiplier: int, max_p
     c.max_beams = max_beams
     c.enc_abs_pos = int(not cfg.enc_rope)
     return c
+
+
+def _pack_int32(seqs, n: int):
+    """n int32 sequences (lists, arrays or None) -> (owner of the memory, c_void_p[n] pointing into it or NULL, c_int[n] lengths)."""
+    if len(seqs) != n:
+        raise IsstError(f"{len(seqs)} sequences for {n} streams")
+    lens = [0 if s is None else len(s) for s in seqs]
+    total = sum(lens)
+    if total == 0:
+        return None, (C.c_void_p * n)(), (C.c_int * n)(*lens)
+    live = [s for s, l in zip(seqs, lens) if l]
+    if all(isinstance(s, np.ndarray) for s in live):
+        flat = np.concatenate(live).astype(np.int32, copy=False)
+    else:
+        flat = np.fromiter(itertools.chain.from_iterable(live), dtype=np.int32, count=total)
+    flat = np.ascontiguousarray(flat)
+    base = flat.ctypes.data
+    ptrs, off = [], 0
+    for l in lens:
+        ptrs.append(base + 4 * off if l else None)
+        off += l
+    return flat, (C.c_void_p * n)(*ptrs), (C.c_int * n)(*lens)
 
 
 class Engine:
@@ -373,28 +396,29 @@ class Engine:
         p.do_sample, p.temperature, p.top_k = int(gen.do_sample), float(gen.temperature), int(gen.top_k)
         p.top_p, p.epsilon_cutoff, p.seed = float(gen.top_p), float(gen.epsilon_cutoff), int(gen.seed)
         sid_arr = (C.c_int * n)(*stream_ids)
-        prompts = [np.asarray(x, dtype=np.int32) for x in prompt_ids]
-        prevs = [np.asarray(x, dtype=np.int32) for x in prev_target_ids]
-        outs = [np.zeros(gen.max_new_tokens, dtype=np.int32) for _ in range(n)]
-        forced = [None] * n if forced_tokens is None else [
-            None if f is None else np.asarray(f, dtype=np.int32) for f in forced_tokens]
-
-        def vp(arrs):
-            return (C.c_void_p * n)(*[None if a is None or a.size == 0 else a.ctypes.data for a in arrs])
-
-        def lens(arrs):
-            return (C.c_int * n)(*[0 if a is None else int(a.size) for a in arrs])
-
+        # every int32 sequence of the call lives in ONE buffer per argument, the per-stream pointers are offsets into it (64 streams: the
+        # marshalling is host time during which the GPU idles between two steps)
+        keep_p, prompt_ptrs, prompt_lens = _pack_int32(prompt_ids, n)
+        keep_v, prev_ptrs, prev_lens = _pack_int32(prev_target_ids, n)
+        keep_f, forced_ptrs, forced_lens = _pack_int32([None] * n if forced_tokens is None else forced_tokens, n)
+        outs = np.zeros((n, max(1, gen.max_new_tokens)), dtype=np.int32)
+        out_base, out_stride = outs.ctypes.data, outs.strides[0]
+        out_ptrs = (C.c_void_p * n)(*[out_base + i * out_stride for i in range(n)])
         out_lens = (C.c_int * n)()
         logits = np.zeros((n, gen.max_new_tokens, self.cfg.vocab), dtype=np.float32) if return_logits else None
-        pcm_ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in pcm]) if on_device else vp(pcm)
-        args = (self.h, C.byref(p), n, sid_arr, pcm_ptrs, n_samples, vp(prompts), lens(prompts), vp(prevs), lens(prevs), vp(forced), lens(forced),
-                (C.c_void_p * n)(*[o.ctypes.data for o in outs]), out_lens, None if logits is None else logits.ctypes.data, _stream_ptr())
+        if on_device:
+            pcm_ptrs = (C.c_void_p * n)(*[x.data_ptr() for x in pcm])
+        else:
+            pcm_ptrs = (C.c_void_p * n)(*[x.ctypes.data for x in pcm])
+        args = (self.h, C.byref(p), n, sid_arr, pcm_ptrs, n_samples, prompt_ptrs, prompt_lens, prev_ptrs, prev_lens, forced_ptrs, forced_lens,
+                out_ptrs, out_lens, None if logits is None else logits.ctypes.data, _stream_ptr())
         t0 = time.perf_counter()
         rc = self.lib.isst_generate(*args)
         self.last_call_seconds = time.perf_counter() - t0  # wall time inside the library (it returns once the last token id is on the host)
         self._check(rc, "isst_generate")
-        return [outs[i][: out_lens[i]].tolist() for i in range(n)], logits
+        del keep_p, keep_v, keep_f
+        rows = outs.tolist()
+        return [rows[i][: out_lens[i]] for i in range(n)], logits
 
     def encode_speech(self, sid: int, pcm: np.ndarray, multiplier: int = 1) -> torch.Tensor:
         """speech_encoder.encode_speech for one stream -> (S, llm_dim) bf16 CPU tensor (test aid)."""

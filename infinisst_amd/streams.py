@@ -17,6 +17,7 @@ import time
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -35,6 +36,30 @@ class _Slot:
     chunks: int = 0
     evictions: int = 0
     last_generated: List[int] = field(default_factory=list)  # every id sampled in the last chunk, the never-fed final one included
+    # target_ids once more as int32 in a buffer of a few windows, so that the per-tick window handed to the library is a view, not a
+    # list -> array conversion per stream (64 streams: that conversion was a fifth of the host time of a step)
+    hist: Optional[np.ndarray] = None
+    hist_n: int = 0
+
+    def push_targets(self, ids: Sequence[int], lookback: int):
+        k = len(ids)
+        if self.hist is None:
+            self.hist = np.zeros(4 * max(1, lookback) + 64, dtype=np.int32)
+        if self.hist_n + k > self.hist.size:  # compact: only the last `lookback` ids are ever read
+            keep = min(self.hist_n, lookback)
+            tail = self.hist[self.hist_n - keep:self.hist_n].copy()
+            if keep + k > self.hist.size:
+                self.hist = np.zeros(keep + k + 4 * max(1, lookback), dtype=np.int32)
+            self.hist[:keep] = tail
+            self.hist_n = keep
+        if k:
+            self.hist[self.hist_n:self.hist_n + k] = ids
+            self.hist_n += k
+
+    def window(self, lookback: int) -> Optional[np.ndarray]:
+        if self.hist is None or self.hist_n == 0 or lookback <= 0:
+            return None
+        return self.hist[max(0, self.hist_n - lookback):self.hist_n]
 
 
 class StreamBatch:
@@ -57,6 +82,7 @@ class StreamBatch:
         self.system_prompt_size = system_prompt_size
         self.prompt_fn = prompt_fn
         self.slots: List[Optional[_Slot]] = []
+        self._prompt_cache = {}  # (first chunk?, multiplier) -> int32 array: prompt_fn is a pure function of the two
         self.reset_timers()
 
     def reset_timers(self):
@@ -82,7 +108,7 @@ class StreamBatch:
         """S2TAgentStates.reset (:60-67): fresh speech cache / KV cache / target ids; the checkpoint list is agent-level and stays."""
         s = self._slot(idx)
         self.engine.reset_stream(s.sid)
-        s.started, s.target_ids = False, []
+        s.started, s.target_ids, s.hist_n = False, [], 0
 
     def _slot(self, idx: int) -> _Slot:
         if idx < 0 or idx >= len(self.slots) or self.slots[idx] is None:
@@ -104,6 +130,13 @@ class StreamBatch:
         s = self._slot(idx)
         s.ckpts, s.started = list(ckpts), started
 
+    def _prompt(self, first: bool, multiplier: int) -> np.ndarray:
+        key = (bool(first), int(multiplier))
+        got = self._prompt_cache.get(key)
+        if got is None:
+            got = self._prompt_cache[key] = np.asarray(self.prompt_fn(first, multiplier), dtype=np.int32)
+        return got
+
     # ------------------------------------------------------------------ one tick
     def step(self, audio: Sequence, forced_tokens=None, return_logits: bool = False):
         """`audio[i]`: the new samples of open stream i (fp32 numpy array, or a contiguous fp32 CUDA tensor: resident audio), already
@@ -120,8 +153,8 @@ class StreamBatch:
             return (outs, None) if return_logits else outs
         gen = self.gen
         slots = [self.slots[i] for i in active]
-        prompts = [self.prompt_fn(not s.started, gen.latency_multiplier) for s in slots]
-        prevs = [s.target_ids[-gen.no_repeat_ngram_lookback:] for s in slots]
+        prompts = [self._prompt(not s.started, gen.latency_multiplier) for s in slots]
+        prevs = [s.window(gen.no_repeat_ngram_lookback) for s in slots]
         pin = self.system_prompt_size if gen.always_cache_system_prompt else 0
         forced = None if forced_tokens is None else [forced_tokens[i] for i in active]
         gens, logits = self.engine.generate(gen, [s.sid for s in slots], [audio[i] for i in active], prompts, prevs,
@@ -139,6 +172,7 @@ class StreamBatch:
                 s.evictions += 1
             out = g[:-1]
             s.target_ids.extend(out)
+            s.push_targets(out, gen.no_repeat_ngram_lookback)
             if len(s.target_ids) > 4 * max(1, gen.no_repeat_ngram_lookback):  # only the last `lookback` ids are ever read
                 s.target_ids = s.target_ids[-gen.no_repeat_ngram_lookback:]
             outs[i] = out

@@ -308,6 +308,36 @@ def test_agent_constructs_from_args_alone(tmp_path, monkeypatch):
         A.InfiniSST(bad)
 
 
+def test_marshalling_helpers_keep_every_sequence():
+    """engine._pack_int32 (one buffer per argument, per-stream pointers into it) and streams._Slot's int32 window of target ids."""
+    import ctypes as C
+    from infinisst_amd.engine import _pack_int32
+    from infinisst_amd.streams import _Slot
+    rng = np.random.default_rng(3)
+    for as_arrays in (False, True):
+        seqs = [None, [], [5], list(range(7)), None, [int(x) for x in rng.integers(0, 1 << 20, size=100)]]
+        given = [None if q is None else (np.asarray(q, dtype=np.int32) if as_arrays else q) for q in seqs]
+        keep, ptrs, lens = _pack_int32(given, len(seqs))
+        for q, p_, l in zip(seqs, ptrs, lens):
+            assert l == (0 if q is None else len(q))
+            if l:
+                assert list(np.ctypeslib.as_array(C.cast(p_, C.POINTER(C.c_int)), shape=(l,))) == q
+            else:
+                assert not p_
+    keep, ptrs, lens = _pack_int32([None, []], 2)
+    assert keep is None and not ptrs[0] and not ptrs[1] and list(lens) == [0, 0]
+    slot, ref, look = _Slot(sid=0), [], 10
+    assert slot.window(look) is None
+    for step in range(300):
+        new = [int(x) for x in rng.integers(0, 1000, size=int(rng.integers(0, 9)))]
+        ref.extend(new)
+        slot.push_targets(new, look)
+        w = slot.window(look)
+        assert ([] if w is None else w.tolist()) == ref[-look:]
+    slot.push_targets(list(range(500)), look)  # one push longer than the whole buffer
+    assert slot.window(look).tolist() == list(range(490, 500))
+
+
 def test_position_table_rows_are_the_oracle_sinusoid():
     """rope.encoder_position_table (what --rope 0 hands the library): row lookup by the bf16 rounding of the position reproduces
     oracle.sinusoidal_positional_embedding at any offset, and the identity rotary tables leave q / k alone."""
@@ -452,7 +482,7 @@ class _FakeMultiEngine:
             st["len"] += len(pr) + n_gen - 1
             st["chunk"] += 1
             outs.append([int(x) for x in rng.integers(10, 900, size=n_gen)])
-            self.calls.append(dict(key=sid + self.key_offset, n=len(sids), prompt_len=len(pr), prev=list(pv), samples=len(a)))
+            self.calls.append(dict(key=sid + self.key_offset, n=len(sids), prompt_len=len(pr), prev=[] if pv is None else [int(x) for x in pv], samples=len(a)))
         return outs, None
 
     def stream_info(self, sid):

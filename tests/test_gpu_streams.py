@@ -27,7 +27,7 @@ class _Recording:
                                          forced_tokens=kw.get("forced_tokens"), return_logits=True)
         self.last_call_seconds = self.eng.last_call_seconds
         for i, sid in enumerate(sids):
-            self.last[sid] = (list(outs[i]), logits[i].copy(), list(prompts[i]), list(prevs[i]))
+            self.last[sid] = (list(outs[i]), logits[i].copy(), [int(t) for t in prompts[i]], [] if prevs[i] is None else [int(t) for t in prevs[i]])
         return outs, None
 
 
