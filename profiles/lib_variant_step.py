@@ -7,6 +7,8 @@ from infinisst_amd import engine as E
 lib = E.load_library(os.path.abspath(sys.argv[1])); E._lib = lib
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+if os.environ.get("AB_ATTN_WGS"):  # decode attention: target number of workgroups (splits per (stream, kv head) follow from it)
+    lib.isst_op_set_attn_tuning(int(os.environ["AB_ATTN_WGS"]))
 import bench
 from infinisst_amd.config import GenConfig, full_config
 cfg = full_config().replace(eos_ids=())
