@@ -6,6 +6,7 @@
 // model/patches/patch_llm.py:231-336 and model/patches/patch_hf.py:586-624).  No CPU fallback exists: every compute
 // step is a HIP kernel launch on the caller's stream.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1582,11 +1583,25 @@ extern "C" int isst_encode_speech(isst_handle* h, int stream_id, const float* pc
     return ISST_OK;
 }
 
+// ISST_HOST_TRACE=1: one line per isst_generate on stderr with the host-side timeline of the call (us): gap since the previous call returned, entry -> encoder
+// and prefill enqueued, the waits for each token, the host work between a token's arrival and the next pass being enqueued
+struct HostTrace {
+    bool on = false;
+    std::chrono::steady_clock::time_point t_entry, t_prev_return;
+    bool have_prev = false;
+    double enq_first = 0, wait = 0, between = 0, enq_pass = 0;
+    int waits = 0;
+    static double us(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
+};
+static HostTrace g_ht;
 extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const float* const* pcm, int n_samples,
                              const int* const* prompt_ids, const int* prompt_lens, const int* const* prev_target_ids, const int* n_prev,
                              const int* const* forced_tokens, const int* n_forced, int* const* out_ids, int* out_lens, float* logits_out,
                              void* hip_stream) {
     if (!h) return ISST_ERR_ARG;
+    static const bool ht_env = std::getenv("ISST_HOST_TRACE") && std::atoi(std::getenv("ISST_HOST_TRACE")) > 0;
+    g_ht.on = ht_env;
+    if (g_ht.on) { g_ht.t_entry = std::chrono::steady_clock::now(); g_ht.enq_first = g_ht.wait = g_ht.between = g_ht.enq_pass = 0; g_ht.waits = 0; }
     CHK(check_ready(h));
     const isst_config& c = h->cfg;
     if (!p || !stream_ids || !pcm || !prompt_ids || !prompt_lens || !out_ids || !out_lens) return h->fail(ISST_ERR_ARG, "null argument");
@@ -1790,9 +1805,13 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     };
 
     if (const int rc = sample_tail(n)) return rc;
+    std::chrono::steady_clock::time_point ht_a, ht_b;
+    if (g_ht.on) { ht_a = std::chrono::steady_clock::now(); g_ht.enq_first = HostTrace::us(g_ht.t_entry, ht_a); }
     while (true) {
         const int na = (int)active.size();
+        if (g_ht.on) ht_a = std::chrono::steady_clock::now();
         HIPCHK(hipStreamSynchronize(st));
+        if (g_ht.on) { ht_b = std::chrono::steady_clock::now(); g_ht.wait += HostTrace::us(ht_a, ht_b); g_ht.waits++; }
         if (p->do_sample)  // HF _sample with do_sample: warpers, softmax, one draw per row (patch_hf.py:606-624)
             for (int r = 0; r < na; ++r)
                 h->tok_host[r] = warp_and_sample(h->samp_host + (size_t)r * h->vocab_pad, c.vocab, p->temperature, p->top_k, p->top_p, p->epsilon_cutoff,
@@ -1831,7 +1850,9 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             mh.samp[r].n_enc = n_prev ? n_prev[i] : 0;
             mh.samp[r].ids_off = i * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
         }
+        if (g_ht.on) { ht_a = std::chrono::steady_clock::now(); g_ht.between += HostTrace::us(ht_b, ht_a); }
         if (const int rc = decode_step(nr)) return rc;  // (the failing call has already recorded its message)
+        if (g_ht.on) g_ht.enq_pass += HostTrace::us(ht_a, std::chrono::steady_clock::now());
     }
     // ---- 4. state: the cache holds the prompt and every generated token except the last one ----
     for (int i = 0; i < n; ++i) {
@@ -1839,6 +1860,14 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         s.llm_total = total0[i] + rows_len[i] + gen_count[i] - 1;
         s.chunks++;
         out_lens[i] = gen_count[i];
+    }
+    if (g_ht.on) {
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[isst host] n=%d since_prev_return %.1f  entry->prefill_enqueued %.1f  waits %d total %.1f  token->next_enqueue_start avg %.1f  enqueue_pass avg %.1f  call %.1f us\n", n,
+                     g_ht.have_prev ? HostTrace::us(g_ht.t_prev_return, g_ht.t_entry) : -1.0, g_ht.enq_first, g_ht.waits, g_ht.wait,
+                     g_ht.waits > 1 ? g_ht.between / (g_ht.waits - 1) : 0.0, g_ht.waits > 1 ? g_ht.enq_pass / (g_ht.waits - 1) : 0.0, HostTrace::us(g_ht.t_entry, now));
+        g_ht.t_prev_return = now;
+        g_ht.have_prev = true;
     }
     return ISST_OK;
 }
