@@ -412,6 +412,28 @@ def test_gemm_dense_is_bit_identical_to_gemm_tiled(M, N, K):
         _dense_mode(1)
 
 
+@pytest.mark.parametrize("M,N,K,lda,off", [(300, 512, 256, 448, 64), (1000, 272, 512, 512 + 8, 8), (200, 256, 384, 128, 0)])
+def test_gemm_dense_strided_and_overlapping_rows(M, N, K, lda, off):
+    """A given as a window of a wider matrix (lda > K, base not at a row start) and as OVERLAPPING rows (lda < K: the implicit-GEMM form of a strided
+    convolution, patch_speech_encoder.py:245-251 / model/speech_encoder.py:233): the LDS-DMA staging addresses rows by lda like every other kernel."""
+    g = torch.Generator().manual_seed(M + N + K + lda)
+    flat = bf(torch.randn(off + (M - 1) * lda + K + 64, generator=g)).to(DEV)
+    A = torch.as_strided(flat, (M, K), (lda, 1), off)
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf(torch.randn(N, generator=g))
+    Wp = E.op_pack_weight(W.to(DEV))
+    try:
+        _dense_mode(0)
+        want = E.op_gemm(A, Wp, N, "bias", bias=bias.to(DEV))
+        _dense_mode(2)
+        got = E.op_gemm(A, Wp, N, "bias", bias=bias.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        _dense_mode(1)
+    assert torch.equal(got, want), f"{int((got != want).sum())} elements differ from gemm_tiled"
+    close_bf16(got, ref_linear(A.cpu().contiguous(), W, "bias", bias, None), f"dense strided M{M} N{N} K{K} lda{lda}", ulps=2.5, atol=2e-3)
+
+
 @pytest.mark.parametrize("M,N,K,ks", [(384, 1024, 2048, 4), (1408, 512, 4096, 2), (130, 512, 512, 2), (700, 256, 1024, 8)])
 def test_gemm_dense_split_k_slabs(M, N, K, ks):
     """K slices of the dense kernel (EPI_PARTIAL: fp32 slabs) + the reducing residual / RMSNorm kernel, against the same pair on gemm_tiled (bit-identical:
