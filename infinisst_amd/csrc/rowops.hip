@@ -127,11 +127,84 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const bf16_t* __rest
     }
 }
 
+
+// The full-size form (C == 512, k == KK): a wave walks FR consecutive frames of one stream.  Each lane owns 8 CONSECUTIVE channels -- their KK x 8 weights,
+// bias and LayerNorm affine stay in registers for all FR frames (the one-frame kernel above re-reads 80 two-byte weights per lane and frame: at 64 streams
+// that is 16 M scattered vector loads, 594 us for 2 GFLOP) -- the frames' input samples are loaded once per wave (lane l holds samples l and l + 64 of the
+// wave's window) and broadcast by v_readlane, and a frame's 8 outputs leave as one 16-byte store.  Same rounding points, taps summed in the same order.
+template <int KK, int FR>
+__global__ __launch_bounds__(256) void conv0_frames_kernel(const bf16_t* __restrict__ audio, long audio_batch, const bf16_t* __restrict__ w /*[512][KK]*/,
+                                                           const bf16_t* __restrict__ bias, const bf16_t* __restrict__ ln_w, const bf16_t* __restrict__ ln_b,
+                                                           bf16_t* __restrict__ out, long out_batch, int T, int stride) {
+    constexpr int C = 512;
+    static_assert((KK * 8) % 8 == 0 && (FR - 1) * 7 + KK <= 128, "window of a wave (stride <= 7): two samples per lane");
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t0 = (blockIdx.x * 4 + wv) * FR;
+    if (t0 >= T) return;
+    const int nfr = min(FR, T - t0);
+    const bf16_t* a = audio + (long)blockIdx.y * audio_batch + (long)t0 * stride;
+    const int span = (nfr - 1) * stride + KK;  // (the launcher guarantees stride <= 7: span <= 128)
+    const int s0 = lane < span ? __float_as_int(bf2f(a[lane])) : 0;
+    const int s1 = lane + 64 < span ? __float_as_int(bf2f(a[lane + 64])) : 0;
+    float wr[8 * KK];  // wr[i * KK + j]: tap j of channel 8 lane + i
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(w + (long)lane * (8 * KK) + q * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[q * 8 + e] = f[e];
+    }
+    float bv[8], gw[8], gb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (bias) unpack8(*reinterpret_cast<const u32x4_t*>(bias + lane * 8), bv);
+    unpack8(*reinterpret_cast<const u32x4_t*>(ln_w + lane * 8), gw);
+    unpack8(*reinterpret_cast<const u32x4_t*>(ln_b + lane * 8), gb);
+    bf16_t* o = out + (long)blockIdx.y * out_batch + (long)t0 * C + lane * 8;
+    for (int f = 0; f < nfr; ++f) {
+        float x[KK];
+#pragma unroll
+        for (int j = 0; j < KK; ++j) {
+            const int idx = f * stride + j;  // wave-uniform
+            x[j] = __int_as_float(idx < 64 ? __builtin_amdgcn_readlane(s0, idx) : __builtin_amdgcn_readlane(s1, idx - 64));
+        }
+        float v[8], sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < KK; ++j) acc += x[j] * wr[i * KK + j];
+            if (bias) acc += bv[i];
+            v[i] = bfr(acc);
+            sum += v[i];
+        }
+        const float mean = wave_sum(sum) / C;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; sq += d * d; }
+        const float rstd = rsqrtf(wave_sum(sq) / C + 1e-5f);
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = gelu_erf(bfr((v[i] - mean) * rstd * gw[i] + gb[i]));
+        *reinterpret_cast<u32x4_t*>(o + (long)f * C) = pack8(y);
+    }
+}
+
 int launch_conv0(const bf16_t* audio, long audio_batch, const bf16_t* w, const bf16_t* bias, const bf16_t* ln_w,
                  const bf16_t* ln_b, bf16_t* out, long out_batch, int T, int C, int k, int stride, int batch,
                  hipStream_t s) {
     if (T <= 0) return ISST_OK;
     if (k > 16 || C > 512) return ISST_ERR_ARG;
+    if (C == 512 && k == 10 && stride <= 7 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && out_batch % 8 == 0) {
+        // wav2vec2's first layer.  Many frames (several streams): 16 per wave; one stream's 3 199 frames: 4 per wave, so that 200 workgroups remain
+        if ((long)batch * T >= 32768) {
+            hipLaunchKernelGGL((conv0_frames_kernel<10, 16>), dim3((T + 63) / 64, batch), dim3(256), 0, s, audio, audio_batch, w, bias, ln_w, ln_b, out, out_batch, T, stride);
+        } else {
+            hipLaunchKernelGGL((conv0_frames_kernel<10, 4>), dim3((T + 15) / 16, batch), dim3(256), 0, s, audio, audio_batch, w, bias, ln_w, ln_b, out, out_batch, T, stride);
+        }
+        return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+    }
     dim3 grid((T + 3) / 4, batch), block(256);
     if (C <= 64)
         hipLaunchKernelGGL(conv0_ln_gelu_kernel<1>, grid, block, 0, s, audio, audio_batch, w, bias, ln_w, ln_b, out, out_batch, T, C, k, stride);

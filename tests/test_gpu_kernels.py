@@ -205,11 +205,12 @@ def test_rmsnorm(D):
     close_bf16(out, ollm.rmsnorm(x, w, 1e-5), f"rmsnorm D{D}", ulps=2.0, atol=1e-3)
 
 
-@pytest.mark.parametrize("C", [64, 512])
-def test_conv0_ln_gelu(C):
+@pytest.mark.parametrize("C,n_samples", [(64, 399 + 5120), (512, 399 + 5120), (512, 5 * 33001 + 7), (512, 10 + 5 * 2)])
+def test_conv0_ln_gelu(C, n_samples):
+    """(512 channels: the register-resident form, 4 frames per wave below 32768 frames and 16 from there on; frame counts that are no multiple of either)"""
     cfg = toy_config().replace(conv_layers=[(C, 10, 5)])
     w = synth.random_weights(cfg.replace(enc_layers=0, llm_layers=0), dtype=torch.bfloat16, std=0.3, norm_jitter=0.1, seed=C)
-    audio = bf(torch.from_numpy(synth.synthetic_audio(399 + 5120)))
+    audio = bf(torch.from_numpy(synth.synthetic_audio(n_samples)))
     p = oenc.ENC + "feature_extractor.conv_layers.0."
     out = E.op_conv0(audio.to(DEV), w[p + "0.weight"].to(DEV), w[p + "0.bias"].to(DEV), w[p + "2.1.weight"].to(DEV),
                      w[p + "2.1.bias"].to(DEV), 10, 5)
