@@ -537,6 +537,11 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
     f32x4_t o[8];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) o[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // smallest position among this wave's real columns (columns past ncols are never stored: they may see anything)
+    int cpos_min = cv ? cpos : 0x7fffffff;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) cpos_min = min(cpos_min, __shfl_xor(cpos_min, off, WAVE));
+    cpos_min = __builtin_amdgcn_readfirstlane(cpos_min);
 
     // ---- loader roles (the launch always has 8 waves): wave w stages keys (even) or values (odd) of the stage's tile w >> 1 ----
     const bool load_k = (wave & 1) == 0;
@@ -620,23 +625,35 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
                 const bool sys_tile = t0 < d.sys_cap;
                 int xb = t0 - d.sys_cap - v.ring_start;
                 if (xb < 0) xb += d.ring_cap;
+                // a tile whose 16 slots are all live and all at or before every column's own position needs no mask at all (every cached tile of a
+                // steady-state chunk but the last two or three): the scalar test below replaces 4 x (ring arithmetic + two compares + select) per lane
+                const int j_last = sys_tile ? t0 + 15 : v.sys_len + xb + 15;
+                const bool plain = (sys_tile ? t0 + 15 < v.sys_len : xb + 15 < d.ring_cap) && j_last < total_u && j_last <= cpos_min;
+                if (plain) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int jc;
-                    if (sys_tile) {
-                        jc = t0 + 4 * fq + r;
-                        if (jc >= v.sys_len) jc = 0x7fffffff;
-                    } else {
-                        int x = xb + 4 * fq + r;
-                        if (x >= d.ring_cap) x -= d.ring_cap;
-                        jc = v.sys_len + x;
+                    for (int r = 0; r < 4; ++r) {
+                        sc[r] = st[r] * scale;
+                        mx = fmaxf(mx, sc[r]);
                     }
-                    const bool ok = jc < total_u && jc <= cpos;
-                    sc[r] = ok ? st[r] * scale : -INFINITY;
-                    mx = fmaxf(mx, sc[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int jc;
+                        if (sys_tile) {
+                            jc = t0 + 4 * fq + r;
+                            if (jc >= v.sys_len) jc = 0x7fffffff;
+                        } else {
+                            int x = xb + 4 * fq + r;
+                            if (x >= d.ring_cap) x -= d.ring_cap;
+                            jc = v.sys_len + x;
+                        }
+                        const bool ok = jc < total_u && jc <= cpos;
+                        sc[r] = ok ? st[r] * scale : -INFINITY;
+                        mx = fmaxf(mx, sc[r]);
+                    }
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
                 const float m_new = fmaxf(m_run, mx);
                 const float resc = (m_run == -INFINITY) ? 0.f : PF_EXP(m_run - m_new);
                 float p[4], ls = 0.f;
@@ -646,7 +663,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
                     ls += p[r];
                 }
                 ls += __shfl_xor(ls, 16, WAVE);
-                ls += __shfl_xor(ls, 32, WAVE);
+            ls += __shfl_xor(ls, 32, WAVE);
                 l_run = l_run * resc + ls;
                 m_run = m_new;
                 // rescale of O only when some column's running max moved (wave-uniform test; x * 1.0f is exact, so skipping changes no bit):
