@@ -67,6 +67,36 @@ def test_gemm_plain_and_epilogues(M, N, K):
         close_bf16(out, ref_linear(A, W, epi, bias, res), f"gemm {epi} M{M} N{N} K{K}", ulps=2.5, atol=atol)
 
 
+def test_gemm_random_shapes_across_every_kernel_boundary():
+    """70 seeded random (rows, columns, depth, epilogue) draws -- rows clustered around the dispatch boundaries of launch_gemm (12 | 13: GEMV -> gemm_mid,
+    64 | 65: -> the tiled / dense kernels, 128, 256, 320, 640: tile and heuristic edges), ragged column counts, depths from one 32-wide MFMA step up --
+    through the one entry point the engine uses, each against the fp32 reference with the epilogue's rounding points."""
+    rng = np.random.default_rng(20261003)
+    edges = [1, 2, 8, 12, 13, 16, 17, 32, 33, 48, 63, 64, 65, 66, 127, 128, 129, 255, 256, 257, 319, 320, 321, 639, 640, 641, 1023, 1408]
+    epis = ("none", "bias", "bias_gelu", "res", "bias_res", "f32", "swiglu")
+    for trial in range(70):
+        M = int(rng.choice(edges)) if trial % 3 else int(rng.integers(1, 900))
+        N = 16 * int(rng.integers(1, 70))
+        K = 32 * int(rng.choice([1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128]))
+        epi = epis[trial % len(epis)]
+        if epi == "swiglu":
+            N = max(32, N - N % 32)
+        g = torch.Generator().manual_seed(trial)
+        A = bf(torch.randn(M, K, generator=g))
+        W = bf(torch.randn(N, K, generator=g) * (0.4 / K ** 0.5))
+        bias, res = bf(torch.randn(N, generator=g)), bf(torch.randn(M, N, generator=g))
+        out = E.op_gemm(A.to(DEV), E.op_pack_weight(W.to(DEV)), N, epi, bias=bias.to(DEV) if "bias" in epi else None, res=res.to(DEV) if "res" in epi else None)
+        torch.cuda.synchronize()
+        if epi == "swiglu":  # packed rows alternate (gate tile, up tile): output column j of tile pair p = silu(gate) * up (HF LlamaMLP, patch_llm.py call site)
+            acc = (A.float() @ W.float().t()).view(M, N // 32, 2, 16)
+            r = lambda t: t.to(torch.bfloat16).float()
+            want = bf(r(torch.nn.functional.silu(r(acc[:, :, 0]))) * r(acc[:, :, 1])).reshape(M, N // 2)
+            close_bf16(out, want, f"trial {trial}: swiglu M{M} N{N} K{K}", ulps=4.0, atol=3.2e-2)
+        else:
+            atol = 2e-3 if epi in ("none", "bias", "f32") else 3.2e-2
+            close_bf16(out, ref_linear(A, W, epi, bias, res), f"trial {trial}: {epi} M{M} N{N} K{K}", ulps=2.5, atol=atol)
+
+
 def test_gemm_asymmetric_identity():
     """A = I against an asymmetric W catches swapped fragment maps (cdna_hip_programming.md section 3)."""
     K = N = 64
