@@ -386,6 +386,81 @@ def test_full_size_free_running_ids_with_peaked_logits():
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+# The reference's PRODUCTION decoding (--beam 4, scripts/infer/infinisst.sh:48) at full size, steady state.
+# ------------------------------------------------------------------------------------------------------------------------
+BEAM_LP_TOL = 0.5   # processed log-probs against the bf16 oracle under the peaked recipe (raw logits: LOGIT_TOLERANCE)
+BEAM_GAP = 1.0      # a candidate whose neighbours in the oracle's ranking are further away than this must be the device's candidate of that rank too
+
+
+def test_full_size_beam4_teacher_forced_candidates_match_oracle():
+    """patch_hf.py:687-967 (the loop, pinned by beam_loop.npz) + :43-302 (the scorer, beam_scorer.npz) at FULL size: one steady-state chunk
+    (45 pinned + 975 ring entries imported, encoder window full), num_beams 4, peaked weights.  The engine is teacher-forced along the ORACLE's
+    (token, parent) choices, so both sides are in the same state at every one of the 10 steps, and what the scorer consumes is compared step by
+    step: per beam the top 2B processed log-probs within BEAM_LP_TOL, the candidate TOKEN of every rank whose oracle neighbours are more than
+    BEAM_GAP away, the running beam scores; required: >= 150 decisive candidate ranks, and the oracle's sequence unless the final hypotheses
+    tie."""
+    from oracle import beam as obeam
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    B = 4
+    cfg = full_config().replace(eos_ids=())  # no EOS: B live beams at every step on both sides
+    dev = torch.device("cuda")
+    w_dev = synth.random_weights_device(cfg, dev, recipe="peaked")
+    sys_n = len(synth.system_prompt_ids(cfg))
+    eng = Engine(cfg, max_streams=1, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=B)
+    eng.load_weights(w_dev)
+    w = {k: v.cpu() for k, v in w_dev.items()}
+    del w_dev
+    gen = GenConfig(max_new_tokens=10, max_llm_cache_size=1000, always_cache_system_prompt=True, beam=B)
+    kv0, enc0, src0 = _random_state(cfg, sys_n, seed=13)
+    prompt = synth.chunk_prompt_ids(cfg, 1, first=False)
+    sid = eng.open_stream()
+    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
+    _import_state(eng, sid, cfg, sys_n, kv0, enc0, src0, llm_ring_start=ring_cap - 300, enc_ring_start=560)
+    sc = _oracle_cache(cfg, enc0, src0, torch.bfloat16)
+    rope_e, rope_l = oenc.make_rope(cfg), ollm.llm_rope_tables(cfg, 2048, torch.bfloat16)
+    seg = synth.synthetic_audio(cfg.chunk_samples, stream_id=4242)
+    prev = [int(t) for t in np.random.default_rng(5).integers(1000, 90000, size=40)]  # a previous-target window for the encoder n-gram processor
+    with torch.inference_mode():
+        ref = obeam.beam_generate(w, cfg, gen, B, prompt, torch.from_numpy(seg).unsqueeze(0).bfloat16(), kv0, sc, rope_l, rope_e, prev)
+    assert len(ref.steps) == gen.max_new_tokens
+    eng.beam_trace_begin(B, [st.next_tokens for st in ref.steps], [st.next_parents for st in ref.steps])
+    outs, _ = eng.generate(gen, [sid], [seg], [prompt], [prev], system_prompt_size=0)
+    trace = eng.beam_trace_end()
+    assert len(trace) == len(ref.steps)
+    n_keep = 2 * B
+    worst_v = worst_s = 0.0
+    checked = decisive = 0
+    for step, (st, (val, idx, scb)) in enumerate(zip(ref.steps, trace)):
+        rows = 1 if step == 0 else B
+        assert val.shape == (rows, n_keep)
+        for b in range(rows):
+            lp = (st.scores[b] - st.beam_scores_in[b]).float()
+            top = torch.topk(lp, n_keep + 1)
+            ov, oi = top.values.numpy(), top.indices.numpy()
+            dv = np.abs(val[b] - ov[:n_keep])
+            worst_v = max(worst_v, float(dv.max()))
+            assert dv.max() <= BEAM_LP_TOL, f"step {step} beam {b}: top log-probs differ by {dv.max():.3f}"
+            for j in range(n_keep):
+                checked += 1
+                lo = ov[j - 1] - ov[j] if j > 0 else np.inf
+                hi = ov[j] - ov[j + 1]
+                if min(lo, hi) > BEAM_GAP:
+                    decisive += 1
+                    assert idx[b, j] == oi[j], f"step {step} beam {b} rank {j}: token {idx[b, j]} vs oracle {oi[j]} (gaps {lo:.2f} / {hi:.2f})"
+            ds = abs(float(scb[b]) - float(st.beam_scores_in[b]))
+            worst_s = max(worst_s, ds)
+            assert ds <= BEAM_LP_TOL * max(1, step), f"step {step} beam {b}: beam score {scb[b]} vs {st.beam_scores_in[b]}"
+    finals = sorted(ref.steps[-1].next_scores, reverse=True)
+    print(f"full-size beam 4, teacher-forced: worst |d log-prob| {worst_v:.3f}, worst |d beam score| {worst_s:.3f}, {decisive}/{checked} candidate ranks decisive; "
+          f"oracle sequence {ref.sequences[len(prompt):]}, engine {outs[0]}; final scores {[round(f, 2) for f in finals]}", flush=True)
+    assert decisive >= 150
+    if finals[0] - finals[1] > BEAM_GAP:
+        assert outs[0] == ref.sequences[len(prompt):]
+    assert eng.stream_info(sid)["llm_cache_len"] == sys_n + N_RING + len(prompt) + gen.max_new_tokens - 1
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[4]: an unbounded stream at FULL size -- rolling whole-chunk eviction for hundreds of chunks.
 # ------------------------------------------------------------------------------------------------------------------------
 LONG_CHUNKS = 640
