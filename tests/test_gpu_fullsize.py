@@ -385,6 +385,67 @@ def test_full_size_free_running_ids_with_peaked_logits():
     eng.close()
 
 
+def test_full_size_64_streams_ids_with_peaked_logits():
+    """The id half of `north_star` for configs[2]: 64 concurrent streams in ONE call at full size (1408-row prefill on gemm_dense, 64-row decode passes
+    on gemm_mid with the in-launch reductions, one workgroup per (stream, kv head) in the decode attention), peaked weights, steady state, FREE-running.
+    Four of the streams (batch rows 0, 29, 62, 63: each its own audio and its own previous-target window, so their continuations differ) are then replayed by the bf16 oracle along the engine's tokens: on every
+    decisive step (processed top-2 margin > DECISIVE_MARGIN) the engine's token must be the oracle's argmax, every raw logit within LOGIT_TOLERANCE."""
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    cfg = full_config()
+    dev = torch.device("cuda")
+    w_dev = synth.random_weights_device(cfg, dev, recipe="peaked")
+    sys_n = len(synth.system_prompt_ids(cfg))
+    n = 64
+    eng = Engine(cfg, max_streams=n, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n)
+    eng.load_weights(w_dev)
+    w = {k: v.cpu() for k, v in w_dev.items()}
+    del w_dev
+    gen = GenConfig(max_new_tokens=10, max_llm_cache_size=1000, always_cache_system_prompt=True)
+    kv0, enc0, src0 = _random_state(cfg, sys_n, seed=17)
+    prompt = synth.chunk_prompt_ids(cfg, 1, first=False)
+    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
+    sids = [eng.open_stream() for _ in range(n)]
+    for i, sid in enumerate(sids):
+        _import_state(eng, sid, cfg, sys_n, kv0, enc0, src0, llm_ring_start=(ring_cap - 400 + 29 * i) % ring_cap, enc_ring_start=(500 + 13 * i) % 640)
+    segs = [synth.synthetic_audio(cfg.chunk_samples, stream_id=7000 + i) for i in range(n)]
+    # under this recipe the continuation is a chain driven by the last token, the same for every stream -- so three of every four streams get a previous-target
+    # window that holds a 5-gram of that chain at a stream-specific place: the encoder-n-gram processor (agents/infinisst.py:298-300) then bans the structured
+    # continuation at a different step per stream and the batch rows part ways
+    perms = synth.peaked_permutations(cfg)
+    chain, t = [], prompt[-1]
+    for _ in range(12):
+        t = synth.peaked_successors(cfg, t, perms)[0]
+        chain.append(int(t))
+    prevs = [[] if i % 4 == 0 else chain[(i % 4) - 1:(i % 4) + 4] for i in range(n)]
+    outs, logits = eng.generate(gen, sids, segs, [prompt] * n, prevs, return_logits=True)
+    assert all(len(o) == 10 for o in outs), "no EOS expected inside 10 steps of the peaked chain"
+    assert outs[0] == chain[:10] and len({tuple(o) for o in outs}) >= 4, "the bans must send the streams down different continuations"
+    rope_e, rope_l = oenc.make_rope(cfg), ollm.llm_rope_tables(cfg, 2048, torch.bfloat16)
+    n_steps = n_decisive = n_mismatch = 0
+    worst = 0.0
+    for i in (0, 29, 62, 63):  # i % 4 = 0, 1, 2, 3: no ban, and a ban at three different steps
+        kv = [[t.clone() for t in layer] for layer in kv0]
+        sc = _oracle_cache(cfg, enc0, src0, torch.bfloat16)
+        with torch.inference_mode():
+            ref = ogen.generate(w, cfg, gen, prompt, torch.from_numpy(segs[i]).unsqueeze(0).bfloat16(), kv, sc, rope_l, rope_e, prevs[i], forced_tokens=outs[i])
+        assert len(ref.step_scores) == len(outs[i])
+        for s_, tok in enumerate(outs[i]):
+            d = float(np.abs(logits[i, s_] - ref.step_logits[s_].float().numpy()).max())
+            worst = max(worst, d)
+            top = torch.topk(ref.step_scores[s_], 2)
+            n_steps += 1
+            if float(top.values[0] - top.values[1]) > DECISIVE_MARGIN:
+                n_decisive += 1
+                if int(top.indices[0]) != tok:
+                    n_mismatch += 1
+                    print(f"stream {i} step {s_}: engine {tok}, oracle {int(top.indices[0])} (logit max |d| {d:.3f})", flush=True)
+        assert eng.stream_info(sids[i])["llm_cache_len"] == ollm.kv_len(kv)
+    print(f"64 streams, peaked ids: {n_steps} oracle-checked steps on 4 streams, {n_decisive} decisive, {n_mismatch} mismatches, worst |logit - oracle| {worst:.3f}", flush=True)
+    assert n_mismatch == 0 and n_decisive >= 32
+    assert worst <= LOGIT_TOLERANCE
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # The reference's PRODUCTION decoding (--beam 4, scripts/infer/infinisst.sh:48) at full size, steady state.
 # ------------------------------------------------------------------------------------------------------------------------
