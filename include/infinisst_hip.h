@@ -81,7 +81,9 @@ typedef struct isst_gen_params {
     float length_penalty;              /* BeamSearchScorer length_penalty (HF default 1.0; 0 is read as 1.0) */
     int pcm_on_device;                 /* nonzero: pcm[i] are DEVICE pointers (fp32, n_samples each): the caller already holds the audio in
                                         * HBM.  0: host pointers, moved by the library as agents/infinisst.py:222 `.to(device)` does */
-    /* the sample branch (agents/infinisst.py:311-315 -> patch_hf.py:606-624 -> HF _sample [3P]); num_beams must be <= 1 with it */
+    /* the sample branch (agents/infinisst.py:311-315 -> patch_hf.py:606-624 -> HF _sample [3P]); with num_beams > 1: beam sample (patch_hf.py:871-875) --
+     * max(2, 1 + n_eos) * num_beams draws WITHOUT replacement from the softmax over all beams' warped scores replace the top-k; draw j of step s uses the
+     * uniform of step counter 64 s + j */
     int do_sample;                     /* do_sample= ; 0: greedy argmax */
     float temperature;                 /* temperature= (1.0 or <= 0: off) */
     int top_k;                         /* top_k= (0: off) */
@@ -254,6 +256,11 @@ int isst_op_conv0(const uint16_t* audio, const uint16_t* w, const uint16_t* bias
  * scores (warped in place, -inf = removed) and the inverse-CDF draw at u in [0, 1); the uniform of a (stream, chunk, step) */
 int isst_op_warp_sample(float* scores, int vocab, float temperature, int top_k, float top_p, float epsilon_cutoff, double u, int* token);
 double isst_op_sample_uniform(unsigned long long seed, int stream, int chunk, int step);
+/* the warpers alone; min_tokens_to_keep = 1 in the sample branch, n_eos + 1 under beam search (HF `_get_logits_processor`) */
+int isst_op_warp(float* scores, int vocab, float temperature, int top_k, float top_p, float epsilon_cutoff, int min_tokens_to_keep);
+/* torch.multinomial(softmax(scores), k) without replacement as k sequential inverse-CDF draws (index order) at the given uniforms: fp32 softmax, fp64 running sums;
+ * picked[j] = flat index of draw j; ISST_ERR_STATE when fewer than k entries have non-zero probability (torch raises there) */
+int isst_op_multinomial_wor(const float* scores, long n, int k, const double* uniforms, long* picked);
 /* logits [vocab] fp32 (modified in place) -> *out_token (device int) */
 int isst_op_sample(float* logits, int vocab, const int* ids, int n_ids, const int* enc_ids, int n_enc, const int* suppress,
                    int n_suppress, float repetition_penalty, int ngram, int enc_ngram, int* out_token, void* hip_stream);

@@ -167,12 +167,11 @@ class InfiniSST(_AgentBase):
         self.suppress_non_language = getattr(args, "suppress_non_language", False)
         self.max_new_tokens = args.max_new_tokens
         # the sample branch (reference :311-315): warpers + draw in the library (csrc/warp.hip); the draws come from a counter-based generator, so they
-        # are reproducible but not torch.multinomial's
+        # are reproducible but not torch.multinomial's.  With --beam > 1 this is HF's beam sample (patch_hf.py:871-875): 2 x beams draws without replacement
+        # from the softmax over all beams' warped scores instead of their top-k
         self.do_sample = bool(getattr(args, "do_sample", False))
         self.top_p, self.top_k = float(getattr(args, "top_p", 1.0)), int(getattr(args, "top_k", 0))
         self.epsilon_cutoff, self.temperature = float(getattr(args, "epsilon_cutoff", 0.0)), float(getattr(args, "temperature", 1.0))
-        if self.do_sample and self.beam > 1:
-            raise NotImplementedError("--do-sample with --beam > 1 (beam sample) is not implemented")
         self.pseudo_batch_size = getattr(args, "pseudo_batch_size", 1)  # accepted, not used: see add_args
         self.dpo_sampling = getattr(args, "dpo_sampling", False)         # reference :108-110
         self.output_file = getattr(args, "output_file", "translations.json")

@@ -1367,11 +1367,44 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         CHK(launch_log_softmax(h->logits, h->vocab_pad, V, h->lse_max, h->lse_sum, rows, st));
         CHK(launch_sample_process(h->logits, h->vocab_pad, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
                                   p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, rows, st));
-        CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val, h->top_idx, rows, st));
-        HIPCHK(hipMemcpyAsync(h->top_val_host, h->top_val, sizeof(float) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h->top_idx_host, h->top_idx, sizeof(int) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        h->kv_ops_used = 0;  // every earlier copy batch has run
+        if (p->do_sample) {
+            // beam SAMPLE (:871-875): the processed log-probs of every row come to the host; there the warpers (part of the processor list under do_sample),
+            // + beam score, softmax over a stream's rows_per x V scores, n_keep draws without replacement (warp.hip) -- written into the same candidate
+            // arrays the top-k fills below (value = warped log-prob of the drawn token, so that value + beam score is the reference's gathered score)
+            HIPCHK(hipMemcpyAsync(h->samp_host, h->logits, (size_t)rows * h->vocab_pad * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h->kv_ops_used = 0;
+            std::vector<float> flat((size_t)rows_per * V);
+            std::vector<double> us(n_keep);
+            std::vector<long> picked(n_keep);
+            for (int i = 0; i < n; ++i) {
+                for (int b = 0; b < rows_per; ++b) {
+                    float* row = h->samp_host + (size_t)(i * rows_per + b) * h->vocab_pad;
+                    warp_scores(row, V, p->temperature, p->top_k, p->top_p, p->epsilon_cutoff, c.n_eos + 1);  // min_tokens_to_keep of beam methods
+                    const float bsc = bs[i].score[b];
+                    for (int v2 = 0; v2 < V; ++v2) flat[(size_t)b * V + v2] = row[v2] + bsc;
+                }
+                for (int j = 0; j < n_keep; ++j) us[j] = sample_uniform(p->seed, stream_ids[i], h->streams[stream_ids[i]].chunks, 64 * step + j);
+                if (multinomial_without_replacement(flat.data(), (long)rows_per * V, n_keep, us.data(), picked.data()) != ISST_OK)
+                    return h->fail(ISST_ERR_STATE, "beam sample: fewer than %d tokens with non-zero probability at step %d (torch.multinomial raises here too)", n_keep, step);
+                // candidate j of the stream goes to the slot (row of its beam, next free column); unused slots are marked invalid
+                std::vector<int> used(rows_per, 0);
+                for (int b = 0; b < rows_per; ++b)
+                    for (int j = 0; j < BEAM_TOPK; ++j) h->top_idx_host[(i * rows_per + b) * BEAM_TOPK + j] = -1;
+                for (int j = 0; j < n_keep; ++j) {
+                    const int b = (int)(picked[j] / V), tok = (int)(picked[j] % V);
+                    const int r = i * rows_per + b, slot = used[b]++;
+                    h->top_val_host[r * BEAM_TOPK + slot] = h->samp_host[(size_t)r * h->vocab_pad + tok];
+                    h->top_idx_host[r * BEAM_TOPK + slot] = tok;
+                }
+            }
+        } else {
+            CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val, h->top_idx, rows, st));
+            HIPCHK(hipMemcpyAsync(h->top_val_host, h->top_val, sizeof(float) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h->top_idx_host, h->top_idx, sizeof(int) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h->kv_ops_used = 0;  // every earlier copy batch has run
+        }
 
         // ---- scorer (beam_search_process, :43-157) ----
         bool all_done = true;
@@ -1452,7 +1485,8 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                     const int tok = h->bforce_tok[(size_t)step * B + b], par = h->bforce_par[(size_t)step * B + b];
                     if (tok < 0 || tok >= V || par < 0 || par >= rows_per) return h->fail(ISST_ERR_ARG, "forced beam choice (%d, %d) out of range at step %d", tok, par, step);
                     float lp = 0.f;
-                    HIPCHK(hipMemcpy(&lp, h->logits + (size_t)(i * rows_per + par) * h->vocab_pad + tok, sizeof(float), hipMemcpyDeviceToHost));
+                    if (p->do_sample) lp = h->samp_host[(size_t)(i * rows_per + par) * h->vocab_pad + tok];  // (the warped row is on the host)
+                    else HIPCHK(hipMemcpy(&lp, h->logits + (size_t)(i * rows_per + par) * h->vocab_pad + tok, sizeof(float), hipMemcpyDeviceToHost));
                     ntok[b] = tok; npar[b] = par; nscore[b] = S.score[par] + lp;
                 }
             }
@@ -1619,15 +1653,14 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     if (forced_tokens && n_forced)
         for (int i = 0; i < n; ++i) any_forced = any_forced || (forced_tokens[i] != nullptr && n_forced[i] > 0);
     if (B > 1 && (any_forced || logits_out)) return h->fail(ISST_ERR_ARG, "forced_tokens / logits_out are greedy-only test aids");
-    if (p->do_sample && B > 1) return h->fail(ISST_ERR_ARG, "do_sample with num_beams > 1 (beam sample) is not implemented");
     if (p->do_sample && (p->top_k < 0 || !(p->top_p > 0.f) || p->epsilon_cutoff < 0.f || p->epsilon_cutoff >= 1.f))
         return h->fail(ISST_ERR_ARG, "sampling arguments out of range (top_k >= 0, top_p > 0, 0 <= epsilon_cutoff < 1)");
-    if (p->do_sample && h->samp_host_rows < (size_t)n) {
+    if (p->do_sample && h->samp_host_rows < (size_t)n * B) {  // (beam sample: the processed scores of every beam's row come to the host)
         if (h->samp_host) (void)hipHostFree(h->samp_host);
         h->samp_host = nullptr;
         h->samp_host_rows = 0;
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->samp_host), (size_t)n * h->vocab_pad * sizeof(float)) != hipSuccess) return h->fail(ISST_ERR_NOMEM, "pinned score buffer");
-        h->samp_host_rows = (size_t)n;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->samp_host), (size_t)n * B * h->vocab_pad * sizeof(float)) != hipSuccess) return h->fail(ISST_ERR_NOMEM, "pinned score buffer");
+        h->samp_host_rows = (size_t)n * B;
     }
     for (int i = 0; i < n; ++i) {
         const int id = stream_ids[i];

@@ -125,6 +125,8 @@ int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval
 // processors only (stage 1 of launch_sample), in place on the rows named by ss[]
 // warp.hip (host): HF's logits warpers (Temperature -> TopK -> TopP -> Epsilon) on one row of processed scores, then an inverse-CDF draw at `u`
 int warp_and_sample(float* scores, int n, float temperature, int top_k, float top_p, float epsilon, double u);
+void warp_scores(float* scores, int n, float temperature, int top_k, float top_p, float epsilon, int min_keep);
+int multinomial_without_replacement(const float* scores, long n, int k, const double* u, long* picked);
 double sample_uniform(uint64_t seed, int stream, int chunk, int step);
 int launch_sample_process(float* logits, long ld_logits, const SampleStream* ss, const int* ids_pool, const int* enc_pool, const int* suppress,
                           int n_suppress, float rep_penalty, int ngram, int enc_ngram, int n_rows, hipStream_t s);

@@ -72,7 +72,7 @@ EXPORTS = [
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
     "isst_op_attn_combine", "isst_op_gemm_attn_merge", "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_begin_rows", "isst_profile_end", "isst_op_pack_weight",
-    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample", "isst_op_warp_sample", "isst_op_sample_uniform",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample", "isst_op_warp", "isst_op_warp_sample", "isst_op_sample_uniform", "isst_op_multinomial_wor",
 ]
 
 
@@ -622,6 +622,30 @@ def op_warp_sample(scores: np.ndarray, temperature: float, top_k: int, top_p: fl
     if rc:
         raise IsstError(f"isst_op_warp_sample -> {rc}")
     return s, tok.value
+
+
+def op_warp(scores: np.ndarray, temperature: float, top_k: int, top_p: float, epsilon_cutoff: float, min_tokens_to_keep: int = 1) -> np.ndarray:
+    """HF's warpers on one row of processed scores (host code: csrc/warp.hip); returns the warped copy."""
+    lib = load_library()
+    s = np.ascontiguousarray(scores, dtype=np.float32).copy()
+    lib.isst_op_warp.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int]
+    rc = lib.isst_op_warp(s.ctypes.data, s.size, temperature, top_k, top_p, epsilon_cutoff, min_tokens_to_keep)
+    if rc:
+        raise IsstError(f"isst_op_warp -> {rc}")
+    return s
+
+
+def op_multinomial_wor(scores: np.ndarray, k: int, uniforms: Sequence[float]) -> list:
+    """`torch.multinomial(softmax(scores), k)` without replacement as k sequential inverse-CDF draws at the given uniforms (host code: csrc/warp.hip)."""
+    lib = load_library()
+    s = np.ascontiguousarray(scores, dtype=np.float32)
+    u = np.ascontiguousarray(uniforms, dtype=np.float64)
+    out = np.zeros(k, dtype=np.int64)
+    lib.isst_op_multinomial_wor.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p]
+    rc = lib.isst_op_multinomial_wor(s.ctypes.data, s.size, k, u.ctypes.data, out.ctypes.data)
+    if rc:
+        raise IsstError(f"isst_op_multinomial_wor -> {rc}")
+    return out.tolist()
 
 
 def op_sample_uniform(seed: int, stream: int, chunk: int, step: int) -> float:

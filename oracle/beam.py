@@ -132,13 +132,15 @@ def finalize(hyps: BeamHypotheses, done: bool, seqs: List[List[int]], beam_score
 
 
 def beam_search_loop(forward, process, num_beams: int, input_ids: List[int], kv, eos_ids: Sequence[int], max_new_tokens: int,
-                     length_penalty: float = 1.0, clone=clone_kv):
+                     length_penalty: float = 1.0, clone=clone_kv, draw=None):
     """generation_mixin_beam_search for batch size 1 (patch_hf.py:687-967) over a pluggable model.
 
     `forward(tokens, kv, first) -> logits (V,)` runs one beam's forward pass and appends to that beam's `kv` in place (step 0:
     the whole prompt, later steps: the last token -- model/llm.py:114-115); `process(log_probs, seq) -> scores` are the logits
-    processors (:839, applied to log-probs).  Returns (sequence, best_kv, steps).  Pinned against the reference's own loop,
-    compiled from patch_hf.py's text and driven on a toy model (tests/golden/gen_golden.py::gen_beam_loop -> beam_loop.npz)."""
+    processors (:839, applied to log-probs; with do_sample the warpers are part of them).  `draw(flat_scores, n, step) -> indices`: the beam-SAMPLE branch
+    (:871-875: softmax over all beams' scores, n draws without replacement, then sorted by score) instead of the top-k; None = beam search.
+    Returns (sequence, best_kv, steps).  Pinned against the reference's own loop, compiled from patch_hf.py's text and driven on a toy model
+    (tests/golden/gen_golden.py::gen_beam_loop -> beam_loop.npz; its do_sample cases run with torch.multinomial replaced by the same `draw`)."""
     prompt_len = len(input_ids)
     max_length = prompt_len + max_new_tokens
     n_keep = max(2, 1 + len(eos_ids)) * num_beams  # :869-870
@@ -158,10 +160,16 @@ def beam_search_loop(forward, process, num_beams: int, input_ids: List[int], kv,
             rows.append(sc + torch.tensor(beam_scores[b], dtype=torch.float32))  # :840 (fp32 add, as beam_scores[:, None])
         V = rows[0].numel()
         flat = torch.cat(rows)
-        top = torch.topk(flat, n_keep, largest=True, sorted=True)  # :878
-        cand_scores = [float(x) for x in top.values]
-        cand_beams = [int(i) // V for i in top.indices]
-        cand_tokens = [int(i) % V for i in top.indices]
+        if draw is None:
+            top = torch.topk(flat, n_keep, largest=True, sorted=True)  # :878
+            top_values, top_indices = top.values, top.indices
+        else:  # :871-875
+            picked = torch.tensor(draw(flat, n_keep, step), dtype=torch.long)
+            vals, order = torch.sort(flat[picked], descending=True)
+            top_values, top_indices = vals, picked[order]
+        cand_scores = [float(x) for x in top_values]
+        cand_beams = [int(i) // V for i in top_indices]
+        cand_tokens = [int(i) % V for i in top_indices]
         ns, nt, npar, done = scorer_process(hyps, done, seqs, cand_scores, cand_tokens, cand_beams, kvs, eos_ids, num_beams, prompt_len, clone)
         steps.append(BeamStepRecord(rows, cand_scores, cand_tokens, cand_beams, nt, npar, ns, list(beam_scores)))
         seqs = [seqs[p] + [t] for p, t in zip(npar, nt)]  # :902 input_ids[beam_idx] + token
@@ -175,7 +183,7 @@ def beam_search_loop(forward, process, num_beams: int, input_ids: List[int], kv,
 
 
 def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batch: torch.Tensor, kv, speech_cache, rope_llm,
-                  rope_enc, encoder_input_ids: Sequence[int], length_penalty: float = 1.0) -> BeamOutput:
+                  rope_enc, encoder_input_ids: Sequence[int], length_penalty: float = 1.0, sample_stream: int = 0, sample_chunk: int = 0) -> BeamOutput:
     """One chunk with beam search.  `kv` (the stream's cache before this chunk) is not modified; the winning
     hypothesis' cache is returned (reference agents/infinisst.py:334-336: past_key_values[0])."""
     m = gen.latency_multiplier
@@ -186,8 +194,16 @@ def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batc
         return ollm.model_forward(w, cfg, torch.tensor(tokens), beam_kv, rope_llm, speech=feats if first else None)
 
     def process(lp, seq):
-        return ogen.process_logits(lp, seq, encoder_input_ids, gen.repetition_penalty, gen.no_repeat_ngram_size,
-                                   gen.no_repeat_ngram_size, gen.suppress_tokens)
+        sc = ogen.process_logits(lp, seq, encoder_input_ids, gen.repetition_penalty, gen.no_repeat_ngram_size,
+                                 gen.no_repeat_ngram_size, gen.suppress_tokens)
+        if gen.do_sample:  # the warpers `_get_logits_processor` appends for do_sample are part of the processor list (beam_loop.npz records the order)
+            sc = ogen.warp_logits(sc, gen.temperature, gen.top_k, gen.top_p, gen.epsilon_cutoff, min_tokens_to_keep=len(cfg.eos_ids) + 1)
+        return sc
 
-    out, best_kv, steps = beam_search_loop(forward, process, num_beams, input_ids, kv, cfg.eos_ids, gen.max_new_tokens, length_penalty)
+    draw = None
+    if gen.do_sample:  # uniforms keyed like the greedy-sample branch; draw j of step s uses counter 64 s + j (csrc/warp.hip, engine.hip beam_decode)
+        def draw(flat, n, step):
+            return ogen.multinomial_without_replacement(flat, n, [ogen.sample_uniform(gen.seed, sample_stream, sample_chunk, 64 * step + j) for j in range(n)])
+
+    out, best_kv, steps = beam_search_loop(forward, process, num_beams, input_ids, kv, cfg.eos_ids, gen.max_new_tokens, length_penalty, draw=draw)
     return BeamOutput(sequences=out, kv=best_kv, steps=steps, speech_features=feats)

@@ -18,6 +18,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import llm as ollm
@@ -69,26 +70,29 @@ def process_logits(scores: torch.Tensor, input_ids: Sequence[int], encoder_input
     return s
 
 
-def warp_logits(scores: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, epsilon_cutoff: float = 0.0) -> torch.Tensor:
+def warp_logits(scores: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, epsilon_cutoff: float = 0.0,
+                min_tokens_to_keep: int = 1) -> torch.Tensor:
     """[3P transformers] the warpers `_get_logits_processor` appends for do_sample, in its order: TemperatureLogitsWarper -> TopKLogitsWarper ->
-    TopPLogitsWarper -> EpsilonLogitsWarper (min_tokens_to_keep = 1, filter value -inf), restated from that library's published code and pinned to the
-    image's transformers 5.15 classes (tests/golden/sampling_warpers.npz).  scores (V,) fp32, processed -> warped copy."""
+    TopPLogitsWarper -> EpsilonLogitsWarper (filter value -inf), restated from that library's published code and pinned to the image's transformers 5.15
+    classes (tests/golden/sampling_warpers.npz).  `min_tokens_to_keep`: 1 for the sample branch, len(eos ids) + 1 under beam search ("keep at least one
+    non-eos token", the same function).  scores (V,) fp32, processed -> warped copy."""
     s = scores.clone()
     ninf = float("-inf")
+    keep = max(1, int(min_tokens_to_keep))
     if temperature > 0 and temperature != 1.0:
         s = s / temperature
     if top_k > 0:
-        k = min(top_k, s.numel())
+        k = min(max(top_k, keep), s.numel())
         s = s.masked_fill(s < torch.topk(s, k)[0][-1], ninf)
     if top_p < 1.0:
         sorted_logits, sorted_idx = torch.sort(s, descending=False)
         cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
         remove = cum <= (1 - top_p)
-        remove[-1:] = False
+        remove[-keep:] = False
         s = s.masked_fill(remove.scatter(0, sorted_idx, remove), ninf)
     if 0 < epsilon_cutoff < 1:
         probs = s.softmax(dim=-1)
-        s = s.masked_fill((probs < epsilon_cutoff) & (s < torch.topk(s, 1)[0][-1]), ninf)
+        s = s.masked_fill((probs < epsilon_cutoff) & (s < torch.topk(s, min(keep, s.numel()))[0][-1]), ninf)
     return s
 
 
@@ -118,6 +122,31 @@ def draw(warped: torch.Tensor, u: float) -> int:
     cum = torch.cumsum(p, dim=0)
     idx = int(torch.searchsorted(cum, torch.tensor(u * float(cum[-1]), dtype=torch.float64), right=True))  # first index whose running sum exceeds the target
     return idx if idx < p.numel() else int(torch.nonzero(p > 0).flatten()[-1])
+
+
+def multinomial_without_replacement(scores: torch.Tensor, n: int, uniforms: Sequence[float]) -> List[int]:
+    """`torch.multinomial(softmax(scores), num_samples=n)` (replacement=False: patch_hf.py:871-873, the beam-sample branch) as n sequential inverse-CDF draws
+    in index order at the given uniforms, each over what is left (the definition of sampling without replacement; torch's own stream of random numbers cannot be
+    reproduced).  softmax in fp32 as the reference computes it, the running sums in fp64, left to right.  Raises like torch when fewer than n entries have
+    non-zero probability."""
+    return draw_without_replacement(torch.softmax(scores.float(), dim=-1), n, uniforms)
+
+
+def draw_without_replacement(probs: torch.Tensor, n: int, uniforms: Sequence[float]) -> List[int]:
+    """The draws of `multinomial_without_replacement` from probabilities (what torch.multinomial is handed at patch_hf.py:873)."""
+    p = probs.double().numpy().copy()
+    picked: List[int] = []
+    for j in range(n):
+        cum = np.cumsum(p)  # sequential fp64 adds, index order
+        total = float(cum[-1]) if cum.size else 0.0
+        if not total > 0.0:
+            raise RuntimeError("invalid multinomial distribution (with replacement=False, not enough non-negative category to sample)")
+        idx = int(np.searchsorted(cum, uniforms[j] * total, side="right"))  # first index whose running sum exceeds the target
+        if idx >= p.size:  # the target fell on the very end: the last live entry
+            idx = int(np.flatnonzero(p > 0)[-1])
+        picked.append(idx)
+        p[idx] = 0.0
+    return picked
 
 
 @dataclass

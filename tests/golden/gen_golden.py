@@ -809,7 +809,24 @@ def gen_beam_loop():
                                         num_key_value_heads=1, vocab_size=V))
     out = {"transformers_version": np.array(transformers.__version__)}
     cases = [(4, 1.0, 9, 10, 0.0, 101), (4, 1.0, 14, 10, 2.5, 102), (2, 1.0, 7, 12, 1.5, 103), (3, 0.6, 11, 9, 2.0, 104),
-             (4, 1.0, 22, 20, 1.0, 105), (4, 1.0, 8, 6, 4.0, 106)]
+             (4, 1.0, 22, 20, 1.0, 105), (4, 1.0, 8, 6, 4.0, 106), (4, 1.0, 9, 8, 1.0, 107), (2, 1.0, 12, 10, 2.0, 108)]
+    # the last two run the loop's do_sample branch (:871-875: beam sample): (temperature, top_k, top_p, epsilon_cutoff).  torch.multinomial's random stream cannot be
+    # restated, so the compiled function sees a `torch` whose multinomial is the oracle's counter-based sequential draw (oracle/generate.py
+    # draw_without_replacement at sample_uniform(seed, 0, 0, 64 step + j)): everything else of the branch -- softmax over all beams, gather, sort, scorer -- is the reference's
+    samples = {6: (0.8, 0, 1.0, 0.0), 7: (1.6, 40, 0.995, 0.0)}  # (every step must leave >= max(2, 1 + n_eos) * beams tokens with non-zero probability: torch.multinomial raises otherwise)
+    from oracle import generate as ogen
+
+    class TorchWithCountedDraw:
+        def __init__(self, seed):
+            self.seed = seed
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        def multinomial(self, probs, num_samples, replacement=False):
+            assert not replacement and probs.shape[0] == 1
+            us = [ogen.sample_uniform(self.seed, 0, 0, 64 * trace["n"] + j) for j in range(num_samples)]
+            return torch.tensor([ogen.draw_without_replacement(probs[0], num_samples, us)], dtype=torch.long)
     eos = [57, 58, 59]
     for ci, (B, lp, prompt_len, max_new, eos_bias, seed) in enumerate(cases):
         g = torch.Generator().manual_seed(seed)
@@ -824,8 +841,12 @@ def gen_beam_loop():
         enc_ids = torch.randint(3, small, (1, 30), generator=g)
         suppress = [5, 40]
         ngram = 3 if ci in (1, 4) else 5
+        smp = samples.get(ci)
+        skw = {} if smp is None else dict(do_sample=True, temperature=smp[0], top_k=smp[1], top_p=smp[2], epsilon_cutoff=smp[3])
         gc = GenerationConfig(repetition_penalty=1.2, no_repeat_ngram_size=ngram, encoder_no_repeat_ngram_size=ngram,
-                              suppress_tokens=suppress, num_beams=B, max_new_tokens=max_new, pad_token_id=60, eos_token_id=eos)
+                              suppress_tokens=suppress, num_beams=B, max_new_tokens=max_new, pad_token_id=60, eos_token_id=eos, **skw)
+        if smp is not None:
+            gc._eos_token_tensor = torch.tensor(eos)  # (generate() sets it in _prepare_special_tokens; the warpers' min_tokens_to_keep reads it)
         procs = tiny._get_logits_processor(generation_config=gc, input_ids_seq_length=prompt_len, encoder_input_ids=enc_ids,
                                            prefix_allowed_tokens_fn=None, logits_processor=LogitsProcessorList(), device="cpu",
                                            model_kwargs={})
@@ -870,7 +891,7 @@ def gen_beam_loop():
                 return past_key_values
 
         # the stream's cache before this chunk: `n_past` tokens already consumed (batch 1), expanded by the reference's own function
-        n_past = [0, 6, 3, 0, 17, 5][ci]
+        n_past = [0, 6, 3, 0, 17, 5, 4, 0][ci]
         past_tokens = torch.randint(3, V - 4, (n_past,), generator=g)
         past = Cache447()
         if n_past:
@@ -881,9 +902,12 @@ def gen_beam_loop():
                                                                           past_key_values=past)
         gcfg = types.SimpleNamespace(_pad_token_tensor=torch.tensor(60), _eos_token_tensor=torch.tensor(eos), output_attentions=False,
                                      output_hidden_states=False, output_scores=False, output_logits=False,
-                                     return_dict_in_generate=True, low_memory=False, do_sample=False)
+                                     return_dict_in_generate=True, low_memory=False, do_sample=smp is not None)
         trace.update(n=0, pre=f"c{ci}_")
         scorer = Scorer(B, lp)
+        ns["generation_mixin_beam_search"].__globals__["torch"] = TorchWithCountedDraw(seed) if smp is not None else torch
+        out[f"c{ci}_sample"] = np.array([0.0, 0.0, 0.0, 0.0] if smp is None else list(smp), dtype=np.float64)
+        out[f"c{ci}_seed"] = np.array(seed)
         res = ns["generation_mixin_beam_search"](Model(), ids_x, scorer, logits_processor=procs,
                                                  stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(prompt_len + max_new)]),
                                                  generation_config=gcfg, synced_gpus=False, **kw_x)
@@ -960,12 +984,21 @@ def gen_sampling_warpers():
     out = {"transformers_version": np.array(transformers.__version__)}
     g = torch.Generator().manual_seed(99)
     cases = [(0.7, 50, 0.9, 0.0), (1.0, 0, 0.8, 0.0), (1.3, 10, 1.0, 0.0), (1.0, 0, 1.0, 0.004), (0.5, 40, 0.95, 0.002), (1.0, 1, 1.0, 0.0), (2.0, 0, 0.3, 0.0),
-             (0.8, 400, 0.99, 0.0005)]
-    for ci, (temp, top_k, top_p, eps) in enumerate(cases):
+             (0.8, 400, 0.99, 0.0005),
+             # under beam search the same function builds the warpers with min_tokens_to_keep = len(eos ids) + 1 (5th entry: the eos id count)
+             (1.0, 2, 1.0, 0.0, 3), (1.0, 0, 0.05, 0.0, 3), (1.0, 0, 1.0, 0.2, 3), (0.9, 3, 0.1, 0.05, 1)]
+    for ci, case in enumerate(cases):
+        temp, top_k, top_p, eps = case[:4]
+        n_eos = case[4] if len(case) > 4 else None
         kw = dict(do_sample=True, temperature=temp, top_k=top_k, top_p=top_p, pad_token_id=0)
         if eps > 0:
             kw["epsilon_cutoff"] = eps
+        if n_eos is not None:
+            kw.update(num_beams=4, eos_token_id=list(range(V - n_eos, V)))
         gc = GenerationConfig(**kw)
+        if n_eos is not None:
+            gc._eos_token_tensor = torch.tensor(list(range(V - n_eos, V)))
+        out[f"c{ci}_min_keep"] = np.array(1 if n_eos is None else n_eos + 1)
         procs = tiny._get_logits_processor(generation_config=gc, input_ids_seq_length=3, encoder_input_ids=None, prefix_allowed_tokens_fn=None,
                                            logits_processor=LogitsProcessorList(), device="cpu", model_kwargs={})
         scores = torch.randn(1, V, generator=g) * (3.0 if ci % 2 else 1.5)

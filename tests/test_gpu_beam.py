@@ -400,3 +400,72 @@ def test_beam_shared_prefix_survives_evictions_and_ring_wrap():
             eng.kv_evict(g, new_size, sys_n)
             evictions += 1
     assert evictions >= 4, f"only {evictions} evictions: the ring never wrapped"
+
+
+def test_beam_sample_with_a_cold_temperature_is_beam_search():
+    """`--do-sample --beam 4` (patch_hf.py:871-875: 2B draws without replacement from the softmax over all beams' warped scores instead of their top-k).
+    At a temperature of 0.02 (colder and fewer than 2B tokens keep a non-zero fp32 probability: torch.multinomial raises, and so does the library) the draws
+    take the largest remaining scores with near-certainty, so the head of the drawn set is the head of the top-k set and -- all scores being scaled by the
+    same 1 / T -- every decision of the scorer is the beam search's: three chunks per trial (growing cache, the winner's KV carried on),
+    the sampled run against the plain beam search of the same engine on the same audio; this exercises the whole sample plumbing (rows to the host,
+    warpers, flattening with the beam scores, the draws, the candidate hand-over to the scorer, EOS-closed hypotheses)."""
+    cfg = toy_config()
+    B = 4
+    gen_b = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=400)
+    gen_s = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=400, do_sample=True, temperature=0.02, seed=7)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=48)
+    eng = Engine(cfg, max_streams=2, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
+    eng.load_weights(w)
+    same = total = 0
+    for trial in range(6):
+        a, b = eng.open_stream(), eng.open_stream()
+        audio = synth.synthetic_audio(cfg.chunk_samples * 3, stream_id=70 + trial)
+        prev = []
+        for c in range(3):
+            seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+            prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            out_b, _ = eng.generate(gen_b, [a], [seg], [prompt], [prev])
+            out_s, _ = eng.generate(gen_s, [b], [seg], [prompt], [prev])
+            total += 1
+            if out_b[0] == out_s[0]:
+                same += 1
+            else:  # from here on the two streams hold different caches: stop comparing this trial
+                print(f"trial {trial} chunk {c}: beam search {out_b[0]} vs cold beam sample {out_s[0]}")
+                break
+            assert eng.stream_info(a)["llm_cache_len"] == eng.stream_info(b)["llm_cache_len"]
+            prev = prev + out_b[0][:-1]
+        eng.close_stream(a)
+        eng.close_stream(b)
+    print(f"cold beam sample == beam search on {same} of {total} chunks")
+    assert same >= total - 1 and total >= 16
+    eng.close()
+
+
+def test_beam_sample_is_seeded_reproducible_and_refuses_what_torch_refuses():
+    """Temperature 1: the draws are a pure function of (seed, stream, chunk, step, draw) -- the same call twice gives the same tokens, another seed
+    gives other tokens, every token is a valid id and the cache advances like a beam search's.  top_k = 1 leaves one live token per beam, fewer than
+    the 2B draws the loop asks for: torch.multinomial raises there, the library fails loudly too."""
+    from infinisst_amd.engine import IsstError
+    cfg = toy_config()
+    B = 4
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=49)
+    eng = Engine(cfg, max_streams=3, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=400, max_system_prompt=64, max_beams=B)
+    eng.load_weights(w)
+    audio = synth.synthetic_audio(cfg.chunk_samples, stream_id=81)
+    prompt = synth.chunk_prompt_ids(cfg, 1, first=True)
+    outs = {}
+    for seed in (1, 1, 2, 3):
+        sid = eng.open_stream()
+        gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=400, do_sample=True, temperature=1.0, top_k=50, top_p=0.98, seed=seed)
+        o, _ = eng.generate(gen, [sid], [audio], [prompt], [[]])
+        assert all(0 <= t < cfg.vocab for t in o[0]) and 1 <= len(o[0]) <= 6
+        assert eng.stream_info(sid)["llm_cache_len"] == len(prompt) + len(o[0]) - 1
+        eng.close_stream(sid)
+        if seed in outs:
+            assert outs[seed] == o[0], "the same seed, stream slot and chunk must draw the same tokens"
+        outs[seed] = o[0]
+    assert len({tuple(v) for v in outs.values()}) >= 2, f"three seeds, one continuation: {outs}"
+    sid = eng.open_stream()
+    with pytest.raises(IsstError, match="non-zero probability"):
+        eng.generate(GenConfig(max_new_tokens=6, beam=B, do_sample=True, top_k=1, seed=1), [sid], [audio], [prompt], [[]])
+    eng.close()

@@ -589,6 +589,6 @@ def test_sample_branch_draws_from_the_oracle_distribution():
     assert a1 == a2
     print(f"sample branch: {steps} steps, {len(distinct)} distinct tokens drawn; another seed: {a1[0]}")
     assert steps >= 16 and len(distinct) >= 8, "the draws must actually vary (top_k 50 at temperature 0.8 over near-flat toy logits)"
-    # beam sample is refused
-    with pytest.raises(IsstError):
+    # beams on an engine created for greedy decoding only (max_beams 1) are refused (beam sample itself: tests/test_gpu_beam.py)
+    with pytest.raises(IsstError, match="max_beams"):
         eng.generate(GenConfig(max_new_tokens=4, beam=2, do_sample=True), [sid3], [other[:cfg.chunk_samples]], [prompt], [[]])

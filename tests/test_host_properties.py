@@ -3,6 +3,7 @@ speech splice's row map and the sampling warpers, each against the oracle's rest
 fixtures under tests/golden/ pin the oracle, these widen the HIP side's host code around them.  No GPU: the C entry points used here
 (isst_op_splice_map, isst_op_warp_sample) are host functions of the library."""
 import numpy as np
+import pytest
 import torch
 from hypothesis import given, settings, strategies as st
 
@@ -104,6 +105,45 @@ def test_host_warpers_equal_the_oracle_on_random_scores(seed, vocab, temp, top_k
     fin = np.isfinite(got)
     assert np.allclose(got[fin], ref_scores.numpy()[fin], rtol=1e-6, atol=1e-6)
     assert tok == ogen.draw(ref_scores, u) or _near_a_cdf_edge(ref_scores, u)
+
+
+@settings(max_examples=80, deadline=None)
+@given(seed=st.integers(min_value=0, max_value=10 ** 6), vocab=st.integers(min_value=8, max_value=500), temp=st.sampled_from([0.6, 1.0, 1.4]),
+       top_k=st.sampled_from([0, 2, 40]), top_p=st.sampled_from([0.05, 0.7, 1.0]), eps=st.sampled_from([0.0, 0.01, 0.3]), min_keep=st.sampled_from([1, 2, 4]))
+def test_host_warpers_with_min_tokens_to_keep_equal_the_oracle(seed, vocab, temp, top_k, top_p, eps, min_keep):
+    """Under beam search HF builds the same warpers with min_tokens_to_keep = eos ids + 1 (pinned for the oracle by sampling_warpers.npz cases 8-11 and
+    by the beam-sample cases of beam_loop.npz): csrc/warp.hip against oracle.generate.warp_logits, aggressive cut-offs included."""
+    rng = np.random.default_rng(seed)
+    sc = (rng.standard_normal(vocab) * 3).astype(np.float32)
+    sc[rng.random(vocab) < 0.1] = -np.inf
+    sc[:min_keep] = np.sort(rng.standard_normal(min_keep).astype(np.float32))  # (at least min_keep finite entries)
+    ref = ogen.warp_logits(torch.from_numpy(sc.copy()), temp, top_k, top_p, eps, min_tokens_to_keep=min_keep).numpy()
+    got = E.op_warp(sc, temp, int(top_k), top_p, eps, min_keep)
+    assert np.array_equal(np.isinf(got), np.isinf(ref)), "kept set"
+    fin = np.isfinite(ref)
+    assert np.allclose(got[fin], ref[fin], rtol=1e-6, atol=1e-6) and int(fin.sum()) >= min(min_keep, int(np.isfinite(sc).sum()))
+
+
+@settings(max_examples=120, deadline=None)
+@given(seed=st.integers(min_value=0, max_value=10 ** 6), n=st.integers(min_value=4, max_value=4000), k=st.integers(min_value=1, max_value=16))
+def test_draws_without_replacement_equal_the_oracle(seed, n, k):
+    """The beam-sample draw (patch_hf.py:871-873: torch.multinomial without replacement over all beams' scores) as csrc/warp.hip does it against
+    oracle.generate.multinomial_without_replacement: same picks in the same order, all distinct, never an entry of zero probability; an impossible
+    request (fewer live entries than draws) is refused by both."""
+    rng = np.random.default_rng(seed)
+    sc = (rng.standard_normal(n) * 4).astype(np.float32)
+    sc[rng.random(n) < 0.3] = -np.inf
+    us = rng.random(k).tolist()
+    try:
+        ref = ogen.multinomial_without_replacement(torch.from_numpy(sc), k, us)
+    except (RuntimeError, IndexError):
+        ref = None  # fewer live entries than draws (probabilities that underflow to zero count as dead): torch raises, so must the library
+    if ref is None:
+        with pytest.raises(E.IsstError):
+            E.op_multinomial_wor(sc, k, us)
+        return
+    got = E.op_multinomial_wor(sc, k, us)
+    assert got == ref and len(set(got)) == k and all(np.isfinite(sc[i]) for i in got)
 
 
 def _near_a_cdf_edge(scores, u, margin=1e-6):

@@ -244,19 +244,31 @@ def test_beam_loop_matches_reference(golden_dir):
     from toy_beam_model import toy_beam_forward
     g = load(golden_dir, "beam_loop.npz")
     eos = [int(e) for e in g["eos"]]
-    n_eos_hyps = 0
+    n_eos_hyps = n_sampled = 0
     for ci in range(int(g["n_cases"])):
         B, prompt_len, max_new, n_steps, ngram = (int(v) for v in g[f"c{ci}_cfg"])
+        temp, top_k, top_p, eps = (float(x) for x in g[f"c{ci}_sample"])  # all zero: beam search; else the loop's do_sample branch (:871-875, beam sample)
+        sampled = temp > 0
+        n_sampled += int(sampled)
+        warpers = [n for n, on in (("TemperatureLogitsWarper", sampled and temp != 1.0), ("TopKLogitsWarper", sampled and top_k > 0),
+                                   ("TopPLogitsWarper", sampled and top_p < 1.0), ("EpsilonLogitsWarper", sampled and eps > 0)) if on]
         assert [str(x) for x in g[f"c{ci}_processor_order"]] == ["RepetitionPenaltyLogitsProcessor", "NoRepeatNGramLogitsProcessor",
-                                                                  "EncoderNoRepeatNGramLogitsProcessor", "SuppressTokensLogitsProcessor"]
+                                                                  "EncoderNoRepeatNGramLogitsProcessor", "SuppressTokensLogitsProcessor"] + warpers
         E, O, bias = (torch.from_numpy(g[f"c{ci}_{k}"]) for k in ("E", "O", "bias"))
         fwd = toy_beam_forward(E, O, bias, float(g[f"c{ci}_decay"]))
         enc_ids = [int(t) for t in g[f"c{ci}_enc_ids"]]
         suppress = [int(t) for t in g[f"c{ci}_suppress"]]
         process = lambda lp, seq: ogen.process_logits(lp, seq, enc_ids, 1.2, ngram, ngram, suppress)
+        draw = None
+        if sampled:  # the warpers are part of the processor list (min_tokens_to_keep = eos ids + 1 under beam search); the draws: the counter-based sampler
+            #          the fixture's run had in place of torch.multinomial (stream 0, chunk 0, counter 64 step + j)
+            seed = int(g[f"c{ci}_seed"])
+            process = lambda lp, seq: ogen.warp_logits(ogen.process_logits(lp, seq, enc_ids, 1.2, ngram, ngram, suppress), temp, int(top_k), top_p, eps,
+                                                       min_tokens_to_keep=len(eos) + 1)
+            draw = lambda flat, n, step: ogen.multinomial_without_replacement(flat, n, [ogen.sample_uniform(seed, 0, 0, 64 * step + j) for j in range(n)])
         past = [E[int(t)].clone() for t in g[f"c{ci}_past_tokens"]]
         out, best_kv, steps = obeam.beam_search_loop(fwd, process, B, [int(t) for t in g[f"c{ci}_prompt"]], past, eos, max_new,
-                                                     float(g[f"c{ci}_lp"]), clone=lambda kv: [t.clone() for t in kv])
+                                                     float(g[f"c{ci}_lp"]), clone=lambda kv: [t.clone() for t in kv], draw=draw)
         assert len(steps) == n_steps, f"case {ci}: {len(steps)} steps, reference {n_steps}"
         for st, rec in enumerate(steps):
             pre = f"c{ci}_s{st}_"
@@ -271,6 +283,7 @@ def test_beam_loop_matches_reference(golden_dir):
         np.testing.assert_allclose(torch.stack(best_kv).numpy(), g[f"c{ci}_winner_kv"], rtol=0, atol=0,
                                    err_msg=f"case {ci}: the winner must carry its own cache")
     assert n_eos_hyps >= 3, "the fixture must exercise EOS-closed hypotheses"
+    assert n_sampled == 2, "the fixture must exercise the beam-sample branch"
 
 
 def test_logits_processors_match_transformers(golden_dir):
@@ -291,7 +304,7 @@ def test_logits_processors_match_transformers(golden_dir):
 
 def test_sampling_warpers_match_transformers(golden_dir):
     """oracle.generate.warp_logits (the sample branch, agents/infinisst.py:311-315 -> patch_hf.py:606-624) against the warpers transformers 5.15's own
-    `_get_logits_processor` builds for do_sample -- Temperature -> TopK -> TopP -> Epsilon, the order is part of the fixture -- on 8 parameter sets:
+    `_get_logits_processor` builds for do_sample -- Temperature -> TopK -> TopP -> Epsilon, the order is part of the fixture -- on 12 parameter sets (4 of them as under beam search: min_tokens_to_keep = eos ids + 1):
     the same tokens removed, the same surviving scores bit for bit."""
     from oracle import generate as ogen
     g = load(golden_dir, "sampling_warpers.npz")
@@ -300,8 +313,10 @@ def test_sampling_warpers_match_transformers(golden_dir):
         want_order = [n for n, on in (("TemperatureLogitsWarper", temp != 1.0), ("TopKLogitsWarper", top_k > 0), ("TopPLogitsWarper", top_p < 1.0),
                                       ("EpsilonLogitsWarper", eps > 0)) if on]
         assert [str(x) for x in g[f"c{ci}_order"]] == want_order, f"case {ci}: warper order"
-        got = ogen.warp_logits(torch.from_numpy(g[f"c{ci}_scores"]), temp, int(top_k), top_p, eps).numpy()
+        min_keep = int(g[f"c{ci}_min_keep"])  # 1: the sample branch; eos ids + 1: what the same function builds under beam search
+        got = ogen.warp_logits(torch.from_numpy(g[f"c{ci}_scores"]), temp, int(top_k), top_p, eps, min_tokens_to_keep=min_keep).numpy()
         ref = g[f"c{ci}_out"]
+        assert int(np.isfinite(ref).sum()) >= min_keep
         assert np.array_equal(np.isinf(got), np.isinf(ref)), f"case {ci}: kept sets differ"
         assert np.array_equal(got[~np.isinf(ref)], ref[~np.isinf(ref)]), f"case {ci}: warped scores differ"
     # the draw: inverse CDF in vocabulary order; the uniforms are a pure function of (seed, stream, chunk, step)
