@@ -122,6 +122,11 @@ int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16
 int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* psum, int rows, hipStream_t s);
 int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
                      hipStream_t s);
+// the same in ONE launch; the tokens also go to the pinned array `host_tokens`, and `*host_seq` receives the launch's sequence number (tickets[1], kept on
+// the device) once every stream's token is there.  tickets: 2 + max streams ints, zero before the first launch
+int launch_sample_fused(float* logits, long ld_logits, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool, const int* suppress,
+                        int n_suppress, float rep_penalty, int ngram, int enc_ngram, int* out_tokens, float* scratch_val, int* scratch_idx, int* tickets,
+                        int* host_tokens, int* host_seq, int n_streams, hipStream_t s);
 // processors only (stage 1 of launch_sample), in place on the rows named by ss[]
 // warp.hip (host): HF's logits warpers (Temperature -> TopK -> TopP -> Epsilon) on one row of processed scores, then an inverse-CDF draw at `u`
 int warp_and_sample(float* scores, int n, float temperature, int top_k, float top_p, float epsilon, double u);

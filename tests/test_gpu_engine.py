@@ -418,6 +418,44 @@ def test_decode_step_graph_replay_is_bit_identical(monkeypatch):
     assert run(True) == run(False)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_sampling_tail_equals_the_three_launch_tail(monkeypatch, graph):
+    """Up to 16 rows the greedy sampling tail is ONE launch (sample.hip sample_fused_kernel: processors on each block's slice of the row, argmax, last-arriver
+    merge, tokens + a sequence number into pinned host memory, the host waits on that number instead of synchronising the stream); ISST_FUSED_SAMPLE=0 keeps the
+    three launches + D2H copy + synchronisation.  Same tokens, same cache lengths, chunk after chunk -- launched directly and replayed from a captured graph
+    (the sequence number lives on the device, so replays count correctly) -- with repeated tokens in the history (penalty, n-gram bans) and two streams in a call."""
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=43, recipe="peaked")
+    gen = GenConfig(max_new_tokens=7, max_llm_cache_size=150, no_repeat_ngram_size=3)
+    audio = [synth.synthetic_audio(cfg.chunk_samples * 5, stream_id=20 + k) for k in range(2)]
+
+    def run(fused):
+        monkeypatch.setenv("ISST_FUSED_SAMPLE", "1" if fused else "0")
+        if graph:
+            monkeypatch.setenv("ISST_GRAPH", "1")
+        else:
+            monkeypatch.delenv("ISST_GRAPH", raising=False)
+        eng = make_engine(cfg, w, debug_taps=False, max_multiplier=1)
+        sids = [eng.open_stream(), eng.open_stream()]
+        out, prev = [], [[], []]
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for c in range(5):
+                segs = [a[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples] for a in audio]
+                ids, _ = eng.generate(gen, sids, segs, [synth.chunk_prompt_ids(cfg, 1, first=(c == 0))] * 2, prev)
+                out.append((ids, [eng.stream_info(s_)["llm_cache_len"] for s_ in sids]))
+                prev = [prev[k] + ids[k][:-1] for k in range(2)]
+                for s_ in sids:
+                    if eng.stream_info(s_)["llm_cache_len"] > 120:
+                        eng.kv_evict(s_, 60, 0)
+            torch.cuda.synchronize()
+        eng.close()
+        return out
+
+    a, b = run(True), run(False)
+    assert a == b
+    assert len({tuple(t) for ids, _ in a for t in ids}) > 2
+
+
 @pytest.mark.parametrize("target_wgs", [1, 6])
 def test_attention_span_forms_match_oracle(target_wgs):
     """The many-stream forms of the decoder attention, forced on one stream through the tuning hook: target 1 = one workgroup per
