@@ -1406,9 +1406,8 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 }
             }
         } else {
-            CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val, h->top_idx, rows, st));
-            HIPCHK(hipMemcpyAsync(h->top_val_host, h->top_val, sizeof(float) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(h->top_idx_host, h->top_idx, sizeof(int) * rows * BEAM_TOPK, hipMemcpyDeviceToHost, st));
+            // (the final selection stores its <= 32 candidates per row straight into the pinned host arrays: no device copy, no two D2H launches per step)
+            CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val_host, h->top_idx_host, rows, st));
             HIPCHK(hipStreamSynchronize(st));
             h->kv_ops_used = 0;  // every earlier copy batch has run
         }
