@@ -1814,9 +1814,9 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             ++h->samp_seq_expected;
             return ISST_OK;
         }
+        // (three launches; the last one stores the tokens straight into the pinned host array -- no D2H launch behind it)
         CHK(launch_sample(h->logits, h->vocab_pad, c.vocab, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
-                          p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->out_tok, h->samp_val, h->samp_idx, na, st));
-        HIPCHK(hipMemcpyAsync(h->tok_host, h->out_tok, sizeof(int) * na, hipMemcpyDeviceToHost, st));
+                          p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->tok_host, h->samp_val, h->samp_idx, na, st));
         return ISST_OK;
     };
     // the tokens of the tail that was enqueued last are on the host.  Fused tail: wait for its sequence number in pinned memory (the kernel stores it, system scope,
