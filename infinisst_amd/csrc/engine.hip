@@ -529,6 +529,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         hipHostMalloc(reinterpret_cast<void**>(&h->top_idx_host), sizeof(int) * NB * BEAM_TOPK) != hipSuccess) {
         h->fail(ISST_ERR_NOMEM, "pinned host allocation failed"); return die(ISST_ERR_NOMEM);
     }
+    std::memset(h->tok_host, 0, sizeof(int) * (NB + 16));  // the published sequence number starts at 0 = "no fused tail yet" (samp_seq_expected counts from 1)
     if (hipDeviceSynchronize() != hipSuccess) { h->fail(ISST_ERR_HIP, "device sync after allocation failed"); return die(ISST_ERR_HIP); }
     *out = h;
     return ISST_OK;
