@@ -396,7 +396,7 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
 // tuning overrides for profiles/gemv_sweep.py (0 = heuristic)
 static int g_tune_w = 0, g_force_skinny = 0, g_tune_merge_w = 0, g_tune_flags = 0;
 // w: waves per workgroup of the skinny kernel (0 = heuristic, < 0 = never use the mid / tiled kernels); ntb: passed on to gemm_mid (its width / timing knobs)
-void gemm_set_tuning(int w, int ntb) { if (w >= 800000) { gemm_dense_set(w - 800000); return; } if (w >= 700000) { g_tune_flags = w - 700000; return; } if (w >= 300000) { g_tune_merge_w = w - 300000; return; } if (w >= 200000) { gemm_mid_set_min_rows(w - 200000); return; } if (w >= 100000) { gemm_tiled_set_raster(w - 100000); return; } g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
+void gemm_set_tuning(int w, int ntb) { if (w >= 900000) { gemm_wide_set((w - 900000) / 10, (w - 900000) % 10); return; } if (w >= 800000) { gemm_dense_set(w - 800000); return; } if (w >= 700000) { g_tune_flags = w - 700000; return; } if (w >= 300000) { g_tune_merge_w = w - 300000; return; } if (w >= 200000) { gemm_mid_set_min_rows(w - 200000); return; } if (w >= 100000) { gemm_tiled_set_raster(w - 100000); return; } g_tune_w = w < 0 ? 0 : w; g_force_skinny = w < 0; gemm_mid_set_tuning(ntb); }
 
 static inline bool gemm_can_stage(const GemmArgs& g) {
     return g.batch == 1 && g.M <= 16 && (size_t)g.M * g.K * 2 <= 64 * 1024 && g.M <= GEMM_FUSED_NORM_MAX_M;
@@ -474,10 +474,12 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.batch <= 0) return ISST_OK;
     if (g.K % 32 != 0 || g.N % 16 != 0 || g.lda % 8 != 0) return ISST_ERR_ARG;
     if ((!g.attn_partial && (reinterpret_cast<uintptr_t>(g.A) & 15)) || (reinterpret_cast<uintptr_t>(g.Wp) & 15)) return ISST_ERR_ARG;
-    if (!g.attn_partial && gemm_mid_supported(g) && gemm_mid_preferred(g) && !g_force_skinny) {
+    if (!g.attn_partial && gemm_mid_supported(g) && gemm_mid_preferred(g) && !g_force_skinny && !(gemm_wide_supported(g) && gemm_wide_preferred(g))) {
         if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return ISST_ERR_ARG;
         return launch_gemm_mid(g, stream);
     }
+    // 65..256 rows against a long weight stream (decode passes of many streams / streams x beams): weights read once, deep register rings
+    if (!g_force_skinny && gemm_wide_supported(g) && gemm_wide_preferred(g)) return launch_gemm_wide(g, stream);
     if (!g.attn_partial && gemm_tiled_supported(g) && !g_force_skinny) {
         const bool ok = (g.epi != EPI_BIAS && g.epi != EPI_BIAS_GELU && g.epi != EPI_BIAS_RES) || g.bias;
         if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return ISST_ERR_ARG;

@@ -1,0 +1,284 @@
+// Weight-streaming MFMA GEMM for 65..256 rows on gfx950:  out[M,N] = epi(A[M,K] @ W[N,K]^T), every weight byte read ONCE.
+//
+// Where it runs: the decode passes of 65..256 batched rows -- 65..256 concurrent streams, or 17..64 streams x beam 4, the reference's
+// production decoding (agents/infinisst.py:86 asserts beam > 1; scripts/infer/infinisst.sh:48) -- through q/k/v, o_proj, gate/up, down_proj
+// (patch_llm.py:260-262,334 and HF LlamaMLP [3P]) and lm_head (model/llm.py:236-262).  These launches are still HBM-bound (intensity
+// 128..256 flop per weight byte against a ridge of ~300), but until round 4 they fell onto gemm_tiled.hip, whose one-K-step prefetch keeps
+// ~32 KB in flight per CU: 3.3 TB/s on gate/up at 128 rows (profiles/r03/trace_busy_prof128.txt), and at 129..256 rows it read the weights twice.
+//
+// Structure -- gemm_tiled's dataflow (bit-identical results: same MFMA, same ascending K order per accumulator, same epilogue arithmetic)
+// rebuilt around what a weight stream needs on this part, ~100+ KB in flight per CU (MI355X_MICROARCH.md: ~25 GB/s per CU x 3-4 us loaded latency):
+//   * workgroup = 4 waves = ONE wave per SIMD, so a wave may hold up to 512 registers (unified VGPR + AGPR file): the accumulators of
+//     ALL rows (MT m-tiles x 2 n-tiles: 64 registers at 128 rows, 128 at 256 rows) plus two statically indexed register RINGS;
+//   * wave w owns n-tiles 2w, 2w+1 of the workgroup's 8 (128 columns; the (gate, up) pair of SwiGLU sits in one wave) x all rows x all of
+//     K: no K split across waves, no cross-wave reduction, one accumulation chain per output element in ascending K;
+//   * W ring: the wave's weight fragments stream straight from the fragment-major packed layout into VGPRs (1 KiB coalesced per load,
+//     non-temporal), DW K-steps (64 deep each: 4 KiB per wave and step) ahead -- 96 KB per CU at DW = 6;
+//   * A ring: activations (L2-resident, shared by every workgroup) are loaded in full 128-byte lines (8 rows x 128 B per wave-load), DA
+//     K-steps ahead in registers, and written to LDS one step ahead of use as ready-made MFMA A fragments ([k-step][m-tile][lane] x 16 B:
+//     conflict-free ds_write_b128 / ds_read_b128), double buffered, one barrier per K-step; every wave reads all rows' fragments and feeds
+//     two MFMAs from each;
+//   * every load is an unconditional bounds-checked buffer load through a descriptor covering exactly the slice: steps past the end and
+//     rows past M read zeros without traffic, so the loop has no branch around a load and hipcc emits counted s_waitcnt vmcnt(n)
+//     (program order of the prologue pinned with sched_barrier: left alone hipcc fills a ring back to front and the first wait drains it);
+//   * narrow outputs (q/k/v, o_proj, down_proj: 32..48 column blocks) split K over blockIdx.y into fp32 slabs (EPI_PARTIAL) that the
+//     residual + RMSNorm kernel (or launch_slab_reduce) sums in slice order, exactly as gemm_tiled's split-K does.
+#include "common.h"
+
+#define WIDE_TK 64          // K elements per step (two MFMA k-steps); one barrier per step
+#define WIDE_NT 8           // n-tiles per workgroup (128 columns)
+
+constexpr int wide_gcd(int a, int b) { return b == 0 ? a : wide_gcd(b, a % b); }
+constexpr int wide_lcm(int a, int b) { return a / wide_gcd(a, b) * b; }
+
+// acc += A x B (v_mfma_f32_16x16x32_bf16) with the accumulator TIED to one AGPR quad.  Through the builtin hipcc renames the 16..32 accumulators
+// inside the unrolled ring period (dst != srcC) and repairs the names at the back edge with ~50 v_accvgpr_read / _write / _mov per K-step -- 40 %
+// on top of the step's 32 MFMAs, with one wave per SIMD and nothing to hide them behind.  What the compiler no longer does for this statement
+// (cdna_hip_programming.md section 5.7): it pads no hazard around it.  Inside the k-loop the only consumer of an accumulator is the next MFMA
+// taking it whole as C (no wait states needed); the operands come from ds_read / buffer_load, which the compiler still waits for (they are
+// ordinary register operands of the statement); the first non-MFMA reader is the epilogue, behind the s_nop pair after the loop.
+__device__ __forceinline__ void wide_mfma(f32x4_t& c, const u32x4_t& a, const u32x4_t& b) {
+    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+#ifdef ISST_WIDE_TRACE
+// diagnostic build (make trace -> libinfinisst_hip_trace.so, profiles/wide_trace_probe.py): wave 0 of every workgroup stamps the shader clock
+// (s_memtime; slots 0 and 3: the 100 MHz wall clock) into a device array the probe reads back: loop entry / exit, the end of every K-step, and the
+// phases of step 8.  In the product build no stamp executes.
+#define WIDE_TRACE_SLOTS 256
+__device__ unsigned long long g_wide_trace[2048 * WIDE_TRACE_SLOTS];
+extern "C" int isst_debug_wide_trace_read(void* dst, long bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wide_trace), bytes < (long)sizeof(g_wide_trace) ? bytes : (long)sizeof(g_wide_trace)) == hipSuccess ? 0 : -2;
+}
+#define WIDE_SLOT(i) g_wide_trace[(long)((blockIdx.x + gridDim.x * blockIdx.y) & 2047) * WIDE_TRACE_SLOTS + (i)]
+#define WIDE_STAMP(i) do { if (wave == 0) { const unsigned long long tt = __builtin_amdgcn_s_memtime(); if (lane == 0) WIDE_SLOT(i) = tt; } } while (0)
+#define WIDE_STAMP_RT(i) do { if (wave == 0) { const unsigned long long tt = __builtin_amdgcn_s_memrealtime(); if (lane == 0) WIDE_SLOT(i) = tt; } } while (0)
+#else
+#define WIDE_STAMP(i) do { } while (0)
+#define WIDE_STAMP_RT(i) do { } while (0)
+#endif
+
+template <int MT, int DW, int DA, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_wide_kernel(GemmArgs g, int steps, int dbg) {
+    constexpr int AU = MT / 2;            // staging units (8 rows x 128 B) per wave and step
+    constexpr int ABUF = MT * 2048;       // bytes of one staged step: [2 k-steps][MT][64 lanes][16 B]
+    constexpr int U = wide_lcm(wide_lcm(DW, DA), 2);  // unroll period: ring slots and the LDS buffer parity are compile-time constants
+    static_assert(U % DW == 0 && U % DA == 0 && U % 2 == 0, "unroll period");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 x ABUF
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the descriptors below are built from it
+    const int fr = lane & 15, fq = lane >> 4;
+    const int KT = g.K >> 5, NTILES = g.N >> 4;
+    const int nt0 = blockIdx.x * WIDE_NT + wave * 2;
+    const int slice = blockIdx.y;
+    const int step0 = slice * steps;
+    const int m0 = blockIdx.z * (MT * 16);
+
+    f32x4_t acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+    // ---- W: one descriptor per n-tile over exactly this slice's k-tiles (tiles past N: empty) ----
+    const bool nv0 = nt0 < NTILES, nv1 = nt0 + 1 < NTILES;
+    __amdgpu_buffer_rsrc_t wrs[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const bool v = nb ? nv1 : nv0;
+        wrs[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + ((long)(v ? nt0 + nb : 0) * KT + (long)step0 * 2) * 512, 0, (v && !(dbg & 1)) ? steps * 2048 : 0, 0x00020000);  // (dbg: timing-only builds with a descriptor emptied, profiles/wide_probe.py)
+    }
+    const int woff = lane * 16;
+    auto load_w = [&](int t, int kk, int nb) -> u32x4_t { return __builtin_amdgcn_raw_buffer_load_b128(wrs[nb], woff + (t * 2 + kk) * 1024, 0, 2 /* nt: read once */); };
+
+    // ---- A: unit = 8 rows x 128 B of one step; lane -> (row rlo = lane & 7, 16-byte piece p = lane >> 3) ----
+    const int rlo = lane & 7, p = lane >> 3;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, (dbg & 2) ? 0 : (int)((((long)g.M - 1) * g.lda + g.K) * 2), 0x00020000);
+    unsigned aoff[AU];  // byte offset of this lane's piece of step 0 (rows past M: outside the descriptor -> zeros, no traffic)
+    int adst[AU];       // byte offset inside one LDS buffer
+#pragma unroll
+    for (int a = 0; a < AU; ++a) {
+        const int row = (wave * AU + a) * 8 + rlo;  // 0 .. MT*16-1
+        aoff[a] = (m0 + row < g.M) ? (unsigned)((((long)(m0 + row)) * g.lda + (long)step0 * WIDE_TK + p * 8) * 2) : 0xC0000000u;
+        adst[a] = ((((p >> 2) * MT + (row >> 4)) * 64) + (p & 3) * 16 + (row & 15)) * 16;
+    }
+    // (steps past the slice -- the ring runs ahead of the end, and the loop is padded to its unroll period -- read zeros as well: a scalar select, no branch)
+    auto load_a = [&](int t, int a) -> u32x4_t { return __builtin_amdgcn_raw_buffer_load_b128(ars, t < steps ? aoff[a] + (unsigned)t * (WIDE_TK * 2) : 0xC0000000u, 0, 0); };
+
+    u32x4_t areg[DA][AU];     // A steps t+2 .. t+1+DA (slot = step % DA)
+    u32x4_t wreg[DW][2][2];   // W steps t .. t+DW-1 (slot = step % DW): [k-step of the step][n-tile]
+    // ---- prologue: program order = order of first use (A step 0, W step 0, A step 1, W step 1, ...), pinned ----
+#pragma unroll
+    for (int s = 0; s < (DW > DA ? DW : DA); ++s) {
+        if (s < DA) {
+#pragma unroll
+            for (int a = 0; a < AU; ++a) areg[s][a] = load_a(s, a);
+        }
+        if (s < DW) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) { wreg[s][kk][0] = load_w(s, kk, 0); wreg[s][kk][1] = load_w(s, kk, 1); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // images of steps 0 and 1 (three LDS buffers: step t's and t+1's are complete while t+2's is being written)
+    static_assert(DA >= 2, "two images are staged before the loop");
+#pragma unroll
+    for (int s0 = 0; s0 < 2; ++s0) {
+#pragma unroll
+        for (int a = 0; a < AU; ++a) *reinterpret_cast<u32x4_t*>(smem + s0 * ABUF + adst[a]) = areg[s0][a];
+#pragma unroll
+        for (int a = 0; a < AU; ++a) areg[s0][a] = load_a(DA + s0, a);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+
+    // A fragments travel in GROUPS of 8 (one k-step x 8 m-tiles = 16 MFMAs = 256 matrix-pipe cycles) through two register sets: the next group --
+    // of this step, or the FIRST group of the next step, whose image the previous barrier already published -- is requested before the MFMAs
+    // of the current one.  With ONE wave per SIMD nobody else covers an LDS round trip; this way the matrix pipe never waits for one (left to
+    // itself hipcc emits read -> wait -> 2 MFMAs, sixteen times per step).  Order pinned with sched_barrier.
+    constexpr int MH = MT / 8, NG = 2 * MH;
+    const unsigned char* frd = smem + lane * 16;
+    u32x4_t af[2][8];
+    auto rd = [&](const unsigned char* buf, int gi, int slot) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) af[slot][j] = *reinterpret_cast<const u32x4_t*>(buf + ((gi / MH) * MT + (gi % MH) * 8 + j) * 1024);
+    };
+    rd(frd, 0, 0);
+    int b0 = 0, b1 = ABUF, b2 = 2 * ABUF;  // LDS buffers of steps t, t+1, t+2
+    WIDE_STAMP_RT(0); WIDE_STAMP(1);
+    for (int t0 = 0; t0 < steps; t0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            // NO condition on t: an iteration past the last step (steps % U != 0) multiplies zeros by zeros -- every path through the loop issues the
+            // same loads in the same order, which is what lets hipcc count its waits (a skipped iteration makes the back edge's wait a drain)
+            const int sa = (u + 2) % DA, sw = u % DW;
+            if (t == 8) WIDE_STAMP(205);
+            // ONE instruction stream per SIMD: whatever is issued between two MFMAs runs in the shadow of the first (an MFMA holds the issue port for
+            // 8 of its 16 cycles), whatever is issued in a block of its own stalls the matrix pipe (measured with the trace build: 8 ds_read_b128
+            // 128 cycles, 4 buffer loads 150, the image write + 4 loads 340 -- 1120 cycles per step for 512 cycles of MFMA).  So every MFMA is
+            // followed by exactly one filler: the next group's 8 fragment reads first, then the image write / the ring refills.  Pinned pair by pair.
+            unsigned char* nbuf = smem + b2;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                const int kk = gi / MH, mh = gi % MH;
+                const unsigned char* nrd = (gi + 1 < NG) ? frd + b0 + (((gi + 1) / MH) * MT + ((gi + 1) % MH) * 8) * 1024 : frd + b1;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    wide_mfma(acc[mh * 8 + (k >> 1)][k & 1], af[gi & 1][k >> 1], wreg[sw][kk][k & 1]);
+                    if (k < 8) {
+                        af[(gi + 1) & 1][k] = *reinterpret_cast<const u32x4_t*>(nrd + k * 1024);
+                    } else {
+                        const int i = k - 8 + 8 * gi;  // filler index of the step: 0 .. 8 NG - 1
+                        if (i < AU) *reinterpret_cast<u32x4_t*>(nbuf + adst[i]) = areg[sa][i];          // image of step t+2 (its loads were issued DA steps ago)
+                        else if (i < 2 * AU) areg[sa][i - AU] = load_a(t + 2 + DA, i - AU);              // ... and the registers re-armed
+                        else if (i >= 8 * NG - 4) wreg[sw][(i - (8 * NG - 4)) >> 1][(i - (8 * NG - 4)) & 1] = load_w(t + DW, (i - (8 * NG - 4)) >> 1, (i - (8 * NG - 4)) & 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (t == 8) WIDE_STAMP(210 + gi);
+            }
+            if (t == 8) WIDE_STAMP(206);
+            __syncthreads();
+            if (t < 200) WIDE_STAMP(4 + t);
+            const int bt = b0; b0 = b1; b1 = b2; b2 = bt;
+        }
+    }
+
+    WIDE_STAMP(2); WIDE_STAMP_RT(3);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have left the pipe before the epilogue's v_accvgpr_read (wide_mfma)
+    // ---- epilogue straight from the accumulators (gemm_tiled.hip's arithmetic, rounding point for rounding point):
+    //      acc[mt][nb][r] = C[m0 + mt*16 + 4 fq + r][(nt0 + nb)*16 + fr] ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + mt * 16 + fq * 4 + r;
+            if (row >= g.M) continue;
+            if constexpr (EPI == EPI_SWIGLU) {
+                const int col = (nt0 >> 1) * 16 + fr;
+                if (nv0 && col < g.n_valid)
+                    reinterpret_cast<bf16_t*>(g.out)[(long)row * g.ldo + col] = f2bf(bfr(silu(bfr(acc[mt][0][r]))) * bfr(acc[mt][1][r]));
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int col = (nt0 + nb) * 16 + fr;
+                    if (!(nb ? nv1 : nv0) || col >= g.n_valid) continue;
+                    const float s = acc[mt][nb][r];
+                    if constexpr (EPI == EPI_PARTIAL) {
+                        reinterpret_cast<float*>(g.out)[(long)slice * g.out_batch + (long)row * g.ldo + col] = s;
+                    } else if constexpr (EPI == EPI_F32) {
+                        reinterpret_cast<float*>(g.out)[(long)row * g.ldo + col] = bfr(s);
+                    } else {
+                        float v;
+                        if constexpr (EPI == EPI_NONE) v = s;
+                        else if constexpr (EPI == EPI_BIAS) v = s + bf2f(g.bias[col]);
+                        else if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(bfr(s + bf2f(g.bias[col])));
+                        else if constexpr (EPI == EPI_RES) v = bf2f(g.res[(long)row * g.ldres + col]) + bfr(s);
+                        else v = bf2f(g.res[(long)row * g.ldres + col]) + bfr(s + bf2f(g.bias[col]));
+                        reinterpret_cast<bf16_t*>(g.out)[(long)row * g.ldo + col] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// tuning hooks (gemm_wide_set): mode 0 = never, 1 = heuristic, 2 = wherever supported; variant = ring depths (profiles/wide_probe.py)
+static int g_wide_mode = 1, g_wide_variant = 0, g_wide_max_rows = 256, g_wide_dbg = 0;
+void gemm_wide_set(int mode, int variant) { g_wide_dbg = mode / 10; g_wide_mode = mode % 10; g_wide_variant = variant; }
+
+bool gemm_wide_supported(const GemmArgs& g) {
+    const int ks = g.ksplit > 1 ? g.ksplit : 1;
+    if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return false;
+    return g_wide_mode != 0 && g.batch == 1 && g.M > 64 && g.M <= g_wide_max_rows && g.K % (WIDE_TK * ks) == 0 && g.K / (WIDE_TK * ks) >= 2 && g.N % 16 == 0 && g.lda % 8 == 0 &&
+           !g.norm_w && !g.attn_partial && !g.tickets && (g.epi != EPI_SWIGLU || g.N % 32 == 0) && ((long)g.M - 1) * g.lda + g.K < (1L << 29);
+}
+// worth it where the weight stream is long (as gemm_mid_preferred): the encoder's 2-8 MB projections at 96 rows are latency-bound
+bool gemm_wide_preferred(const GemmArgs& g) { return g_wide_mode == 2 || (long)g.N * g.K >= (8L << 20); }
+
+template <int MT, int DW, int DA, int EPI>
+static int launch_wide_cfg(const GemmArgs& g, hipStream_t stream) {
+    const int ks = g.epi == EPI_PARTIAL ? (g.ksplit > 1 ? g.ksplit : 1) : 1;
+    const int NTILES = g.N / 16;
+    dim3 grid((NTILES + WIDE_NT - 1) / WIDE_NT, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(256);
+    const size_t lds = (size_t)3 * MT * 2048;
+    static bool attr = false;
+    if (lds > 64 * 1024 && !attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<MT, DW, DA, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_wide_kernel<MT, DW, DA, EPI>), grid, block, lds, stream, g, g.K / WIDE_TK / ks, g_wide_dbg);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+template <int EPI>
+static int launch_wide_epi(const GemmArgs& g, hipStream_t stream) {
+#ifdef ISST_WIDE_PROBE
+    if (g.M <= 128) {
+        if (g_wide_variant == 1) return launch_wide_cfg<8, 4, 2, EPI>(g, stream);
+        if (g_wide_variant == 2) return launch_wide_cfg<8, 8, 4, EPI>(g, stream);
+        if (g_wide_variant == 3) return launch_wide_cfg<8, 8, 2, EPI>(g, stream);
+        return launch_wide_cfg<8, 6, 3, EPI>(g, stream);
+    }
+    if (g_wide_variant == 1) return launch_wide_cfg<16, 4, 2, EPI>(g, stream);
+    if (g_wide_variant == 2) return launch_wide_cfg<16, 6, 2, EPI>(g, stream);
+    return launch_wide_cfg<16, 6, 3, EPI>(g, stream);
+#else
+    if (g.M <= 128) return launch_wide_cfg<8, 6, 3, EPI>(g, stream);
+    return launch_wide_cfg<16, 6, 3, EPI>(g, stream);
+#endif
+}
+
+int launch_gemm_wide(const GemmArgs& g, hipStream_t stream) {
+    if (!gemm_wide_supported(g)) return ISST_ERR_ARG;
+    switch (g.epi) {
+        case EPI_NONE: return launch_wide_epi<EPI_NONE>(g, stream);
+        case EPI_SWIGLU: return launch_wide_epi<EPI_SWIGLU>(g, stream);
+        case EPI_PARTIAL: return launch_wide_epi<EPI_PARTIAL>(g, stream);
+        case EPI_F32: return launch_wide_epi<EPI_F32>(g, stream);
+        case EPI_BIAS: return g.bias ? launch_wide_epi<EPI_BIAS>(g, stream) : ISST_ERR_ARG;
+        case EPI_BIAS_GELU: return g.bias ? launch_wide_epi<EPI_BIAS_GELU>(g, stream) : ISST_ERR_ARG;
+        case EPI_RES: return g.res ? launch_wide_epi<EPI_RES>(g, stream) : ISST_ERR_ARG;
+        case EPI_BIAS_RES: return (g.res && g.bias) ? launch_wide_epi<EPI_BIAS_RES>(g, stream) : ISST_ERR_ARG;
+    }
+    return ISST_ERR_ARG;
+}
