@@ -184,6 +184,7 @@ struct isst_handle {
     float *lpartial = nullptr, *logits = nullptr;
     int* attn_cnt = nullptr;
     float* lslab = nullptr;  // split-K slabs of o_proj / down_proj at 17..512 rows: [slices][rows][llm_dim] fp32
+    long lslab_elems = 0;    // fp32 elements lslab holds: every K-slice choice and every EPI_PARTIAL launch is checked against it
     int* out_tok = nullptr;
     float* samp_val = nullptr;  // partial argmax scratch, 64 per stream
     int* samp_idx = nullptr;
@@ -489,7 +490,8 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->ltickets_n = std::max(DL, (H + 2 * KV) * 128) / 32 + 16;  // a ticketed launch indexes tickets[blockIdx.x]; its narrowest workgroup spans 32 columns (gemm_mid NP = 1)
     h->ltickets = h->dalloc<int>((size_t)h->ltickets_n, true);
     h->attn_cnt = h->dalloc<int>(64, true);  // arrival counters of the in-kernel split-KV combine (llm_attn.hip), one per kv head; zero between launches
-    h->lslab = h->dalloc<float>((size_t)LLM_SLAB_ROWS * std::max(DL, (H + 2 * KV) * 128));
+    h->lslab_elems = (long)LLM_SLAB_ROWS * std::max(DL, (H + 2 * KV) * 128);
+    h->lslab = h->dalloc<float>((size_t)h->lslab_elems);
     const size_t NB = (size_t)ns * h->max_beams;  // decode rows of a beam step
     h->logits = h->dalloc<float>(NB * h->vocab_pad);
     h->out_tok = h->dalloc<int>(NB);
@@ -812,7 +814,7 @@ int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int e
 // profiles/rows_probe.py): enough slices for ~384 workgroups.
 // (the dense kernel keeps 3 workgroups per CU resident, 768 chip-wide: slicing up to that count instead of 384 and up to 2048 rows instead of
 //  1024 gave, same box, 64 / 32 / 16 / 8 streams 100.6 -> 99.7 / 71.5 -> 70.0 / 53.8 -> 53.4 / 45.9 -> 45.3 ms per chunk; 1152 was worse again at 16-32)
-int pick_ksplit(int K, int N, int rows) {
+int pick_ksplit(int K, int N, int rows, long slab_cap) {
     if (rows <= 64) {
         // (N <= 2048 = the encoder's out_proj / fc2, 16..32 column blocks: fc2 20.1 us as GEMM + LayerNorm, 16.6 / 14.7 / 16.5 us with 2 / 4 / 8 slices
         //  + the reducing LayerNorm; out_proj 14.2 -> 11.5 us with 2: profiles/enc_probe.py)
@@ -822,7 +824,16 @@ int pick_ksplit(int K, int N, int rows) {
             if (K % (256 * s) == 0 && K / (256 * s) >= 1) return s;
         return 1;
     }
-    const long slab_cap = (long)LLM_SLAB_ROWS * 4096;  // fp32 elements the slab buffer always holds (isst_create: LLM_SLAB_ROWS x max(llm_dim, q/k/v width))
+    // (slab_cap: fp32 elements of the caller's slab buffer -- isst_handle::lslab_elems; a slice count is only chosen if its slabs fit)
+    if (rows <= 256 && (long)N * K >= (8L << 20)) {  // (= gemm_wide_preferred: shorter weight streams keep gemm_tiled and its slice choice below)
+        // gemm_wide.hip (65..256 rows: one 8-wave workgroup per CU, 128 columns, all rows): enough K slices to give most of the 256 CUs a workgroup and
+        // no more -- a second round of workgroups doubles the launch (profiles/r04/wide_probe.txt, GEMM + reducing norm, us, 128 rows: q/k/v 40.1 / 30.3 /
+        // 26.9 / 34.8 for 1 / 2 / 4 / 8 slices (48 column blocks); down_proj 46.2 / 36.6 for 4 / 8 (32 column blocks); o_proj 25.0 / 24.7)
+        const long blocks = (N + 127) / 128;
+        int s = 1;
+        while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= 256 && (long)s * 2 * rows * N <= slab_cap && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
+        return s;
+    }
     if (gemm_dense_would_run(rows, N, K)) {
         // 256 x 256 tiles, one workgroup per CU (gemm_dense.hip): rounds of 1/s-length tiles + the slab traffic each further slice adds (write + read of
         // rows x N fp32: about 4 % of a round per slice at these shapes).  profiles/dense_split_probe.py, GEMM + reducing norm, us:
@@ -857,6 +868,8 @@ int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& 
     g.A = A; g.lda = lda; g.Wp = L.wp;
     g.out = slabs; g.ldo = L.n_valid; g.out_batch = (long)M * L.n_valid;
     g.M = M; g.N = L.N; g.K = L.K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = L.n_valid; g.ksplit = ksplit;
+    if (slabs == h->lslab && (long)(ksplit > 1 ? ksplit : 1) * M * L.n_valid > h->lslab_elems)
+        return h->fail(ISST_ERR_STATE, "split-K launch of %d slices x %d rows x %d columns exceeds the slab buffer (%ld fp32)", ksplit, M, L.n_valid, h->lslab_elems);
     if (g.tickets && (L.N + 31) / 32 > h->ltickets_n) return h->fail(ISST_ERR_STATE, "ticketed split-K launch over %d columns needs %d arrival counters, %d allocated", L.N, (L.N + 31) / 32, h->ltickets_n);
     CHK(launch_gemm(g, st));
     return ISST_OK;
@@ -946,7 +959,7 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
 #define ISST_ESPLIT_MIN_ROWS 16
 #endif
     const bool esplit = ER > ISST_ESPLIT_MIN_ROWS && ER <= ENC_SPLIT_MAX_ROWS;
-    const int s_out = esplit ? pick_ksplit(D, D, ER) : 1, s_fc2 = esplit ? pick_ksplit(c.enc_ffn, D, ER) : 1;
+    const int s_out = esplit ? pick_ksplit(D, D, ER, h->lslab_elems) : 1, s_fc2 = esplit ? pick_ksplit(c.enc_ffn, D, ER, h->lslab_elems) : 1;
     const long eslab = (long)ER * D;
     const EncLayer* pend = nullptr;  // layer whose fc2 slabs h->ex still lacks
     for (int l = 0; l < c.enc_layers; ++l) {
@@ -1076,8 +1089,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     // residual + RMSNorm kernel that follows reduces the slabs (gemm_mid.hip); `pending`: lx still lacks the previous
     // layer's down_proj slabs
     const bool split_rows = rows > ISST_MID_MIN_ROWS && rows <= LLM_SPLIT_MAX_ROWS;
-    const int so = split_rows ? pick_ksplit(H * 128, DL, rows) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL, rows) : 1;
-    const int sq = (rows > 128 && rows <= LLM_SPLIT_MAX_ROWS) ? pick_ksplit(DL, (H + 2 * KV) * 128, rows) : 1;  // q/k/v: 65..128 rows run on gemm_mid
+    const int so = split_rows ? pick_ksplit(H * 128, DL, rows, h->lslab_elems) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL, rows, h->lslab_elems) : 1;
+    const int sq = (rows > 64 && rows <= LLM_SPLIT_MAX_ROWS) ? pick_ksplit(DL, (H + 2 * KV) * 128, rows, h->lslab_elems) : 1;  // (65..256 rows: gemm_wide's 48 column blocks in 4 slices)
     const long slab = (long)rows * DL;
     // 13..64 rows: no residual + RMSNorm launches (gemm_mid.hip: the producer reduces, the consumer normalises while staging)
     const bool fr = h->fuse_reduce && split_rows && rows <= 64 && so > 1 && sd > 1 && DL % 128 == 0;

@@ -38,7 +38,7 @@ constexpr int wide_lcm(int a, int b) { return a / wide_gcd(a, b) * b; }
 // taking it whole as C (no wait states needed); the operands come from ds_read / buffer_load, which the compiler still waits for (they are
 // ordinary register operands of the statement); the first non-MFMA reader is the epilogue, behind the s_nop pair after the loop.
 __device__ __forceinline__ void wide_mfma(f32x4_t& c, const u32x4_t& a, const u32x4_t& b) {
-    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));  // ("+v": with an AGPR operand hipcc splits the 256 registers of a two-waves-per-SIMD kernel 128 / 128)
 }
 
 #ifdef ISST_WIDE_TRACE
@@ -58,131 +58,148 @@ extern "C" int isst_debug_wide_trace_read(void* dst, long bytes) {
 #define WIDE_STAMP_RT(i) do { } while (0)
 #endif
 
-template <int MT, int DW, int DA, int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_wide_kernel(GemmArgs g, int steps, int dbg) {
-    constexpr int AU = MT / 2;            // staging units (8 rows x 128 B) per wave and step
-    constexpr int ABUF = MT * 2048;       // bytes of one staged step: [2 k-steps][MT][64 lanes][16 B]
-    constexpr int U = wide_lcm(wide_lcm(DW, DA), 2);  // unroll period: ring slots and the LDS buffer parity are compile-time constants
-    static_assert(U % DW == 0 && U % DA == 0 && U % 2 == 0, "unroll period");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 x ABUF
+typedef __attribute__((address_space(3))) void* wlds_ptr;
+
+template <int MT, int DW, int NS, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps, int dbg) {
+    constexpr int AU = MT / 2;            // LDS-DMA units (8 rows x 128 B = 1 KiB) per loader wave and step
+    constexpr int ABUF = MT * 2048;       // bytes of one staged step: [MT m-tiles][16 rows][128 B], 16-byte chunks XOR-swizzled
+    static_assert(NS >= 4 && NS * ABUF <= 160 * 1024, "ring stages");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NS x ABUF (all LDS of the kernel: cdna_hip_programming.md section 5, trap 4a)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the descriptors below are built from it
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: roles, descriptors and DMA destinations are built from it
     const int fr = lane & 15, fq = lane >> 4;
     const int KT = g.K >> 5, NTILES = g.N >> 4;
-    const int nt0 = blockIdx.x * WIDE_NT + wave * 2;
     const int slice = blockIdx.y;
     const int step0 = slice * steps;
     const int m0 = blockIdx.z * (MT * 16);
 
+    if (wave >= 4) {
+        // ================= loader waves: the A ring, by LDS-DMA =================
+        // unit un = lw*AU + a = rows un*8 .. un*8+7 of the step, 128 B each; lane -> (row = lane >> 3, destination chunk = lane & 7); the chunk a lane
+        // FETCHES is its destination chunk XOR ((row in m-tile >> 1) & 7): the DMA writes lane-linear, so the swizzle that makes the consumers'
+        // ds_read_b128 conflict-free sits on the source side (gemm_dense.hip's image; rule 21).  Rows past M repeat row M-1 (never stored).
+        const int lw = wave - 4;
+        const bf16_t* asrc[AU];
+#pragma unroll
+        for (int a = 0; a < AU; ++a) {
+            const int un = lw * AU + a;
+            const int rim = (un & 1) * 8 + (lane >> 3);
+            const int row = min(m0 + un * 8 + (lane >> 3), g.M - 1);
+            asrc[a] = g.A + (long)row * g.lda + (long)step0 * WIDE_TK + (((lane & 7) ^ ((rim >> 1) & 7)) << 3);
+        }
+        auto dma = [&](int s /* step */, int stage) {  // steps past the slice re-read its last step into a stage nobody reads (issue and wait counts stay uniform)
+            const long ko = (long)(s < steps ? s : steps - 1) * WIDE_TK;
+            unsigned char* dst = smem + stage * ABUF + lw * AU * 1024;
+            if (!(dbg & 2)) {
+#pragma unroll
+                for (int a = 0; a < AU; ++a) __builtin_amdgcn_global_load_lds((const void*)(asrc[a] + ko), (wlds_ptr)(dst + a * 1024), 16, 0, 0);
+            }
+        };
+        // before the first barrier: steps 0 .. NS-2 issued, steps 0 and 1 landed
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0) dma(s0, s0);
+        if constexpr ((NS - 3) * AU == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr ((NS - 3) * AU == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr ((NS - 3) * AU == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr ((NS - 3) * AU == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr ((NS - 3) * AU == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if constexpr ((NS - 3) * AU == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int stage = NS - 1;  // stage of step t - 1 + NS
+        const int T = (steps + DW - 1) / DW * DW;  // the consumers' loop is padded to the ring's unroll period: the same number of barriers on both sides
+        for (int t = 0; t < T; ++t) {
+            // stage (t-1) % NS was read for the last time in step t-1 (every consumer passed barrier t-1 behind its reads): refill it with step t-1+NS;
+            // then all but the NS-3 youngest steps have landed, i.e. step t+2 is complete before barrier t -- the consumers read it from step t+1 on
+            dma(t - 1 + NS, stage);
+            stage = stage + 1 == NS ? 0 : stage + 1;
+            if constexpr ((NS - 3) * AU == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr ((NS - 3) * AU == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr ((NS - 3) * AU == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr ((NS - 3) * AU == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr ((NS - 3) * AU == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if constexpr ((NS - 3) * AU == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued DMAs must not land in LDS after the workgroup has gone
+        return;
+    }
+
+    // ================= consumer waves: the W ring in registers, fragments from LDS, MFMA =================
+    WIDE_STAMP_RT(240); WIDE_STAMP(241);
+    const int nt0 = blockIdx.x * WIDE_NT + wave * 2;
     f32x4_t acc[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[mt][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 
-    // ---- W: one descriptor per n-tile over exactly this slice's k-tiles (tiles past N: empty) ----
+    // W: one descriptor per n-tile over exactly this slice's k-tiles (tiles past N: empty; steps past the slice read zeros without traffic)
     const bool nv0 = nt0 < NTILES, nv1 = nt0 + 1 < NTILES;
     __amdgpu_buffer_rsrc_t wrs[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const bool v = nb ? nv1 : nv0;
-        wrs[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + ((long)(v ? nt0 + nb : 0) * KT + (long)step0 * 2) * 512, 0, (v && !(dbg & 1)) ? steps * 2048 : 0, 0x00020000);  // (dbg: timing-only builds with a descriptor emptied, profiles/wide_probe.py)
+        wrs[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + ((long)(v ? nt0 + nb : 0) * KT + (long)step0 * 2) * 512, 0, (v && !(dbg & 1)) ? steps * 2048 : 0, 0x00020000);  // (dbg: timing-only runs with a stream emptied, profiles/wide_probe.py)
     }
     const int woff = lane * 16;
     auto load_w = [&](int t, int kk, int nb) -> u32x4_t { return __builtin_amdgcn_raw_buffer_load_b128(wrs[nb], woff + (t * 2 + kk) * 1024, 0, 2 /* nt: read once */); };
-
-    // ---- A: unit = 8 rows x 128 B of one step; lane -> (row rlo = lane & 7, 16-byte piece p = lane >> 3) ----
-    const int rlo = lane & 7, p = lane >> 3;
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, (dbg & 2) ? 0 : (int)((((long)g.M - 1) * g.lda + g.K) * 2), 0x00020000);
-    unsigned aoff[AU];  // byte offset of this lane's piece of step 0 (rows past M: outside the descriptor -> zeros, no traffic)
-    int adst[AU];       // byte offset inside one LDS buffer
-#pragma unroll
-    for (int a = 0; a < AU; ++a) {
-        const int row = (wave * AU + a) * 8 + rlo;  // 0 .. MT*16-1
-        aoff[a] = (m0 + row < g.M) ? (unsigned)((((long)(m0 + row)) * g.lda + (long)step0 * WIDE_TK + p * 8) * 2) : 0xC0000000u;
-        adst[a] = ((((p >> 2) * MT + (row >> 4)) * 64) + (p & 3) * 16 + (row & 15)) * 16;
-    }
-    // (steps past the slice -- the ring runs ahead of the end, and the loop is padded to its unroll period -- read zeros as well: a scalar select, no branch)
-    auto load_a = [&](int t, int a) -> u32x4_t { return __builtin_amdgcn_raw_buffer_load_b128(ars, t < steps ? aoff[a] + (unsigned)t * (WIDE_TK * 2) : 0xC0000000u, 0, 0); };
-
-    u32x4_t areg[DA][AU];     // A steps t+2 .. t+1+DA (slot = step % DA)
     u32x4_t wreg[DW][2][2];   // W steps t .. t+DW-1 (slot = step % DW): [k-step of the step][n-tile]
-    // ---- prologue: program order = order of first use (A step 0, W step 0, A step 1, W step 1, ...), pinned ----
 #pragma unroll
-    for (int s = 0; s < (DW > DA ? DW : DA); ++s) {
-        if (s < DA) {
+    for (int s = 0; s < DW; ++s) {  // program order = order of use, pinned (left alone hipcc fills a ring back to front and the first wait drains it)
 #pragma unroll
-            for (int a = 0; a < AU; ++a) areg[s][a] = load_a(s, a);
-        }
-        if (s < DW) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) { wreg[s][kk][0] = load_w(s, kk, 0); wreg[s][kk][1] = load_w(s, kk, 1); }
-        }
+        for (int kk = 0; kk < 2; ++kk) { wreg[s][kk][0] = load_w(s, kk, 0); wreg[s][kk][1] = load_w(s, kk, 1); }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // images of steps 0 and 1 (three LDS buffers: step t's and t+1's are complete while t+2's is being written)
-    static_assert(DA >= 2, "two images are staged before the loop");
-#pragma unroll
-    for (int s0 = 0; s0 < 2; ++s0) {
-#pragma unroll
-        for (int a = 0; a < AU; ++a) *reinterpret_cast<u32x4_t*>(smem + s0 * ABUF + adst[a]) = areg[s0][a];
-#pragma unroll
-        for (int a = 0; a < AU; ++a) areg[s0][a] = load_a(DA + s0, a);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-
-    // A fragments travel in GROUPS of 8 (one k-step x 8 m-tiles = 16 MFMAs = 256 matrix-pipe cycles) through two register sets: the next group --
-    // of this step, or the FIRST group of the next step, whose image the previous barrier already published -- is requested before the MFMAs
-    // of the current one.  With ONE wave per SIMD nobody else covers an LDS round trip; this way the matrix pipe never waits for one (left to
-    // itself hipcc emits read -> wait -> 2 MFMAs, sixteen times per step).  Order pinned with sched_barrier.
+    // fragment (m-tile mt, k-step ks) of a stage: lane (fr, fq) reads 16 B at mt*2048 + fr*128 + (((ks*4 + fq) ^ ((fr >> 1) & 7)) << 4)
+    const int rd0 = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+    const int rd1 = fr * 128 + (((4 + fq) ^ ((fr >> 1) & 7)) << 4);
+    // A fragments travel in GROUPS of 8 (one k-step x 8 m-tiles = 16 MFMAs = 256 matrix-pipe cycles) through two register sets: the next group -- of
+    // this step, or the FIRST group of the next step, whose image the previous barrier already published -- is requested under the MFMAs of the
+    // current one.
     constexpr int MH = MT / 8, NG = 2 * MH;
-    const unsigned char* frd = smem + lane * 16;
     u32x4_t af[2][8];
-    auto rd = [&](const unsigned char* buf, int gi, int slot) {
+    __builtin_amdgcn_s_barrier();  // steps 0 and 1 are in LDS
 #pragma unroll
-        for (int j = 0; j < 8; ++j) af[slot][j] = *reinterpret_cast<const u32x4_t*>(buf + ((gi / MH) * MT + (gi % MH) * 8 + j) * 1024);
-    };
-    rd(frd, 0, 0);
-    int b0 = 0, b1 = ABUF, b2 = 2 * ABUF;  // LDS buffers of steps t, t+1, t+2
+    for (int j = 0; j < 8; ++j) af[0][j] = *reinterpret_cast<const u32x4_t*>(smem + rd0 + j * 2048);
     WIDE_STAMP_RT(0); WIDE_STAMP(1);
-    for (int t0 = 0; t0 < steps; t0 += U) {
+    int st0 = 0, st1 = ABUF;  // LDS offsets of the stages of steps t and t+1
+    for (int t0 = 0; t0 < steps; t0 += DW) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < DW; ++u) {
             const int t = t0 + u;
-            // NO condition on t: an iteration past the last step (steps % U != 0) multiplies zeros by zeros -- every path through the loop issues the
-            // same loads in the same order, which is what lets hipcc count its waits (a skipped iteration makes the back edge's wait a drain)
-            const int sa = (u + 2) % DA, sw = u % DW;
+            // NO condition on t: an iteration past the last step (steps % DW != 0) multiplies the slice's last rows (the loaders re-read them) by zero
+            // weights (past the descriptor) -- every path through the loop issues the same loads in the same order, which is what lets hipcc count
+            // its waits (a skipped iteration makes the back edge's wait a drain), and both roles pass the same number of barriers
+            const int sw = u;
             if (t == 8) WIDE_STAMP(205);
-            // ONE instruction stream per SIMD: whatever is issued between two MFMAs runs in the shadow of the first (an MFMA holds the issue port for
-            // 8 of its 16 cycles), whatever is issued in a block of its own stalls the matrix pipe (measured with the trace build: 8 ds_read_b128
-            // 128 cycles, 4 buffer loads 150, the image write + 4 loads 340 -- 1120 cycles per step for 512 cycles of MFMA).  So every MFMA is
-            // followed by exactly one filler: the next group's 8 fragment reads first, then the image write / the ring refills.  Pinned pair by pair.
-            unsigned char* nbuf = smem + b2;
+            // ONE MFMA instruction stream per SIMD: whatever is issued between two MFMAs runs in the shadow of the first (an MFMA holds the issue port for
+            // 8 of its 16 cycles), whatever is issued in a block of its own stalls the matrix pipe (trace build: 8 ds_read_b128 128 cycles, 4 buffer
+            // loads 150).  So every MFMA is followed by at most one filler: the next group's 8 fragment reads, then the ring refill.  Pinned pair by pair.
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 const int kk = gi / MH, mh = gi % MH;
-                const unsigned char* nrd = (gi + 1 < NG) ? frd + b0 + (((gi + 1) / MH) * MT + ((gi + 1) % MH) * 8) * 1024 : frd + b1;
+                const int ngi = (gi + 1) % NG;
+                const unsigned char* nrd = smem + ((gi + 1 < NG) ? st0 : st1) + ((ngi / MH) ? rd1 : rd0) + (ngi % MH) * 8 * 2048;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     wide_mfma(acc[mh * 8 + (k >> 1)][k & 1], af[gi & 1][k >> 1], wreg[sw][kk][k & 1]);
-                    if (k < 8) {
-                        af[(gi + 1) & 1][k] = *reinterpret_cast<const u32x4_t*>(nrd + k * 1024);
-                    } else {
-                        const int i = k - 8 + 8 * gi;  // filler index of the step: 0 .. 8 NG - 1
-                        if (i < AU) *reinterpret_cast<u32x4_t*>(nbuf + adst[i]) = areg[sa][i];          // image of step t+2 (its loads were issued DA steps ago)
-                        else if (i < 2 * AU) areg[sa][i - AU] = load_a(t + 2 + DA, i - AU);              // ... and the registers re-armed
-                        else if (i >= 8 * NG - 4) wreg[sw][(i - (8 * NG - 4)) >> 1][(i - (8 * NG - 4)) & 1] = load_w(t + DW, (i - (8 * NG - 4)) >> 1, (i - (8 * NG - 4)) & 1);
-                    }
+                    if (k < 8) af[(gi + 1) & 1][k] = *reinterpret_cast<const u32x4_t*>(nrd + k * 2048);
+                    else if (gi == NG - 1 && k >= 12) wreg[sw][(k - 12) >> 1][(k - 12) & 1] = load_w(t + DW, (k - 12) >> 1, (k - 12) & 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (t == 8) WIDE_STAMP(210 + gi);
             }
             if (t == 8) WIDE_STAMP(206);
-            __syncthreads();
+            // the stage of step t is free once every consumer's reads of it have returned: all LDS reads but the 8 youngest (the first group of step
+            // t+1) -- LDS operations of a wave complete in order
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if (t < 200) WIDE_STAMP(4 + t);
-            const int bt = b0; b0 = b1; b1 = b2; b2 = bt;
+            st0 = st1;
+            st1 = st1 + ABUF == NS * ABUF ? 0 : st1 + ABUF;
         }
     }
-
     WIDE_STAMP(2); WIDE_STAMP_RT(3);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have left the pipe before the epilogue's v_accvgpr_read (wide_mfma)
     // ---- epilogue straight from the accumulators (gemm_tiled.hip's arithmetic, rounding point for rounding point):
@@ -220,6 +237,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wide_kernel(GemmArgs g, int steps
             }
         }
     }
+    WIDE_STAMP(242); WIDE_STAMP_RT(243);
 }
 
 // tuning hooks (gemm_wide_set): mode 0 = never, 1 = heuristic, 2 = wherever supported; variant = ring depths (profiles/wide_probe.py)
@@ -235,18 +253,18 @@ bool gemm_wide_supported(const GemmArgs& g) {
 // worth it where the weight stream is long (as gemm_mid_preferred): the encoder's 2-8 MB projections at 96 rows are latency-bound
 bool gemm_wide_preferred(const GemmArgs& g) { return g_wide_mode == 2 || (long)g.N * g.K >= (8L << 20); }
 
-template <int MT, int DW, int DA, int EPI>
+template <int MT, int DW, int NS, int EPI>
 static int launch_wide_cfg(const GemmArgs& g, hipStream_t stream) {
     const int ks = g.epi == EPI_PARTIAL ? (g.ksplit > 1 ? g.ksplit : 1) : 1;
     const int NTILES = g.N / 16;
-    dim3 grid((NTILES + WIDE_NT - 1) / WIDE_NT, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(256);
-    const size_t lds = (size_t)3 * MT * 2048;
+    dim3 grid((NTILES + WIDE_NT - 1) / WIDE_NT, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(512);
+    const size_t lds = (size_t)NS * MT * 2048;
     static bool attr = false;
-    if (lds > 64 * 1024 && !attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<MT, DW, DA, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+    if (lds >= 64 * 1024 && !attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<MT, DW, NS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_wide_kernel<MT, DW, DA, EPI>), grid, block, lds, stream, g, g.K / WIDE_TK / ks, g_wide_dbg);
+    hipLaunchKernelGGL((gemm_wide_kernel<MT, DW, NS, EPI>), grid, block, lds, stream, g, g.K / WIDE_TK / ks, g_wide_dbg);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
@@ -254,17 +272,18 @@ template <int EPI>
 static int launch_wide_epi(const GemmArgs& g, hipStream_t stream) {
 #ifdef ISST_WIDE_PROBE
     if (g.M <= 128) {
-        if (g_wide_variant == 1) return launch_wide_cfg<8, 4, 2, EPI>(g, stream);
-        if (g_wide_variant == 2) return launch_wide_cfg<8, 8, 4, EPI>(g, stream);
-        if (g_wide_variant == 3) return launch_wide_cfg<8, 8, 2, EPI>(g, stream);
-        return launch_wide_cfg<8, 6, 3, EPI>(g, stream);
+        if (g_wide_variant == 1) return launch_wide_cfg<8, 4, 8, EPI>(g, stream);
+        if (g_wide_variant == 2) return launch_wide_cfg<8, 6, 6, EPI>(g, stream);
+        if (g_wide_variant == 3) return launch_wide_cfg<8, 6, 8, EPI>(g, stream);
+        return launch_wide_cfg<8, 4, 6, EPI>(g, stream);
     }
-    if (g_wide_variant == 1) return launch_wide_cfg<16, 4, 2, EPI>(g, stream);
-    if (g_wide_variant == 2) return launch_wide_cfg<16, 6, 2, EPI>(g, stream);
-    return launch_wide_cfg<16, 6, 3, EPI>(g, stream);
+    if (g_wide_variant == 1) return launch_wide_cfg<16, 3, 4, EPI>(g, stream);
+    if (g_wide_variant == 2) return launch_wide_cfg<16, 4, 4, EPI>(g, stream);
+    if (g_wide_variant == 3) return launch_wide_cfg<16, 4, 5, EPI>(g, stream);
+    return launch_wide_cfg<16, 2, 4, EPI>(g, stream);
 #else
-    if (g.M <= 128) return launch_wide_cfg<8, 6, 3, EPI>(g, stream);
-    return launch_wide_cfg<16, 6, 3, EPI>(g, stream);
+    if (g.M <= 128) return launch_wide_cfg<8, 4, 6, EPI>(g, stream);
+    return launch_wide_cfg<16, 2, 4, EPI>(g, stream);
 #endif
 }
 

@@ -27,6 +27,8 @@ loop_cyc = b[:, 2] - b[:, 1]; loop_rt = (b[:, 3] - b[:, 0]) * 10.0  # ns
 print(f"M={M} variant {var} dbg {dbg}: k-loop {np.median(loop_cyc):.0f} cycles (min {loop_cyc.min()}, max {loop_cyc.max()}), {np.median(loop_rt) / 1e3:.2f} us -> clock {np.median(loop_cyc / loop_rt):.3f} GHz")
 steps = b[:, 4:4 + 64]
 d = np.diff(steps, axis=1)
+pro = b[:, 1] - b[:, 241]; epi = b[:, 242] - b[:, 2]; tot_rt = (b[:, 243] - b[:, 240]) * 10.0
+print(f"entry -> loop entry {np.median(pro):.0f} cycles; loop exit -> stored {np.median(epi):.0f} cycles; wave 0 lifetime {np.median(tot_rt) / 1e3:.2f} us; launch envelope (first entry -> last exit) {(b[:, 243].max() - b[:, 240].min()) / 100:.2f} us; entries spread {(b[:, 240].max() - b[:, 240].min()) / 100:.2f} us")
 print("cycles per step (median over workgroups), steps 1..63:", " ".join(f"{int(x)}" for x in np.median(d, axis=0)))
 print(f"first step end - loop entry: {np.median(steps[:, 0] - b[:, 1]):.0f}")
 NG = 2 if M <= 128 else 4
