@@ -827,11 +827,13 @@ int pick_ksplit(int K, int N, int rows, long slab_cap) {
     // (slab_cap: fp32 elements of the caller's slab buffer -- isst_handle::lslab_elems; a slice count is only chosen if its slabs fit)
     if (rows <= 256 && (long)N * K >= (8L << 20)) {  // (= gemm_wide_preferred: shorter weight streams keep gemm_tiled and its slice choice below)
         // gemm_wide.hip (65..256 rows: one 8-wave workgroup per CU, 128 columns, all rows): enough K slices to give most of the 256 CUs a workgroup and
-        // no more -- a second round of workgroups doubles the launch (profiles/r04/wide_probe.txt, GEMM + reducing norm, us, 128 rows: q/k/v 40.1 / 30.3 /
-        // 26.9 / 34.8 for 1 / 2 / 4 / 8 slices (48 column blocks); down_proj 46.2 / 36.6 for 4 / 8 (32 column blocks); o_proj 25.0 / 24.7)
+        // no more -- a second round of workgroups doubles the launch (profiles/r04/wide_probe.txt, GEMM + reducing norm, us, 128 rows: q/k/v 38.7 / 29.1 /
+        // 25.6 / 33.1 for 1 / 2 / 4 / 8 slices (48 column blocks); down_proj 45.7 / 35.7 for 4 / 8 (32 column blocks))
         const long blocks = (N + 127) / 128;
         int s = 1;
-        while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= 256 && (long)s * 2 * rows * N <= slab_cap && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
+        // ... and no fewer than 16 K-steps per slice: the launch's fixed cost (ring fill 3.3 us, epilogue + slab traffic) is not amortised below that
+        // (o_proj, K = 4096: 21.6 us with 4 slices = 128 workgroups against 22.4 with 8 = 256 at 128 rows, 27.3 / 30.5 at 256: profiles/r04/wide_probe_v4*)
+        while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= 256 && (long)s * 2 * rows * N <= slab_cap && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 16) s *= 2;
         return s;
     }
     if (gemm_dense_would_run(rows, N, K)) {
@@ -1194,7 +1196,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st, h->lx, DL, h->lssq));
             pending_fused = l + 1 < c.llm_layers;
             if (!pending_fused && tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
-        } else if (sd > 1 && l + 1 < c.llm_layers) {
+        } else if (sd > 1) {  // (the last layer too: the slabs are summed by the final norm's launch below -- unsplit, its 32 column blocks walk all of K alone)
             CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st));
             pending = true;
         } else {
@@ -1202,7 +1204,17 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
         }
     }
-    if (splice) {  // prefill: the last prompt row of every stream is gathered and normalised
+    bool final_normed = false;
+    if (pending) {  // the last layer's down_proj slabs: lx += sum; on a decode pass (every row is a last row) the same launch writes the final norm
+        const bool fold = !splice && n_last == rows && n_last > LLM_FUSED_NORM_MAX_ROWS_LM_HEAD;
+        CHK(launch_rmsnorm_reduce(h->lslab, slab, sd, h->lx, DL, fold ? h->final_norm : nullptr, h->llast, DL, rows, DL, c.rms_eps, st));
+        if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(c.llm_layers - 1), h->lx, (int64_t)rows * DL, st));
+        pending = false;
+        final_normed = fold;
+    }
+    if (final_normed) {
+        CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
+    } else if (splice) {  // prefill: the last prompt row of every stream is gathered and normalised
         CHK(launch_rmsnorm(h->lx, DL, d.last_rows, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
         if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "final", h->llast, (int64_t)n_last * DL, st));
         CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));

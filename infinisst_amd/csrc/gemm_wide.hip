@@ -123,7 +123,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued DMAs must not land in LDS after the workgroup has gone
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued DMAs have landed ...
+        __builtin_amdgcn_s_barrier();                      // ... before the consumers reuse the ring for their epilogue
         return;
     }
 
@@ -201,8 +202,84 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
         }
     }
     WIDE_STAMP(2); WIDE_STAMP_RT(3);
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have left the pipe before the epilogue's v_accvgpr_read (wide_mfma)
-    // ---- epilogue straight from the accumulators (gemm_tiled.hip's arithmetic, rounding point for rounding point):
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs have left the pipe before the epilogue reads the accumulators (wide_mfma)
+    __builtin_amdgcn_s_barrier();  // every DMA has landed, every fragment read has returned: the ring is free (the loaders leave here)
+    // ---- epilogue through LDS: every value is written once into a [rows][workgroup columns] image of the idle ring -- after the bias / GELU / SwiGLU
+    //      arithmetic, i.e. at the reference's rounding point in front of the residual add -- and read back as 16 bytes per lane: a store instruction then
+    //      covers whole 128 / 256 / 512-byte row segments instead of 4 rows x 32 (bf16) or 64 (fp32) bytes of the accumulator layout, and the residual is
+    //      read the same way (the straight-from-accumulator form below took 9200 cycles = 4.4 us of a 46 us gate/up launch: profiles/r04/wide_trace_v3*).
+    //      The 16-byte chunk index of a row is XORed with its fq (rows 4 apart alias on the banks).  Same arithmetic, same bits.
+    {
+        constexpr bool F32_OUT = EPI == EPI_PARTIAL || EPI == EPI_F32;
+        constexpr int WC = EPI == EPI_SWIGLU ? 64 : 128;     // output columns of the workgroup
+        constexpr int ES = F32_OUT ? 4 : 2;
+        constexpr int RS = WC * ES, CPR = RS / 16, EPC = 16 / ES;  // image row stride (bytes), chunks per row, elements per chunk
+        constexpr int SWS = F32_OUT ? 2 : 1;                  // chunk XOR = fq << SWS: the 2 (bf16) / 4 (fp32) chunks a wave-store spans per row, times 4 row groups
+        static_assert(MT * 16 * RS <= NS * ABUF, "the image fits the ring");
+        unsigned char* outp = reinterpret_cast<unsigned char*>(g.out) + (EPI == EPI_PARTIAL ? (long)slice * g.out_batch * 4 : 0);
+        const bool fast = (g.n_valid % EPC) == 0 && (g.ldo % EPC) == 0 && (reinterpret_cast<uintptr_t>(outp) & 15) == 0 &&
+                          ((EPI != EPI_RES && EPI != EPI_BIAS_RES) || ((g.ldres & 7) == 0 && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0));
+        if (fast) {
+            const int wcol = (EPI == EPI_SWIGLU ? wave * 16 : wave * 32) + fr;  // column inside the workgroup's image (+ nb * 16)
+            float bv[2] = {0.f, 0.f};
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int col = (nt0 + nb) * 16 + fr;
+                    bv[nb] = col < g.n_valid ? bf2f(g.bias[col]) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    unsigned char* rowp = smem + (mt * 16 + fq * 4 + r) * RS;
+                    if constexpr (EPI == EPI_SWIGLU) {
+                        const float v = bfr(silu(bfr(acc[mt][0][r]))) * bfr(acc[mt][1][r]);
+                        *reinterpret_cast<bf16_t*>(rowp + (((wcol >> 3) ^ (fq << SWS)) << 4) + (wcol & 7) * 2) = f2bf(v);
+                    } else {
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const int c = wcol + nb * 16;
+                            const float sacc = acc[mt][nb][r];
+                            if constexpr (EPI == EPI_PARTIAL) {
+                                *reinterpret_cast<float*>(rowp + (((c >> 2) ^ (fq << SWS)) << 4) + (c & 3) * 4) = sacc;
+                            } else if constexpr (EPI == EPI_F32) {
+                                *reinterpret_cast<float*>(rowp + (((c >> 2) ^ (fq << SWS)) << 4) + (c & 3) * 4) = bfr(sacc);
+                            } else {
+                                float v;
+                                if constexpr (EPI == EPI_NONE || EPI == EPI_RES) v = sacc;
+                                else if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RES) v = sacc + bv[nb];
+                                else v = gelu_erf(bfr(sacc + bv[nb]));
+                                *reinterpret_cast<bf16_t*>(rowp + (((c >> 3) ^ (fq << SWS)) << 4) + (c & 7) * 2) = f2bf(v);
+                            }
+                        }
+                    }
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's image writes
+            __builtin_amdgcn_s_barrier();        // (the four consumer waves: the loaders have exited)
+            const int col_base = blockIdx.x * WC;
+#pragma unroll 4
+            for (int cid = tid; cid < MT * 16 * CPR; cid += 256) {
+                const int lrow = cid / CPR, c = cid % CPR;
+                const int row = m0 + lrow, gcol = col_base + c * EPC;
+                u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + lrow * RS + ((c ^ (((lrow >> 2) & 3) << SWS)) << 4));
+                if (row < g.M && gcol < g.n_valid) {
+                    if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
+                        const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(g.res + (long)row * g.ldres + gcol);
+                        v.x = pack_bf(lo_bf(rv.x) + lo_bf(v.x), hi_bf(rv.x) + hi_bf(v.x));
+                        v.y = pack_bf(lo_bf(rv.y) + lo_bf(v.y), hi_bf(rv.y) + hi_bf(v.y));
+                        v.z = pack_bf(lo_bf(rv.z) + lo_bf(v.z), hi_bf(rv.z) + hi_bf(v.z));
+                        v.w = pack_bf(lo_bf(rv.w) + lo_bf(v.w), hi_bf(rv.w) + hi_bf(v.w));
+                    }
+                    *reinterpret_cast<u32x4_t*>(outp + ((long)row * g.ldo + gcol) * ES) = v;
+                }
+            }
+            WIDE_STAMP(242); WIDE_STAMP_RT(243);
+            return;
+        }
+    }
+    // ---- general form (ragged n_valid, unaligned rows), straight from the accumulators (gemm_tiled.hip's arithmetic, rounding point for rounding point):
     //      acc[mt][nb][r] = C[m0 + mt*16 + 4 fq + r][(nt0 + nb)*16 + fr] ----
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
