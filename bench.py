@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--streams64-steps", type=int, default=16)
     ap.add_argument("--no-beam4", action="store_true", help="skip the num_beams = 4 leg (the reference's production decoding) that follows the timed region at N=1")
     ap.add_argument("--beam4-steps", type=int, default=16)
+    ap.add_argument("--no-streams64-beam4", action="store_true", help="skip the 64 streams x num_beams 4 leg (the reference's production decoding on configs[2]) at N=1")
+    ap.add_argument("--streams64-beam4-steps", type=int, default=8)
     ap.add_argument("--host-audio-steps", type=int, default=16, help="steps of the PCIe-inclusive leg (chunks handed over as host arrays) after the timed region")
     ap.add_argument("--cold-start", action="store_true", help="do NOT import the steady state: streams start empty (first-chunk behaviour; then use --warmup >= 40)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
@@ -314,6 +316,72 @@ def run_beam4(cfg, gen, weights, device, args):
     return out
 
 
+def run_streams64_beam4(cfg, gen, weights, device, args):
+    """The reference's production decoding (`--beam 4`: agents/infinisst.py:86 asserts beam > 1, scripts/infer/infinisst.sh:48) on BASELINE.json
+    configs[2]: 64 concurrent streams x 4 beams = 256 decode rows per pass, steady state imported.  Also brackets the decode gate/up launch of every
+    layer (gemm_wide.hip at 256 rows: the dominant weight stream of these passes) with HIP events in two more steps."""
+    import dataclasses
+    g4 = dataclasses.replace(gen, beam=4)
+    out, loop, eng = run_leg(cfg, g4, weights, device, args, 64, args.streams64_beam4_steps,
+                             "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 64 streams x num_beams 4 on 1 MI355X "
+                             "(the reference's production decoding on BASELINE.json configs[2])")
+    out["roofline"]["note"] = ("whole-step HBM fraction with the KV bytes of ONE arena per stream (the beams share every key below the chunk's first "
+                               "generated token); the 1408-row prefill is MFMA-bound")
+    try:
+        eng.profile_begin(256, 256)
+        for _ in range(2):
+            loop.step()
+        us, n = eng.profile_end()
+        wbytes = 2 * cfg.llm_ffn * cfg.llm_dim * 2
+        out["decode_gate_up"] = {"kernel": "gemm_wide_kernel<16, 2, 4, EPI_SWIGLU> (256 rows, weights read once; gemm_wide.hip)", "bound": "hbm",
+                                 "launch_us_in_step": round(us, 2), "launches_timed": n, "algorithmic_bytes_per_launch": wbytes,
+                                 "achieved": round(wbytes / (us * 1e-6) / 1e9, 1) if us > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(wbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
+                                 "timed_with": "HIP event pairs around that launch in every layer of two more steps (isst_profile_begin_rows; each bracket "
+                                               "contains the ~2.5 us dispatch latency)"}
+    except Exception as e:
+        out["decode_gate_up"] = {"failed": f"{type(e).__name__}: {e}"}
+    eng.close()
+    return out
+
+
+def run_streams64_all_ranks(cfg, gen, weights, device, args, tg, world, rank):
+    """BASELINE.json configs[3]: 64 concurrent streams on EVERY GPU of the node (512 on 8), independent -- no data-path collective.  Every rank builds its
+    64-stream engine, imports the steady state and times the same K steps between barriers; time = max over ranks, audio = sum over ranks.  The
+    reference runs one GPU per SLURM array task (scripts/infer/infinisst.sh:5-13)."""
+    eng, _, sys_n = build_engine(cfg, 64, args.gen_tokens, device, gen.beam, weights)
+    mine = S.assign_streams(64 * world, rank, world)
+    loop = ChunkLoop(eng, cfg, gen, mine, sys_n, host_audio=False)
+    loop.import_steady_state(device)
+    for _ in range(8):
+        loop.step()
+    torch.cuda.synchronize()
+    tg.barrier()
+    torch.cuda.synchronize()
+    steps = args.streams64_steps
+    dt_local, lat, host_s = timed_steps(loop, steps)
+    torch.cuda.synchronize()
+    tg.barrier()
+    dt = tg.max(dt_local)
+    audio = tg.sum(0.96 * steps * len(mine))
+    all_lat = tg.gather(lat)
+    host_ms = tg.max(1e3 * host_s / steps)
+    info = eng.stream_info(loop.sids[0])
+    evictions = tg.sum(loop.evictions)
+    eng.close()
+    if rank != 0:
+        return None
+    ms = 1e3 * dt / steps
+    return {"workload": f"InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 960 ms chunks, 64 streams on each of {world} MI355X = {64 * world} streams, "
+                        "no collective (BASELINE.json configs[3] shape)",
+            "streams_per_gpu": 64, "streams_total": 64 * world, "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "steps": steps, "ms_per_step": round(ms, 3), "xrt": round(audio / dt, 2), "xrt_per_gpu": round(audio / dt / world, 2),
+            "p50_chunk_latency_ms": round(1e3 * float(np.percentile(all_lat, 50)), 3), "p95_chunk_latency_ms": round(1e3 * float(np.percentile(all_lat, 95)), 3),
+            "host_ms_per_step_max_over_ranks": round(host_ms, 3), "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"],
+            "evictions_all_ranks": int(evictions), "timing": "barrier + device synchronisation on both sides, max over ranks; audio summed over ranks",
+            "roofline": whole_step_roofline(cfg, 64, args.gen_tokens, info["llm_cache_len"], ms)}
+
+
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 (the 5 PF headline includes 2:1 sparsity)
 
 
@@ -534,7 +602,7 @@ class DryEngine:
         self.lens[sid] = new_size + keep
 
 
-def dry_run(args, world, rank):
+def dry_run(args, world, rank, cores=None):
     """Launcher self-test (no GPU, no compute): the ranks meet over gloo, deal the global stream ids, step their streams through the
     product's StreamBatch over a sleeping stand-in engine, and go through exactly the barrier / max-over-ranks / gather path of a real run."""
     if world > 1:
@@ -560,8 +628,27 @@ def dry_run(args, world, rank):
     audio_s = tg.sum(0.96 * args.steps * len(mine))
     all_lat = tg.gather(lat)
     evictions = tg.sum(batch.evictions)
+    # the configs[3] leg of a real N > 1 run (run_streams64_all_ranks): 64 streams on EVERY rank, the same barrier / max / sum path
+    s64 = None
+    if world > 1 and not args.no_streams64:
+        mine64 = S.assign_streams(64 * world, rank, world)
+        b64 = S.StreamBatch(DryEngine(rank, args.gen_tokens), gen, sys_n, lambda first, m: synth.chunk_prompt_ids(cfg, m, first=first))
+        idx64 = [b64.open() for _ in mine64]
+        tg.barrier()
+        t1 = time.perf_counter()
+        for _ in range(4):
+            b64.step([seg] * len(idx64))
+        dt64_local = time.perf_counter() - t1
+        tg.barrier()
+        dt64 = tg.max(dt64_local)
+        audio64 = tg.sum(0.96 * 4 * len(mine64))
+        core_sets = tg.gather([float(c) for c in (cores or [])])
+        s64 = {"streams_per_gpu": 64, "streams_total": int(round(tg.sum(len(mine64)))), "ranks_seen": dist.get_world_size(), "steps": 4,
+               "ms_per_step": round(1e3 * dt64 / 4, 3), "xrt": round(audio64 / dt64, 2), "cores_pinned_all_ranks": len(core_sets),
+               "cores_pinned_distinct": len(set(core_sets))}
     if rank == 0:
         print(json.dumps({"metric": "DRY RUN of the launcher (no compute, not a measurement)", "dry_run": True, "value": round(audio_s / elapsed, 3),
+                          "streams64": s64, "host_cores_of_rank0": list(cores or []),
                           "unit": "audio-seconds per wall-second", "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1, "timing_collectives": tg.describe(),
                           "steps": args.steps, "warmup": args.warmup, "streams_of_rank0": mine, "latencies_gathered": len(all_lat),
                           "evictions_all_ranks": int(evictions), "host_ms_per_step": round(1e3 * batch.host_seconds / max(1, batch.ticks), 3),
@@ -577,8 +664,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    # host cores of this rank: local to its GPU's NUMA node, disjoint from the other ranks' -- set BEFORE anything touches the GPU
+    cores = S.pin_rank_to_local_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else sorted(os.sched_getaffinity(0))
     if args.dry_run:
-        return dry_run(args, world, rank)
+        return dry_run(args, world, rank, cores)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
@@ -630,8 +719,17 @@ def main():
     base = None
     s64 = None
     b4 = None
+    s64b4 = None
     host_leg = None
     host_ms = 1e3 * loop.batch.host_seconds / max(1, loop.batch.ticks)
+    if world > 1 and args.streams == 1 and args.beam == 1 and not args.toy and not args.no_streams64:
+        # N > 1: configs[3] -- the 64-stream leg on EVERY rank (the N = 1 headline above stays what BENCH measures, so N = 1 SCALE agrees with it)
+        try:
+            s64 = run_streams64_all_ranks(cfg, gen, weights, device, args, tg, world, rank)
+            if rank == 0:
+                log(f"64-streams-per-GPU leg done on {world} ranks: {s64['xrt']} xRT aggregate, {s64['ms_per_step']} ms per step")
+        except Exception as e:  # report, never hide (a rank that fails here leaves the others at the barrier: the launcher's timeout ends the job)
+            s64 = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if not args.host_audio and args.host_audio_steps > 0:
             host_leg = host_audio_leg(loop, args.host_audio_steps, len(mine))
@@ -654,6 +752,12 @@ def main():
                 log(f"beam-4 leg done: {b4['xrt']} xRT, {b4['ms_per_step']} ms per step")
             except Exception as e:  # report, never hide
                 b4 = {"failed": f"{type(e).__name__}: {e}"}
+        if legs and not args.no_streams64_beam4:
+            try:
+                s64b4 = run_streams64_beam4(cfg, gen, weights, device, args)
+                log(f"64 streams x beam 4 leg done: {s64b4['xrt']} xRT, {s64b4['ms_per_step']} ms per step")
+            except Exception as e:  # report, never hide
+                s64b4 = {"failed": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 base = cpu_baseline(cfg, gen, weights, sys_n, args.cpu_threads, args.cpu_layers, args.cpu_chunks)
@@ -703,6 +807,8 @@ def main():
             "cpu_baseline": base,
             "streams64": s64,
             "beam4": b4,
+            "streams64_beam4": s64b4,
+            "host_cores_of_rank0": f"{len(cores)} cores ({cores[0]}..{cores[-1]})" if cores else None,
         }
         print(json.dumps(line), flush=True)
     if dist.is_initialized():

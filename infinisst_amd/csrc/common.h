@@ -159,6 +159,7 @@ void gemm_dense_set(int mode);                                     // profiling 
 bool gemm_wide_supported(const GemmArgs& g);                       // gemm_wide.hip: 65..256 rows, weights read once (4 waves, one per SIMD, register rings)
 bool gemm_wide_preferred(const GemmArgs& g);
 int launch_gemm_wide(const GemmArgs& g, hipStream_t stream);
+bool gemm_wide_enabled();
 void gemm_wide_set(int mode, int variant);                         // profiling aid: mode 0 never, 1 heuristic, 2 wherever supported; variant = ring depths
 bool gemm_mid_supported(const GemmArgs& g);                        // gemm_mid.hip: 17..64 rows, A staged through LDS
 bool gemm_mid_preferred(const GemmArgs& g);                       // ... and long enough a weight stream to pay for the staging

@@ -376,6 +376,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_QKV_SLICES")) h->qkv_slices = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_WIDE")) gemm_wide_set(atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 1, 0);  // A/B runs: 0 = the 65..256-row passes on gemm_mid / gemm_tiled as before round 4 (process-wide)
     const isst_config& c = h->cfg;
     auto die = [&](int code) { g_create_error = h->err; isst_destroy(h); return code; };
 
@@ -825,7 +826,7 @@ int pick_ksplit(int K, int N, int rows, long slab_cap) {
         return 1;
     }
     // (slab_cap: fp32 elements of the caller's slab buffer -- isst_handle::lslab_elems; a slice count is only chosen if its slabs fit)
-    if (rows <= 256 && (long)N * K >= (8L << 20)) {  // (= gemm_wide_preferred: shorter weight streams keep gemm_tiled and its slice choice below)
+    if (gemm_wide_enabled() && rows <= 256 && (long)N * K >= (8L << 20)) {  // (= gemm_wide_preferred: shorter weight streams keep gemm_tiled and its slice choice below)
         // gemm_wide.hip (65..256 rows: one 8-wave workgroup per CU, 128 columns, all rows): enough K slices to give most of the 256 CUs a workgroup and
         // no more -- a second round of workgroups doubles the launch (profiles/r04/wide_probe.txt, GEMM + reducing norm, us, 128 rows: q/k/v 38.7 / 29.1 /
         // 25.6 / 33.1 for 1 / 2 / 4 / 8 slices (48 column blocks); down_proj 45.7 / 35.7 for 4 / 8 (32 column blocks))
@@ -1092,7 +1093,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     // layer's down_proj slabs
     const bool split_rows = rows > ISST_MID_MIN_ROWS && rows <= LLM_SPLIT_MAX_ROWS;
     const int so = split_rows ? pick_ksplit(H * 128, DL, rows, h->lslab_elems) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL, rows, h->lslab_elems) : 1;
-    const int sq = (rows > 64 && rows <= LLM_SPLIT_MAX_ROWS) ? pick_ksplit(DL, (H + 2 * KV) * 128, rows, h->lslab_elems) : 1;  // (65..256 rows: gemm_wide's 48 column blocks in 4 slices)
+    const int sq = (rows > (gemm_wide_enabled() ? 64 : 128) && rows <= LLM_SPLIT_MAX_ROWS) ? pick_ksplit(DL, (H + 2 * KV) * 128, rows, h->lslab_elems) : 1;  // (65..256 rows: gemm_wide's 48 column blocks in 4 slices)
     const long slab = (long)rows * DL;
     // 13..64 rows: no residual + RMSNorm launches (gemm_mid.hip: the producer reduces, the consumer normalises while staging)
     const bool fr = h->fuse_reduce && split_rows && rows <= 64 && so > 1 && sd > 1 && DL % 128 == 0;

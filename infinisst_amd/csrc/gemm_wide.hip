@@ -319,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
 
 // tuning hooks (gemm_wide_set): mode 0 = never, 1 = heuristic, 2 = wherever supported; variant = ring depths (profiles/wide_probe.py)
 static int g_wide_mode = 1, g_wide_variant = 0, g_wide_max_rows = 256, g_wide_dbg = 0;
+bool gemm_wide_enabled() { return g_wide_mode != 0; }
 void gemm_wide_set(int mode, int variant) { g_wide_dbg = mode / 10; g_wide_mode = mode % 10; g_wide_variant = variant; }
 
 bool gemm_wide_supported(const GemmArgs& g) {

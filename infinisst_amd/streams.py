@@ -27,6 +27,66 @@ def assign_streams(n_streams: int, rank: int, world_size: int) -> List[int]:
     return [s for s in range(n_streams) if s % world_size == rank]
 
 
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def local_cores_of_rank(local_rank: int, local_world: int, sysfs: str = "/sys/class/drm", allowed: Optional[Sequence[int]] = None) -> List[int]:
+    """Host cores rank `local_rank` of `local_world` ranks on this node should run on: the cores local to its GPU's NUMA node (sysfs:
+    the amdgpu cards in PCI order, `local_cpulist`), shared evenly with the other ranks on that node; an even split of the allowed
+    cores when sysfs does not answer (no GPUs here, a visibility mask, fewer cards than ranks).  The reference runs one GPU per SLURM
+    array task (scripts/infer/infinisst.sh:5-13) and leaves placement to the scheduler; one process per GPU on one node has to do
+    it itself -- eight Python hosts on the cores of one socket would time each other, not the GPUs.  Touches no GPU."""
+    import os
+    allowed = sorted(allowed if allowed is not None else os.sched_getaffinity(0))
+    local_world = max(1, local_world)
+
+    def even_split(cpus: Sequence[int], idx: int, n: int) -> List[int]:
+        per = max(1, len(cpus) // max(1, n))
+        part = list(cpus[idx * per:(idx + 1) * per]) if idx < n - 1 else list(cpus[idx * per:])
+        return part or list(cpus)
+
+    cards = []
+    masked = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    try:
+        for name in sorted(os.listdir(sysfs)) if not masked else []:
+            dev = os.path.join(sysfs, name, "device")
+            if not name.startswith("card") or "-" in name or not os.path.exists(os.path.join(dev, "local_cpulist")):
+                continue
+            with open(os.path.join(dev, "vendor")) as f:
+                if f.read().strip() != "0x1002":
+                    continue
+            if not os.path.exists(os.path.join(dev, "mem_info_vram_total")):
+                continue
+            with open(os.path.join(dev, "local_cpulist")) as f:
+                cards.append((os.path.basename(os.path.realpath(dev)), [c for c in _parse_cpulist(f.read()) if c in set(allowed)]))
+    except OSError:
+        cards = []
+    cards.sort()
+    if len(cards) >= local_world and 0 <= local_rank < len(cards) and cards[local_rank][1]:
+        mine = cards[local_rank][1]
+        peers = [i for i in range(local_world) if cards[i][1] == mine]
+        return even_split(mine, peers.index(local_rank), len(peers))
+    return even_split(allowed, local_rank % local_world, local_world)
+
+
+def pin_rank_to_local_cores(local_rank: int, local_world: int) -> List[int]:
+    """Set this process's affinity (before anything touches the GPU) and return the cores chosen."""
+    import os
+    cores = local_cores_of_rank(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError:
+        return sorted(os.sched_getaffinity(0))
+    return cores
+
+
 @dataclass
 class _Slot:
     sid: int

@@ -453,30 +453,21 @@ BEAM_LP_TOL = 0.5   # processed log-probs against the bf16 oracle under the peak
 BEAM_GAP = 1.0      # a candidate whose neighbours in the oracle's ranking are further away than this must be the device's candidate of that rank too
 
 
-def test_full_size_beam4_teacher_forced_candidates_match_oracle():
-    """patch_hf.py:687-967 (the loop, pinned by beam_loop.npz) + :43-302 (the scorer, beam_scorer.npz) at FULL size: one steady-state chunk
-    (45 pinned + 975 ring entries imported, encoder window full), num_beams 4, peaked weights.  The engine is teacher-forced along the ORACLE's
-    (token, parent) choices, so both sides are in the same state at every one of the 10 steps, and what the scorer consumes is compared step by
-    step: per beam the top 2B processed log-probs within BEAM_LP_TOL, the candidate TOKEN of every rank whose oracle neighbours are more than
-    BEAM_GAP away, the running beam scores; required: >= 150 decisive candidate ranks, and the oracle's sequence unless the final hypotheses
-    tie."""
+@pytest.fixture(scope="module")
+def beam4_ref():
+    """Peaked weights (device + host copies), one steady-state stream state and the ORACLE's beam-4 search over one chunk of it (oracle/beam.py:
+    patch_hf.py:687-967 + :43-302) -- shared by the one-stream and the many-stream beam tests (the oracle run is the expensive part)."""
     from oracle import beam as obeam
     torch.set_num_threads(min(64, torch.get_num_threads()))
     B = 4
     cfg = full_config().replace(eos_ids=())  # no EOS: B live beams at every step on both sides
     dev = torch.device("cuda")
     w_dev = synth.random_weights_device(cfg, dev, recipe="peaked")
-    sys_n = len(synth.system_prompt_ids(cfg))
-    eng = Engine(cfg, max_streams=1, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=B)
-    eng.load_weights(w_dev)
     w = {k: v.cpu() for k, v in w_dev.items()}
-    del w_dev
+    sys_n = len(synth.system_prompt_ids(cfg))
     gen = GenConfig(max_new_tokens=10, max_llm_cache_size=1000, always_cache_system_prompt=True, beam=B)
     kv0, enc0, src0 = _random_state(cfg, sys_n, seed=13)
     prompt = synth.chunk_prompt_ids(cfg, 1, first=False)
-    sid = eng.open_stream()
-    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
-    _import_state(eng, sid, cfg, sys_n, kv0, enc0, src0, llm_ring_start=ring_cap - 300, enc_ring_start=560)
     sc = _oracle_cache(cfg, enc0, src0, torch.bfloat16)
     rope_e, rope_l = oenc.make_rope(cfg), ollm.llm_rope_tables(cfg, 2048, torch.bfloat16)
     seg = synth.synthetic_audio(cfg.chunk_samples, stream_id=4242)
@@ -484,9 +475,13 @@ def test_full_size_beam4_teacher_forced_candidates_match_oracle():
     with torch.inference_mode():
         ref = obeam.beam_generate(w, cfg, gen, B, prompt, torch.from_numpy(seg).unsqueeze(0).bfloat16(), kv0, sc, rope_l, rope_e, prev)
     assert len(ref.steps) == gen.max_new_tokens
-    eng.beam_trace_begin(B, [st.next_tokens for st in ref.steps], [st.next_parents for st in ref.steps])
-    outs, _ = eng.generate(gen, [sid], [seg], [prompt], [prev], system_prompt_size=0)
-    trace = eng.beam_trace_end()
+    del w
+    yield dict(B=B, cfg=cfg, w_dev=w_dev, sys_n=sys_n, gen=gen, kv0=kv0, enc0=enc0, src0=src0, prompt=prompt, seg=seg, prev=prev, ref=ref)
+
+
+def _check_beam_trace(ref, trace, B, tag):
+    """What the scorer consumes, step by step: per beam the top 2B processed log-probs within BEAM_LP_TOL, the candidate TOKEN of every rank whose
+    oracle neighbours are more than BEAM_GAP away, the running beam scores.  Returns (decisive ranks, checked ranks)."""
     assert len(trace) == len(ref.steps)
     n_keep = 2 * B
     worst_v = worst_s = 0.0
@@ -500,24 +495,76 @@ def test_full_size_beam4_teacher_forced_candidates_match_oracle():
             ov, oi = top.values.numpy(), top.indices.numpy()
             dv = np.abs(val[b] - ov[:n_keep])
             worst_v = max(worst_v, float(dv.max()))
-            assert dv.max() <= BEAM_LP_TOL, f"step {step} beam {b}: top log-probs differ by {dv.max():.3f}"
+            assert dv.max() <= BEAM_LP_TOL, f"{tag} step {step} beam {b}: top log-probs differ by {dv.max():.3f}"
             for j in range(n_keep):
                 checked += 1
                 lo = ov[j - 1] - ov[j] if j > 0 else np.inf
                 hi = ov[j] - ov[j + 1]
                 if min(lo, hi) > BEAM_GAP:
                     decisive += 1
-                    assert idx[b, j] == oi[j], f"step {step} beam {b} rank {j}: token {idx[b, j]} vs oracle {oi[j]} (gaps {lo:.2f} / {hi:.2f})"
+                    assert idx[b, j] == oi[j], f"{tag} step {step} beam {b} rank {j}: token {idx[b, j]} vs oracle {oi[j]} (gaps {lo:.2f} / {hi:.2f})"
             ds = abs(float(scb[b]) - float(st.beam_scores_in[b]))
             worst_s = max(worst_s, ds)
-            assert ds <= BEAM_LP_TOL * max(1, step), f"step {step} beam {b}: beam score {scb[b]} vs {st.beam_scores_in[b]}"
+            assert ds <= BEAM_LP_TOL * max(1, step), f"{tag} step {step} beam {b}: beam score {scb[b]} vs {st.beam_scores_in[b]}"
+    print(f"{tag}: worst |d log-prob| {worst_v:.3f}, worst |d beam score| {worst_s:.3f}, {decisive}/{checked} candidate ranks decisive", flush=True)
+    return decisive, checked
+
+
+def test_full_size_beam4_teacher_forced_candidates_match_oracle(beam4_ref):
+    """patch_hf.py:687-967 (the loop, pinned by beam_loop.npz) + :43-302 (the scorer, beam_scorer.npz) at FULL size: one steady-state chunk
+    (45 pinned + 975 ring entries imported, encoder window full), num_beams 4, peaked weights.  The engine is teacher-forced along the ORACLE's
+    (token, parent) choices, so both sides are in the same state at every one of the 10 steps, and what the scorer consumes is compared step by
+    step; required: >= 150 decisive candidate ranks, and the oracle's sequence unless the final hypotheses tie."""
+    r = beam4_ref
+    B, cfg, sys_n, gen, prompt, ref = r["B"], r["cfg"], r["sys_n"], r["gen"], r["prompt"], r["ref"]
+    eng = Engine(cfg, max_streams=1, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=B)
+    eng.load_weights(r["w_dev"])
+    sid = eng.open_stream()
+    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
+    _import_state(eng, sid, cfg, sys_n, r["kv0"], r["enc0"], r["src0"], llm_ring_start=ring_cap - 300, enc_ring_start=560)
+    eng.beam_trace_begin(B, [st.next_tokens for st in ref.steps], [st.next_parents for st in ref.steps])
+    outs, _ = eng.generate(gen, [sid], [r["seg"]], [prompt], [r["prev"]], system_prompt_size=0)
+    trace = eng.beam_trace_end()
+    decisive, checked = _check_beam_trace(ref, trace, B, "full-size beam 4, teacher-forced")
     finals = sorted(ref.steps[-1].next_scores, reverse=True)
-    print(f"full-size beam 4, teacher-forced: worst |d log-prob| {worst_v:.3f}, worst |d beam score| {worst_s:.3f}, {decisive}/{checked} candidate ranks decisive; "
-          f"oracle sequence {ref.sequences[len(prompt):]}, engine {outs[0]}; final scores {[round(f, 2) for f in finals]}", flush=True)
+    print(f"oracle sequence {ref.sequences[len(prompt):]}, engine {outs[0]}; final scores {[round(f, 2) for f in finals]}", flush=True)
     assert decisive >= 150
     if finals[0] - finals[1] > BEAM_GAP:
         assert outs[0] == ref.sequences[len(prompt):]
     assert eng.stream_info(sid)["llm_cache_len"] == sys_n + N_RING + len(prompt) + gen.max_new_tokens - 1
+    eng.close()
+
+
+@pytest.mark.parametrize("n_streams", [20, 40])
+def test_full_size_many_streams_beam4_match_oracle(beam4_ref, n_streams):
+    """The reference's production decoding (agents/infinisst.py:86 asserts beam > 1; scripts/infer/infinisst.sh:48) on MANY streams in one call at FULL
+    size: n streams x 4 beams = 80 / 160 decode rows per pass -- the row counts that run on gemm_wide.hip (128- and 256-row workgroups; round 4), with
+    a 440 / 880-row prefill.  Every stream is handed the SAME steady state (1020 cached entries, wrapping rings) and the same audio.  Stream 0 is
+    teacher-forced along the ORACLE's (token, parent) choices and its candidates are held to the oracle step by step (as in the one-stream test);
+    the other streams search freely: identical inputs through row-independent kernels must give them identical results, equal to the oracle's
+    sequence unless its final hypotheses tie; cache lengths equal the reference's."""
+    r = beam4_ref
+    B, cfg, sys_n, gen, prompt, ref = r["B"], r["cfg"], r["sys_n"], r["gen"], r["prompt"], r["ref"]
+    eng = Engine(cfg, max_streams=n_streams, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=B)
+    eng.load_weights(r["w_dev"])
+    sids = [eng.open_stream() for _ in range(n_streams)]
+    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
+    for sid in sids:
+        _import_state(eng, sid, cfg, sys_n, r["kv0"], r["enc0"], r["src0"], llm_ring_start=ring_cap - 300, enc_ring_start=560)
+    eng.beam_trace_begin(B, [st.next_tokens for st in ref.steps], [st.next_parents for st in ref.steps])
+    outs, _ = eng.generate(gen, sids, [r["seg"]] * n_streams, [prompt] * n_streams, [r["prev"]] * n_streams, system_prompt_size=0)
+    trace = eng.beam_trace_end()
+    decisive, checked = _check_beam_trace(ref, trace, B, f"full-size {n_streams} streams x beam 4, stream 0 teacher-forced")
+    assert decisive >= 150
+    want = ref.sequences[len(prompt):]
+    finals = sorted(ref.steps[-1].next_scores, reverse=True)
+    free = outs[1:]
+    assert all(o == free[0] for o in free), f"identical streams parted: {sorted(set(map(tuple, free)))}"
+    print(f"oracle sequence {want}; free-running streams {free[0]}; final scores {[round(f, 2) for f in finals]}", flush=True)
+    if finals[0] - finals[1] > BEAM_GAP:
+        assert outs[0] == want
+    for sid in sids:
+        assert eng.stream_info(sid)["llm_cache_len"] == sys_n + N_RING + len(prompt) + gen.max_new_tokens - 1
     eng.close()
 
 

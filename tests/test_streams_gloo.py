@@ -64,6 +64,44 @@ def test_bench_starts_its_own_ranks_and_relays_rank0_json():
     assert j["streams_of_rank0"] == [0, 2, 4] and j["latencies_gathered"] == 24
     assert j["evictions_all_ranks"] >= 6  # the product's StreamBatch ran on every rank: all 6 streams outgrew the 200-entry budget
     assert j["ms_per_step"] >= 4.0  # the slower rank (4 ms per step) sets the time
+    # BASELINE.json configs[3]: at N > 1 the 64-streams-per-GPU leg runs on EVERY rank behind the same barriers (bench.run_streams64_all_ranks)
+    s64 = j["streams64"]
+    assert s64["ranks_seen"] == 2 and s64["streams_per_gpu"] == 64 and s64["streams_total"] == 128
+    assert s64["ms_per_step"] >= 4.0 and s64["xrt"] > 0
+    # every rank pinned itself to its own host cores before touching a GPU (streams.pin_rank_to_local_cores): disjoint sets
+    assert s64["cores_pinned_all_ranks"] == s64["cores_pinned_distinct"] >= 2
+    assert j["host_cores_of_rank0"]
+
+
+def test_local_cores_follow_the_gpus_numa_node(tmp_path):
+    """streams.local_cores_of_rank over a fake sysfs: 4 amdgpu cards, two per NUMA node (PCI order), one non-AMD card and one connector entry that
+    must be ignored; ranks on one node split its cores, a visibility mask or too few cards fall back to an even split of the allowed cores."""
+    sys.path.insert(0, ROOT)
+    from infinisst_amd import streams
+    layout = {"card0": ("0x1002", "0-7", "0000:05:00.0", True), "card1": ("0x1002", "0-7", "0000:15:00.0", True),
+              "card2": ("0x1a03", "0-15", "0000:03:00.0", False),  # the board's VGA controller
+              "card3": ("0x1002", "8-15", "0000:85:00.0", True), "card4": ("0x1002", "8-15", "0000:95:00.0", True)}
+    for name, (vendor, cpus, bdf, vram) in layout.items():
+        dev = tmp_path / "pci" / bdf
+        dev.mkdir(parents=True)
+        (dev / "vendor").write_text(vendor + "\n")
+        (dev / "local_cpulist").write_text(cpus + "\n")
+        if vram:
+            (dev / "mem_info_vram_total").write_text("1\n")
+        (tmp_path / name).mkdir()
+        os.symlink(dev, tmp_path / name / "device")
+    (tmp_path / "card0-DP-1").mkdir()
+    allowed = list(range(16))
+    got = [streams.local_cores_of_rank(r, 4, sysfs=str(tmp_path), allowed=allowed) for r in range(4)]
+    assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    assert streams.local_cores_of_rank(1, 2, sysfs=str(tmp_path), allowed=allowed) == [4, 5, 6, 7]      # two ranks: both GPUs sit on node 0
+    assert streams.local_cores_of_rank(5, 8, sysfs=str(tmp_path), allowed=allowed) == [10, 11]           # more ranks than cards: even split
+    assert streams.local_cores_of_rank(0, 1, sysfs=str(tmp_path / "missing"), allowed=allowed) == allowed
+    os.environ["HIP_VISIBLE_DEVICES"] = "3"
+    try:
+        assert streams.local_cores_of_rank(1, 4, sysfs=str(tmp_path), allowed=allowed) == [4, 5, 6, 7]  # masked: the card order is unknown -> even split
+    finally:
+        del os.environ["HIP_VISIBLE_DEVICES"]
 
 
 def test_bench_parent_reports_a_failing_rank():
