@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--streams64-steps", type=int, default=16)
     ap.add_argument("--no-beam4", action="store_true", help="skip the num_beams = 4 leg (the reference's production decoding) that follows the timed region at N=1")
     ap.add_argument("--beam4-steps", type=int, default=16)
+    ap.add_argument("--no-multipliers", action="store_true", help="skip the latency-multiplier table (m = 2, 3, 4 at num_beams 4) at N=1")
+    ap.add_argument("--multiplier-steps", type=int, default=8)
     ap.add_argument("--no-streams64-beam4", action="store_true", help="skip the 64 streams x num_beams 4 leg (the reference's production decoding on configs[2]) at N=1")
     ap.add_argument("--streams64-beam4-steps", type=int, default=8)
     ap.add_argument("--host-audio-steps", type=int, default=16, help="steps of the PCIe-inclusive leg (chunks handed over as host arrays) after the timed region")
@@ -122,10 +124,14 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def build_engine(cfg, n_streams, gen_tokens, device, beams=1, weights=None):
+def max_prompt_len(sys_n, multiplier=1):
+    return sys_n + 20 + 12 * multiplier  # the first chunk's prompt (system prompt + a 9 + 12 m token turn) with slack; sys_n + 32 at m = 1
+
+
+def build_engine(cfg, n_streams, gen_tokens, device, beams=1, weights=None, multiplier=1):
     from infinisst_amd.engine import Engine
     sys_n = len(synth.system_prompt_ids(cfg))
-    eng = Engine(cfg, max_streams=n_streams, max_multiplier=1, max_prompt_len=sys_n + 32, max_new_tokens=max(gen_tokens, 10),
+    eng = Engine(cfg, max_streams=n_streams, max_multiplier=multiplier, max_prompt_len=max_prompt_len(sys_n, multiplier), max_new_tokens=max(gen_tokens, 10),
                  max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=beams)
     log(f"engine created ({n_streams} stream slots)")
     if weights is None:
@@ -149,11 +155,12 @@ class ChunkLoop:
         The audio of every stream is resident in HBM before the timed region (isst_gen_params.pcm_on_device) unless `host_audio`:
         then every chunk's samples are handed over as host arrays and uploaded inside the step, as the reference agent does."""
         self.eng, self.cfg, self.gen, self.sys_n = eng, cfg, gen, sys_n
+        self.m = gen.latency_multiplier  # a step hands every stream m x 960 ms of audio (agents/infinisst.py:125-128)
         self.batch = S.StreamBatch(eng, gen, sys_n, lambda first, m: synth.chunk_prompt_ids(cfg, m, first=first))
         self.idx = [self.batch.open() for _ in stream_ids]
         self.sids = [self.batch.stream_id(i) for i in self.idx]
-        n_chunks = 64
-        self.audio = [synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=g) for g in stream_ids]
+        n_chunks = 64 if self.m == 1 else 16
+        self.audio = [synth.synthetic_audio(cfg.chunk_samples * self.m * n_chunks, stream_id=g) for g in stream_ids]
         self.audio_dev = None
         self.set_host_audio(host_audio)
         self.n_chunks = n_chunks
@@ -165,7 +172,7 @@ class ChunkLoop:
         self.host_audio = host_audio
         if not host_audio and self.audio_dev is None:
             self.audio_dev = [torch.from_numpy(a).to("cuda") for a in self.audio]
-        cs = self.cfg.chunk_samples
+        cs = self.cfg.chunk_samples * self.m
         src = self.audio if host_audio else self.audio_dev
         self.segs = [[a[k * cs:(k + 1) * cs] for a in src] for k in range(len(self.audio[0]) // cs)]
 
@@ -179,22 +186,23 @@ class ChunkLoop:
         window, audio history = real samples; ring starts near the physical end of both rings so that they wrap within a few steps.
         The contents are random bf16 of the scale the model produces (they do not influence the timing)."""
         cfg, eng = self.cfg, self.eng
-        per_chunk = len(synth.chunk_prompt_ids(cfg, 1, first=False)) + self.gen.max_new_tokens - 1
-        total = self.sys_n + STEADY_CHUNKS * per_chunk
+        per_chunk = len(synth.chunk_prompt_ids(cfg, self.m, first=False)) + self.gen.max_new_tokens - 1
+        n_steady = max(1, (STEADY_CHUNKS * 31) // per_chunk)  # as many whole chunks as fit the same ~961 entries (31 at m = 1 with 10 tokens)
+        total = self.sys_n + n_steady * per_chunk
         g = torch.Generator(device=device)
         g.manual_seed(7)
         kv = [[torch.randn((cfg.llm_kv_heads, total, cfg.llm_head_dim), device=device, generator=g).bfloat16().cpu() for _ in range(2)]
               for _ in range(cfg.llm_layers)]
         enc = [[(0.6 * torch.randn((cfg.enc_heads, cfg.max_cache_size, cfg.enc_head_dim), device=device, generator=g)).bfloat16().cpu() for _ in range(2)]
                for _ in range(cfg.enc_layers)]
-        ring_cap = 64 * ((1000 + (self.sys_n + 32) + max(self.gen.max_new_tokens, 10) + 8 + 63) // 64)  # engine.hip isst_create
-        enc_cap = 64 * ((cfg.max_cache_size + cfg.block_size + 63) // 64)
+        ring_cap = 64 * ((1000 + max_prompt_len(self.sys_n, self.m) + max(self.gen.max_new_tokens, 10) + 8 + 63) // 64)  # engine.hip isst_create
+        enc_cap = 64 * ((cfg.max_cache_size + cfg.block_size * self.m + 63) // 64)
         for i, sid in enumerate(self.sids):
             eng.import_llm_kv(sid, kv, sys_len=self.sys_n, ring_start=(ring_cap - 200 + 13 * i) % ring_cap)
             tail = torch.from_numpy(self.audio[i][-cfg.first_chunk_offset:].copy())
             eng.import_speech_cache(sid, enc, n_steps=cfg.block_size * 40, audio_tail=tail, ring_start=(enc_cap - 100 + 7 * i) % enc_cap)
             first_ck = self.sys_n + per_chunk  # cache length after the first chunk (system prompt + its turn), then one more turn each
-            ckpts = [first_ck + k * per_chunk for k in range(STEADY_CHUNKS)]
+            ckpts = [first_ck + k * per_chunk for k in range(n_steady)]
             assert ckpts[-1] == total
             self.batch.adopt_state(self.idx[i], ckpts)
 
@@ -254,7 +262,7 @@ def run_leg(cfg, gen, weights, device, args, n_streams, steps, workload, extra_e
     saved = {k: os.environ.get(k) for k in (extra_env or {})}
     os.environ.update(extra_env or {})
     try:
-        eng, _, sys_n = build_engine(cfg, n_streams, args.gen_tokens, device, gen.beam, weights)
+        eng, _, sys_n = build_engine(cfg, n_streams, gen.max_new_tokens, device, gen.beam, weights, gen.latency_multiplier)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -269,13 +277,13 @@ def run_leg(cfg, gen, weights, device, args, n_streams, steps, workload, extra_e
     info = eng.stream_info(loop.sids[0])
     ms = 1e3 * dt / steps
     out = {"workload": workload, "streams": n_streams, "num_beams": gen.beam, "steps": steps, "ms_per_step": round(ms, 3),
-           "xrt": round(0.96 * n_streams * steps / dt, 2),
+           "xrt": round(0.96 * gen.latency_multiplier * n_streams * steps / dt, 2),
            "p50_chunk_latency_ms": round(1e3 * float(np.percentile(lat, 50)), 3), "p95_chunk_latency_ms": round(1e3 * float(np.percentile(lat, 95)), 3),
            "host_ms_per_step": round(1e3 * host_s / steps, 3),
            "host_ms_per_step_is": "wall time of a step spent in Python / ctypes outside isst_generate (prompt lists, argument marshalling, "
                                   "per-stream checkpoint walk and isst_kv_evict)",
            "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "evictions_per_stream": loop.evictions // n_streams,
-           "roofline": whole_step_roofline(cfg, n_streams, args.gen_tokens, info["llm_cache_len"], ms)}
+           "roofline": whole_step_roofline(cfg, n_streams, gen.max_new_tokens, info["llm_cache_len"], ms)}
     return out, loop, eng
 
 
@@ -314,6 +322,27 @@ def run_beam4(cfg, gen, weights, device, args):
     out["reference_published"] = {"rtf": 0.382, "xrt": 2.62, "hardware": "1x L40S (inferred)", "source": "plots/plot.ipynb:528-531"}
     eng.close()
     return out
+
+
+def run_multipliers(cfg, gen, weights, device, args, b4):
+    """Latency multipliers 1..4 at the reference's production decoding (num_beams 4, max_new_tokens 10 m; agents/infinisst.py:125-128,245,
+    scripts/infer/infinisst.sh:42-48): one stream, steady state imported, a step = m x 960 ms of audio.  The table lines up with the only numbers
+    the reference publishes, RTF at m = 1..4 (plots/plot.ipynb:528-531).  m = 1 is the `beam4` leg."""
+    import dataclasses
+    rows = []
+    if b4 and "xrt" in b4:
+        rows.append({"multiplier": 1, "chunk_ms": 960, "max_new_tokens": 10, "xrt": b4["xrt"], "ms_per_step": b4["ms_per_step"], "p50_chunk_latency_ms": b4["p50_chunk_latency_ms"],
+                     "rtf": round(1.0 / b4["xrt"], 4)})
+    for m in (2, 3, 4):
+        g = dataclasses.replace(gen, beam=4, latency_multiplier=m, max_new_tokens=10 * m)
+        out, loop, eng = run_leg(cfg, g, weights, device, args, 1, args.multiplier_steps, f"1 stream, num_beams 4, latency multiplier {m}")
+        eng.close()
+        del loop, eng
+        rows.append({"multiplier": m, "chunk_ms": 960 * m, "max_new_tokens": 10 * m, "xrt": out["xrt"], "ms_per_step": out["ms_per_step"],
+                     "p50_chunk_latency_ms": out["p50_chunk_latency_ms"], "rtf": round(1.0 / out["xrt"], 4), "llm_kv_entries": out["llm_kv_entries"],
+                     "evictions_per_stream": out["evictions_per_stream"]})
+    return {"workload": "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 1 stream on 1 MI355X, num_beams 4, chunks of m x 960 ms, max_new_tokens 10 m",
+            "rows": rows, "reference_published": {"what": "RTF at m = 1..4 (L40S, inferred)", "source": "plots/plot.ipynb:528-531"}}
 
 
 def run_streams64_beam4(cfg, gen, weights, device, args):
@@ -720,6 +749,7 @@ def main():
     s64 = None
     b4 = None
     s64b4 = None
+    mult = None
     host_leg = None
     host_ms = 1e3 * loop.batch.host_seconds / max(1, loop.batch.ticks)
     if world > 1 and args.streams == 1 and args.beam == 1 and not args.toy and not args.no_streams64:
@@ -752,6 +782,12 @@ def main():
                 log(f"beam-4 leg done: {b4['xrt']} xRT, {b4['ms_per_step']} ms per step")
             except Exception as e:  # report, never hide
                 b4 = {"failed": f"{type(e).__name__}: {e}"}
+        if legs and not args.no_multipliers:
+            try:
+                mult = run_multipliers(cfg, gen, weights, device, args, b4)
+                log("latency-multiplier table done: " + ", ".join(f"m={r['multiplier']}: {r['xrt']} xRT" for r in mult["rows"]))
+            except Exception as e:  # report, never hide
+                mult = {"failed": f"{type(e).__name__}: {e}"}
         if legs and not args.no_streams64_beam4:
             try:
                 s64b4 = run_streams64_beam4(cfg, gen, weights, device, args)
@@ -808,6 +844,7 @@ def main():
             "streams64": s64,
             "beam4": b4,
             "streams64_beam4": s64b4,
+            "multipliers": mult,
             "host_cores_of_rank0": f"{len(cores)} cores ({cores[0]}..{cores[-1]})" if cores else None,
         }
         print(json.dumps(line), flush=True)

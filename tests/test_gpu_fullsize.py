@@ -231,6 +231,55 @@ def test_full_size_steady_state_matches_oracle(full, steady):
     eng.close_stream(sid)
 
 
+@pytest.mark.parametrize("m", [2, 4])
+def test_full_size_latency_multipliers_match_oracle(full, m):
+    """Latency multipliers 2 and 4 at FULL size (agents/infinisst.py:125-128,245; scripts/infer/infinisst.sh:42-47 -- the settings besides m = 1 the
+    reference publishes numbers for, plots/plot.ipynb:528-531), where they take other dispatch paths than m = 1: a chunk of m x 960 ms is 48 m encoder
+    frames (Q = 96 / 192 over a window of 672 / 768 keys), 12 m speech tokens in a 34 / 58-row prompt (prefill on gemm_mid), max_new_tokens = 10 m.
+    One steady-state chunk (1020 cached LLM entries, full encoder window, wrapping rings), teacher-forced along the fp32 oracle's tokens, every pass's
+    logits under the noise-floor criterion of the m = 1 tests, speech features and cache counters equal to the oracle's."""
+    cfg, w_dev, _, sys_n = full
+    eng = Engine(cfg, max_streams=1, max_multiplier=4, max_prompt_len=sys_n + 64, max_new_tokens=40, max_llm_cache_size=1000, max_system_prompt=sys_n,
+                 debug_taps=True)
+    eng.load_weights(w_dev)
+    w = {k: v.cpu() for k, v in w_dev.items()}
+    w32 = {k: v.float() for k, v in w.items()}
+    kv0, enc0, src0 = _random_state(cfg, sys_n, seed=20 + m)
+    gen = GenConfig(latency_multiplier=m, max_new_tokens=10 * m)
+    audio = synth.synthetic_audio(cfg.chunk_samples * m, stream_id=5000 + m)
+    kv = [[t.clone() for t in layer] for layer in kv0]
+    kv32 = [[t.float() for t in layer] for layer in kv0]
+    sc, sc32 = _oracle_cache(cfg, enc0, src0, torch.bfloat16), _oracle_cache(cfg, enc0, src0, torch.float32)
+    rope_e = oenc.make_rope(cfg)
+    rope_l, rope_l32 = ollm.llm_rope_tables(cfg, 2048, torch.bfloat16), ollm.llm_rope_tables(cfg, 2048, torch.float32)
+    prompt = synth.chunk_prompt_ids(cfg, m, first=False)
+    assert len(prompt) == 10 + 12 * m
+    x = torch.from_numpy(audio).unsqueeze(0).bfloat16()
+    with torch.inference_mode():
+        ref32 = ogen.generate(w32, cfg, gen, prompt, x.float(), kv32, sc32, rope_l32, rope_e, [])
+        forced = ref32.sequences[len(prompt):]
+        ref = ogen.generate(w, cfg, gen, prompt, x, kv, sc, rope_l, rope_e, [], forced_tokens=forced)
+    del w32, w
+    ch = dict(logits32=[l.float().numpy() for l in ref32.step_logits], logits=[l.float().numpy() for l in ref.step_logits])
+    sid = eng.open_stream()
+    ring_cap = 64 * ((1000 + (sys_n + 64) + 40 + 8 + 63) // 64)
+    _import_state(eng, sid, cfg, sys_n, kv0, enc0, src0, llm_ring_start=ring_cap - 300, enc_ring_start=600)  # both rings wrap
+    outs, logits = eng.generate(gen, [sid], [audio], [prompt], [[]], forced_tokens=[forced], return_logits=True)
+    assert outs[0] == forced and len(forced) == 10 * m
+    feat = eng.debug_tap("speech").view(-1, cfg.llm_dim).float()
+    want = ref.speech_features.float()
+    assert feat.shape == want.shape == (12 * m, cfg.llm_dim)
+    d = (feat - want).abs()
+    print(f"m = {m}: speech features max |d| {float(d.max()):.4f}")
+    assert float(d.max()) <= 0.06 + 0.02 * float(want.abs().max())
+    for s in range(10 * m):
+        _check_against_noise_floor(f"m = {m}", logits[0, s], ch, s)
+    info = eng.stream_info(sid)
+    assert info["llm_cache_len"] == ollm.kv_len(kv) == sys_n + N_RING + len(prompt) + 10 * m - 1
+    assert info["enc_cache_len"] == sc.layers[0].k.shape[1] and info["enc_n_steps"] == sc.n_steps == 48 * 20 + 48 * m
+    eng.close()
+
+
 def test_full_size_64_streams_steady_state(full, steady):
     """configs[2] at full size: 64 concurrent streams in ONE call -- 1408-row prefill on the dense GEMM with the
     XCD rasterisation, 64-row decode passes on gemm_mid, one workgroup per (stream, kv head) in the decode attention -- all in the
