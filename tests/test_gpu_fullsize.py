@@ -76,20 +76,21 @@ def test_full_size_two_chunks_match_oracle(full):
     eng.close_stream(sid)
 
 
-def test_full_size_batched_equals_single(full):
+def test_full_size_replay_is_deterministic(full):
+    """The same chunks through a second stream slot of the same engine, teacher-forced with the first run's tokens: every logit bit must repeat
+    (fixed reduction orders everywhere, no atomics on the path).  A DETERMINISM test -- what a stream's logits do when it shares a call with other
+    streams is the next test's subject."""
     cfg, _, eng, sys_n = full
     gen = GenConfig(max_new_tokens=4)
     a, b = eng.open_stream(), eng.open_stream()
-    audio = [synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=i) for i in (1, 2)]
+    audio = synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=1)
     for c in range(2):
-        segs = [x[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples] for x in audio]
+        seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
         prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
-        o1, l1 = eng.generate(gen, [a], [segs[0]], [prompt], [[]], return_logits=True)
-        eng.reset_stream(b) if c == 0 else None
-        # stream b replays stream a's audio inside a 2-stream batch next to another stream? -> compare a (single) with b (batched with itself shifted)
-        o2, l2 = eng.generate(gen, [b], [segs[0]], [prompt], [[]], forced_tokens=[o1[0]], return_logits=True)
+        o1, l1 = eng.generate(gen, [a], [seg], [prompt], [[]], return_logits=True)
+        o2, l2 = eng.generate(gen, [b], [seg], [prompt], [[]], forced_tokens=[o1[0]], return_logits=True)
         n = min(len(o1[0]), len(o2[0]))
-        assert np.array_equal(l1[0][:n], l2[0][:n]), "the same stream replayed must be bit-identical (deterministic kernels)"
+        assert n == len(o1[0]) and np.array_equal(l1[0][:n], l2[0][:n]), "the same stream replayed must be bit-identical (deterministic kernels)"
     eng.close_stream(a)
     eng.close_stream(b)
 
@@ -120,7 +121,7 @@ def test_full_size_multi_stream_batch_matches_single_stream(full, n):
             assert np.array_equal(l4[i][:k], l4[0][:k]), "identical streams of one batch must be bit-identical"
         d = np.abs(l4[0][:k] - l1[0][:k])
         print(f"chunk {c}: {n}-stream vs 1-stream logits mean |d| {d.mean():.4f} max {d.max():.4f}")
-        assert d.mean() <= 0.15 and d.max() <= 1.0
+        assert d.mean() <= 0.12 and d.max() <= 0.8  # (measured: mean 0.07, max 0.55 -- the fp32 summation orders of the two dispatch paths)
     eng1.close_stream(s1)
     eng4.close()
 
@@ -431,6 +432,72 @@ def test_full_size_free_running_ids_with_peaked_logits():
     assert frac >= 0.90 and n_decisive >= 130
     assert worst <= LOGIT_TOLERANCE
     assert batch.evictions == PEAKED_CHUNKS
+    eng.close()
+
+
+def test_full_size_token_ids_depend_on_the_speech_features():
+    """A full-size id test in which WRONG SPEECH FEATURES FLIP A TOKEN (VERDICT r03 next #8c): under the peaked recipe the greedy chain is driven by the
+    last token alone, so the other id tests prove processors / sampling / feedback and leave the encoder to the logit tolerance.  Here one lm_head
+    level is tied to what the speech rows put into the residual stream.  On a stream's FIRST chunk (66-row prompt: the 12 spliced speech rows are a
+    fifth of what the last position attends to) the fp32 oracle's first-pass logits z_A, z_B of two different chunks of audio differ by a small
+    vector -- per entry below the bf16 noise, which is why no ordinary id test can see it -- and the rows of a token pair (t_A, t_B) are set to
+    +-(c^T lm_head), c = beta P(z_A - z_B) / |P(z_A - z_B)|^2 with P projecting out the mean of the two: a LINEAR readout of the hidden state along
+    the speech-sensitive direction that scores +beta/2 for t_A and -beta/2 for t_B on audio A and the opposite on audio B, far above every other
+    logit.  The first generated token is then decided by the audio (through conv stack, encoder, shrink, projector, splice and 32 layers of attention
+    over the spliced rows).  Both streams run in ONE call on the GPU; required: the bf16 oracle's (audio-dependent) first token on both, the pair's
+    logits on the right side by more than beta / 4, and the oracle's continuation while its top-2 margin is decisive."""
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    cfg = full_config().replace(eos_ids=())
+    dev = torch.device("cuda")
+    w_dev = synth.random_weights_device(cfg, dev, recipe="peaked")
+    w = {k: v.cpu() for k, v in w_dev.items()}
+    sys_n = len(synth.system_prompt_ids(cfg))
+    gen1 = GenConfig(max_new_tokens=1, max_llm_cache_size=1000, always_cache_system_prompt=True)
+    gen = GenConfig(max_new_tokens=10, max_llm_cache_size=1000, always_cache_system_prompt=True)
+    prompt = synth.chunk_prompt_ids(cfg, 1, first=True)
+    rope_e = oenc.make_rope(cfg)
+    rope_l, rope_l32 = ollm.llm_rope_tables(cfg, 2048, torch.bfloat16), ollm.llm_rope_tables(cfg, 2048, torch.float32)
+    audios = [synth.synthetic_audio(cfg.chunk_samples, stream_id=s) for s in (101, 202)]
+
+    def oracle(weights, g, audio, rope, dtype):
+        x = torch.cat([torch.zeros(cfg.first_chunk_offset), torch.from_numpy(audio)]).unsqueeze(0).bfloat16().to(dtype)
+        with torch.inference_mode():
+            return ogen.generate(weights, cfg, g, prompt, x, ollm.new_kv(cfg), oenc.new_cache(cfg), rope, rope_e, [])
+    w32 = {k: v.float() for k, v in w.items()}
+    z = [oracle(w32, gen1, a, rope_l32, torch.float32).step_logits[0].float() for a in audios]
+    del w32
+    t_a, t_b = 70001, 70002
+    delta, mean = z[0] - z[1], 0.5 * (z[0] + z[1])
+    delta[[t_a, t_b]] = 0.0
+    mean[[t_a, t_b]] = 0.0
+    pd = delta - (delta @ mean) / (mean @ mean) * mean
+    beta = 400.0
+    c = beta * pd / (pd @ pd)
+    print(f"speech-dependent part of the first-pass logits (fp32 oracle): |z_A - z_B| = {float(delta.norm()):.2f} over {delta.numel()} entries (mean |.| "
+          f"{float(delta.abs().mean()):.4f}, max {float(delta.abs().max()):.3f}); |c| = {float(c.norm()):.2f}", flush=True)
+    head = w["lm_head.weight"]
+    row = (c.to(torch.float32) @ head.float()).to(torch.bfloat16)
+    head[t_a], head[t_b] = row, -row
+    w_dev["lm_head.weight"][t_a], w_dev["lm_head.weight"][t_b] = row.to(dev), (-row).to(dev)
+    eng = Engine(cfg, max_streams=2, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n)
+    eng.load_weights(w_dev)
+    del w_dev
+    refs = [oracle(w, gen, a, rope_l, torch.bfloat16) for a in audios]
+    want = [r.sequences[len(prompt):] for r in refs]
+    assert want[0][0] == t_a and want[1][0] == t_b, (want[0][:2], want[1][:2])
+    sids = [eng.open_stream() for _ in range(2)]
+    outs, logits = eng.generate(gen, sids, audios, [prompt] * 2, [[]] * 2, system_prompt_size=sys_n, return_logits=True)
+    for i, (name, tok, other) in enumerate((("A", t_a, t_b), ("B", t_b, t_a))):
+        zo, zh = refs[i].step_logits[0].float().numpy(), logits[i, 0]
+        print(f"audio {name}: oracle first token {want[i][0]} (pair logits {zo[tok]:.1f} / {zo[other]:.1f}, next best {np.sort(zo)[-2]:.1f}); engine {outs[i][0]} "
+              f"(pair logits {zh[tok]:.1f} / {zh[other]:.1f}); sequences oracle {want[i]} engine {outs[i]}", flush=True)
+        assert outs[i][0] == tok, f"audio {name}: the speech-keyed token came out as {outs[i][0]}"
+        assert zo[tok] > beta / 4 and zo[other] < -beta / 4 and zh[tok] > beta / 4 and zh[other] < -beta / 4
+        for s_, (sc_, tok_o) in enumerate(zip(refs[i].step_scores, want[i])):  # the oracle's continuation while its processed top-2 margin is decisive
+            top2 = torch.topk(sc_.float(), 2).values
+            if float(top2[0] - top2[1]) <= 0.25 * beta:  # (the pair's scores move with the bf16 noise along c: a step between the two is not decisive)
+                break
+            assert outs[i][s_] == tok_o, f"audio {name} step {s_}: {outs[i][s_]} vs oracle {tok_o}"
     eng.close()
 
 
