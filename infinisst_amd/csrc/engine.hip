@@ -526,10 +526,10 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     for (const void* p : must)
         if (!p) { h->fail(ISST_ERR_NOMEM, "state/workspace allocation failed"); return die(ISST_ERR_NOMEM); }
     if (hipHostMalloc(reinterpret_cast<void**>(&h->meta_host), h->meta_bytes) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&h->tok_host), sizeof(int) * (NB + 16)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->tok_host), sizeof(int) * (NB + 16), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||  // (kernels store tokens + a sequence number here that the host polls: fine-grained whatever HIP_HOST_COHERENT says)
         hipHostMalloc(reinterpret_cast<void**>(&h->pcm_host), sizeof(float) * ((size_t)c.max_streams * h->n_new_max + c.max_streams)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&h->top_val_host), sizeof(float) * NB * BEAM_TOPK) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&h->top_idx_host), sizeof(int) * NB * BEAM_TOPK) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void**>(&h->top_val_host), sizeof(float) * NB * BEAM_TOPK, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->top_idx_host), sizeof(int) * NB * BEAM_TOPK, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         h->fail(ISST_ERR_NOMEM, "pinned host allocation failed"); return die(ISST_ERR_NOMEM);
     }
     std::memset(h->tok_host, 0, sizeof(int) * (NB + 16));  // the published sequence number starts at 0 = "no fused tail yet" (samp_seq_expected counts from 1)
@@ -1660,7 +1660,7 @@ struct HostTrace {
     int waits = 0;
     static double us(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
 };
-static HostTrace g_ht;
+static thread_local HostTrace g_ht;  // (per thread: isst_generate may run on several handles from several threads)
 extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const float* const* pcm, int n_samples,
                              const int* const* prompt_ids, const int* prompt_lens, const int* const* prev_target_ids, const int* n_prev,
                              const int* const* forced_tokens, const int* n_forced, int* const* out_ids, int* out_lens, float* logits_out,
@@ -1852,8 +1852,11 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     auto wait_tokens = [&]() -> int {
         if (!tail_fused || p->do_sample || logits_out) {
             HIPCHK(hipStreamSynchronize(st));
-            if (tail_fused && !p->do_sample && *reinterpret_cast<volatile int*>(h->tok_host + h->tok_cap) != h->samp_seq_expected)
-                return h->fail(ISST_ERR_HIP, "sampling tail %d did not publish its tokens", h->samp_seq_expected);
+            if (tail_fused && !p->do_sample && *reinterpret_cast<volatile int*>(h->tok_host + h->tok_cap) != h->samp_seq_expected) {
+                const int want = h->samp_seq_expected;
+                h->samp_seq_expected = *reinterpret_cast<volatile int*>(h->tok_host + h->tok_cap);  // the stream has drained: adopt the device's count, later calls start in step
+                return h->fail(ISST_ERR_HIP, "sampling tail %d did not publish its tokens", want);
+            }
             return ISST_OK;
         }
         volatile int* seq = h->tok_host + h->tok_cap;
@@ -1863,7 +1866,9 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipSuccess) {
                     if (*seq == h->samp_seq_expected) break;
-                    return h->fail(ISST_ERR_HIP, "sampling tail %d did not publish its tokens", h->samp_seq_expected);
+                    const int want = h->samp_seq_expected;
+                    h->samp_seq_expected = *seq;  // drained without publishing: adopt the device's count, later calls start in step
+                    return h->fail(ISST_ERR_HIP, "sampling tail %d did not publish its tokens", want);
                 }
                 if (q != hipErrorNotReady) return h->fail(ISST_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
             }
@@ -1883,6 +1888,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         }
         isst_handle::DecodeGraph& g = h->dgraph;
         bool captured_now = false;
+        const int seq_before = h->samp_seq_expected;  // the host's count of fused tails moves only with a launch that was really enqueued (every error path below restores it)
         if (!g.exec || g.rows != nr || g.n_suppress != p->n_suppress || g.ngram != p->no_repeat_ngram_size ||
             g.enc_ngram != p->encoder_no_repeat_ngram_size || g.penalty != p->repetition_penalty) {
             captured_now = true;  // (sample_tail below counts the fused tail once; the launch that follows is its first execution)
@@ -1896,17 +1902,19 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             const hipError_t ce = hipStreamEndCapture(st, &graph);
             if (rc != ISST_OK || ce != hipSuccess || !graph) {
                 if (graph) (void)hipGraphDestroy(graph);
+                h->samp_seq_expected = seq_before;
                 return rc != ISST_OK ? rc : h->fail(ISST_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
             }
             const hipError_t ie = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess) { g.exec = nullptr; return h->fail(ISST_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+            if (ie != hipSuccess) { g.exec = nullptr; h->samp_seq_expected = seq_before; return h->fail(ISST_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
             g.rows = nr; g.n_suppress = p->n_suppress; g.ngram = p->no_repeat_ngram_size; g.enc_ngram = p->encoder_no_repeat_ngram_size;
             g.penalty = p->repetition_penalty;
         }
         tail_fused = h->fused_sample && nr <= 16 && !p->do_sample;  // (what sample_tail chose when this row count was captured)
-        if (!captured_now && tail_fused) ++h->samp_seq_expected;  // a replay runs the captured fused tail once more
-        HIPCHK(hipGraphLaunch(g.exec, st));
+        const hipError_t le = hipGraphLaunch(g.exec, st);
+        if (le != hipSuccess) { h->samp_seq_expected = seq_before; return h->fail(ISST_ERR_HIP, "hipGraphLaunch: %s", hipGetErrorString(le)); }
+        if (!captured_now && tail_fused) ++h->samp_seq_expected;  // a replay ran the captured fused tail once more (counted only once it is enqueued)
         return ISST_OK;
     };
 

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const bool v = nb ? nv1 : nv0;
-        wrs[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + ((long)(v ? nt0 + nb : 0) * KT + (long)step0 * 2) * 512, 0, (v && !(dbg & 1)) ? steps * 2048 : 0, 0x00020000);  // (dbg: timing-only runs with a stream emptied, profiles/wide_probe.py)
+        wrs[nb] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.Wp) + ((long)(v ? nt0 + nb : 0) * KT + (long)step0 * 2) * 512, 0, (v && !(dbg & 1)) ? steps * 2048 : 0, 0x00020000);  // (dbg: timing-only runs with a stream emptied, profiles/gemm_wide_probe.py)
     }
     const int woff = lane * 16;
     auto load_w = [&](int t, int kk, int nb) -> u32x4_t { return __builtin_amdgcn_raw_buffer_load_b128(wrs[nb], woff + (t * 2 + kk) * 1024, 0, 2 /* nt: read once */); };
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
     WIDE_STAMP(242); WIDE_STAMP_RT(243);
 }
 
-// tuning hooks (gemm_wide_set): mode 0 = never, 1 = heuristic, 2 = wherever supported; variant = ring depths (profiles/wide_probe.py)
+// tuning hooks (gemm_wide_set): mode 0 = never, 1 = heuristic, 2 = wherever supported; variant = ring depths (profiles/gemm_wide_probe.py)
 static int g_wide_mode = 1, g_wide_variant = 0, g_wide_max_rows = 256, g_wide_dbg = 0;
 bool gemm_wide_enabled() { return g_wide_mode != 0; }
 void gemm_wide_set(int mode, int variant) { g_wide_dbg = mode / 10; g_wide_mode = mode % 10; g_wide_variant = variant; }

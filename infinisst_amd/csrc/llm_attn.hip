@@ -653,7 +653,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
                     }
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
                 const float m_new = fmaxf(m_run, mx);
                 const float resc = (m_run == -INFINITY) ? 0.f : PF_EXP(m_run - m_new);
                 float p[4], ls = 0.f;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
                     ls += p[r];
                 }
                 ls += __shfl_xor(ls, 16, WAVE);
-            ls += __shfl_xor(ls, 32, WAVE);
+                ls += __shfl_xor(ls, 32, WAVE);
                 l_run = l_run * resc + ls;
                 m_run = m_new;
                 // rescale of O only when some column's running max moved (wave-uniform test; x * 1.0f is exact, so skipping changes no bit):

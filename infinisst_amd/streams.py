@@ -117,6 +117,8 @@ class _Slot:
             self.hist_n += k
 
     def window(self, lookback: int) -> Optional[np.ndarray]:
+        # lookback <= 0: NO encoder ids.  A deliberate deviation: the reference's `target_ids[-0:]` (agents/infinisst.py:298-300) is the WHOLE history --
+        # an unbounded id list per stream and tick; every script of the reference passes 100, and the single-stream agent (agent.py) keeps the slice as is.
         if self.hist is None or self.hist_n == 0 or lookback <= 0:
             return None
         return self.hist[max(0, self.hist_n - lookback):self.hist_n]
@@ -282,7 +284,7 @@ class TimingGroup:
     failure is REPORTED (`describe()`), not hidden.  (IPC / topology trouble has nothing to do with the stream-parallel data path, which
     has no collective.)  Without a gloo side group RCCL stays the only path and an error propagates."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, probe_timeout_s: float = 120.0):
         self.device = device
         self.gloo = None
         self.gloo_error = None
@@ -293,21 +295,52 @@ class TimingGroup:
                 self.gloo = dist.new_group(backend="gloo")
             except Exception as e:  # pragma: no cover
                 self.gloo_error = f"{type(e).__name__}: {e}"
-            ok = 1.0
+            # The probe must not be able to hang the ranks in DIFFERENT collectives: a rank whose all-reduce raises at launch (communicator / IPC trouble)
+            # would otherwise go on to the gloo agreement while its peers sit inside the RCCL collective forever.  So (1) the all-reduce is launched
+            # asynchronously and nobody waits for it yet, (2) the ranks agree over gloo whether every LAUNCH worked -- all of them reach this point --
+            # and only then (3) wait for completion, on the host, with a deadline, and (4) agree on the outcome.  A pending RCCL operation that is
+            # given up is never waited for.
+            work, t, launched = None, None, 1.0
             try:
                 t = torch.ones(1, dtype=torch.float64, device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                ok = 1.0 if float(t.item()) == float(dist.get_world_size()) else 0.0
+                work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+            except Exception as e:
+                if self.gloo is None:
+                    raise
+                launched, self.rccl_error = 0.0, f"{type(e).__name__}: {e}"
+            if self.gloo is not None and not self._agree(launched, "an RCCL all-reduce could not be launched on another rank"):
+                return
+            ok = 1.0
+            try:
+                deadline = time.monotonic() + probe_timeout_s
+                while work is not None and not work.is_completed() and time.monotonic() < deadline:
+                    time.sleep(0.005)
+                if work is not None and not work.is_completed():
+                    if self.gloo is None:
+                        raise RuntimeError(f"the RCCL probe all-reduce did not complete within {probe_timeout_s:.0f} s")
+                    ok, self.rccl_error = 0.0, f"the RCCL probe all-reduce did not complete within {probe_timeout_s:.0f} s"
+                else:
+                    if work is not None:
+                        work.wait()
+                    ok = 1.0 if float(t.item()) == float(dist.get_world_size()) else 0.0
+                    if ok < 1.0:
+                        self.rccl_error = "the RCCL probe all-reduce returned a wrong sum"
             except Exception as e:
                 if self.gloo is None:
                     raise
                 ok, self.rccl_error = 0.0, f"{type(e).__name__}: {e}"
             if self.gloo is not None:
-                flag = torch.tensor([ok], dtype=torch.float64)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.gloo)
-                if float(flag.item()) < 1.0:
-                    self.use_rccl = False
-                    self.rccl_error = self.rccl_error or "an RCCL all-reduce failed on another rank"
+                self._agree(ok, "an RCCL all-reduce failed on another rank")
+
+    def _agree(self, mine: float, why_other: str) -> bool:
+        """MIN of the ranks' flags over the gloo side group; any 0 switches EVERY rank to gloo.  Returns whether RCCL stays in use."""
+        flag = torch.tensor([mine], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.gloo)
+        if float(flag.item()) < 1.0:
+            self.use_rccl = False
+            self.rccl_error = self.rccl_error or why_other
+            return False
+        return True
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1

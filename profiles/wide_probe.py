@@ -1,60 +1,34 @@
-"""Probe (round 4): the decode GEMMs at 65..256 rows -- the old dispatch (gemm_mid as two 64-row blocks / gemm_tiled / gemm_dense; isst_op_set_gemm_tuning(900000 + 0, 0)
-switches gemm_wide off) against gemm_wide.hip's ring-depth variants (build with `make EXTRA=-DISST_WIDE_PROBE`), cold rotating weights (> 700 MB of copies per shape),
-outputs compared bit for bit with the old path.  K-sliced shapes run GEMM (fp32 slabs) + the reducing residual / RMSNorm launch, as the engine does."""
+"""Probe: the 64-row decode projections on gemm_mid (A staged through LDS chunk by chunk) against the skinny kernel with 4 / 8 n-tiles per workgroup
+(A fragments straight from L2 into registers, no LDS, no barrier in the k-loop).  Weights rotate over copies.
+NEEDS profiles/r02/gemm_wide_skinny_experiment.patch applied (the 600000+ntb tuning codes exist only there)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from infinisst_amd import engine as E
 dev = "cuda"; lib = E.load_library(); P = E._ptr
-ROWS = [int(x) for x in os.environ.get("ROWS", "128,256,96,192").split(",")]
-VARIANTS = [int(x) for x in os.environ.get("VARIANTS", "0,1,2,3").split(",")]
-SH = {"qkv": (6144, 4096, "none", (1, 2, 4, 8)), "o_proj": (4096, 4096, "res", (4, 8)), "gate_up": (28672, 4096, "swiglu", (1,)), "down": (4096, 14336, "res", (4, 8)),
-      "lm_head": (128272, 4096, "f32", (1,))}
-ONLY = os.environ.get("SHAPES")
-def timeit(run, n=30):
-    for i in range(3): run(i)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(n): run(i)
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
-for M in ROWS:
-    for name, (N, K, epi, splits) in SH.items():
-        if ONLY and name not in ONLY.split(","): continue
-        Np = (N + 15) // 16 * 16
-        copies = max(3, (700 << 20) // (Np * K * 2) + 1)
-        packs = [E.op_pack_weight((torch.randn(N, K, device=dev) * 0.02).bfloat16()) for _ in range(copies)]
-        PAD = int(os.environ.get("LDA_PAD", "0"))  # elements added to the row stride of A (rows of 8 KB all start in the same L2 channel)
-        A = torch.randn(M, K + PAD, device=dev).bfloat16()
-        LDA = K + PAD
-        for ks in splits:
-            line = f"M={M:3d} {name:8s} ks={ks}  W={Np * K * 2 / 1e6:7.1f} MB ({Np * K * 2 / 6.6e6:6.1f} us at 6.6 TB/s):"
-            ref = None
-            DBG = [int(x) for x in os.environ.get("DBG", "0").split(",")]  # 1: W descriptor emptied, 2: A descriptor emptied, 3: both (timing only)
-            for mode, var in [(0, 0)] + [(2 + 10 * d, v) for v in VARIANTS for d in DBG]:
-                lib.isst_op_set_gemm_tuning(900000 + mode * 10 + var, 0)
-                if ks == 1:
-                    n_out = N // 2 if epi == "swiglu" else N
-                    out = torch.zeros(M, n_out, device=dev, dtype=torch.float32 if epi == "f32" else torch.bfloat16)
-                    def run(i):
-                        rc = lib.isst_op_gemm(P(A), LDA, P(packs[i % copies]), None, None, 0, P(out), out.stride(0), M, Np, K, n_out, E.EPI[epi], None, 0.0, E._stream_ptr())
-                        assert rc == 0, rc
-                    us = timeit(run)
-                    run(0); torch.cuda.synchronize(); got = out.clone()
-                else:
-                    x0 = torch.randn(M, N, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).bfloat16()
-                    x = x0.clone(); nw = torch.ones(N, device=dev).bfloat16(); xo = torch.empty_like(x)
-                    slabs = torch.empty(ks, M, N, device=dev, dtype=torch.float32)
-                    def run(i):
-                        rc = lib.isst_op_gemm_splitk_rmsnorm(P(A), LDA, P(packs[i % copies]), P(x), P(nw), P(xo), P(slabs), M, N, K, ks, 1e-5, E._stream_ptr())
-                        assert rc == 0, rc
-                    us = timeit(run)
-                    x.copy_(x0); run(0); torch.cuda.synchronize(); got = x.clone()
-                if ref is None: ref = got; tag = "old"
-                elif mode >= 10: tag = f"v{var}/dbg{mode // 10}"
-                else: tag = f"v{var}" + ("" if torch.equal(got, ref) else f"(DIFF {float((got.float() - ref.float()).abs().max()):.3g})")
-                line += f"  {tag} {us:6.1f}"
-            print(line, flush=True)
-        del packs
-lib.isst_op_set_gemm_tuning(900000 + 10, 0)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+for name, N, K, epi in (("q/k/v", 6144, 4096, "none"), ("gate/up", 28672, 4096, "swiglu"), ("o_proj", 4096, 4096, "res"), ("down", 4096, 14336, "res")):
+    copies = max(2, min(8, int(600e6 / (N * K * 2)) + 1))
+    packs = [E.op_pack_weight((torch.randn(N, K, device=dev) * 0.02).bfloat16()) for _ in range(copies)]
+    x = torch.randn(M, K, device=dev).bfloat16()
+    n_out = N // 2 if epi == "swiglu" else N
+    res = torch.randn(M, n_out, device=dev).bfloat16() if epi == "res" else None
+    out = torch.empty(M, n_out, device=dev, dtype=torch.bfloat16)
+    line, ref = [], None
+    for tag, flag in (("mid", 0), ("wide4", 4), ("wide8", 8)):
+        lib.isst_op_set_gemm_tuning(600000 + flag, 0)
+        def run(i):
+            rc = lib.isst_op_gemm(P(x), K, P(packs[i % copies]), None, P(res), n_out, P(out), n_out, M, N, K, n_out, E.EPI[epi], None, 0.0, E._stream_ptr())
+            assert rc == 0, rc
+        for i in range(8): run(i)
+        run(0); torch.cuda.synchronize()
+        if ref is None: ref = out.clone()
+        d = (out.float() - ref.float()).abs().max().item()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(100): run(i)
+        e1.record(); torch.cuda.synchronize()
+        line.append(f"{tag} {e0.elapsed_time(e1) / 100 * 1e3:6.2f} us (max |d| vs mid {d:.3g})")
+    print(f"{name:8s} M={M} N={N:6d} K={K:6d}: " + "   ".join(line) + f"   weights alone at 6.6 TB/s {N * K * 2 / 6.6e6:5.2f} us", flush=True)
+    del packs
+lib.isst_op_set_gemm_tuning(600000, 0)

@@ -113,3 +113,56 @@ def test_bench_parent_reports_a_failing_rank():
     r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--toy", "--no-cpu-baseline")
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_timing_group_probe_cannot_strand_ranks(monkeypatch):
+    """streams.TimingGroup decides ONCE whether RCCL works, and no outcome of the probe may leave ranks in different collectives: the
+    all-reduce is launched asynchronously, the ranks agree over gloo whether every LAUNCH worked before anybody waits, completion is awaited on the
+    host with a deadline, and the outcome is agreed again.  Driven here with stand-ins for torch.distributed (no GPU): a launch that raises, a launch
+    that never completes, a healthy one."""
+    sys.path.insert(0, ROOT)
+    import torch
+    from infinisst_amd import streams
+
+    class Work:
+        def __init__(self, done):
+            self.done, self.waited = done, False
+
+        def is_completed(self):
+            return self.done
+
+        def wait(self):
+            self.waited = True
+
+    log = []
+
+    def install(mode):
+        log.clear()
+        monkeypatch.setattr(streams.dist, "is_available", lambda: True)
+        monkeypatch.setattr(streams.dist, "is_initialized", lambda: True)
+        monkeypatch.setattr(streams.dist, "get_world_size", lambda *a, **k: 2)
+        monkeypatch.setattr(streams.dist, "new_group", lambda backend=None: "gloo-group")
+
+        def all_reduce(t, op=None, group=None, async_op=False):
+            if group == "gloo-group":
+                log.append(("gloo", float(t.item())))
+                return None
+            log.append(("rccl", async_op))
+            if mode == "raise":
+                raise RuntimeError("hipIpcGetMemHandle: invalid argument")
+            t.fill_(2.0)
+            return Work(done=(mode == "ok"))
+        monkeypatch.setattr(streams.dist, "all_reduce", all_reduce)
+
+    install("raise")
+    tg = streams.TimingGroup(torch.device("cpu"), probe_timeout_s=0.05)
+    assert not tg.use_rccl and "hipIpcGetMemHandle" in tg.rccl_error
+    assert log == [("rccl", True), ("gloo", 0.0)]            # the failing rank goes STRAIGHT to the agreement; nobody waited on RCCL
+    install("hang")
+    tg = streams.TimingGroup(torch.device("cpu"), probe_timeout_s=0.05)
+    assert not tg.use_rccl and "did not complete" in tg.rccl_error
+    assert log == [("rccl", True), ("gloo", 1.0), ("gloo", 0.0)]  # launched everywhere, then timed out on the host, then agreed to fall back
+    install("ok")
+    tg = streams.TimingGroup(torch.device("cpu"), probe_timeout_s=0.05)
+    assert tg.use_rccl and tg.rccl_error is None and tg.describe() == "rccl"
+    assert log == [("rccl", True), ("gloo", 1.0), ("gloo", 1.0)]
