@@ -2046,8 +2046,8 @@ extern "C" int isst_op_gemm_norm_ssq(const uint16_t* x, int64_t ldx, const uint1
     g.A = x; g.lda = ldx; g.Wp = packed; g.out = out; g.ldo = ldo;
     g.M = M; g.N = round_up(N, 16); g.K = K; g.batch = 1; g.epi = epi; g.n_valid = n_valid;
     g.norm_w = norm_w; g.norm_eps = norm_eps; g.ssq = ssq; g.ssq_n = K / 32;
-    if (!gemm_mid_supported(g)) return ISST_ERR_ARG;
-    return launch_gemm_mid(g, reinterpret_cast<hipStream_t>(hip_stream));
+    if (!gemm_mid_supported(g) && !gemm_wide_supported(g)) return ISST_ERR_ARG;
+    return launch_gemm(g, reinterpret_cast<hipStream_t>(hip_stream));  // (gemm_mid.hip, or gemm_wide.hip for the widest projections from 33 rows on)
 }
 extern "C" int isst_op_gemm_splitk_layernorm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, uint16_t* x,
                                              const uint16_t* ln_w, const uint16_t* ln_b, uint16_t* out, float* slabs, int M, int N, int K, int ksplit,

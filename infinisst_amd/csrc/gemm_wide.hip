@@ -59,12 +59,23 @@ extern "C" int isst_debug_wide_trace_read(void* dst, long bytes) {
 #endif
 
 typedef __attribute__((address_space(3))) void* wlds_ptr;
+// s_waitcnt vmcnt(N) alone (expcnt / lgkmcnt left at their maxima): simm16 = vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
+template <int N>
+__device__ __forceinline__ void wide_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | 0xf00 | ((N >> 4) << 14));
+}
 
-template <int MT, int DW, int NS, int EPI>
+// NORM: A = x is RMS-normalised on its way to the MFMAs with 1/rms from the producer's sums of squares (GemmArgs::ssq: the consumer half of the launch-free
+// residual + RMSNorm of gemm_mid.hip) -- by the LOADER waves, in LDS, one step ahead of its publication (an LDS-DMA has no register stage to do it in).
+template <int MT, int DW, int NS, int EPI, bool NORM = false>
 __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps, int dbg) {
     constexpr int AU = MT / 2;            // LDS-DMA units (8 rows x 128 B = 1 KiB) per loader wave and step
     constexpr int ABUF = MT * 2048;       // bytes of one staged step: [MT m-tiles][16 rows][128 B], 16-byte chunks XOR-swizzled
     static_assert(NS >= 4 && NS * ABUF <= 160 * 1024, "ring stages");
+    constexpr int U = DW < 4 ? 4 : DW;    // unroll period of the consumers' loop (a multiple of DW that divides the usual step counts: every trip round the back edge costs ~350 cycles)
+    static_assert(U % DW == 0, "ring slots are compile-time constants");
+    constexpr int RING = NS * ABUF;       // NORM: behind the ring 1/rms of the tile's rows (MT*16 fp32), then the norm weight (K bf16)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NS x ABUF (all LDS of the kernel: cdna_hip_programming.md section 5, trap 4a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: roles, descriptors and DMA destinations are built from it
@@ -99,28 +110,81 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
         // before the first barrier: steps 0 .. NS-2 issued, steps 0 and 1 landed
 #pragma unroll
         for (int s0 = 0; s0 < NS - 1; ++s0) dma(s0, s0);
-        if constexpr ((NS - 3) * AU == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if constexpr ((NS - 3) * AU == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr ((NS - 3) * AU == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if constexpr ((NS - 3) * AU == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if constexpr ((NS - 3) * AU == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        else if constexpr ((NS - 3) * AU == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* rsS = reinterpret_cast<float*>(smem + RING);
+        unsigned char* wS = smem + RING + MT * 16 * 4;
+        // NORM: bf16(w * bf16(x * 1/rms)) over this wave's own units of the staged step `s` ([3P] HF LlamaRMSNorm's rounding points, as gemm_mid's consumer):
+        // a lane re-reads the 16 bytes its DMA lane wrote (row lane >> 3 of the unit, the chunk that came from source chunk (lane & 7) ^ swizzle)
+        auto normalise = [&](int s, int stage) {
+            const int sc = s < steps ? s : steps - 1;
+#pragma unroll
+            for (int a = 0; a < AU; ++a) {
+                const int un = lw * AU + a;
+                const int rim = (un & 1) * 8 + (lane >> 3);
+                unsigned char* px = smem + stage * ABUF + un * 1024 + lane * 16;
+                const u32x4_t xv = *reinterpret_cast<const u32x4_t*>(px);
+                const u32x4_t nwv = *reinterpret_cast<const u32x4_t*>(wS + (((long)step0 + sc) * WIDE_TK + (((lane & 7) ^ ((rim >> 1) & 7)) << 3)) * 2);
+                const float rs = rsS[un * 8 + (lane >> 3)];
+                u32x4_t o;
+                o.x = pack_bf(lo_bf(nwv.x) * bfr(lo_bf(xv.x) * rs), hi_bf(nwv.x) * bfr(hi_bf(xv.x) * rs));
+                o.y = pack_bf(lo_bf(nwv.y) * bfr(lo_bf(xv.y) * rs), hi_bf(nwv.y) * bfr(hi_bf(xv.y) * rs));
+                o.z = pack_bf(lo_bf(nwv.z) * bfr(lo_bf(xv.z) * rs), hi_bf(nwv.z) * bfr(hi_bf(xv.z) * rs));
+                o.w = pack_bf(lo_bf(nwv.w) * bfr(lo_bf(xv.w) * rs), hi_bf(nwv.w) * bfr(hi_bf(xv.w) * rs));
+                *reinterpret_cast<u32x4_t*>(px) = o;
+            }
+        };
+        if constexpr (NORM) {
+            // 1/rms of every row of the tile from the producer's per-32-column sums of squares: 4 lanes per row, the SAME summation order as gemm_mid's
+            // consumer (16 floats in flight per lane, then the fixed tree) -- a row gives the same 1/rms through either kernel.  These are ordinary loads:
+            // hipcc drains the DMAs above in front of their first use, which costs nothing here (steps 0 and 1 have to have landed anyway)
+            const int lt = tid - 256;
+            for (int row = lt >> 2; row < MT * 16; row += 64) {
+                const int q = lt & 3, grow = min(m0 + row, g.M - 1);
+                const int per = g.ssq_n >> 2;
+                const float* sp = g.ssq + (long)grow * g.ssq_n + q * per;
+                float pq = 0.f;
+                if ((per & 15) == 0) {
+                    for (int i0 = 0; i0 < per; i0 += 16) {
+                        f32x4_t t4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) t4[u] = *reinterpret_cast<const f32x4_t*>(sp + i0 + 4 * u);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { pq += t4[u].x; pq += t4[u].y; pq += t4[u].z; pq += t4[u].w; }
+                    }
+                } else if ((per & 3) == 0) {
+                    for (int i0 = 0; i0 < per; i0 += 4) { const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(sp + i0); pq += t4.x; pq += t4.y; pq += t4.z; pq += t4.w; }
+                } else {
+                    for (int i = 0; i < per; ++i) pq += sp[i];
+                }
+                const float o1 = __shfl_xor(pq, 1, WAVE);
+                const float s2 = (q & 1) ? o1 + pq : pq + o1;   // (even + odd), the same operand order in both lanes
+                const float o2 = __shfl_xor(s2, 2, WAVE);
+                const float tot = (q & 2) ? o2 + s2 : s2 + o2;
+                if (q == 0) rsS[row] = rsqrtf(tot / g.K + g.norm_eps);
+            }
+            for (int i = lt; i < (g.K >> 3); i += 256) *reinterpret_cast<u32x4_t*>(wS + i * 16) = *reinterpret_cast<const u32x4_t*>(g.norm_w + i * 8);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // 1/rms and the norm weight are in LDS for all four loader waves (the consumers pass this barrier too)
+            normalise(0, 0);
+            normalise(1, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            wide_wait_vmcnt<(NS - 3) * AU>();
+        }
         __builtin_amdgcn_s_barrier();
         int stage = NS - 1;  // stage of step t - 1 + NS
-        const int T = (steps + DW - 1) / DW * DW;  // the consumers' loop is padded to the ring's unroll period: the same number of barriers on both sides
+        int stage2 = 2 % NS; // stage of step t + 2
+        const int T = (steps + U - 1) / U * U;  // the consumers' loop is padded to its unroll period: the same number of barriers on both sides
         for (int t = 0; t < T; ++t) {
             // stage (t-1) % NS was read for the last time in step t-1 (every consumer passed barrier t-1 behind its reads): refill it with step t-1+NS;
             // then all but the NS-3 youngest steps have landed, i.e. step t+2 is complete before barrier t -- the consumers read it from step t+1 on
             dma(t - 1 + NS, stage);
             stage = stage + 1 == NS ? 0 : stage + 1;
-            if constexpr ((NS - 3) * AU == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr ((NS - 3) * AU == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if constexpr ((NS - 3) * AU == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if constexpr ((NS - 3) * AU == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if constexpr ((NS - 3) * AU == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else if constexpr ((NS - 3) * AU == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wide_wait_vmcnt<(NS - 3) * AU>();
+            if constexpr (NORM) {
+                normalise(t + 2, stage2);
+                stage2 = stage2 + 1 == NS ? 0 : stage2 + 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rewritten rows are in LDS before the barrier publishes them
+            }
             __builtin_amdgcn_s_barrier();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued DMAs have landed ...
@@ -158,21 +222,24 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
     // A fragments travel in GROUPS of 8 (one k-step x 8 m-tiles = 16 MFMAs = 256 matrix-pipe cycles) through two register sets: the next group -- of
     // this step, or the FIRST group of the next step, whose image the previous barrier already published -- is requested under the MFMAs of the
     // current one.
-    constexpr int MH = MT / 8, NG = 2 * MH;
-    u32x4_t af[2][8];
+    constexpr int GS = MT >= 8 ? 8 : MT;       // fragments per group (MT = 4: 64 rows, 8 MFMAs per group)
+    constexpr int MH = MT / GS, NG = 2 * MH;
+    static_assert(GS >= 4 && MT % GS == 0, "a group carries its GS fragment reads and the 4 ring loads as fillers");
+    u32x4_t af[2][GS];
+    if constexpr (NORM) __builtin_amdgcn_s_barrier();  // (the loaders' 1/rms + norm-weight staging barrier)
     __builtin_amdgcn_s_barrier();  // steps 0 and 1 are in LDS
 #pragma unroll
-    for (int j = 0; j < 8; ++j) af[0][j] = *reinterpret_cast<const u32x4_t*>(smem + rd0 + j * 2048);
+    for (int j = 0; j < GS; ++j) af[0][j] = *reinterpret_cast<const u32x4_t*>(smem + rd0 + j * 2048);
     WIDE_STAMP_RT(0); WIDE_STAMP(1);
     int st0 = 0, st1 = ABUF;  // LDS offsets of the stages of steps t and t+1
-    for (int t0 = 0; t0 < steps; t0 += DW) {
+    for (int t0 = 0; t0 < steps; t0 += U) {
 #pragma unroll
-        for (int u = 0; u < DW; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int t = t0 + u;
             // NO condition on t: an iteration past the last step (steps % DW != 0) multiplies the slice's last rows (the loaders re-read them) by zero
             // weights (past the descriptor) -- every path through the loop issues the same loads in the same order, which is what lets hipcc count
             // its waits (a skipped iteration makes the back edge's wait a drain), and both roles pass the same number of barriers
-            const int sw = u;
+            const int sw = u % DW;
             if (t == 8) WIDE_STAMP(205);
             // ONE MFMA instruction stream per SIMD: whatever is issued between two MFMAs runs in the shadow of the first (an MFMA holds the issue port for
             // 8 of its 16 cycles), whatever is issued in a block of its own stalls the matrix pipe (trace build: 8 ds_read_b128 128 cycles, 4 buffer
@@ -181,20 +248,21 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
             for (int gi = 0; gi < NG; ++gi) {
                 const int kk = gi / MH, mh = gi % MH;
                 const int ngi = (gi + 1) % NG;
-                const unsigned char* nrd = smem + ((gi + 1 < NG) ? st0 : st1) + ((ngi / MH) ? rd1 : rd0) + (ngi % MH) * 8 * 2048;
+                const unsigned char* nrd = smem + ((gi + 1 < NG) ? st0 : st1) + ((ngi / MH) ? rd1 : rd0) + (ngi % MH) * GS * 2048;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    wide_mfma(acc[mh * 8 + (k >> 1)][k & 1], af[gi & 1][k >> 1], wreg[sw][kk][k & 1]);
-                    if (k < 8) af[(gi + 1) & 1][k] = *reinterpret_cast<const u32x4_t*>(nrd + k * 2048);
-                    else if (gi == NG - 1 && k >= 12) wreg[sw][(k - 12) >> 1][(k - 12) & 1] = load_w(t + DW, (k - 12) >> 1, (k - 12) & 1);
+                for (int k = 0; k < 2 * GS; ++k) {
+                    wide_mfma(acc[mh * GS + (k >> 1)][k & 1], af[gi & 1][k >> 1], wreg[sw][kk][k & 1]);
+                    if (k < GS) af[(gi + 1) & 1][k] = *reinterpret_cast<const u32x4_t*>(nrd + k * 2048);
+                    else if (gi == NG - 1 && k >= 2 * GS - 4) wreg[sw][(k - (2 * GS - 4)) >> 1][(k - (2 * GS - 4)) & 1] = load_w(t + DW, (k - (2 * GS - 4)) >> 1, (k - (2 * GS - 4)) & 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (t == 8) WIDE_STAMP(210 + gi);
             }
             if (t == 8) WIDE_STAMP(206);
-            // the stage of step t is free once every consumer's reads of it have returned: all LDS reads but the 8 youngest (the first group of step
+            // the stage of step t is free once every consumer's reads of it have returned: all LDS reads but the GS youngest (the first group of step
             // t+1) -- LDS operations of a wave complete in order
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            if constexpr (GS == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (t < 200) WIDE_STAMP(4 + t);
             st0 = st1;
@@ -318,51 +386,55 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
 }
 
 // tuning hooks (gemm_wide_set): mode 0 = never, 1 = heuristic, 2 = wherever supported; variant = ring depths (profiles/gemm_wide_probe.py)
-static int g_wide_mode = 1, g_wide_variant = 0, g_wide_max_rows = 256, g_wide_dbg = 0;
+static int g_wide_mode = 1, g_wide_variant = 0, g_wide_max_rows = 256, g_wide_min_rows = 65, g_wide_dbg = 0;
 bool gemm_wide_enabled() { return g_wide_mode != 0; }
-void gemm_wide_set(int mode, int variant) { g_wide_dbg = mode / 10; g_wide_mode = mode % 10; g_wide_variant = variant; }
+void gemm_wide_set(int mode, int variant) { g_wide_dbg = (mode / 10) % 10; g_wide_mode = mode % 10; g_wide_variant = variant; g_wide_min_rows = mode >= 100 ? 17 : 65; }  // (mode + 100: also 17..64 rows, probes)
 
+// rows: 65..256 for every long weight stream; from 49 rows for the WIDEST ones when they normalise on stage (gate/up and lm_head of a 49..64-stream decode
+// pass: 41.0 against gemm_mid's 45.1 us at 64 rows, profiles/r04/gemm_wide_rows64_probe.txt -- the narrow projections tie gemm_mid there and stay on it)
+static bool wide_rows_ok(const GemmArgs& g) {
+    if (g.M >= g_wide_min_rows && g.M <= g_wide_max_rows) return true;
+    return g.norm_w && g.ssq && g.M >= 49 && g.M <= 64 && (long)g.N * g.K >= (64L << 20);
+}
 bool gemm_wide_supported(const GemmArgs& g) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     if (g.epi == EPI_PARTIAL ? g.ksplit < 1 : g.ksplit > 1) return false;
-    return g_wide_mode != 0 && g.batch == 1 && g.M > 64 && g.M <= g_wide_max_rows && g.K % (WIDE_TK * ks) == 0 && g.K / (WIDE_TK * ks) >= 2 && g.N % 16 == 0 && g.lda % 8 == 0 &&
-           !g.norm_w && !g.attn_partial && !g.tickets && (g.epi != EPI_SWIGLU || g.N % 32 == 0) && ((long)g.M - 1) * g.lda + g.K < (1L << 29);
+    if (g.norm_w && !(g.ssq && g.ssq_n * 32 == g.K && g.ssq_n % 4 == 0 && ks == 1 && g.K <= 8192 && (g.epi == EPI_NONE || g.epi == EPI_SWIGLU || g.epi == EPI_F32))) return false;
+    return g_wide_mode != 0 && g.batch == 1 && wide_rows_ok(g) && g.K % (WIDE_TK * ks) == 0 && g.K / (WIDE_TK * ks) >= 2 && g.N % 16 == 0 && g.lda % 8 == 0 &&
+           !g.attn_partial && !g.tickets && (g.epi != EPI_SWIGLU || g.N % 32 == 0) && ((long)g.M - 1) * g.lda + g.K < (1L << 29);
 }
 // worth it where the weight stream is long (as gemm_mid_preferred): the encoder's 2-8 MB projections at 96 rows are latency-bound
 bool gemm_wide_preferred(const GemmArgs& g) { return g_wide_mode == 2 || (long)g.N * g.K >= (8L << 20); }
 
-template <int MT, int DW, int NS, int EPI>
-static int launch_wide_cfg(const GemmArgs& g, hipStream_t stream) {
+template <int MT, int DW, int NS, int EPI, bool NORM>
+static int launch_wide_cfg2(const GemmArgs& g, hipStream_t stream) {
     const int ks = g.epi == EPI_PARTIAL ? (g.ksplit > 1 ? g.ksplit : 1) : 1;
     const int NTILES = g.N / 16;
     dim3 grid((NTILES + WIDE_NT - 1) / WIDE_NT, ks, (g.M + MT * 16 - 1) / (MT * 16)), block(512);
-    const size_t lds = (size_t)NS * MT * 2048;
-    static bool attr = false;
-    if (lds >= 64 * 1024 && !attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<MT, DW, NS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
-        attr = true;
+    const size_t lds = (size_t)NS * MT * 2048 + (NORM ? (size_t)MT * 16 * 4 + (size_t)g.K * 2 : 0);  // NORM: + 1/rms of the rows + the norm weight
+    static size_t attr_lds = 0;  // (NORM: the size depends on K)
+    if (lds >= 64 * 1024 && lds > attr_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_kernel<MT, DW, NS, EPI, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+        attr_lds = lds;
     }
-    hipLaunchKernelGGL((gemm_wide_kernel<MT, DW, NS, EPI>), grid, block, lds, stream, g, g.K / WIDE_TK / ks, g_wide_dbg);
+    hipLaunchKernelGGL((gemm_wide_kernel<MT, DW, NS, EPI, NORM>), grid, block, lds, stream, g, g.K / WIDE_TK / ks, g_wide_dbg);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
+template <int MT, int DW, int NS, int EPI>
+static int launch_wide_cfg(const GemmArgs& g, hipStream_t stream) {
+    if constexpr (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_F32) {
+        if (g.norm_w) return launch_wide_cfg2<MT, DW, NS, EPI, true>(g, stream);
+    }
+    return launch_wide_cfg2<MT, DW, NS, EPI, false>(g, stream);
+}
 
+// ring depths (profiles/gemm_wide_probe.py, r04/wide_probe_v4*): W ring 4 K-steps / A ring 6 stages up to 128 rows (deeper rings measured equal or slower);
+// 256 rows: the 128 accumulator registers of a consumer leave room for a W ring of 2 steps, and the 32 KB stages for 4 of them
 template <int EPI>
 static int launch_wide_epi(const GemmArgs& g, hipStream_t stream) {
-#ifdef ISST_WIDE_PROBE
-    if (g.M <= 128) {
-        if (g_wide_variant == 1) return launch_wide_cfg<8, 4, 8, EPI>(g, stream);
-        if (g_wide_variant == 2) return launch_wide_cfg<8, 6, 6, EPI>(g, stream);
-        if (g_wide_variant == 3) return launch_wide_cfg<8, 6, 8, EPI>(g, stream);
-        return launch_wide_cfg<8, 4, 6, EPI>(g, stream);
-    }
-    if (g_wide_variant == 1) return launch_wide_cfg<16, 3, 4, EPI>(g, stream);
-    if (g_wide_variant == 2) return launch_wide_cfg<16, 4, 4, EPI>(g, stream);
-    if (g_wide_variant == 3) return launch_wide_cfg<16, 4, 5, EPI>(g, stream);
-    return launch_wide_cfg<16, 2, 4, EPI>(g, stream);
-#else
+    if (g.M <= 64) return launch_wide_cfg<4, 4, 6, EPI>(g, stream);
     if (g.M <= 128) return launch_wide_cfg<8, 4, 6, EPI>(g, stream);
     return launch_wide_cfg<16, 2, 4, EPI>(g, stream);
-#endif
 }
 
 int launch_gemm_wide(const GemmArgs& g, hipStream_t stream) {

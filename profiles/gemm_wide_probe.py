@@ -32,7 +32,8 @@ for M in ROWS:
             line = f"M={M:3d} {name:8s} ks={ks}  W={Np * K * 2 / 1e6:7.1f} MB ({Np * K * 2 / 6.6e6:6.1f} us at 6.6 TB/s):"
             ref = None
             DBG = [int(x) for x in os.environ.get("DBG", "0").split(",")]  # 1: W descriptor emptied, 2: A descriptor emptied, 3: both (timing only)
-            for mode, var in [(0, 0)] + [(2 + 10 * d, v) for v in VARIANTS for d in DBG]:
+            LOW = 100 if os.environ.get("LOWROWS") else 0  # + 100: gemm_wide also takes 17..64 rows (MT = 4 form)
+            for mode, var in [(0, 0)] + [(LOW + 2 + 10 * d, v) for v in VARIANTS for d in DBG]:
                 lib.isst_op_set_gemm_tuning(900000 + mode * 10 + var, 0)
                 if ks == 1:
                     n_out = N // 2 if epi == "swiglu" else N
@@ -52,7 +53,7 @@ for M in ROWS:
                     us = timeit(run)
                     x.copy_(x0); run(0); torch.cuda.synchronize(); got = x.clone()
                 if ref is None: ref = got; tag = "old"
-                elif mode >= 10: tag = f"v{var}/dbg{mode // 10}"
+                elif (mode % 100) >= 10: tag = f"v{var}/dbg{(mode % 100) // 10}"
                 else: tag = f"v{var}" + ("" if torch.equal(got, ref) else f"(DIFF {float((got.float() - ref.float()).abs().max()):.3g})")
                 line += f"  {tag} {us:6.1f}"
             print(line, flush=True)

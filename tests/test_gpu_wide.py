@@ -74,3 +74,38 @@ def test_gemm_wide_split_k_slabs(M, N, K, ks):
     close_bf16(x1, want, f"wide split-K M{M} N{N} K{K} ks{ks}", ulps=2.5, atol=3.2e-2)
     close_bf16(n1, ollm.rmsnorm(x1.cpu(), nw, 1e-5), "norm of the updated rows", ulps=2.0, atol=1e-3)
     assert torch.equal(x0, x1) and torch.equal(n0, n1), f"{int((x0 != x1).sum())} elements differ from gemm_tiled's slabs"
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(33, 16384, 4096, "swiglu"), (64, 16400, 4096, "f32"), (48, 16384, 4096, "none"), (100, 4096, 4096, "swiglu"), (200, 1040, 2048, "f32")])
+def test_gemm_wide_normalises_on_stage(M, N, K, epi):
+    """The consumer half of the launch-free residual + RMSNorm on gemm_wide (round 4): A = x is normalised by the LOADER waves, in LDS, with 1/rms from
+    the producer's per-32-column sums of squares and HF LlamaRMSNorm's rounding points [3P] -- gate/up and lm_head of a 33..64-stream decode pass take
+    this form (the widest weight streams; rows 65+ through mode 2).  Against the oracle arithmetic bf16(w * bf16(x / rms)) @ W^T with the epilogue's
+    rounding points, and against the unfused pair (RMSNorm launch + plain projection)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = bf(torch.randn(M, K, generator=g) * 3.0)
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    nw = bf(1 + 0.2 * torch.randn(K, generator=g))
+    ssq = (x.float() ** 2).view(M, K // 32, 32).sum(-1).contiguous()
+    Wp = E.op_pack_weight(W.to(DEV))
+    try:
+        _wide_mode(2)
+        got = E.op_gemm_norm_ssq(x.to(DEV), Wp, N, nw.to(DEV), ssq.to(DEV), epi)
+        _wide_mode(1)
+        xn_dev = E.op_rmsnorm(x.to(DEV), nw.to(DEV))
+        unfused = E.op_gemm(xn_dev, Wp, N, epi)
+        torch.cuda.synchronize()
+    finally:
+        _wide_mode(1)
+    xn = ollm.rmsnorm(x, nw, 1e-5)
+    acc = xn.float() @ W.float().t()
+    if epi == "swiglu":
+        gg, uu = acc.view(M, N // 32, 2, 16)[:, :, 0].reshape(M, -1), acc.view(M, N // 32, 2, 16)[:, :, 1].reshape(M, -1)
+        r = lambda t: t.to(torch.bfloat16).float()
+        want = bf(r(torch.nn.functional.silu(r(gg))) * r(uu))
+    elif epi == "f32":
+        want = acc.to(torch.bfloat16).float()
+    else:
+        want = bf(acc)
+    close_bf16(got, want, f"wide norm-on-stage {epi} M{M} N{N} vs oracle", ulps=3.0, atol=6e-2)
+    close_bf16(got, unfused, f"wide norm-on-stage {epi} M{M} N{N} vs the unfused pair", ulps=3.0, atol=6e-2)
