@@ -1553,7 +1553,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         //      stream are ONE attention group over arena 0 for everything older than this chunk's generated tokens (identical in all
         //      arenas) plus one workgroup per beam for the <= 4 tiles that differ; otherwise every beam is its own group over its arena ----
         const int nr = n * B;
-        const bool shared = h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;
+        const bool shared = h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;  // (isst_generate's `beams_share_prefix`: the pre-pass relies on it)
         for (int i = 0; i < n; ++i) {
             const StreamState& ss = h->streams[stream_ids[i]];
             for (int b = 0; b < B; ++b) {
@@ -1779,7 +1779,12 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         std::memcpy(mh.suppress, p->suppress_tokens, (size_t)p->n_suppress * 4);
         HIPCHK(hipMemcpyAsync(h->meta_dev + mh.suppress_offset, h->meta_host + mh.suppress_offset, (size_t)p->n_suppress * 4, hipMemcpyHostToDevice, st));
     }
-    if (B > 1 && h->rot_keys) {  // the rotated-key pre-pass below also covers arenas 1 .. B-1 (the prefill itself only reads views 0 .. n-1)
+    // Beam search: in the shared-prefix form (beam_decode: the B beams of a stream are ONE attention group that reads everything older than this chunk's
+    // generated tokens from arena 0) the rotated copies of arenas 1 .. B-1 are never read below tail_start -- their tails are written by the appends and the
+    // position copies of this chunk -- so the pre-pass rotates arena 0 only: 64 streams x 4 beams 7.9 -> 2.0 ms per chunk (profiles/r04/trace_busy_prof64x4_*).
+    const bool beams_share_prefix = B > 1 && h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;  // = beam_decode's `shared`
+    const int rope_views = n * ((B > 1 && !beams_share_prefix) ? B : 1);
+    if (B > 1 && h->rot_keys && !beams_share_prefix) {  // the rotated-key pre-pass below also covers arenas 1 .. B-1 (the prefill itself only reads views 0 .. n-1)
         int nv = n;
         for (int i = 0; i < n; ++i)
             for (int b = 1; b < B; ++b) {
@@ -1801,14 +1806,14 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             HIPCHK(hipEventCreateWithFlags(&h->side_ev, hipEventDisableTiming));
         }
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, h->side));
-        CHK(launch_llm_rope_cache(md.views, n * B, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, h->side));
+        CHK(launch_llm_rope_cache(md.views, rope_views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, h->side));
         HIPCHK(hipEventRecord(h->side_ev, h->side));
         HIPCHK(hipStreamWaitEvent(st, h->side_ev, 0));
     } else {
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
         // rotate the cached keys of every layer ONCE for this chunk (positions are fixed until the next eviction)
         // (beam search: views n .. n*B-1, written above, are the other beams' arenas of the same streams -- they hold the same cached keys)
-        if (h->rot_keys && any_cached) CHK(launch_llm_rope_cache(md.views, n * B, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
+        if (h->rot_keys && any_cached) CHK(launch_llm_rope_cache(md.views, rope_views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
     }
     CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh, n_units, max_unit_groups));
     if (B > 1)
