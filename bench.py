@@ -195,7 +195,7 @@ class ChunkLoop:
               for _ in range(cfg.llm_layers)]
         enc = [[(0.6 * torch.randn((cfg.enc_heads, cfg.max_cache_size, cfg.enc_head_dim), device=device, generator=g)).bfloat16().cpu() for _ in range(2)]
                for _ in range(cfg.enc_layers)]
-        ring_cap = 64 * ((1000 + max_prompt_len(self.sys_n, self.m) + max(self.gen.max_new_tokens, 10) + 8 + 63) // 64)  # engine.hip isst_create
+        ring_cap = 64 * ((1000 + max_prompt_len(self.sys_n, self.m) + max(self.gen.max_new_tokens, 10) + 8 + 63) // 64)  # engine_core.hip isst_create
         enc_cap = 64 * ((cfg.max_cache_size + cfg.block_size * self.m + 63) // 64)
         for i, sid in enumerate(self.sids):
             eng.import_llm_kv(sid, kv, sys_len=self.sys_n, ring_start=(ring_cap - 200 + 13 * i) % ring_cap)

@@ -1,0 +1,1038 @@
+// Host side of libinfinisst_hip.so, part 3 of 4 (engine_internal.h): the Llama side of one chunk -- splice, prefill, the greedy / sample loop, beam search.
+// It is the MI355X replacement of `self.model.generate(...)` at reference agents/infinisst.py:307-332 (model/llm.py:51-126,192-270,
+// model/patches/patch_llm.py:231-336, model/patches/patch_hf.py:43-302,586-624,687-967).  Every compute step is a HIP kernel launch on the caller's stream.
+#include "engine_internal.h"
+
+namespace isst_impl {
+
+int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int epi, const bf16_t* res, long ldres, void* out, long ldo,
+         int M, hipStream_t st, int batch, long a_batch, long out_batch, long res_batch,
+         const bf16_t* norm_w, float norm_eps, float* ssq) {
+    GemmArgs g{};
+    g.ssq = ssq; g.ssq_n = ssq ? L.K / 32 : 0;
+    g.A = A; g.lda = lda; g.a_batch = a_batch;
+    g.Wp = L.wp; g.bias = L.bias;
+    g.res = res; g.ldres = ldres; g.res_batch = res_batch;
+    g.out = out; g.ldo = ldo; g.out_batch = out_batch;
+    g.M = M; g.N = L.N; g.K = L.K; g.batch = batch; g.epi = epi; g.n_valid = L.n_valid;
+    g.norm_w = norm_w; g.norm_eps = norm_eps;
+    CHK(launch_gemm(g, st));
+    return ISST_OK;
+}
+
+// K slices over workgroups for the narrow-N projections (o_proj, down_proj).  17..64 rows (gemm_mid.hip; measured,
+// profiles/r01/mid_probe.txt): 2 slices for K = 4096, 4 for K = 14336, more only add slab traffic.  65..512 rows (gemm_tiled.hip:
+// 32 column blocks x ceil(rows / 128) row blocks walk all of K alone otherwise -- 217 us for down_proj whatever the row count,
+// profiles/rows_probe.py): enough slices for ~384 workgroups.
+// (the dense kernel keeps 3 workgroups per CU resident, 768 chip-wide: slicing up to that count instead of 384 and up to 2048 rows instead of
+//  1024 gave, same box, 64 / 32 / 16 / 8 streams 100.6 -> 99.7 / 71.5 -> 70.0 / 53.8 -> 53.4 / 45.9 -> 45.3 ms per chunk; 1152 was worse again at 16-32)
+int pick_ksplit(int K, int N, int rows, long slab_cap) {
+    if (rows <= 64) {
+        // (N <= 2048 = the encoder's out_proj / fc2, 16..32 column blocks: fc2 20.1 us as GEMM + LayerNorm, 16.6 / 14.7 / 16.5 us with 2 / 4 / 8 slices
+        //  + the reducing LayerNorm; out_proj 14.2 -> 11.5 us with 2: profiles/enc_probe.py)
+        // (33..64 rows, N = K = 4096 -- o_proj of a many-stream decode pass -- with the in-launch reduction: 2 slices of 32 columns 16.8 us, 4 slices of
+        //  64 columns 15.3; down_proj stays at 4 x 64 columns: 29.2 against 34.7 for 8 and 45.0 for 2; profiles/fused_ks_probe.py)
+        for (int s = (K >= 8192 || (N <= 2048 && K >= 4096) || (rows > 32 && K >= 4096)) ? 4 : 2; s > 1; s >>= 1)
+            if (K % (256 * s) == 0 && K / (256 * s) >= 1) return s;
+        return 1;
+    }
+    // (slab_cap: fp32 elements of the caller's slab buffer -- isst_handle::lslab_elems; a slice count is only chosen if its slabs fit)
+    if (gemm_wide_enabled() && rows <= 256 && (long)N * K >= (8L << 20)) {  // (= gemm_wide_preferred: shorter weight streams keep gemm_tiled and its slice choice below)
+        // gemm_wide.hip (65..256 rows: one 8-wave workgroup per CU, 128 columns, all rows): enough K slices to give most of the 256 CUs a workgroup and
+        // no more -- a second round of workgroups doubles the launch (profiles/r04/wide_probe.txt, GEMM + reducing norm, us, 128 rows: q/k/v 38.7 / 29.1 /
+        // 25.6 / 33.1 for 1 / 2 / 4 / 8 slices (48 column blocks); down_proj 45.7 / 35.7 for 4 / 8 (32 column blocks))
+        const long blocks = (N + 127) / 128;
+        int s = 1;
+        // ... and no fewer than 16 K-steps per slice: the launch's fixed cost (ring fill 3.3 us, epilogue + slab traffic) is not amortised below that
+        // (o_proj, K = 4096: 21.6 us with 4 slices = 128 workgroups against 22.4 with 8 = 256 at 128 rows, 27.3 / 30.5 at 256: profiles/r04/wide_probe_v4*)
+        while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= 256 && (long)s * 2 * rows * N <= slab_cap && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 16) s *= 2;
+        return s;
+    }
+    if (gemm_dense_would_run(rows, N, K)) {
+        // 256 x 256 tiles, one workgroup per CU (gemm_dense.hip): rounds of 1/s-length tiles + the slab traffic each further slice adds (write + read of
+        // rows x N fp32: about 4 % of a round per slice at these shapes).  profiles/dense_split_probe.py, GEMM + reducing norm, us:
+        //   1408 rows  o_proj 82.7 / 62.4 / 79.9 / 102.0 for 1 / 2 / 4 / 8 slices, down_proj 241 / 161 / 178 / 183;   704 rows  o_proj 79 / 52 / 43 / 59, down 248 / 139 / 94 / 116
+        const long tiles = (long)((N + 255) / 256) * ((rows + 255) / 256);
+        int best = 1;
+        double best_cost = 1e30;
+        for (int s = 1; s <= LLM_KSPLIT_MAX; s *= 2) {
+            if (K % (64 * s) != 0 || K / (64 * s) < 4 || (s > 1 && (long)s * rows * N > slab_cap)) break;
+            const double cost = (double)((tiles * s + 255) / 256) / s + 0.04 * s;
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+        }
+        return best;
+    }
+    const int blocks = ((N + 127) / 128) * ((rows + 127) / 128);
+    int s = 1;
+    while (s < LLM_KSPLIT_MAX && blocks * s * 2 <= LLM_SPLIT_TARGET_WGS && (long)s * 2 * rows * N <= slab_cap && K % (64 * s * 2) == 0 && K / (64 * s * 2) >= 8) s *= 2;
+    return s;
+}
+// slabs[ksplit][M][N] (fp32) = A @ W^T per K slice; reduced by launch_rmsnorm_reduce
+// x != null (13..64 rows): the launch also reduces -- x = bf16(x + bf16(sum of the slabs)) by the last K-slice workgroup of every column block,
+// sums of squares of the new x per row and 32 columns into ssq (GemmArgs::tickets)
+int gemm_partial(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, float* slabs, int M, int ksplit, hipStream_t st,
+                 bf16_t* x, long ldx, float* ssq, bf16_t* plain_out, long ld_plain,
+                 const bf16_t* norm_w, float norm_eps, float* ssq_in) {
+    GemmArgs g{};
+    if (x) { g.res = x; g.ldres = ldx; g.ssq = ssq; g.ssq_n = L.n_valid / 32; g.tickets = h->ltickets; }
+    if (plain_out) {  // q/k/v in K slices: the last slice workgroup writes bf16(sum) to plain_out; A may be normalised while staged (norm_w + ssq_in)
+        g.res = plain_out; g.ldres = ld_plain; g.reduce_plain = 1; g.tickets = h->ltickets;
+        g.norm_w = norm_w; g.norm_eps = norm_eps; g.ssq = ssq_in; g.ssq_n = ssq_in ? L.K / 32 : 0;
+    }
+    g.A = A; g.lda = lda; g.Wp = L.wp;
+    g.out = slabs; g.ldo = L.n_valid; g.out_batch = (long)M * L.n_valid;
+    g.M = M; g.N = L.N; g.K = L.K; g.batch = 1; g.epi = EPI_PARTIAL; g.n_valid = L.n_valid; g.ksplit = ksplit;
+    if (slabs == h->lslab && (long)(ksplit > 1 ? ksplit : 1) * M * L.n_valid > h->lslab_elems)
+        return h->fail(ISST_ERR_STATE, "split-K launch of %d slices x %d rows x %d columns exceeds the slab buffer (%ld fp32)", ksplit, M, L.n_valid, h->lslab_elems);
+    if (g.tickets && (L.N + 31) / 32 > h->ltickets_n) return h->fail(ISST_ERR_STATE, "ticketed split-K launch over %d columns needs %d arrival counters, %d allocated", L.N, (L.N + 31) / 32, h->ltickets_n);
+    CHK(launch_gemm(g, st));
+    return ISST_OK;
+}
+
+}  // namespace isst_impl
+
+namespace {
+
+struct StepMeta {
+    int *row_stream, *row_pos, *ids, *speech_row, *last_rows;
+    int2* groups;  // attention row groups of this launch
+    int2* units;   // prefill: runs of <= 8 consecutive groups of one stream (llm_attn_prefill_kernel)
+    LlmStreamView* views;
+    SampleStream* samp;
+    int *ids_pool, *enc_pool, *suppress;
+    KvCopyOp* ops;  // position copies of a beam step
+    size_t step_bytes;      // bytes from the block start up to (not including) the suppress list
+    size_t suppress_offset;
+};
+// carve the metadata block (same offsets on host and device)
+StepMeta carve(isst_handle* h, unsigned char* base) {
+    StepMeta m;
+    const size_t LR = h->llm_rows_max, ns = (size_t)h->cfg.max_streams * h->max_beams;
+    unsigned char* p = base + 4096;  // first 4 KiB: encoder views
+    auto take = [&](size_t bytes) { unsigned char* r = p; p += (bytes + 15) / 16 * 16; return r; };
+    m.row_stream = reinterpret_cast<int*>(take(LR * 4)); m.row_pos = reinterpret_cast<int*>(take(LR * 4));
+    m.ids = reinterpret_cast<int*>(take(LR * 4)); m.speech_row = reinterpret_cast<int*>(take(LR * 4));
+    m.last_rows = reinterpret_cast<int*>(take(ns * 4));
+    m.groups = reinterpret_cast<int2*>(take(LR * 8));
+    m.units = reinterpret_cast<int2*>(take(LR * 8));
+    m.views = reinterpret_cast<LlmStreamView*>(take(ns * sizeof(LlmStreamView)));
+    m.samp = reinterpret_cast<SampleStream*>(take(ns * sizeof(SampleStream)));
+    m.ids_pool = reinterpret_cast<int*>(take(ns * h->max_ids * 4));
+    m.enc_pool = reinterpret_cast<int*>(take(ns * h->max_enc_ids * 4));
+    m.ops = reinterpret_cast<KvCopyOp*>(take(ns * 4 * sizeof(KvCopyOp) * KV_OPS_SLOTS));
+    m.step_bytes = (size_t)(p - base);
+    m.suppress_offset = m.step_bytes;
+    m.suppress = reinterpret_cast<int*>(take(65536 * 4));
+    return m;
+}
+
+// one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
+int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_groups, int max_group_rows, bool splice, const char* tap_prefix,
+                hipStream_t st, const StepMeta* hm = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0) {
+    const isst_config& c = h->cfg;
+    const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
+    // one group (one stream's decode step): its metadata travels in the kernel arguments (llm_attn.hip LlmAttnOne)
+    LlmAttnOne one{};
+    if (hm && n_groups == 1) {
+        const int2 g0 = hm->groups[0];
+        bool consecutive = true;
+        for (int k = 1; k < g0.y; ++k) consecutive = consecutive && hm->row_pos[g0.x + k] == hm->row_pos[g0.x] + k;
+        if (consecutive) {
+            one.enabled = 1;
+            one.grp = g0;
+            one.pos0 = hm->row_pos[g0.x];
+            one.v = hm->views[hm->row_stream[g0.x]];
+        }
+    }
+    CHK(launch_embed_splice(d.ids, splice ? d.speech_row : nullptr, h->embed, h->speech, h->lx, rows, DL, st));
+    if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "embed", h->lx, (int64_t)rows * DL, st));
+    // 17..64 rows (one stream's prefill, a 64-stream decode pass): o_proj and down_proj split K over workgroups and the
+    // residual + RMSNorm kernel that follows reduces the slabs (gemm_mid.hip); `pending`: lx still lacks the previous
+    // layer's down_proj slabs
+    const bool split_rows = rows > ISST_MID_MIN_ROWS && rows <= LLM_SPLIT_MAX_ROWS;
+    const int so = split_rows ? pick_ksplit(H * 128, DL, rows, h->lslab_elems) : 1, sd = split_rows ? pick_ksplit(c.llm_ffn, DL, rows, h->lslab_elems) : 1;
+    const int sq = (rows > (gemm_wide_enabled() ? 64 : 128) && rows <= LLM_SPLIT_MAX_ROWS) ? pick_ksplit(DL, (H + 2 * KV) * 128, rows, h->lslab_elems) : 1;  // (65..256 rows: gemm_wide's 48 column blocks in 4 slices)
+    const long slab = (long)rows * DL;
+    // 13..64 rows: no residual + RMSNorm launches (gemm_mid.hip: the producer reduces, the consumer normalises while staging)
+    const bool fr = h->fuse_reduce && split_rows && rows <= 64 && so > 1 && sd > 1 && DL % 128 == 0;
+    // ... and q/k/v in K slices with the same in-launch reduction (192 workgroups of 32 columns leave a quarter of the CUs idle and give the others one
+    // workgroup each; ISST_QKV_SLICES=1 forces the unsplit launch)
+    // A/B on one box, ms per step: 64 streams 92.63 (1 slice) / 91.33 (2) / 92.61 (4); 16 streams 51.24 / 51.52 / 50.84 -- two slices from 33 rows
+    const int qs = h->qkv_slices > 0 ? h->qkv_slices : (rows > 32 ? 2 : 1);
+    const int sqf = (fr && qs > 1 && DL % (256 * qs) == 0) ? qs : 1;
+    bool pending = false, pending_fused = false;
+    // in-situ timing (isst_profile_begin / _begin_rows): an event pair around the gate/up launch of every layer of a pass whose row count is in the
+    // profiled range -- opens the bracket and hands back the event that closes it
+    auto prof_open = [&](hipEvent_t* close) -> int {
+        *close = nullptr;
+        if (!h->prof_on || rows < h->prof_rows_lo || rows > h->prof_rows_hi) return ISST_OK;
+        if (h->prof_used + 2 > h->prof_ev.size()) {
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                h->prof_ev.push_back(e);
+            }
+        }
+        HIPCHK(hipEventRecord(h->prof_ev[h->prof_used], st));
+        *close = h->prof_ev[h->prof_used + 1];
+        h->prof_used += 2;
+        return ISST_OK;
+    };
+    for (int l = 0; l < c.llm_layers; ++l) {
+        const LlmLayer& L = h->llm[l];
+        hipEvent_t pe = nullptr;
+        // decode shapes: RMSNorm is applied inside the projection's A-fragment load (gemm.hip NORM); larger row counts
+        // (prefill, many streams) run the norm kernel once instead of once per workgroup
+        const bool fuse = rows <= LLM_FUSED_NORM_MAX_ROWS;
+        if (fuse) {
+            CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps));
+        } else {
+            bool qkv_done = false;
+            if (pending_fused) {  // lx is complete (the down_proj launch reduced its own slabs); q/k/v normalises it on the way into LDS
+                if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
+                pending_fused = false;
+                if (sqf > 1)
+                    CHK(gemm_partial(h, h->lx, DL, L.qkv, h->lslab, rows, sqf, st, nullptr, 0, nullptr, h->lqkv, (H + 2 * KV) * 128, L.in_norm, c.rms_eps, h->lssq));
+                else
+                    CHK(gemm(h, h->lx, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st, 1, 0, 0, 0, L.in_norm, c.rms_eps, h->lssq));
+                qkv_done = true;
+            } else if (pending) {
+                CHK(launch_rmsnorm_reduce(h->lslab, slab, sd, h->lx, DL, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+                if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l - 1), h->lx, (int64_t)rows * DL, st));
+                pending = false;
+            } else {
+                CHK(launch_rmsnorm(h->lx, DL, nullptr, L.in_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+            }
+            if (qkv_done) {
+            } else if (sqf > 1) {  // (first layer: the norm launch ran; the K slices still pay)
+                CHK(gemm_partial(h, h->lxn, DL, L.qkv, h->lslab, rows, sqf, st, nullptr, 0, nullptr, h->lqkv, (H + 2 * KV) * 128));
+            } else if (sq > 1) {  // 129..1024 rows: the 48 column blocks of the dense kernel get K slices; a small pass sums the slabs to bf16
+                CHK(gemm_partial(h, h->lxn, DL, L.qkv, h->lslab, rows, sq, st));
+                CHK(launch_slab_reduce(h->lslab, (long)rows * (H + 2 * KV) * 128, sq, h->lqkv, (H + 2 * KV) * 128, rows, (H + 2 * KV) * 128, st));
+            } else {
+                CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
+            }
+        }
+        // one or two decode rows: no combine launch -- o_proj merges the split-KV partials while it stages its A row (gemm.hip AMODE 3)
+        int merge_splits = 0;
+        const bool merge_in_oproj = h->fuse_combine && !h->inline_combine && so == 1 && rows <= ATTN_MERGE_MAX_ROWS && n_units == 0 && n_beam_wgs == 0;
+        CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
+                                 h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
+                                 max_unit_groups, n_beam_wgs, merge_in_oproj ? &merge_splits : nullptr, h->inline_combine ? h->attn_cnt : nullptr));
+        if (so > 1 && fr) {
+            CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st, h->lx, DL, h->lssq));
+            CHK(prof_open(&pe));
+            CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps, h->lssq));
+            if (pe) HIPCHK(hipEventRecord(pe, st));
+        } else if (so > 1) {
+            CHK(gemm_partial(h, h->lattn, H * 128, L.o, h->lslab, rows, so, st));
+            CHK(launch_rmsnorm_reduce(h->lslab, slab, so, h->lx, DL, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+            CHK(prof_open(&pe));
+            CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+            if (pe) HIPCHK(hipEventRecord(pe, st));
+        } else {
+            if (merge_splits > 0) {
+                GemmArgs g{};
+                g.A = h->lattn; g.lda = H * 128; g.Wp = L.o.wp; g.res = h->lx; g.ldres = DL; g.out = h->lx; g.ldo = DL;
+                g.M = rows; g.N = L.o.N; g.K = L.o.K; g.batch = 1; g.epi = EPI_RES; g.n_valid = L.o.n_valid;
+                g.attn_partial = h->lpartial; g.attn_splits = merge_splits;
+                CHK(launch_gemm(g, st));
+            } else {
+                CHK(gemm(h, h->lattn, H * 128, L.o, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
+            }
+            if (fuse) {
+                CHK(prof_open(&pe));
+                CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
+                if (pe) HIPCHK(hipEventRecord(pe, st));
+            } else {
+                CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
+                CHK(prof_open(&pe));
+                CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+                if (pe) HIPCHK(hipEventRecord(pe, st));
+            }
+        }
+        if (sd > 1 && fr) {  // (the last layer too: lx is complete when the launch ends, and lm_head can take the sums of squares)
+            CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st, h->lx, DL, h->lssq));
+            pending_fused = l + 1 < c.llm_layers;
+            if (!pending_fused && tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
+        } else if (sd > 1) {  // (the last layer too: the slabs are summed by the final norm's launch below -- unsplit, its 32 column blocks walk all of K alone)
+            CHK(gemm_partial(h, h->lact, c.llm_ffn, L.down, h->lslab, rows, sd, st));
+            pending = true;
+        } else {
+            CHK(gemm(h, h->lact, c.llm_ffn, L.down, EPI_RES, h->lx, DL, h->lx, DL, rows, st));
+            if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(l), h->lx, (int64_t)rows * DL, st));
+        }
+    }
+    bool final_normed = false;
+    if (pending) {  // the last layer's down_proj slabs: lx += sum; on a decode pass (every row is a last row) the same launch writes the final norm
+        const bool fold = !splice && n_last == rows && n_last > LLM_FUSED_NORM_MAX_ROWS_LM_HEAD;
+        CHK(launch_rmsnorm_reduce(h->lslab, slab, sd, h->lx, DL, fold ? h->final_norm : nullptr, h->llast, DL, rows, DL, c.rms_eps, st));
+        if (tap_prefix && h->cfg.debug_taps) CHK(tap(h, std::string(tap_prefix) + "layer_" + std::to_string(c.llm_layers - 1), h->lx, (int64_t)rows * DL, st));
+        pending = false;
+        final_normed = fold;
+    }
+    if (final_normed) {
+        CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
+    } else if (splice) {  // prefill: the last prompt row of every stream is gathered and normalised
+        CHK(launch_rmsnorm(h->lx, DL, d.last_rows, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
+        if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "final", h->llast, (int64_t)n_last * DL, st));
+        CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
+    } else if (n_last <= LLM_FUSED_NORM_MAX_ROWS_LM_HEAD) {  // decode: rows == last rows, final norm fused into the lm_head projection
+        CHK(gemm(h, h->lx, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st, 1, 0, 0, 0, h->final_norm, c.rms_eps));
+    } else if (fr && n_last == rows) {  // 13..64 decode rows: the last down_proj launch left the sums of squares; lm_head normalises while it stages
+        CHK(gemm(h, h->lx, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st, 1, 0, 0, 0, h->final_norm, c.rms_eps, h->lssq));
+    } else {
+        CHK(launch_rmsnorm(h->lx, DL, nullptr, h->final_norm, h->llast, DL, n_last, DL, c.rms_eps, st));
+        CHK(gemm(h, h->llast, DL, h->lm_head, EPI_F32, nullptr, 0, h->logits, h->vocab_pad, n_last, st));
+    }
+    return ISST_OK;
+}
+
+
+}  // namespace
+
+namespace isst_impl {
+// The speech splice as a row map.  The reference rebuilds the embedding sequence with torch.cat of three SLICES per (user, assistant) header
+// pair (model/llm.py:86-113):   filled = cat(filled[:u+3], speech[index : index + (a-u-5)], filled[a-2:])
+// Slices clamp, so when the encoder produced FEWER features than the prompt has patch slots -- the padded last segment of an utterance at
+// multiplier m > 1 brings 12..12(m-1) features for 12m slots -- the sequence simply gets shorter: the surplus patch rows never reach the
+// decoder; surplus FEATURES are dropped (:105).  Restated literally on row descriptors: desc[t] >= 0: prompt token desc[t]; < 0: feature -1 - desc[t].
+int splice_rows(const int* ids, int len, int user_id, int assistant_id, int start_header_id, int S, std::vector<int>& desc) {
+    std::vector<int> users, assists;
+    for (int t = 1; t < len; ++t) {
+        if (ids[t - 1] != start_header_id) continue;
+        if (ids[t] == user_id) users.push_back(t);
+        if (ids[t] == assistant_id) assists.push_back(t);
+    }
+    desc.resize(len);
+    for (int t = 0; t < len; ++t) desc[t] = t;
+    int index = 0;
+    for (size_t q = 0; q < users.size() && q < assists.size(); ++q) {
+        const int u = users[q], a = assists[q], cnt = a - u - 5;
+        if (cnt < 0) return ISST_ERR_ARG;
+        const int cur = (int)desc.size();
+        const int head = std::min(u + 3, cur), tail = std::min(std::max(a - 2, 0), cur);
+        std::vector<int> nd(desc.begin(), desc.begin() + head);
+        for (int k = std::min(index, S); k < std::min(index + cnt, S); ++k) nd.push_back(-1 - k);
+        nd.insert(nd.end(), desc.begin() + tail, desc.end());
+        desc.swap(nd);
+        index += cnt;
+    }
+    return ISST_OK;
+}
+}  // namespace isst_impl
+
+
+
+// --------------------------------------------------------------------------------------------
+// beam search (reference model/patches/patch_hf.py:43-302, 687-967; production decoding mode, beam = 4)
+// --------------------------------------------------------------------------------------------
+namespace {
+
+struct BeamHyp {
+    double score;
+    std::vector<int> tokens;  // prompt + generated, without the EOS that closed it
+    int fed;                  // generated tokens whose KV exists (positions P0 .. P0 + fed - 1)
+    int buf;                  // tail buffer slot holding that KV, or -1 - beam when it still sits in arena `beam`
+};
+struct BeamHyps {  // BeamHypotheses, patch_hf.py:278-302 + [3P] is_done (early_stopping = False)
+    int num_beams;
+    double length_penalty;
+    std::vector<BeamHyp> beams;
+    double worst = 1e9;
+    // returns the buffer slot freed by an evicted (or rejected) hypothesis, or -1
+    int add(BeamHyp hyp, double sum_logprobs, int generated_len) {
+        hyp.score = sum_logprobs / std::pow((double)generated_len, length_penalty);
+        if ((int)beams.size() < num_beams || hyp.score > worst) {
+            beams.push_back(std::move(hyp));
+            if ((int)beams.size() > num_beams) {
+                std::vector<std::pair<double, int>> ranked;
+                for (size_t i = 0; i < beams.size(); ++i) ranked.push_back({beams[i].score, (int)i});
+                std::sort(ranked.begin(), ranked.end());
+                const int freed = beams[ranked[0].second].buf;
+                beams.erase(beams.begin() + ranked[0].second);
+                worst = ranked[1].first;
+                return freed >= 0 ? freed : -1;
+            }
+            worst = std::min(hyp.score, worst);
+            return -1;
+        }
+        return hyp.buf >= 0 ? hyp.buf : -1;
+    }
+    bool is_done(double best_sum_logprobs, int cur_len, int prompt_len) const {
+        if ((int)beams.size() < num_beams) return false;
+        const double highest = best_sum_logprobs / std::pow((double)(cur_len - prompt_len), length_penalty);
+        return worst >= highest;
+    }
+};
+
+struct BeamStream {  // host state of one stream during a beam call
+    std::vector<std::vector<int>> seq;  // per beam: prompt + generated
+    std::vector<float> score;
+    BeamHyps hyps;
+    bool done = false;
+    std::vector<int> free_bufs;
+};
+
+void push_copy(isst_handle* h, std::vector<KvCopyOp>& ops, int sid, int beam, int buf, int p0, int count, bool to_arena) {
+    if (count <= 0) return;
+    const StreamState& s = h->streams[sid];
+    KvCopyOp op{};
+    op.arena_offset = h->arena_off(sid, beam);
+    op.buf_offset = ((long)sid * h->nbuf + buf) * h->tbuf_stride;
+    op.p0 = p0; op.count = count;
+    op.sys_len = s.llm_sys; op.ring_start = s.llm_ring_start;
+    op.to_arena = to_arena ? 1 : 0;
+    ops.push_back(op);
+}
+// enqueue `ops` (all of them are independent of each other) and clear the list.  The pinned op list has KV_OPS_SLOTS slots used in
+// turn, so that a batch does not have to wait for the previous one's upload: the caller synchronises the stream once per beam step
+// (candidate download) and calls kv_ops_synced(); a slot is only reused after such a point
+int flush_copies(isst_handle* h, std::vector<KvCopyOp>& ops, const StepMeta& mh, const StepMeta& md, hipStream_t st) {
+    if (ops.empty()) return ISST_OK;
+    const size_t cap = (size_t)h->cfg.max_streams * h->max_beams * 4;
+    for (size_t o = 0; o < ops.size(); o += cap) {
+        const int n = (int)std::min(cap, ops.size() - o);
+        int max_count = 0;
+        for (int i = 0; i < n; ++i) max_count = std::max(max_count, ops[o + i].count);
+        if (h->kv_ops_used >= KV_OPS_SLOTS) {  // every slot may still be read by an upload in flight
+            HIPCHK(hipStreamSynchronize(st));
+            h->kv_ops_used = 0;
+        }
+        const size_t slot = (size_t)h->kv_ops_used++ * cap;
+        std::memcpy(mh.ops + slot, ops.data() + o, sizeof(KvCopyOp) * n);
+        HIPCHK(hipMemcpyAsync(md.ops + slot, mh.ops + slot, sizeof(KvCopyOp) * n, hipMemcpyHostToDevice, st));
+        CHK(launch_kv_positions_copy(h->llm_k, h->llm_v, h->rot_keys ? h->llm_kr : nullptr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, md.ops + slot, n, max_count, h->adims,
+                                     h->cfg.llm_layers, h->tcap, st));
+    }
+    ops.clear();
+    return ISST_OK;
+}
+
+// decode phase of a beam call; the prefill (on arena 0 of every stream) has already produced h->logits rows 0..n-1
+int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const int* const* prompt_ids, const int* prompt_lens,
+                const std::vector<int>& rows_len /* KV entries the prompt wrote (<= prompt_lens after a short splice) */, const int* const* prev_target_ids, const int* n_prev, const std::vector<int>& total0, int* const* out_ids, int* out_lens,
+                StepMeta& mh, StepMeta& md, hipStream_t st) {
+    const isst_config& c = h->cfg;
+    const int B = p->num_beams, V = c.vocab;
+    const int n_keep = std::max(2, 1 + c.n_eos) * B;
+    if (n_keep > BEAM_TOPK) return h->fail(ISST_ERR_ARG, "beam search keeps %d candidates per step, at most %d are supported", n_keep, BEAM_TOPK);
+    const double lp = p->length_penalty == 0.f ? 1.0 : (double)p->length_penalty;
+    std::vector<BeamStream> bs(n);
+    std::vector<KvCopyOp> ops;
+    if (h->kv_ops_used) {  // batches of an earlier call that ended without a synchronisation in between (finalize)
+        HIPCHK(hipStreamSynchronize(st));
+        h->kv_ops_used = 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        bs[i].seq.assign(B, std::vector<int>(prompt_ids[i], prompt_ids[i] + prompt_lens[i]));
+        bs[i].score.assign(B, -1e9f);
+        bs[i].score[0] = 0.f;
+        bs[i].hyps.num_beams = B;
+        bs[i].hyps.length_penalty = lp;
+        for (int b = B; b < h->nbuf; ++b) bs[i].free_bufs.push_back(b);  // slots 0..B-1 are reorder temporaries
+        // the prompt's KV was written to arena 0: replicate it into the other beams' arenas (they are identical before it)
+        push_copy(h, ops, stream_ids[i], 0, 0, total0[i], rows_len[i], false);
+    }
+    CHK(flush_copies(h, ops, mh, md, st));
+    for (int i = 0; i < n; ++i)
+        for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], rows_len[i], true);
+    CHK(flush_copies(h, ops, mh, md, st));
+
+    int step = 0;  // tokens already chosen per beam
+    while (true) {
+        const int rows_per = step == 0 ? 1 : B;  // step 0: only beam 0 carries a finite score (:767-771)
+        const int rows = n * rows_per;
+        // ---- log_softmax -> processors (on log-probs) -> per-row top-k ----
+        for (int i = 0; i < n; ++i)
+            for (int b = 0; b < rows_per; ++b) {
+                const int r = i * rows_per + b;
+                const std::vector<int>& sq = bs[i].seq[b];
+                std::memcpy(mh.ids_pool + (size_t)r * h->max_ids, sq.data(), sq.size() * 4);
+                const int ne = n_prev ? n_prev[i] : 0;
+                if (b == 0 && ne) std::memcpy(mh.enc_pool + (size_t)i * h->max_enc_ids, prev_target_ids[i], (size_t)ne * 4);
+                mh.samp[r].n_ids = (int)sq.size(); mh.samp[r].n_enc = ne;
+                mh.samp[r].ids_off = r * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
+            }
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+        CHK(launch_log_softmax(h->logits, h->vocab_pad, V, h->lse_max, h->lse_sum, rows, st));
+        CHK(launch_sample_process(h->logits, h->vocab_pad, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
+                                  p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, rows, st));
+        if (p->do_sample) {
+            // beam SAMPLE (:871-875): the processed log-probs of every row come to the host; there the warpers (part of the processor list under do_sample),
+            // + beam score, softmax over a stream's rows_per x V scores, n_keep draws without replacement (warp.hip) -- written into the same candidate
+            // arrays the top-k fills below (value = warped log-prob of the drawn token, so that value + beam score is the reference's gathered score)
+            HIPCHK(hipMemcpyAsync(h->samp_host, h->logits, (size_t)rows * h->vocab_pad * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h->kv_ops_used = 0;
+            std::vector<float> flat((size_t)rows_per * V);
+            std::vector<double> us(n_keep);
+            std::vector<long> picked(n_keep);
+            for (int i = 0; i < n; ++i) {
+                for (int b = 0; b < rows_per; ++b) {
+                    float* row = h->samp_host + (size_t)(i * rows_per + b) * h->vocab_pad;
+                    warp_scores(row, V, p->temperature, p->top_k, p->top_p, p->epsilon_cutoff, c.n_eos + 1);  // min_tokens_to_keep of beam methods
+                    const float bsc = bs[i].score[b];
+                    for (int v2 = 0; v2 < V; ++v2) flat[(size_t)b * V + v2] = row[v2] + bsc;
+                }
+                for (int j = 0; j < n_keep; ++j) us[j] = sample_uniform(p->seed, stream_ids[i], h->streams[stream_ids[i]].chunks, 64 * step + j);
+                if (multinomial_without_replacement(flat.data(), (long)rows_per * V, n_keep, us.data(), picked.data()) != ISST_OK)
+                    return h->fail(ISST_ERR_STATE, "beam sample: fewer than %d tokens with non-zero probability at step %d (torch.multinomial raises here too)", n_keep, step);
+                // candidate j of the stream goes to the slot (row of its beam, next free column); unused slots are marked invalid
+                std::vector<int> used(rows_per, 0);
+                for (int b = 0; b < rows_per; ++b)
+                    for (int j = 0; j < BEAM_TOPK; ++j) h->top_idx_host[(i * rows_per + b) * BEAM_TOPK + j] = -1;
+                for (int j = 0; j < n_keep; ++j) {
+                    const int b = (int)(picked[j] / V), tok = (int)(picked[j] % V);
+                    const int r = i * rows_per + b, slot = used[b]++;
+                    h->top_val_host[r * BEAM_TOPK + slot] = h->samp_host[(size_t)r * h->vocab_pad + tok];
+                    h->top_idx_host[r * BEAM_TOPK + slot] = tok;
+                }
+            }
+        } else {
+            // (the final selection stores its <= 32 candidates per row straight into the pinned host arrays: no device copy, no two D2H launches per step)
+            CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val_host, h->top_idx_host, rows, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h->kv_ops_used = 0;  // every earlier copy batch has run
+        }
+
+        // ---- scorer (beam_search_process, :43-157) ----
+        bool all_done = true;
+        std::vector<std::vector<int>> parents(n), next_tok(n);
+        for (int i = 0; i < n; ++i) {
+            BeamStream& S = bs[i];
+            const int prompt_len = prompt_lens[i];
+            const int P0 = total0[i] + rows_len[i];  // first position written by the decode phase
+            std::vector<int>& ntok = next_tok[i];
+            std::vector<int>& npar = parents[i];
+            if (S.done) {
+                // a finished batch entry is skipped by the scorer (patch_hf.py:83-92: pad tokens, zero scores, its hypotheses untouched)
+                // while the other streams of the call go on; its rows still ride through the forward pass (their KV beyond the
+                // winner's tail is never read: llm_total is set from the winning hypothesis)
+                const int pad = c.n_eos ? c.eos_ids[0] : 0;
+                for (int b = 0; b < B; ++b) { ntok.push_back(pad); npar.push_back(b); S.seq[b].push_back(pad); }
+                S.score.assign(B, 0.f);
+                continue;
+            }
+            struct Cand { float val; long flat; };
+            std::vector<Cand> cands;
+            for (int b = 0; b < rows_per; ++b)
+                for (int j = 0; j < n_keep; ++j) {
+                    const int r = i * rows_per + b;
+                    const int idx = h->top_idx_host[r * BEAM_TOPK + j];
+                    if (idx < 0 || idx >= V) continue;
+                    cands.push_back({h->top_val_host[r * BEAM_TOPK + j] + S.score[b], (long)b * V + idx});
+                }
+            if (h->btrace_on && i == 0) {
+                isst_handle::BeamTraceStep ts;
+                ts.rows = rows_per; ts.n_keep = n_keep;
+                for (int b = 0; b < rows_per; ++b) {
+                    for (int j = 0; j < n_keep; ++j) {
+                        ts.val.push_back(h->top_val_host[b * BEAM_TOPK + j]);
+                        ts.idx.push_back(h->top_idx_host[b * BEAM_TOPK + j]);
+                    }
+                    ts.score.push_back(S.score[b]);
+                }
+                h->btrace.push_back(std::move(ts));
+            }
+            std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b2) { return a.val > b2.val || (a.val == b2.val && a.flat < b2.flat); });
+            if ((int)cands.size() > n_keep) cands.resize(n_keep);
+            const int cur_len = (int)S.seq[0].size() + 1;
+            std::vector<float> nscore;
+            for (size_t rank = 0; rank < cands.size(); ++rank) {
+                const int b = (int)(cands[rank].flat / V), tok = (int)(cands[rank].flat % V);
+                bool is_eos = false;
+                for (int e = 0; e < c.n_eos; ++e) is_eos = is_eos || tok == c.eos_ids[e];
+                if (is_eos) {
+                    if ((int)rank >= B) continue;
+                    BeamHyp hyp;
+                    hyp.tokens = S.seq[b];
+                    hyp.fed = step;
+                    hyp.buf = -1;
+                    if (step > 0) {  // keep a copy of that beam's tail (the reference clones the whole KV cache, :113-120)
+                        if (S.free_bufs.empty()) return h->fail(ISST_ERR_STATE, "beam search ran out of hypothesis buffers");
+                        hyp.buf = S.free_bufs.back();
+                        S.free_bufs.pop_back();
+                        push_copy(h, ops, stream_ids[i], b, hyp.buf, P0, step, false);
+                    } else {
+                        hyp.buf = -1 - 0;  // empty tail: nothing to keep
+                    }
+                    const int freed = S.hyps.add(std::move(hyp), (double)cands[rank].val, cur_len - prompt_len);
+                    if (freed >= B) S.free_bufs.push_back(freed);
+                } else {
+                    nscore.push_back(cands[rank].val);
+                    ntok.push_back(tok);
+                    npar.push_back(b);
+                }
+                if ((int)ntok.size() == B) break;
+            }
+            if ((int)ntok.size() < B) return h->fail(ISST_ERR_STATE, "beam search: fewer than %d non-EOS candidates", B);
+            if (!cands.empty()) S.done = S.done || S.hyps.is_done((double)cands[0].val, cur_len, prompt_len);
+            if (h->btrace_on && i == 0 && (size_t)(step + 1) * B <= h->bforce_tok.size()) {
+                // teacher forcing (test aid): continue with the caller's (token, parent) choices; a beam's score is its parent's score plus
+                // the processed log-prob of the forced token, read back from the device's score row
+                for (int b = 0; b < B; ++b) {
+                    const int tok = h->bforce_tok[(size_t)step * B + b], par = h->bforce_par[(size_t)step * B + b];
+                    if (tok < 0 || tok >= V || par < 0 || par >= rows_per) return h->fail(ISST_ERR_ARG, "forced beam choice (%d, %d) out of range at step %d", tok, par, step);
+                    float lp = 0.f;
+                    if (p->do_sample) lp = h->samp_host[(size_t)(i * rows_per + par) * h->vocab_pad + tok];  // (the warped row is on the host)
+                    else HIPCHK(hipMemcpy(&lp, h->logits + (size_t)(i * rows_per + par) * h->vocab_pad + tok, sizeof(float), hipMemcpyDeviceToHost));
+                    ntok[b] = tok; npar[b] = par; nscore[b] = S.score[par] + lp;
+                }
+            }
+            // input_ids = cat(input_ids[beam_idx], tokens)  (:899)
+            std::vector<std::vector<int>> nseq(B);
+            for (int b = 0; b < B; ++b) { nseq[b] = S.seq[npar[b]]; nseq[b].push_back(ntok[b]); }
+            S.seq.swap(nseq);
+            S.score = nscore;
+            all_done = all_done && S.done;
+        }
+        CHK(flush_copies(h, ops, mh, md, st));  // hypothesis tails first: the reorder below overwrites arenas
+        ++step;
+        // ---- reorder the tails (:910-913): new beam b continues parent npar[b].  Like the reference this happens BEFORE
+        //      the stop test, so that finalize sees arena b == beam b ----
+        if (step - 1 > 0) {
+            for (int i = 0; i < n; ++i) {
+                const int P0 = total0[i] + rows_len[i];
+                std::set<int> needed;
+                for (int b = 0; b < B; ++b) if (parents[i][b] != b) needed.insert(parents[i][b]);
+                for (int src : needed) push_copy(h, ops, stream_ids[i], src, src, P0, step - 1, false);
+            }
+            CHK(flush_copies(h, ops, mh, md, st));
+            for (int i = 0; i < n; ++i) {
+                const int P0 = total0[i] + rows_len[i];
+                for (int b = 0; b < B; ++b) if (parents[i][b] != b) push_copy(h, ops, stream_ids[i], b, parents[i][b], P0, step - 1, true);
+            }
+            CHK(flush_copies(h, ops, mh, md, st));
+        }
+        if (all_done || step >= p->max_new_tokens) break;  // :920
+        // ---- next forward pass: one row per (stream, beam).  Shared-prefix form (llm_attn.hip, LlmStreamView::n_beams): the B rows of a
+        //      stream are ONE attention group over arena 0 for everything older than this chunk's generated tokens (identical in all
+        //      arenas) plus one workgroup per beam for the <= 4 tiles that differ; otherwise every beam is its own group over its arena ----
+        const int nr = n * B;
+        const bool shared = h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;  // (isst_generate's `beams_share_prefix`: the pre-pass relies on it)
+        for (int i = 0; i < n; ++i) {
+            const StreamState& ss = h->streams[stream_ids[i]];
+            for (int b = 0; b < B; ++b) {
+                const int r = i * B + b;
+                mh.row_stream[r] = shared ? i * B : r;  // view index
+                mh.row_pos[r] = total0[i] + rows_len[i] + step - 1;
+                mh.ids[r] = bs[i].seq[b].back();
+                mh.last_rows[r] = r;
+                mh.views[r].sys_len = ss.llm_sys;
+                mh.views[r].ring_start = ss.llm_ring_start;
+                mh.views[r].kv_offset = h->arena_off(stream_ids[i], b);
+                mh.views[r].new_start = mh.row_pos[r];
+                mh.views[r].row0 = shared ? i * B : r;
+                mh.views[r].rot_keys = h->rot_keys ? 1 : 0;  // every beam's arena carries its rotated keys (pre-pass over all arenas + position copies)
+                mh.views[r].n_beams = shared ? B : 0;
+                mh.views[r].tail_start = total0[i] + rows_len[i];
+                mh.views[r].beam_stride = h->llm_stream_stride;
+                if (shared) {
+                    mh.groups[i].x = i * B;
+                    mh.groups[i].y = B;
+                } else {
+                    mh.groups[r].x = r;
+                    mh.groups[r].y = 1;
+                }
+            }
+        }
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+        CHK(llm_forward(h, md, nr, nr, shared ? n : nr, shared ? B : 1, false, nullptr, st, &mh, 0, 0, shared ? B : 0));
+    }
+
+    // ---- finalize (:159-275): open beams become hypotheses, the best one wins ----
+    for (int i = 0; i < n; ++i) {
+        BeamStream& S = bs[i];
+        const int prompt_len = prompt_lens[i];
+        const int P0 = total0[i] + rows_len[i];
+        if (!S.done)
+            for (int b = 0; b < B; ++b) {
+                BeamHyp hyp;
+                hyp.tokens = S.seq[b];
+                hyp.fed = (int)S.seq[b].size() - prompt_len - 1;  // the last chosen token was never fed
+                hyp.buf = -1 - b;
+                const int freed = S.hyps.add(std::move(hyp), (double)S.score[b], (int)S.seq[b].size() - prompt_len);
+                if (freed >= B) S.free_bufs.push_back(freed);
+            }
+        if (S.hyps.beams.empty()) return h->fail(ISST_ERR_STATE, "beam search produced no hypothesis");
+        size_t best = 0;
+        for (size_t q = 1; q < S.hyps.beams.size(); ++q)
+            if (S.hyps.beams[q].score >= S.hyps.beams[best].score) best = q;  // sorted(...).pop(): the last of equal scores
+        const BeamHyp& win = S.hyps.beams[best];
+        // make every arena of the stream hold the winner's tail
+        if (win.fed > 0) {
+            int src_buf = win.buf;
+            int skip_beam = -1;
+            if (win.buf < 0) {  // still in an arena: stage it through temporary 0
+                skip_beam = -1 - win.buf;
+                push_copy(h, ops, stream_ids[i], skip_beam, 0, P0, win.fed, false);
+                CHK(flush_copies(h, ops, mh, md, st));
+                src_buf = 0;
+            }
+            for (int b = 0; b < B; ++b)
+                if (b != skip_beam) push_copy(h, ops, stream_ids[i], b, src_buf, P0, win.fed, true);
+            CHK(flush_copies(h, ops, mh, md, st));
+        }
+        StreamState& ss = h->streams[stream_ids[i]];
+        ss.llm_total = P0 + win.fed;
+        ss.chunks++;
+        const int max_length = prompt_len + p->max_new_tokens;
+        std::vector<int> outv(win.tokens.begin() + prompt_len, win.tokens.end());
+        if ((int)win.tokens.size() < std::min((int)win.tokens.size() + 1, max_length)) outv.push_back(c.n_eos ? c.eos_ids[0] : 0);
+        for (size_t q = 0; q < outv.size(); ++q) out_ids[i][q] = outv[q];
+        out_lens[i] = (int)outv.size();
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return ISST_OK;
+}
+
+}  // namespace
+
+// ISST_HOST_TRACE=1: one line per isst_generate on stderr with the host-side timeline of the call (us): gap since the previous call returned, entry -> encoder
+// and prefill enqueued, the waits for each token, the host work between a token's arrival and the next pass being enqueued
+struct HostTrace {
+    bool on = false;
+    std::chrono::steady_clock::time_point t_entry, t_prev_return;
+    bool have_prev = false;
+    double enq_first = 0, wait = 0, between = 0, enq_pass = 0;
+    int waits = 0;
+    static double us(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
+};
+static thread_local HostTrace g_ht;  // (per thread: isst_generate may run on several handles from several threads)
+extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const float* const* pcm, int n_samples,
+                             const int* const* prompt_ids, const int* prompt_lens, const int* const* prev_target_ids, const int* n_prev,
+                             const int* const* forced_tokens, const int* n_forced, int* const* out_ids, int* out_lens, float* logits_out,
+                             void* hip_stream) {
+    if (!h) return ISST_ERR_ARG;
+    static const bool ht_env = std::getenv("ISST_HOST_TRACE") && std::atoi(std::getenv("ISST_HOST_TRACE")) > 0;
+    g_ht.on = ht_env;
+    if (g_ht.on) { g_ht.t_entry = std::chrono::steady_clock::now(); g_ht.enq_first = g_ht.wait = g_ht.between = g_ht.enq_pass = 0; g_ht.waits = 0; }
+    CHK(check_ready(h));
+    const isst_config& c = h->cfg;
+    if (!p || !stream_ids || !pcm || !prompt_ids || !prompt_lens || !out_ids || !out_lens) return h->fail(ISST_ERR_ARG, "null argument");
+    if (n < 1 || n > c.max_streams) return h->fail(ISST_ERR_ARG, "n = %d streams, capacity %d", n, c.max_streams);
+    if (n_samples <= 0 || n_samples % h->chunk_samples || n_samples > h->n_new_max)
+        return h->fail(ISST_ERR_ARG, "n_samples %d must be a positive multiple of %d and <= %d", n_samples, h->chunk_samples, h->n_new_max);
+    if (p->multiplier < 1 || p->multiplier > c.max_multiplier || p->max_new_tokens < 1 || p->max_new_tokens > c.max_new_tokens)
+        return h->fail(ISST_ERR_ARG, "multiplier / max_new_tokens out of configured range");
+    if (p->n_suppress < 0 || p->n_suppress > 65536 || (p->n_suppress && !p->suppress_tokens)) return h->fail(ISST_ERR_ARG, "suppress_tokens");
+    if (p->no_repeat_ngram_size < 0 || p->encoder_no_repeat_ngram_size < 0 || p->no_repeat_ngram_size > 64 || p->encoder_no_repeat_ngram_size > 64)
+        return h->fail(ISST_ERR_ARG, "ngram sizes");
+    const int B = p->num_beams > 1 ? p->num_beams : 1;
+    if (B > h->max_beams) return h->fail(ISST_ERR_ARG, "num_beams %d exceeds the configured max_beams %d", B, h->max_beams);
+    bool any_forced = false;
+    if (forced_tokens && n_forced)
+        for (int i = 0; i < n; ++i) any_forced = any_forced || (forced_tokens[i] != nullptr && n_forced[i] > 0);
+    if (B > 1 && (any_forced || logits_out)) return h->fail(ISST_ERR_ARG, "forced_tokens / logits_out are greedy-only test aids");
+    if (p->do_sample && (p->top_k < 0 || !(p->top_p > 0.f) || p->epsilon_cutoff < 0.f || p->epsilon_cutoff >= 1.f))
+        return h->fail(ISST_ERR_ARG, "sampling arguments out of range (top_k >= 0, top_p > 0, 0 <= epsilon_cutoff < 1)");
+    if (p->do_sample && h->samp_host_rows < (size_t)n * B) {  // (beam sample: the processed scores of every beam's row come to the host)
+        if (h->samp_host) (void)hipHostFree(h->samp_host);
+        h->samp_host = nullptr;
+        h->samp_host_rows = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->samp_host), (size_t)n * B * h->vocab_pad * sizeof(float)) != hipSuccess) return h->fail(ISST_ERR_NOMEM, "pinned score buffer");
+        h->samp_host_rows = (size_t)n * B;
+    }
+    for (int i = 0; i < n; ++i) {
+        const int id = stream_ids[i];
+        if (id < 0 || id >= (int)h->streams.size() || !h->streams[id].open) return h->fail(ISST_ERR_ARG, "bad stream id %d", id);
+        for (int j = 0; j < i; ++j) if (stream_ids[j] == id) return h->fail(ISST_ERR_ARG, "stream %d listed twice", id);
+        if (prompt_lens[i] < 1 || prompt_lens[i] > c.max_prompt_len) return h->fail(ISST_ERR_ARG, "prompt length %d (max %d)", prompt_lens[i], c.max_prompt_len);
+        if (n_prev && (n_prev[i] < 0 || n_prev[i] > h->max_enc_ids)) return h->fail(ISST_ERR_ARG, "too many previous target ids");
+        const StreamState& s = h->streams[id];
+        if (s.beams != 0 && s.beams != B && s.llm_total > 0)
+            return h->fail(ISST_ERR_STATE, "stream %d was started with num_beams %d; reset it before switching to %d", id, s.beams, B);
+        const int total = s.llm_total;
+        int sys = s.llm_sys;
+        if (total == 0 && p->system_prompt_size > 0) {
+            if (p->system_prompt_size > h->sys_cap || p->system_prompt_size > prompt_lens[i]) return h->fail(ISST_ERR_ARG, "system_prompt_size %d (capacity %d, prompt %d)", p->system_prompt_size, h->sys_cap, prompt_lens[i]);
+            sys = p->system_prompt_size;
+        }
+        if (total + prompt_lens[i] + p->max_new_tokens - sys > h->ring_cap)
+            return h->fail(ISST_ERR_STATE, "stream %d: LLM cache of %d entries + this chunk exceeds the ring (%d); evict first", id, total, h->ring_cap);
+        for (int t = 0; t < prompt_lens[i]; ++t)
+            if (prompt_ids[i][t] < 0 || prompt_ids[i][t] >= c.vocab) return h->fail(ISST_ERR_ARG, "prompt token %d out of range", prompt_ids[i][t]);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+
+    // ---- 1. speech encoder (model/llm.py:69-81) ----
+    int S = 0;
+    CHK(run_encoder(h, n, stream_ids, pcm, p->pcm_on_device != 0, n_samples, p->multiplier, st, &S));
+
+    // ---- 2. prefill rows, speech splice map (model/llm.py:86-113) ----
+    StepMeta mh = carve(h, h->meta_host), md = carve(h, h->meta_dev);
+    std::vector<int> total0(n), gen_count(n, 0), row0(n), rows_len(n);  // rows_len: decoder rows (= KV entries) of the prompt after the splice
+    std::vector<char> done(n, 0);
+    int R = 0, n_groups = 0, n_units = 0, max_unit_groups = 0;
+    const int gmax = LLM_ATTN_GROUP_ROWS(c.llm_heads / c.llm_kv_heads);
+    for (int i = 0; i < n; ++i) {
+        StreamState& s = h->streams[stream_ids[i]];
+        if (s.llm_total == 0) s.llm_sys = p->system_prompt_size > 0 ? p->system_prompt_size : 0;
+        s.beams = B;
+        total0[i] = s.llm_total;
+        mh.views[i].sys_len = s.llm_sys;
+        mh.views[i].ring_start = s.llm_ring_start;
+        mh.views[i].kv_offset = h->arena_off(stream_ids[i], 0);
+        mh.views[i].new_start = total0[i];
+        mh.views[i].row0 = R;
+        mh.views[i].rot_keys = h->rot_keys ? 1 : 0;
+        mh.views[i].n_beams = 0;
+        row0[i] = R;
+        const int len = prompt_lens[i];
+        const int* ids = prompt_ids[i];
+        std::vector<int> desc;
+        if (splice_rows(ids, len, c.user_id, c.assistant_id, c.start_header_id, S, desc) != ISST_OK)
+            return h->fail(ISST_ERR_ARG, "stream %d: malformed prompt (an assistant header before the end of its user turn)", stream_ids[i]);
+        const int elen = (int)desc.size();
+        if (elen < 1) return h->fail(ISST_ERR_ARG, "stream %d: empty prompt after the speech splice", stream_ids[i]);
+        rows_len[i] = elen;
+        for (int t = 0; t < elen; ++t) {
+            mh.row_stream[R + t] = i;
+            mh.row_pos[R + t] = total0[i] + t;
+            mh.ids[R + t] = desc[t] >= 0 ? ids[desc[t]] : 0;
+            mh.speech_row[R + t] = desc[t] >= 0 ? -1 : i * S + (-1 - desc[t]);
+        }
+        mh.last_rows[i] = R + elen - 1;
+        const int g_first = n_groups;
+        for (int t = 0; t < elen; t += gmax) {  // attention row groups: consecutive rows of one stream
+            mh.groups[n_groups].x = R + t;
+            mh.groups[n_groups].y = std::min(gmax, elen - t);
+            ++n_groups;
+        }
+        for (int g0 = g_first; g0 < n_groups; g0 += 8) {  // units: runs of <= 8 groups of this stream share their key tiles
+            mh.units[n_units].x = g0;
+            mh.units[n_units].y = std::min(8, n_groups - g0);
+            max_unit_groups = std::max(max_unit_groups, mh.units[n_units].y);
+            ++n_units;
+        }
+        R += elen;
+        // sampling context (the processors see the prompt's ids, patch tokens included: input_ids is not shortened)
+        std::memcpy(mh.ids_pool + (size_t)i * h->max_ids, ids, (size_t)len * 4);
+        const int ne = n_prev ? n_prev[i] : 0;
+        if (ne) std::memcpy(mh.enc_pool + (size_t)i * h->max_enc_ids, prev_target_ids[i], (size_t)ne * 4);
+        mh.samp[i].n_ids = len; mh.samp[i].n_enc = ne;
+        mh.samp[i].ids_off = i * h->max_ids; mh.samp[i].enc_off = i * h->max_enc_ids; mh.samp[i].logits_row = i;
+    }
+    if (p->n_suppress) {
+        std::memcpy(mh.suppress, p->suppress_tokens, (size_t)p->n_suppress * 4);
+        HIPCHK(hipMemcpyAsync(h->meta_dev + mh.suppress_offset, h->meta_host + mh.suppress_offset, (size_t)p->n_suppress * 4, hipMemcpyHostToDevice, st));
+    }
+    // Beam search: in the shared-prefix form (beam_decode: the B beams of a stream are ONE attention group that reads everything older than this chunk's
+    // generated tokens from arena 0) the rotated copies of arenas 1 .. B-1 are never read below tail_start -- their tails are written by the appends and the
+    // position copies of this chunk -- so the pre-pass rotates arena 0 only: 64 streams x 4 beams 7.9 -> 2.0 ms per chunk (profiles/r04/trace_busy_prof64x4_*).
+    const bool beams_share_prefix = B > 1 && h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;  // = beam_decode's `shared`
+    const int rope_views = n * ((B > 1 && !beams_share_prefix) ? B : 1);
+    if (B > 1 && h->rot_keys && !beams_share_prefix) {  // the rotated-key pre-pass below also covers arenas 1 .. B-1 (the prefill itself only reads views 0 .. n-1)
+        int nv = n;
+        for (int i = 0; i < n; ++i)
+            for (int b = 1; b < B; ++b) {
+                mh.views[nv] = mh.views[i];
+                mh.views[nv].kv_offset = h->arena_off(stream_ids[i], b);
+                ++nv;
+            }
+    }
+    bool any_cached = false;
+    for (int i = 0; i < n; ++i) any_cached = any_cached || total0[i] > 0;
+    if (h->rot_keys && any_cached && h->rope_side && st != nullptr) {
+        // The host is far ahead of the GPU here (the encoder above is milliseconds of queued work), so the metadata upload and the pre-pass, issued on
+        // the side stream now, run BESIDE the encoder; the prefill waits for both.  (The caller's stream was idle when this call began -- every call ends
+        // with a synchronisation -- so the pre-pass cannot overtake an earlier writer of the caches.)
+        if (!h->side) {
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+            HIPCHK(hipEventCreateWithFlags(&h->side_ev, hipEventDisableTiming));
+        }
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, h->side));
+        CHK(launch_llm_rope_cache(md.views, rope_views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, h->side));
+        HIPCHK(hipEventRecord(h->side_ev, h->side));
+        HIPCHK(hipStreamWaitEvent(st, h->side_ev, 0));
+    } else {
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+        // rotate the cached keys of every layer ONCE for this chunk (positions are fixed until the next eviction)
+        // (beam search: views n .. n*B-1, written above, are the other beams' arenas of the same streams -- they hold the same cached keys)
+        if (h->rot_keys && any_cached) CHK(launch_llm_rope_cache(md.views, rope_views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
+    }
+    CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh, n_units, max_unit_groups));
+    if (B > 1)
+        return beam_decode(h, p, n, stream_ids, prompt_ids, prompt_lens, rows_len, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);
+
+    // ---- 3. greedy loop (patch_hf.py:606-624 -> HF _sample) ----
+    std::vector<int> active(n);
+    for (int i = 0; i < n; ++i) active[i] = i;
+
+    // sampling tail of a pass over `na` rows: (test aid: logits download) -> processors + argmax -> token ids to the host
+    bool tail_fused = false;  // the tail enqueued last went the fused way (wait_tokens then waits on pinned memory)
+    auto sample_tail = [&](int na) -> int {
+        if (logits_out)
+            for (int r = 0; r < na; ++r)
+                HIPCHK(hipMemcpyAsync(logits_out + ((size_t)active[r] * p->max_new_tokens + gen_count[active[r]]) * c.vocab,
+                                      h->logits + (size_t)r * h->vocab_pad, (size_t)c.vocab * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (p->do_sample) {  // processors on the device, the processed rows to the host: warpers + draw happen there (warp.hip) after the synchronisation
+            CHK(launch_sample_process(h->logits, h->vocab_pad, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
+                                      p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, na, st));
+            HIPCHK(hipMemcpyAsync(h->samp_host, h->logits, (size_t)na * h->vocab_pad * sizeof(float), hipMemcpyDeviceToHost, st));
+            return ISST_OK;
+        }
+        // (up to 16 rows.  With many streams the tail is 4096 blocks whose per-block publish fences -- an L2 write-back each -- cost more than the two launches they
+        //  save: 64 streams 84.0-84.5 ms per step fused against 83.4-83.5 with the three-launch tail, while one stream gains 0.18 ms per chunk)
+        tail_fused = h->fused_sample && na <= 16;
+        if (tail_fused) {  // one launch: processors, argmax, the tokens straight into pinned host memory, then the tail's sequence number behind them
+            CHK(launch_sample_fused(h->logits, h->vocab_pad, c.vocab, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
+                                    p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->out_tok, h->samp_val, h->samp_idx, h->samp_tickets, h->tok_host,
+                                    h->tok_host + h->tok_cap, na, st));
+            ++h->samp_seq_expected;
+            return ISST_OK;
+        }
+        // (three launches; the last one stores the tokens straight into the pinned host array -- no D2H launch behind it)
+        CHK(launch_sample(h->logits, h->vocab_pad, c.vocab, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
+                          p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->tok_host, h->samp_val, h->samp_idx, na, st));
+        return ISST_OK;
+    };
+    // the tokens of the tail that was enqueued last are on the host.  Fused tail: wait for its sequence number in pinned memory (the kernel stores it, system scope,
+    // after the tokens) -- the host sees the tokens a completion-signal round trip earlier than through hipStreamSynchronize; a stream that has drained WITHOUT
+    // publishing (a failed launch) ends the wait with an error instead of a hang.  Test aids with pending D2H copies and the sample branch synchronise as before.
+    auto wait_tokens = [&]() -> int {
+        if (!tail_fused || p->do_sample || logits_out) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (tail_fused && !p->do_sample && *reinterpret_cast<volatile int*>(h->tok_host + h->tok_cap) != h->samp_seq_expected) {
+                const int want = h->samp_seq_expected;
+                h->samp_seq_expected = *reinterpret_cast<volatile int*>(h->tok_host + h->tok_cap);  // the stream has drained: adopt the device's count, later calls start in step
+                return h->fail(ISST_ERR_HIP, "sampling tail %d did not publish its tokens", want);
+            }
+            return ISST_OK;
+        }
+        volatile int* seq = h->tok_host + h->tok_cap;
+        for (unsigned long spins = 1;; ++spins) {
+            if (*seq == h->samp_seq_expected) break;
+            if ((spins & 0x3FFFF) == 0) {  // every ~quarter million polls: has the stream drained without the number arriving?
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {
+                    if (*seq == h->samp_seq_expected) break;
+                    const int want = h->samp_seq_expected;
+                    h->samp_seq_expected = *seq;  // drained without publishing: adopt the device's count, later calls start in step
+                    return h->fail(ISST_ERR_HIP, "sampling tail %d did not publish its tokens", want);
+                }
+                if (q != hipErrorNotReady) return h->fail(ISST_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return ISST_OK;
+    };
+    // one decode step over nr rows: metadata upload -> decoder stack -> sampling tail.  Every pointer and dimension in it is
+    // the same from step to step (the per-step values live in the metadata block), so it is captured once per row count and
+    // replayed: ~230 launches become one graph launch
+    auto decode_step = [&](int nr) -> int {
+        const bool graph_ok = h->use_graphs && st != nullptr && !logits_out && !c.debug_taps && !h->prof_on && !p->do_sample;  // (the NULL stream cannot be captured)
+        if (!graph_ok) {
+            HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+            CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st, &mh));
+            return sample_tail(nr);
+        }
+        isst_handle::DecodeGraph& g = h->dgraph;
+        bool captured_now = false;
+        const int seq_before = h->samp_seq_expected;  // the host's count of fused tails moves only with a launch that was really enqueued (every error path below restores it)
+        if (!g.exec || g.rows != nr || g.n_suppress != p->n_suppress || g.ngram != p->no_repeat_ngram_size ||
+            g.enc_ngram != p->encoder_no_repeat_ngram_size || g.penalty != p->repetition_penalty) {
+            captured_now = true;  // (sample_tail below counts the fused tail once; the launch that follows is its first execution)
+            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = ISST_OK;
+            if (hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st) != hipSuccess) rc = ISST_ERR_HIP;
+            if (rc == ISST_OK) rc = llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st, nullptr);  // metadata from device memory: nothing frozen in the arguments
+            if (rc == ISST_OK) rc = sample_tail(nr);
+            const hipError_t ce = hipStreamEndCapture(st, &graph);
+            if (rc != ISST_OK || ce != hipSuccess || !graph) {
+                if (graph) (void)hipGraphDestroy(graph);
+                h->samp_seq_expected = seq_before;
+                return rc != ISST_OK ? rc : h->fail(ISST_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+            }
+            const hipError_t ie = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { g.exec = nullptr; h->samp_seq_expected = seq_before; return h->fail(ISST_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+            g.rows = nr; g.n_suppress = p->n_suppress; g.ngram = p->no_repeat_ngram_size; g.enc_ngram = p->encoder_no_repeat_ngram_size;
+            g.penalty = p->repetition_penalty;
+        }
+        tail_fused = h->fused_sample && nr <= 16 && !p->do_sample;  // (what sample_tail chose when this row count was captured)
+        const hipError_t le = hipGraphLaunch(g.exec, st);
+        if (le != hipSuccess) { h->samp_seq_expected = seq_before; return h->fail(ISST_ERR_HIP, "hipGraphLaunch: %s", hipGetErrorString(le)); }
+        if (!captured_now && tail_fused) ++h->samp_seq_expected;  // a replay ran the captured fused tail once more (counted only once it is enqueued)
+        return ISST_OK;
+    };
+
+    if (const int rc = sample_tail(n)) return rc;
+    std::chrono::steady_clock::time_point ht_a, ht_b;
+    if (g_ht.on) { ht_a = std::chrono::steady_clock::now(); g_ht.enq_first = HostTrace::us(g_ht.t_entry, ht_a); }
+    while (true) {
+        const int na = (int)active.size();
+        if (g_ht.on) ht_a = std::chrono::steady_clock::now();
+        CHK(wait_tokens());
+        if (g_ht.on) { ht_b = std::chrono::steady_clock::now(); g_ht.wait += HostTrace::us(ht_a, ht_b); g_ht.waits++; }
+        if (p->do_sample)  // HF _sample with do_sample: warpers, softmax, one draw per row (patch_hf.py:606-624)
+            for (int r = 0; r < na; ++r)
+                h->tok_host[r] = warp_and_sample(h->samp_host + (size_t)r * h->vocab_pad, c.vocab, p->temperature, p->top_k, p->top_p, p->epsilon_cutoff,
+                                                 sample_uniform(p->seed, stream_ids[active[r]], h->streams[stream_ids[active[r]]].chunks, gen_count[active[r]]));
+        std::vector<int> next_active;
+        for (int r = 0; r < na; ++r) {
+            const int i = active[r];
+            int tok = h->tok_host[r];
+            if (forced_tokens && forced_tokens[i] && n_forced && gen_count[i] < n_forced[i]) tok = forced_tokens[i][gen_count[i]];
+            if (tok < 0 || tok >= c.vocab) return h->fail(ISST_ERR_ARG, "token %d out of range", tok);
+            out_ids[i][gen_count[i]++] = tok;
+            bool stop = gen_count[i] >= p->max_new_tokens;
+            for (int e = 0; e < c.n_eos; ++e) stop = stop || tok == c.eos_ids[e];
+            if (forced_tokens && forced_tokens[i] && n_forced && gen_count[i] >= n_forced[i]) stop = true;
+            if (!stop) next_active.push_back(i);
+            else done[i] = 1;
+        }
+        active.swap(next_active);
+        if (active.empty()) break;
+
+        // next decode step: one row per active stream, the token just sampled at the next position
+        const int nr = (int)active.size();
+        for (int r = 0; r < nr; ++r) {
+            const int i = active[r];
+            const int tok = out_ids[i][gen_count[i] - 1];
+            mh.row_stream[r] = i;
+            mh.row_pos[r] = total0[i] + rows_len[i] + gen_count[i] - 1;
+            mh.views[i].new_start = mh.row_pos[r];
+            mh.views[i].row0 = r;
+            mh.groups[r].x = r;
+            mh.groups[r].y = 1;
+            mh.ids[r] = tok;
+            mh.last_rows[r] = r;
+            mh.ids_pool[(size_t)i * h->max_ids + prompt_lens[i] + gen_count[i] - 1] = tok;
+            mh.samp[r].n_ids = prompt_lens[i] + gen_count[i];
+            mh.samp[r].n_enc = n_prev ? n_prev[i] : 0;
+            mh.samp[r].ids_off = i * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
+        }
+        if (g_ht.on) { ht_a = std::chrono::steady_clock::now(); g_ht.between += HostTrace::us(ht_b, ht_a); }
+        if (const int rc = decode_step(nr)) return rc;  // (the failing call has already recorded its message)
+        if (g_ht.on) g_ht.enq_pass += HostTrace::us(ht_a, std::chrono::steady_clock::now());
+    }
+    // (every call still ENDS with the stream drained -- the side stream of the next call and the host-side eviction rely on it; with the fused tail the last
+    //  wait above returned on the published tokens, a few microseconds before the kernel's own completion)
+    if (tail_fused) HIPCHK(hipStreamSynchronize(st));
+    // ---- 4. state: the cache holds the prompt and every generated token except the last one ----
+    for (int i = 0; i < n; ++i) {
+        StreamState& s = h->streams[stream_ids[i]];
+        s.llm_total = total0[i] + rows_len[i] + gen_count[i] - 1;
+        s.chunks++;
+        out_lens[i] = gen_count[i];
+    }
+    if (g_ht.on) {
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[isst host] n=%d since_prev_return %.1f  entry->prefill_enqueued %.1f  waits %d total %.1f  token->next_enqueue_start avg %.1f  enqueue_pass avg %.1f  call %.1f us\n", n,
+                     g_ht.have_prev ? HostTrace::us(g_ht.t_prev_return, g_ht.t_entry) : -1.0, g_ht.enq_first, g_ht.waits, g_ht.wait,
+                     g_ht.waits > 1 ? g_ht.between / (g_ht.waits - 1) : 0.0, g_ht.waits > 1 ? g_ht.enq_pass / (g_ht.waits - 1) : 0.0, HostTrace::us(g_ht.t_entry, now));
+        g_ht.t_prev_return = now;
+        g_ht.have_prev = true;
+    }
+    return ISST_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// per-kernel entry points
+// --------------------------------------------------------------------------------------------

@@ -224,7 +224,7 @@ class Engine:
         self.max_new_tokens = max_new_tokens
         self.last_call_seconds = 0.0
         r64 = lambda x: (x + 63) // 64 * 64
-        # rows the library wants from isst_set_rope_tables (engine.hip isst_create: sys_cap + ring_cap, enc_cap)
+        # rows the library wants from isst_set_rope_tables (engine_core.hip isst_create: sys_cap + ring_cap, enc_cap)
         self._llm_rope_rows = r64(max_system_prompt) + r64(max_llm_cache_size + max_prompt_len + max_new_tokens + 8)
         self._enc_rope_rows = r64(cfg.max_cache_size + cfg.block_size * max_multiplier)
         self.h = C.c_void_p()

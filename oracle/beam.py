@@ -201,7 +201,7 @@ def beam_generate(w, cfg, gen, num_beams: int, input_ids: List[int], speech_batc
         return sc
 
     draw = None
-    if gen.do_sample:  # uniforms keyed like the greedy-sample branch; draw j of step s uses counter 64 s + j (csrc/warp.hip, engine.hip beam_decode)
+    if gen.do_sample:  # uniforms keyed like the greedy-sample branch; draw j of step s uses counter 64 s + j (csrc/warp.hip, engine_llm.hip beam_decode)
         def draw(flat, n, step):
             return ogen.multinomial_without_replacement(flat, n, [ogen.sample_uniform(gen.seed, sample_stream, sample_chunk, 64 * step + j) for j in range(n)])
 

@@ -381,7 +381,7 @@ def test_policy_closes_the_instance_when_the_last_step_brings_no_audio():
 
 
 def test_splice_row_map_matches_reference_fixture(golden_dir):
-    """The library's host half of the speech splice (engine.hip splice_rows, exported as isst_op_splice_map) against
+    """The library's host half of the speech splice (engine_llm.hip splice_rows, exported as isst_op_splice_map) against
     tests/golden/splice.npz = the reference's SpeechLlamaModel.forward (model/llm.py:86-113): system + user turn, later-chunk layout,
     surplus features; plus the shortfall case (fewer features than patch slots: the reference's slices shorten the sequence), checked
     against the oracle's literal torch.cat restatement."""

@@ -302,7 +302,7 @@ def test_batch_is_deterministic_and_independent_of_stream_order(n):
 
 
 def test_many_streams_decode_rows_beyond_the_library_threshold():
-    """170 streams in one call at toy width: the DECODE passes have 170 rows (> 160: the library-GEMM path of engine.hip with its SwiGLU and
+    """170 streams in one call at toy width: the DECODE passes have 170 rows (> 160: the many-row GEMM path of engine_llm.hip with its SwiGLU and
     residual + RMSNorm passes, last layer's bare residual included), the prefill 170 x prompt rows, the encoder 170 x block rows.  Streams 0, 85 and 169
     are held to the same streams stepped alone (the packed-weight kernels at 1 / few rows) within the batched-vs-single tolerance, two chunks."""
     cfg = toy_config()
