@@ -104,9 +104,6 @@ extern "C" int isst_debug_attn_trace_read(void* dst, long bytes) {
 #ifndef ATTN_KV_NT
 #define ATTN_KV_NT 0
 #endif
-#ifndef ATTN_DECODE_PD
-#define ATTN_DECODE_PD 1
-#endif
 template <int G, int CT, bool MULTI>  // G q-heads per kv head, CT column tiles (16 columns each) per workgroup
 __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
                                                                const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
@@ -116,7 +113,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
                                                                int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct, int n_extra,
                                                                bf16_t* __restrict__ out_final, int* arrive) {
     // arrive != null (one row group per launch, more than one split): the last workgroup of a kv head to arrive combines the splits itself
-    // n_splits: partial slabs per (row, head) = gridDim.x; the last n_extra of them are the per-beam workgroups of the shared-prefix form
+    // n_splits: partial slabs per (row, head) = gridDim.x; the last n_extra (> 0) of them are the per-beam workgroups of the shared-prefix form
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
     __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
     __shared__ int s_ticket;
@@ -130,41 +127,69 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
     const int H = d.heads, KV = d.kv_heads;
     const long ldq = (long)(H + 2 * KV) * HD;
     const int slots = d.sys_cap + d.ring_cap;
-    const bool shared = n_extra > 0 && v.n_beams > 1;
-    const bool tailwg = shared && sp >= n_splits - n_extra;  // this workgroup: the per-beam keys of beam `beam`
-    const int beam = tailwg ? sp - (n_splits - n_extra) : 0;
-    const long base = v.kv_offset + (long)beam * v.beam_stride + (long)layer * d.layer_stride + (long)kvh * slots * HD;
-    bf16_t* kb = kpool + base;    // [slots][128]
-    bf16_t* kr = krpool + base;   // [slots][128] the same keys rotated at their logical position of this chunk (LlmStreamView::rot_keys)
+    // shared-prefix beams, two forms: n_extra > 0 -- the last n_extra workgroups of the x dimension each take ONE beam's own keys (few streams: more
+    // workgroups in flight); n_extra < 0 ("folded", one prefix workgroup per (stream, kv head)) -- wave w walks its share of the prefix tiles and then
+    // the own tiles of beams w, w + 4, ..: the running softmax carries on (a beam's own keys only count for that beam's columns), the four waves meet
+    // in LDS as always and the workgroup writes the attention output itself: no per-beam workgroups, no slabs, no combine launch.  (Measured at
+    // 64 streams x 4 beams: the 2 048 short per-beam workgroups interleaved with the 512 long ones in dispatch order kept the long ones from
+    // starting together -- 98.6 us per launch against 52 for the same keys without beams, profiles/r04/trace_busy_prof64x4.txt.)
+    const bool shared = n_extra != 0 && v.n_beams > 1;
+    const bool fold = shared && n_extra < 0;
+    const bool tailwg = shared && !fold && sp >= n_splits - n_extra;  // this workgroup: the per-beam keys of beam `wg_beam`
+    const int wg_beam = tailwg ? sp - (n_splits - n_extra) : 0;
+    const long base = v.kv_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;  // beam 0's arena; beam b's: + b * v.beam_stride
+    bf16_t* const kb = kpool + base;    // [slots][128]
+    bf16_t* const kr = krpool + base;   // [slots][128] the same keys rotated at their logical position of this chunk (LlmStreamView::rot_keys)
     const bool rot = v.rot_keys != 0;
-    bf16_t* vb = vtpool + base;   // [slots][128] row per key, like K
+    bf16_t* const vb = vtpool + base;   // [slots][128] row per key, like K
     const int total = (one.enabled ? one.pos0 + nrows - 1 : row_pos[r0 + nrows - 1]) + 1;  // keys visible to the last row of the group
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
     // Tiles are walked in a COMPACT index space that holds only the tiles with a live slot: [pinned prefix tiles | ring tiles from the one that
     // holds ring_start on, as many as the live span touches].  The arena is sized for max_llm_cache_size + a chunk + slack, the steady-state
     // cache fills ~85 % of it, and a dead tile costs the same 8 KB of loads as a live one (64 streams: 318 MB per launch instead of 272).
-    // this wave's tiles: compact indices tile_begin + wave, + 4, ... below tile_end
+    // this wave's prefix tiles: compact indices tile_begin + wave, + 4, ... below tile_end
     const int sys_tiles = (v.sys_len + 15) >> 4, ring_tiles = d.ring_cap >> 4, ring_tile0 = v.ring_start >> 4;
     const int ring_len = total - v.sys_len;
     const int ring_live = ring_len > 0 ? min(ring_tiles, ((v.ring_start & 15) + ring_len + 15) >> 4) : 0;
     const int live_tiles = sys_tiles + ring_live;
-    int tile_begin = sp * tiles_per_split, tile_end = min(tile_begin + tiles_per_split, live_tiles);
-    if (tailwg) {  // the (<= 4, host-checked) ring tiles that hold logical positions tail_start .. total-1: wave w takes the w-th
-        const int ring_tiles = d.ring_cap >> 4, ring_tile0 = d.sys_cap >> 4;
+    const int tile_begin = sp * tiles_per_split, tile_end = tailwg ? tile_begin : min(tile_begin + tiles_per_split, live_tiles);
+    const int n_pref = tile_end > tile_begin + wave ? (tile_end - tile_begin - wave + 3) >> 2 : 0;  // (compact spans need not be multiples of 4)
+    // the (<= 4 in the per-beam-workgroup form, host-checked) ring tiles that hold logical positions tail_start .. total-1 of a beam's own arena
+    int tail_first = 0, n_tail = 0;
+    if (shared) {
         const int s_first = (v.ring_start + (v.tail_start - v.sys_len)) % d.ring_cap, s_last = (v.ring_start + (total - 1 - v.sys_len)) % d.ring_cap;
-        const int t_first = s_first >> 4, t_last_r = s_last >> 4;
-        const int n_tail = (t_last_r - t_first + ring_tiles) % ring_tiles + 1;
-        const int mine = ring_tile0 + (t_first + wave) % ring_tiles;
-        tile_begin = mine - wave;  // t = tile_begin + wave below
-        tile_end = wave < n_tail ? mine + 1 : mine;
+        tail_first = s_first >> 4;
+        n_tail = ((s_last >> 4) - tail_first + ring_tiles) % ring_tiles + 1;
     }
-    // compact index -> physical 16-slot tile (the per-beam tail workgroups address physical tiles directly)
-    auto phys = [&](int tc) -> int {
-        if (tailwg) return tc;
+    // own-key tiles of this wave: per-beam workgroup -- the wave-th tile of its beam; folded -- all of them for beams wave, wave + 4, ..
+    const int n_own = tailwg ? (wave < n_tail ? 1 : 0) : fold ? n_tail * ((v.n_beams - wave + 3) >> 2) : 0;
+    const int n_it = n_pref + n_own;
+    // the wave's i-th tile: (physical tile, beam whose arena holds it, own-key tile?), advanced incrementally
+    struct TileIt { int tp, beam, idx; bool own; };
+    auto phys_prefix = [&](int tc) -> int {  // compact index -> physical 16-slot tile
         if (tc < sys_tiles) return tc;
         int r = ring_tile0 + (tc - sys_tiles);
         if (r >= ring_tiles) r -= ring_tiles;
         return (d.sys_cap >> 4) + r;
+    };
+    auto phys_own = [&](int idx) -> int {
+        int r = tail_first + idx;
+        if (r >= ring_tiles) r -= ring_tiles;
+        return (d.sys_cap >> 4) + r;
+    };
+    auto first_own = [&]() -> TileIt {
+        const int idx = tailwg ? wave : 0;
+        return TileIt{phys_own(idx), tailwg ? wg_beam : wave, idx, true};
+    };
+    auto tile_at0 = [&]() -> TileIt { return n_pref > 0 ? TileIt{phys_prefix(tile_begin + wave), 0, tile_begin + wave, false} : first_own(); };
+    auto tile_next = [&](const TileIt& c, int i_next) -> TileIt {  // the tile after c, which is the wave's i_next-th (i_next < n_it)
+        if (!c.own) {
+            if (i_next < n_pref) return TileIt{phys_prefix(c.idx + 4), 0, c.idx + 4, false};
+            return first_own();
+        }
+        int idx = c.idx + 1, beam = c.beam;
+        if (idx >= n_tail) { idx = 0; beam += 4; }
+        return TileIt{phys_own(idx), beam, idx, true};
     };
 
     // ---- rotated query fragments: B[k = dim][n = column c], c = ct*16 + fr -> (row r0 + c / G, head kvh*G + c % G) ----
@@ -198,13 +223,13 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         for (int nt = 0; nt < 8; ++nt) o[ct][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 
-    // this lane's key of tile t as an A-operand row (slot 16 t + fr): source row (arena, or the qkv rows for keys written by
-    // this launch) and logical position
-    auto key_src = [&](int tp, int& jk, bool& k_new) -> const bf16_t* {  // tp: physical tile
-        const int t = tp;
-        jk = llm_logical(v, d, t * 16 + fr, total);
+    // this lane's key of tile `it` as an A-operand row (slot 16 tp + fr of the arena of it.beam): source row (arena, or the qkv rows for keys
+    // written by this launch) and logical position
+    auto key_src = [&](const TileIt& it, int& jk, bool& k_new) -> const bf16_t* {
+        jk = llm_logical(v, d, it.tp * 16 + fr, total);
         k_new = jk >= 0 && jk >= v.new_start;
-        return k_new ? qkv + (long)(v.row0 + beam + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(t * 16 + fr) * HD;
+        return k_new ? qkv + (long)(v.row0 + it.beam + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD
+                     : (rot ? kr : kb) + (long)it.beam * v.beam_stride + (long)(it.tp * 16 + fr) * HD;
     };
     // V tile staging: the lane's value row (16 B x 4, same lane -> (key, dims) map as K) goes to a wave-private LDS image
     // [16 keys][128 dims] (256-byte rows, 16-byte chunks XOR-swizzled so that row writes and transposed reads both spread over the
@@ -220,55 +245,39 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) vr_off[nt] = v_off(4 * fq + tq, 2 * nt + (tp >> 1)) + 8 * (tp & 1);
 
-    int t = tile_begin + wave;
-    // MULTI: PD tiles ahead of the one being worked on are in flight
-    constexpr int PD = MULTI ? ATTN_DECODE_PD : 1;
-    int jk_n[PD];
-    bool knew_n[PD];
-    u32x4_t kraw_n[PD][4];
-    // the lane's value row of tile tt: from the arena, or from the qkv row for a key written by this launch
-    auto val_src = [&](int tt, int jk, bool k_new) -> const bf16_t* {
-        return k_new ? qkv + (long)(v.row0 + beam + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD : vb + (long)(tt * 16 + fr) * HD;
+    // the lane's value row of tile `it`: from the arena, or from the qkv row for a key written by this launch
+    auto val_src = [&](const TileIt& it, int jk, bool k_new) -> const bf16_t* {
+        return k_new ? qkv + (long)(v.row0 + it.beam + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD
+                     : vb + (long)it.beam * v.beam_stride + (long)(it.tp * 16 + fr) * HD;
     };
-    // MULTI: the next tile's key and value rows go in flight before this tile's arithmetic.  The prefetch is unconditional, clamped
-    // to the wave's last tile (slots % 64 == 0 gives every wave the same tile count): a conditional load makes hipcc branch around it
-    // and drain vmcnt(0).
-    const int n_mine = tile_end > tile_begin + wave ? (tile_end - tile_begin - wave + 3) >> 2 : 0;  // (compact spans need not be multiples of 4)
-    const int t_last = tailwg ? t : tile_begin + wave + 4 * (n_mine - 1);
-    u32x4_t vraw_n[PD][4];
+    // MULTI: the next tile's key and value rows go in flight before this tile's arithmetic (one tile ahead; two measured no faster, see above).
+    // The prefetch is unconditional, clamped to the wave's last tile: a conditional load makes hipcc branch around it and drain vmcnt(0).
+    int jk_n = -1;
+    bool knew_n = false;
+    u32x4_t kraw_n[4], vraw_n[4];
+    TileIt cur = tile_at0(), nxt = cur;
+    auto fetch = [&](const TileIt& it) {
+        const bf16_t* src = key_src(it, jk_n, knew_n);
 #pragma unroll
-    for (int st = 0; st < PD; ++st) {
-        jk_n[st] = -1;
-        knew_n[st] = false;
-    }
-    if (t < tile_end) {
+        for (int s = 0; s < 4; ++s) kraw_n[s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+        const bf16_t* vs = val_src(it, jk_n, knew_n);
 #pragma unroll
-        for (int st = 0; st < PD; ++st) {
-            const int tn = phys(MULTI ? min(t + 4 * st, t_last) : t);
-            const bf16_t* src = key_src(tn, jk_n[st], knew_n[st]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) kraw_n[st][s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-            const bf16_t* vs = val_src(tn, jk_n[st], knew_n[st]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) vraw_n[st][s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
-        }
-    }
-    auto tile_body = [&](auto stage) {
-        constexpr int ST = decltype(stage)::value;
-        const int t0 = phys(t) * 16;
-        const int jk = jk_n[ST];
-        const bool k_new = knew_n[ST];
+        for (int s = 0; s < 4; ++s) vraw_n[s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
+    };
+    if (n_it > 0) fetch(cur);
+    auto tile_body = [&](int i) {  // the wave's i-th tile (= cur, already in the prefetch registers)
+        const int t0 = cur.tp * 16;
+        const int beam = cur.beam;
+        const bool own = cur.own;
+        const long boff = (long)beam * v.beam_stride;
+        const int jk = jk_n;
+        const bool k_new = knew_n;
         u32x4_t kraw[4], vraw[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { kraw[s] = kraw_n[ST][s]; vraw[s] = vraw_n[ST][s]; }
+        for (int s = 0; s < 4; ++s) { kraw[s] = kraw_n[s]; vraw[s] = vraw_n[s]; }
         if constexpr (MULTI) {
-            const int tn = phys(min(t + 4 * PD, t_last));
-            const bf16_t* src = key_src(tn, jk_n[ST], knew_n[ST]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) kraw_n[ST][s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-            const bf16_t* vs = val_src(tn, jk_n[ST], knew_n[ST]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) vraw_n[ST][s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
+            nxt = i + 1 < n_it ? tile_next(cur, i + 1) : cur;
+            fetch(nxt);
         }
         const bool tile_live = __any(jk >= 0);
         if (!tile_live) return;
@@ -279,13 +288,13 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         for (int r = 0; r < 4; ++r) jc[r] = llm_logical(v, d, t0 + 4 * fq + r, total);
 
         // ---- append this group's own new keys (unrotated K row, V row) ----
-        if (k_new && (!shared || tailwg)) {  // (shared-prefix beams: beam b's own workgroup appends beam b's key to arena b)
+        if (k_new && (!shared || own)) {  // (shared-prefix beams: whoever walks beam b's own tiles appends beam b's key to arena b)
             const int krow = v.row0 + beam + (jk - v.new_start);
             if (krow >= r0 && krow < r0 + nrows) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    *reinterpret_cast<u32x4_t*>(kb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kraw[s];
-                    *reinterpret_cast<u32x4_t*>(vb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = vraw[s];
+                    *reinterpret_cast<u32x4_t*>(kb + boff + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kraw[s];
+                    *reinterpret_cast<u32x4_t*>(vb + boff + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = vraw[s];
                 }
             }
         }
@@ -300,11 +309,11 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 #pragma unroll
             for (int s = 0; s < 4; ++s) kf[s] = kraw[s];
         }
-        if (rot && k_new && (!shared || tailwg)) {
+        if (rot && k_new && (!shared || own)) {
             const int krow = v.row0 + beam + (jk - v.new_start);
             if (krow >= r0 && krow < r0 + nrows) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kr + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
+                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kr + boff + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
             }
         }
         u32x2_t vf[8];
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 bool ok = jc[r] >= 0 && jc[r] <= cpos[ct];
-                if (shared) ok = ok && (tailwg ? (jc[r] >= v.tail_start && (ct * 16 + fr) / G == beam) : jc[r] < v.tail_start);
+                if (shared) ok = ok && (own ? (jc[r] >= v.tail_start && (ct * 16 + fr) / G == beam) : jc[r] < v.tail_start);
                 sc[r] = ok ? st[r] * scale : -INFINITY;
                 mx = fmaxf(mx, sc[r]);
             }
@@ -369,17 +378,12 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         }
     };
     if constexpr (MULTI) {
-        while (t < tile_end) {
-            tile_body(std::integral_constant<int, 0>{});
-            t += 4;
-            if constexpr (PD > 1) {
-                if (t >= tile_end) break;
-                tile_body(std::integral_constant<int, PD - 1>{});
-                t += 4;
-            }
+        for (int i = 0; i < n_it; ++i) {
+            tile_body(i);
+            cur = nxt;
         }
     } else {
-        if (t < tile_end) tile_body(std::integral_constant<int, 0>{});
+        if (n_it > 0) tile_body(0);
     }
 #ifdef ISST_ATTN_TRACE
     asm volatile("s_nop 0" :: "v"(o[0][0][0]), "v"(o[0][7][3]));
@@ -774,7 +778,13 @@ int launch_llm_rope_cache(const LlmStreamView* sv, int n_streams, const bf16_t* 
 }
 
 static int g_attn_target_wgs = 0, g_attn_prefill_target_wgs = 0;  // profiling aid (isst_op_set_attn_tuning): 0 = the defaults; bits 16.. = prefill
-void llm_attn_set_tuning(int target_wgs) { g_attn_target_wgs = target_wgs & 0xffff; g_attn_prefill_target_wgs = target_wgs >> 16; }
+static bool g_attn_no_fold = false;  // A/B aid: target_wgs < 0 keeps the per-beam workgroups of the shared-prefix form at any stream count
+void llm_attn_set_tuning(int target_wgs) {
+    g_attn_no_fold = target_wgs < 0;
+    if (target_wgs < 0) target_wgs = -target_wgs - 1;
+    g_attn_target_wgs = target_wgs & 0xffff;
+    g_attn_prefill_target_wgs = target_wgs >> 16;
+}
 
 template <int G>
 static int launch_g(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
@@ -841,12 +851,20 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
         // (many streams: the per-workgroup prologue, LDS merge and slab traffic are amortised over more keys)
         n_splits = (target + d.kv_heads * n_groups - 1) / (d.kv_heads * n_groups);
         n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
+        // shared-prefix beam groups from 16 streams on: one span per (stream, kv head), which takes the beams' own keys along (below).  Measured, ms per
+        // step at 4 beams, slot splits + per-beam workgroups against one folded span: 8 streams 54.3 / 56.2, 16: 68.8 / 67.1, 32: 90.7 / 83.1,
+        // 48: 116.6 / 102.5, 64: 131.6 / 116.1, 128: 221.8 / 198.8 (profiles/r04/beam_attention_fold_{ab,sweep}.txt)
+        if (n_beam_wgs > 0 && n_groups >= 16 && g_attn_target_wgs == 0 && !g_attn_no_fold) n_splits = 1;
         if (n_splits + n_beam_wgs > ATTN_MERGE_MAX_SPLITS) n_splits = ATTN_MERGE_MAX_SPLITS - n_beam_wgs;
         const int tiles_per_split = ((total_tiles + n_splits - 1) / n_splits + 3) / 4 * 4;
         n_splits = (total_tiles + tiles_per_split - 1) / tiles_per_split;
         // shared-prefix beam groups (LlmStreamView::n_beams): one more workgroup (and partial slab) per beam (each of its waves takes one tile,
         // in either form of the kernel)
-        n_splits += n_beam_wgs;
+        // ... unless one workgroup per (stream, kv head) already walks the whole prefix: its waves then take the beams' own tiles too ("folded", see the
+        // kernel) and the workgroup writes the attention output itself
+        const bool fold = n_beam_wgs > 0 && n_splits == 1 && tiles_per_split > 4 && !g_attn_no_fold;
+        const int n_extra = fold ? -n_beam_wgs : n_beam_wgs;
+        if (!fold) n_splits += n_beam_wgs;
         // one row group (one stream's decode step) whose workgroups all fit the chip at one per CU: the last workgroup of a kv head to arrive
         // combines the splits inside this launch -- no combine launch, no boundary (the hand-off form this is measured for: one workgroup per CU)
         int hip_cus = 256;
@@ -854,9 +872,9 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
         bf16_t* od = n_splits == 1 ? out : nullptr;
         int* arr = inline_combine ? arrive_counters : nullptr;
         switch (G) {
-            case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_beam_wgs, out, arr); break;
-            case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_beam_wgs, out, arr); break;
-            case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_beam_wgs, out, arr); break;
+            case 1: rc = launch_g<1>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_extra, out, arr); break;
+            case 2: rc = launch_g<2>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_extra, out, arr); break;
+            case 4: rc = launch_g<4>(qkv, row_stream, row_pos, sv, groups, n_groups, max_group_rows, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, s, one1, od, n_extra, out, arr); break;
             default: return ISST_ERR_ARG;
         }
     }

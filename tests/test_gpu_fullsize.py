@@ -7,7 +7,7 @@ import torch
 
 from infinisst_amd import synth
 from infinisst_amd.config import GenConfig, full_config
-from infinisst_amd.engine import Engine
+from infinisst_amd.engine import Engine, load_library
 from oracle import generate as ogen
 from oracle import llm as ollm
 from oracle import speech_encoder as oenc
@@ -651,14 +651,17 @@ def test_full_size_beam4_teacher_forced_candidates_match_oracle(beam4_ref):
     eng.close()
 
 
-@pytest.mark.parametrize("n_streams", [20, 40])
-def test_full_size_many_streams_beam4_match_oracle(beam4_ref, n_streams):
+@pytest.mark.parametrize("n_streams,folded", [(20, True), (20, False), (40, False)])
+def test_full_size_many_streams_beam4_match_oracle(beam4_ref, n_streams, folded):
     """The reference's production decoding (agents/infinisst.py:86 asserts beam > 1; scripts/infer/infinisst.sh:48) on MANY streams in one call at FULL
     size: n streams x 4 beams = 80 / 160 decode rows per pass -- the row counts that run on gemm_wide.hip (128- and 256-row workgroups; round 4), with
     a 440 / 880-row prefill.  Every stream is handed the SAME steady state (1020 cached entries, wrapping rings) and the same audio.  Stream 0 is
     teacher-forced along the ORACLE's (token, parent) choices and its candidates are held to the oracle step by step (as in the one-stream test);
     the other streams search freely: identical inputs through row-independent kernels must give them identical results, equal to the oracle's
-    sequence unless its final hypotheses tie; cache lengths equal the reference's."""
+    sequence unless its final hypotheses tie; cache lengths equal the reference's.
+    `folded`: the decode attention in the form 64+ streams x beams select by themselves (llm_attn.hip: one workgroup per (stream, kv head) walks the
+    shared prefix AND the beams' own keys and writes the output itself), forced here at 20 streams through the span-size knob; otherwise the form
+    with one more workgroup per beam and a combine launch."""
     r = beam4_ref
     B, cfg, sys_n, gen, prompt, ref = r["B"], r["cfg"], r["sys_n"], r["gen"], r["prompt"], r["ref"]
     eng = Engine(cfg, max_streams=n_streams, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=B)
@@ -668,9 +671,14 @@ def test_full_size_many_streams_beam4_match_oracle(beam4_ref, n_streams):
     for sid in sids:
         _import_state(eng, sid, cfg, sys_n, r["kv0"], r["enc0"], r["src0"], llm_ring_start=ring_cap - 300, enc_ring_start=560)
     eng.beam_trace_begin(B, [st.next_tokens for st in ref.steps], [st.next_parents for st in ref.steps])
-    outs, _ = eng.generate(gen, sids, [r["seg"]] * n_streams, [prompt] * n_streams, [r["prev"]] * n_streams, system_prompt_size=0)
+    lib = load_library()
+    lib.isst_op_set_attn_tuning(1 if folded else 0)  # 1 workgroup wanted chip-wide: every (stream, kv head) is one span
+    try:
+        outs, _ = eng.generate(gen, sids, [r["seg"]] * n_streams, [prompt] * n_streams, [r["prev"]] * n_streams, system_prompt_size=0)
+    finally:
+        lib.isst_op_set_attn_tuning(0)
     trace = eng.beam_trace_end()
-    decisive, checked = _check_beam_trace(ref, trace, B, f"full-size {n_streams} streams x beam 4, stream 0 teacher-forced")
+    decisive, checked = _check_beam_trace(ref, trace, B, f"full-size {n_streams} streams x beam 4{' (folded attention)' if folded else ''}, stream 0 teacher-forced")
     assert decisive >= 150
     want = ref.sequences[len(prompt):]
     finals = sorted(ref.steps[-1].next_scores, reverse=True)
