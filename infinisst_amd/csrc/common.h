@@ -118,6 +118,7 @@ __device__ __forceinline__ void attn_merge_issue(const float* __restrict__ src, 
 }
 template <int MAXS>
 __device__ __forceinline__ uint32_t attn_merge_finish(const AttnMergeLoads<MAXS>& ld, int n_splits, int lane) {
+#pragma clang fp contract(off)  // (one arithmetic in every kernel this is inlined into: no compiler-chosen fma)
     const bool mine = lane < n_splits;
     const float m = mine ? __uint_as_float(ld.st.x) : -INFINITY;
     const float M = wave_max(m);

@@ -127,6 +127,13 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_QKV_SLICES")) h->qkv_slices = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_FUSE_ATTN_OPROJ")) { h->fuse_attn_oproj = e[0] && e[0] != '0'; h->fuse_ao_mode = e[0] == '2' ? 1 : 0; }
+    if (const char* e = getenv("ISST_FUSE_AO_DELAY")) h->fuse_ao_delay = atoi(e) >= 0 && atoi(e) <= 64 ? atoi(e) : 0;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) h->n_cus = prop.multiProcessorCount;
+    }
     if (const char* e = getenv("ISST_WIDE")) gemm_wide_set(atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 1, 0);  // A/B runs: 0 = the 65..256-row passes on gemm_mid / gemm_tiled as before round 4 (process-wide)
     const isst_config& c = h->cfg;
     auto die = [&](int code) { g_create_error = h->err; isst_destroy(h); return code; };
@@ -241,6 +248,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->lssq = h->dalloc<float>((size_t)64 * (DL / 32), true);
     h->ltickets_n = std::max(DL, (H + 2 * KV) * 128) / 32 + 16;  // a ticketed launch indexes tickets[blockIdx.x]; its narrowest workgroup spans 32 columns (gemm_mid NP = 1)
     h->ltickets = h->dalloc<int>((size_t)h->ltickets_n, true);
+    h->fuse_bar = h->dalloc<unsigned>(40 * 32, true);
     h->attn_cnt = h->dalloc<int>(64, true);  // arrival counters of the in-kernel split-KV combine (llm_attn.hip), one per kv head; zero between launches
     h->lslab_elems = (long)LLM_SLAB_ROWS * std::max(DL, (H + 2 * KV) * 128);
     h->lslab = h->dalloc<float>((size_t)h->lslab_elems);

@@ -111,6 +111,14 @@ struct isst_handle {
                                   // round trips through memory cost what the kernel boundary costs
     bool fuse_combine = false;    // ISST_FUSE_COMBINE=1: the o_proj GEMV merges the partials while it stages its A row (gemm.hip AMODE 3): every one of
                                   // its 256 workgroups re-reads all 316 KB of slabs through L2 -- 33.7 ms per chunk against 32.3
+    bool fuse_attn_oproj = true;  // one stream's decode step: attention + combine + o_proj + residual as ONE launch (llm_attn.hip llm_attn_oproj_kernel; needs the
+                                  // device to itself: N / 16 workgroups resident at once).  ISST_FUSE_ATTN_OPROJ=0: the three launches.  Bit-identical either way.
+    int fuse_ao_mode = 0;         // ISST_FUSE_ATTN_OPROJ=2 -> 1: the fused launch stops after the combine, o_proj is its own launch (bisecting aid)
+    bool fuse_ao_used = false;    // a fused launch was enqueued since the error word (tok_host[tok_cap + 8]) was last checked
+    unsigned* fuse_bar = nullptr; // its hand-off counters (40 x 128 B, only ever grow)
+    unsigned fuse_phase = 0;      // fused launches enqueued so far (the launch's `phase` argument)
+    int fuse_ao_delay = 4;        // ISST_FUSE_AO_DELAY (swept 0..16: 0-4 equal within noise, 30.93-31.06 ms per chunk; 12: 31.5; 16: 32.0): x ~0.4 us the waves without attention work hold their weight loads back
+    int n_cus = 0;                // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     bool fuse_reduce = true;      // 13..64 rows -- no rmsnorm_reduce launches: the last K-slice workgroup of o_proj / down_proj sums the slabs and writes x
                                   // (+ sums of squares per row and 32 columns), the next projection normalises its rows while it stages them (gemm_mid.hip).
                                   // A/B on one box, ms per step: 16 streams 52.42 -> 51.28, 32: 66.92 -> 66.04, 64: 92.67 -> 92.49, one stream (22-row

@@ -213,9 +213,19 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
                 CHK(gemm(h, h->lxn, DL, L.qkv, EPI_NONE, nullptr, 0, h->lqkv, (H + 2 * KV) * 128, rows, st));
             }
         }
+        // one stream's decode step: attention, combine and o_proj (+ residual) are ONE launch (llm_attn.hip llm_attn_oproj_kernel)
+        const bool fused_ao = h->fuse_attn_oproj && !h->fuse_combine && !h->inline_combine && so == 1 && n_units == 0 && n_beam_wgs == 0 && !tap_prefix &&
+                              L.o.n_valid == L.o.N && llm_attn_oproj_supported(h->adims, rows, n_groups, &one, L.o.N, L.o.K, h->n_cus) > 0;
         // one or two decode rows: no combine launch -- o_proj merges the split-KV partials while it stages its A row (gemm.hip AMODE 3)
         int merge_splits = 0;
         const bool merge_in_oproj = h->fuse_combine && !h->inline_combine && so == 1 && rows <= ATTN_MERGE_MAX_ROWS && n_units == 0 && n_beam_wgs == 0;
+        if (fused_ao) {
+            h->fuse_ao_used = true;
+            CHK(launch_llm_attn_oproj(h->lqkv, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->llm_v, h->lpartial, h->adims, l, one, L.o.wp, L.o.N, L.o.K,
+                                      L.o.n_valid, h->lx + (long)one.grp.x * DL, h->lx + (long)one.grp.x * DL, h->lattn + (long)one.grp.x * H * 128, h->fuse_bar,
+                                      h->tok_host + h->tok_cap + 8, h->n_cus, st, h->fuse_phase + 1, h->fuse_ao_mode, h->fuse_ao_delay));
+            ++h->fuse_phase;  // (counted once the launch is enqueued: the device-side counters advance with executed launches only)
+        } else
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
                                  max_unit_groups, n_beam_wgs, merge_in_oproj ? &merge_splits : nullptr, h->inline_combine ? h->attn_cnt : nullptr));
@@ -231,7 +241,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
             if (pe) HIPCHK(hipEventRecord(pe, st));
         } else {
-            if (merge_splits > 0) {
+            if (fused_ao && h->fuse_ao_mode == 0) {
+            } else if (merge_splits > 0) {
                 GemmArgs g{};
                 g.A = h->lattn; g.lda = H * 128; g.Wp = L.o.wp; g.res = h->lx; g.ldres = DL; g.out = h->lx; g.ldo = DL;
                 g.M = rows; g.N = L.o.N; g.K = L.o.K; g.batch = 1; g.epi = EPI_RES; g.n_valid = L.o.n_valid;
@@ -969,6 +980,15 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         const int na = (int)active.size();
         if (g_ht.on) ht_a = std::chrono::steady_clock::now();
         CHK(wait_tokens());
+        if (h->fuse_ao_used) {  // the fused attention + o_proj launches of this pass: a wait inside one of them that ran out raised the (pinned) error word
+            h->fuse_ao_used = false;
+            volatile int* ferr = h->tok_host + h->tok_cap + 8;
+            if (*ferr != 0) {
+                *ferr = 0;
+                h->fuse_attn_oproj = false;  // (its counters are out of step now; the three launches from here on)
+                return h->fail(ISST_ERR_HIP, "the fused attention + o_proj launch timed out waiting for its own workgroups (is another process using this GPU?); set ISST_FUSE_ATTN_OPROJ=0");
+            }
+        }
         if (g_ht.on) { ht_b = std::chrono::steady_clock::now(); g_ht.wait += HostTrace::us(ht_a, ht_b); g_ht.waits++; }
         if (p->do_sample)  // HF _sample with do_sample: warpers, softmax, one draw per row (patch_hf.py:606-624)
             for (int r = 0; r < na; ++r)

@@ -84,12 +84,14 @@ __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int
 // tiles done / slab stored (profiles/attn_trace_probe.py)
 #ifdef ISST_ATTN_TRACE
 __device__ unsigned long long g_attn_trace[8192 * 8];
+#define ATTN_STAMP_W4(i) do { if (threadIdx.x == 256) { const int wg_ = blockIdx.x; if (wg_ < 8192) g_attn_trace[wg_ * 8 + (i)] = wall_clock64(); } } while (0)
 #define ATTN_STAMP(i) do { if (threadIdx.x == 0) { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (wg_ < 8192) g_attn_trace[wg_ * 8 + (i)] = wall_clock64(); } } while (0)
 extern "C" int isst_debug_attn_trace_read(void* dst, long bytes) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #else
 #define ATTN_STAMP(i) do {} while (0)
+#define ATTN_STAMP_W4(i) do {} while (0)
 #endif
 // exp of the prefill kernel's online softmax: the hardware exp2 on x * log2(e) (two instructions; libm's expf is ~10 with its range handling, and the
 // loop is VALU-issue-bound).  Arguments are <= 0 and results feed a bf16 rounding; PF_EXP_LIBM=1 restores expf for A/B runs.
@@ -104,22 +106,42 @@ extern "C" int isst_debug_attn_trace_read(void* dst, long bytes) {
 #ifndef ATTN_KV_NT
 #define ATTN_KV_NT 0
 #endif
-template <int G, int CT, bool MULTI>  // G q-heads per kv head, CT column tiles (16 columns each) per workgroup
-__global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
-                                                               const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
-                                                               const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
-                                                               const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
-                                                               float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
-                                                               int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct, int n_extra,
-                                                               bf16_t* __restrict__ out_final, int* arrive) {
+// four waves of a workgroup meet at an LDS counter (zero before the first arrival): each wave's LDS writes are complete before its add, LDS
+// executes in order, so a wave that reads 4 finds all of them.  No global-memory wait (a workgroup barrier through __syncthreads has one).
+__device__ __forceinline__ void lds_sync4(int* cnt, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+// The body of the decode / small-group attention as a device function: llm_attn_partial_kernel is a thin wrapper, and llm_attn_oproj_kernel (one
+// stream's decode step fused with the combine and o_proj, below) runs it on the first four waves of its first workgroups.
+//   sp, kvh, zgrp: the (slot split, kv head, row group) this workgroup works on (the wrapper passes blockIdx)
+//   slab_sc1: store the partial slabs write-through (another workgroup of the SAME launch will read them)
+//   sync4: null -- the four waves meet at the workgroup barrier; else an LDS counter (zeroed by the caller) that they meet at instead, so that
+//   further waves of the workgroup (the fused launch's weight-only waves) stay out of it
+//   after_fetch(): called once, right after the wave's first key / value loads have been issued (the fused launch puts its o_proj weight loads
+//   behind them: vmcnt counts in order, so waiting for the keys leaves the weights in flight)
+template <int G, int CT, bool MULTI, class Hook>  // G q-heads per kv head, CT column tiles (16 columns each) per workgroup
+__device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
+                                                      const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
+                                                      const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
+                                                      const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
+                                                      float* __restrict__ partial, const LlmAttnDims& d, int layer, int n_splits,
+                                                      int tiles_per_split, const LlmAttnOne& one, bf16_t* __restrict__ out_direct, int n_extra,
+                                                      bf16_t* __restrict__ out_final, int* arrive, int sp, int kvh, int zgrp, bool slab_sc1,
+                                                      Hook&& after_fetch, int* sync4 = nullptr) {
+    // every mul and add below is rounded on its own, as written: the body is compiled into two kernels whose surrounding code differs, and with
+    // contraction left to the compiler the two copies fused different mul/add pairs (a 1-ulp logit now and then between the two paths)
+#pragma clang fp contract(off)
     // arrive != null (one row group per launch, more than one split): the last workgroup of a kv head to arrive combines the splits itself
     // n_splits: partial slabs per (row, head) = gridDim.x; the last n_extra (> 0) of them are the per-beam workgroups of the shared-prefix form
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
     __shared__ float oS[4][CT * 16][HD + 4];  // +4: rows shift by 4 banks
     __shared__ int s_ticket;
     ATTN_STAMP(0);
-    const int sp = blockIdx.x, kvh = blockIdx.y;
-    const int2 grp = one.enabled ? one.grp : groups[blockIdx.z];
+    const int2 grp = one.enabled ? one.grp : groups[zgrp];
     const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
     const LlmStreamView v = one.enabled ? one.v : sv[row_stream[r0]];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -265,6 +287,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         for (int s = 0; s < 4; ++s) vraw_n[s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
     };
     if (n_it > 0) fetch(cur);
+    after_fetch();
     auto tile_body = [&](int i) {  // the wave's i-th tile (= cur, already in the prefetch registers)
         const int t0 = cur.tp * 16;
         const int beam = cur.beam;
@@ -398,7 +421,9 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 #pragma unroll
             for (int r = 0; r < 4; ++r) oS[wave][ct * 16 + 4 * fq + r][16 * nt + fr] = o[ct][nt][r];
     }
-    __syncthreads();
+    // (LDS only: __syncthreads() would also wait for every outstanding global load)
+    if (sync4) lds_sync4(sync4, lane);
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // four dims per thread: a slab leaves the workgroup as whole 16-byte stores
     const bool inline_combine = arrive != nullptr && !out_direct;
     for (int e = tid; e < ncols * (HD / 4); e += 256) {
@@ -428,7 +453,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
             const u32x4_t ob = __builtin_bit_cast(u32x4_t, O);
             u32x4_t sb;
             sb.x = __float_as_uint(M); sb.y = __float_as_uint(L); sb.z = 0u; sb.w = 0u;
-            if (inline_combine || ATTN_SLAB_SC1) {  // write-through (sc1): the reducing workgroup may sit on another XCD, whose L2 never sees this one's lines
+            if (inline_combine || slab_sc1 || ATTN_SLAB_SC1) {  // write-through (sc1): the reducing workgroup may sit on another XCD, whose L2 never sees this one's lines
                 const __amdgpu_buffer_rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc(dst, 0, ATTN_SLAB * 4, 0x00020000);
                 __builtin_amdgcn_raw_buffer_store_b128(ob, ds, (unsigned)d4 * 4u, 0, 16);
                 if (d4 == 0) __builtin_amdgcn_raw_buffer_store_b128(sb, ds, HD * 4u, 0, 16);
@@ -457,6 +482,163 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
         *reinterpret_cast<uint32_t*>(out_final + ((long)row * H + head) * HD + 2 * lane) = attn_merge_finish<ATTN_MERGE_MAX_SPLITS>(ld, n_splits, lane);
     }
     if (tid == 0) __hip_atomic_store(arrive + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int G, int CT, bool MULTI>
+__global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ row_stream,
+                                                               const int* __restrict__ row_pos, const LlmStreamView* __restrict__ sv,
+                                                               const int2* __restrict__ groups, const bf16_t* __restrict__ rope_cos,
+                                                               const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool,
+                                                               float* __restrict__ partial, LlmAttnDims d, int layer, int n_splits,
+                                                               int tiles_per_split, LlmAttnOne one, bf16_t* __restrict__ out_direct, int n_extra,
+                                                               bf16_t* __restrict__ out_final, int* arrive) {
+    llm_attn_partial_body<G, CT, MULTI>(qkv, row_stream, row_pos, sv, groups, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits,
+                                        tiles_per_split, one, out_direct, n_extra, out_final, arrive, blockIdx.x, blockIdx.y, blockIdx.z, false, [] {});
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// One stream's decode step: attention + split-KV combine + o_proj (+ residual) as ONE launch (round 4).
+//
+// Three dependent launches cost ~19 us per layer at one stream (attention 5.8, combine 4.7, the o_proj GEMV 7.2, two boundaries) for 4 MB of keys and
+// 33.5 MB of weights, and the weights only start streaming when the attention output exists.  Here N / 16 workgroups of 8 waves (256 for
+// Llama-3.1-8B: one per CU, all resident) do all three:
+//   A  every wave fetches ITS k-tiles of the workgroup's 16 o_proj columns into registers (K = 4096: 16 b128 loads, 64 VGPRs: the whole 33.5 MB
+//      matrix ends up in the chip's register files).  The first n_splits x kv_heads workgroups run llm_attn_partial_body on waves 0-3 and store
+//      their slabs write-through; those four waves ask for their weights only AFTER their slab stores (vmcnt counts in order: s_waitcnt
+//      vmcnt(KPW) then means "slabs in memory" while the weights stay in flight) and meet each other at LDS counters, not at the workgroup barrier.
+//      All other waves hold their loads back by `delay` x ~0.4 us: 33.5 MB requested at t = 0 put a 4 us queue in front of the attention's
+//      dependent round trips (queries rotated at 3.5 us instead of 1.0, profiles/r04/attn_oproj_trace_v*.txt).
+//   B  hand-off 1: an attention workgroup adds to ITS kv head's arrival count; workgroup h < heads polls the count of head h's kv head (on wave 4,
+//      whose own loads have landed: a poll is a load, and waiting for it waits for every older load), merges head h's slabs (common.h
+//      attn_merge_*, the combine kernel's arithmetic), stores the 128 outputs write-through and adds to the merge count (8 replicas);
+//   C  hand-off 2: every workgroup polls one replica for heads x phase merges, stages the 8 KB attention row in LDS and runs the skinny GEMV's
+//      arithmetic from registers: wave w multiplies k-tiles w, w + 8, .. in ascending order, the eight partial tiles are summed in wave order,
+//      out = res + bf16(sum) -- the operations of gemm_skinny_kernel<1, 1, EPI_RES, nt, AMODE 0> at 8 waves in the same order, so the result is
+//      bit-identical to the three-launch path (tests/test_gpu_engine.py, test_gpu_fullsize.py).
+// Memory ordering across workgroups is the protocol of the in-launch combine above: sc1 stores, a counted wait for them, relaxed agent-scope
+// counter adds, sc1 loads on the reading side.  The launch needs every workgroup resident at once (the host checks N / 16 <= CU count; the device must
+// not be shared with another process' kernels); every wait is bounded and raises *err (pinned host memory) instead of hanging.
+// Measured (profiles/r04/attn_oproj_trace_v4.txt, fused_attn_oproj_ab_v4.txt): the launch ends 12.0 us after its first wave starts (rocprofv3: 15.2 us
+// in its first form against 17.7 us + two boundaries for the three launches); one stream 31.8 -> 30.95 ms per chunk.  What is left is a chain of
+// ~6 memory round trips behind the attention (store ack, count, slabs, store ack, count, row), each 0.6-1 us while the weights stream.
+// bar: 40 x 128-byte lines of unsigned -- [0..31] one arrival count per kv head (the attention workgroups of that head), [32..39] replicas of the merge
+// count.  Both only grow (wrap-safe compares): launch number `phase` (1, 2, .. counted by the host: the handle's launches are stream-ordered) waits
+// for n_splits x phase arrivals and heads x phase merges.
+// delay: x ~0.4 us that the waves WITHOUT attention work hold their weight loads back -- all 33.5 MB requested at t = 0 put the attention's
+// dependent round trips (queries, keys, values) behind a 4 us queue (profiles/r04/attn_oproj_trace_v1.txt)
+// ------------------------------------------------------------------------------------------------------------------------
+#define FUSED_WAVES 8
+template <int N>
+__device__ __forceinline__ void fused_wait_vmcnt() { __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | 0xf00 | ((N >> 4) << 14)); }  // s_waitcnt vmcnt(N) alone
+#define FUSED_SPIN (1 << 18)
+__device__ __forceinline__ unsigned fused_peek(const unsigned* bar, int line) {
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(bar), 0, 40 * 128, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b32(br, (unsigned)line * 128u, 0, 16);
+}
+// wait until replica `line` has reached `target` (wrap-safe); false: timed out or another workgroup gave up
+__device__ __forceinline__ bool fused_wait(const unsigned* bar, int line, unsigned target, int* err) {
+    for (int it = 0; it < FUSED_SPIN; ++it) {
+        if ((int)(fused_peek(bar, line) - target) >= 0) return true;
+        if ((it & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return false;
+}
+template <int G, int KPW>  // KPW: k-tiles (32 deep) per wave: K = 32 * FUSED_WAVES * KPW
+__global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ rope_cos,
+                                                                              const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* krpool,
+                                                                              bf16_t* vtpool, float* __restrict__ partial, LlmAttnDims d, int layer,
+                                                                              int n_splits, int tiles_per_split, LlmAttnOne one,
+                                                                              const bf16_t* __restrict__ Wp, int n_valid, const bf16_t* res,
+                                                                              bf16_t* out, bf16_t* attn_row, unsigned* bar, int* err, int mode, unsigned phase, int delay) {
+    __shared__ __attribute__((aligned(16))) bf16_t xs[32 * FUSED_WAVES * KPW];
+    __shared__ float red[FUSED_WAVES][64];
+    __shared__ int s_sync[2];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int K = 32 * FUSED_WAVES * KPW, KT = K / 32;
+    const int H = d.heads;
+    ATTN_STAMP(0);
+    if (tid == 0) { s_sync[0] = 0; s_sync[1] = 0; }
+    __syncthreads();
+    // ---- A: this wave's o_proj weights -> registers ----
+    u32x4_t wreg[KPW];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wp) + (long)b * KT * 512, 0, KT * 1024, 0x00020000);
+    auto issue_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) wreg[j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (unsigned)lane * 16u, (wave + FUSED_WAVES * j) * 1024, 2);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto hold = [&]() { for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(16); };
+    const int n_attn = n_splits * d.kv_heads;
+    if (b < n_attn) {
+        const int kvh = b / n_splits;
+        if (wave < 4) {
+            // (these waves ask for their weights only once their slabs are on the way: a wait for the slab stores -- vmcnt counts in order -- then
+            //  leaves exactly the KPW weight loads outstanding; asked for earlier, every wait of the attention itself would also wait for them.
+            //  They meet each other at LDS counters, not at the workgroup barrier: waves 4-7 are busy getting their loads issued)
+            llm_attn_partial_body<G, 1, false>(qkv, nullptr, nullptr, nullptr, nullptr, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer,
+                                               n_splits, tiles_per_split, one, nullptr, 0, nullptr, nullptr, b % n_splits, kvh, 0, true, [] {}, &s_sync[0]);
+            issue_w();
+            fused_wait_vmcnt<KPW>();  // this wave's slab stores (write-through) have completed
+            lds_sync4(&s_sync[1], lane);
+        } else {
+            hold();
+            issue_w();
+        }
+        ATTN_STAMP(4);
+        // ---- hand-off 1: this workgroup's slabs are in memory ----
+        if (tid == 0) __hip_atomic_fetch_add(bar + kvh * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        hold();
+        issue_w();
+    }
+    if (wave == 4) {  // (a wave whose weights went out early and have landed: every poll below is a load, and waiting for it waits for all older loads)
+        // ---- B: head b's merge, once the n_splits workgroups of its kv head have arrived ----
+        if (b < H) {
+            if (fused_wait(bar, b / G, (unsigned)n_splits * phase, err)) {
+                AttnMergeLoads<ATTN_MERGE_MAX_SPLITS> ld;
+                attn_merge_issue<ATTN_MERGE_MAX_SPLITS, 16>(partial + ((long)one.grp.x * H + b) * n_splits * ATTN_SLAB, n_splits, lane, ld);
+                const uint32_t v = attn_merge_finish<ATTN_MERGE_MAX_SPLITS>(ld, n_splits, lane);
+                const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(attn_row, 0, K * 2, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(v, ars, (unsigned)(b * 128 + 2 * lane) * 2u, 0, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (lane < 8) __hip_atomic_fetch_add(bar + (32 + lane) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (also after a timeout: the count stays in step)
+            ATTN_STAMP_W4(5);
+        }
+        // ---- C: wait for every head ----
+        fused_wait(bar, 32 + (b & 7), (unsigned)H * phase, err);
+    }
+    __syncthreads();
+    ATTN_STAMP(6);
+    if (mode == 1) return;  // (bisecting aid, ISST_FUSE_ATTN_OPROJ=2: attention + combine only; the caller launches the o_proj GEMV)
+    {   // the merged attention row -> LDS (sc1 loads: other workgroups stored it)
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(attn_row, 0, K * 2, 0x00020000);
+        for (int c = tid * 8; c < K; c += FUSED_WAVES * 64 * 8)
+            *reinterpret_cast<u32x4_t*>(xs + c) = __builtin_amdgcn_raw_buffer_load_b128(ars, (unsigned)c * 2u, 0, 16);
+    }
+    __syncthreads();
+    const int arow = lane & 15, kq = (lane >> 4) * 8;
+    const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KPW; ++j) {
+        const int kt = wave + FUSED_WAVES * j;
+        const u32x4_t a = arow == 0 ? *reinterpret_cast<const u32x4_t*>(xs + kt * 32 + kq) : zero4;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, wreg[j]), acc, 0, 0, 0);
+    }
+    if (lane < 16) red[wave][lane] = acc[0];  // row 0 of the tile: lanes 0..15, register 0
+    __syncthreads();
+    if (tid < 16) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < FUSED_WAVES; ++w) sum += red[w][tid];
+        const int col = b * 16 + tid;
+        if (col < n_valid) out[col] = f2bf(bf2f(res[col]) + bfr(sum));
+    }
+    ATTN_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -887,5 +1069,46 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
         return ISST_OK;
     }
     hipLaunchKernelGGL(llm_attn_combine_kernel, dim3(d.heads, rows), dim3(64), 0, s, partial, out, d.heads, n_splits);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+// One stream's decode step: attention + combine + o_proj + residual in one launch (llm_attn_oproj_kernel).  ISST_ERR_UNSUPPORTED-style answer (1) when
+// the shape is outside what the launch covers; the caller then runs the three launches.
+int llm_attn_oproj_supported(const LlmAttnDims& d, int rows, int n_groups, const LlmAttnOne* one, int N, int K, int n_cus) {
+    if (!one || !one->enabled || n_groups != 1 || rows != 1 || one->grp.y != 1) return 0;
+    if (K != d.heads * HD || (K != 32 * FUSED_WAVES * 16 && K != 32 * FUSED_WAVES * 2) || N % 128 != 0) return 0;  // (4096: Llama-3.1-8B; 512: the test configs)
+    const int nwg = N / 16;
+    if (nwg > n_cus || nwg < d.heads || d.kv_heads > 32) return 0;
+    const int slots = d.sys_cap + d.ring_cap;
+    if (slots % 64 != 0 || d.sys_cap % 16 != 0) return 0;
+    const int G = d.heads / d.kv_heads;
+    if (G != 1 && G != 2 && G != 4) return 0;
+    int n_splits = nwg / d.kv_heads;  // 64-slot spans (one tile per wave) while they fit the launch
+    if (n_splits > slots / 64) n_splits = slots / 64;
+    if (n_splits < 1 || n_splits > ATTN_MERGE_MAX_SPLITS) return 0;
+    const int tiles_per_split = ((slots / 16 + n_splits - 1) / n_splits + 3) / 4 * 4;
+    return tiles_per_split <= 4 ? n_splits : 0;  // (longer caches than 64 slots x the workgroups available: the three-launch path)
+}
+
+int launch_llm_attn_oproj(const bf16_t* qkv, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool, float* partial,
+                          LlmAttnDims d, int layer, const LlmAttnOne& one, const bf16_t* Wp, int N, int K, int n_valid, const bf16_t* res, bf16_t* out,
+                          bf16_t* attn_row, unsigned* bar, int* err, int n_cus, hipStream_t s, unsigned phase, int mode, int delay) {
+    const int n_splits = llm_attn_oproj_supported(d, 1, 1, &one, N, K, n_cus);
+    if (n_splits <= 0) return ISST_ERR_ARG;
+    const int slots = d.sys_cap + d.ring_cap;
+    const int tiles_per_split = ((slots / 16 + n_splits - 1) / n_splits + 3) / 4 * 4;
+    const int G = d.heads / d.kv_heads;
+    dim3 grid(N / 16), block(FUSED_WAVES * 64);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, block, 0, s, qkv, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, Wp, n_valid,
+                           res, out, attn_row, bar, err, mode, phase, delay);
+    };
+    const bool big = K == 32 * FUSED_WAVES * 16;
+    switch (G) {
+        case 1: if (big) go(llm_attn_oproj_kernel<1, 16>); else go(llm_attn_oproj_kernel<1, 2>); break;
+        case 2: if (big) go(llm_attn_oproj_kernel<2, 16>); else go(llm_attn_oproj_kernel<2, 2>); break;
+        case 4: if (big) go(llm_attn_oproj_kernel<4, 16>); else go(llm_attn_oproj_kernel<4, 2>); break;
+        default: return ISST_ERR_ARG;
+    }
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }

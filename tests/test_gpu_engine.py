@@ -552,6 +552,43 @@ def test_inline_split_kv_combine_is_bit_identical_to_the_combine_launch(monkeypa
         assert np.array_equal(x, y), f"chunk {c}: logits differ between the in-launch combine and the combine launch"
 
 
+def test_fused_attention_combine_oproj_is_bit_identical_to_the_three_launches(monkeypatch):
+    """One stream's decode step runs attention + split-KV combine + o_proj (+ residual) as ONE launch (csrc/llm_attn.hip llm_attn_oproj_kernel: the
+    o_proj weights wait in registers, two in-launch hand-offs through write-through stores and grid counters).  Against ISST_FUSE_ATTN_OPROJ=0 (three
+    launches): identical logits bit for bit over 12 chunks x 8 passes x 2 layers of hand-offs, with evictions and a wrapping ring.  A stale slab, a
+    torn attention row or a counter out of step would show up as a differing logit (or as the launch's time-out error)."""
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=8, max_llm_cache_size=300)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=72)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 12, stream_id=6)
+    sys_n = len(synth.system_prompt_ids(cfg))
+
+    def run(flag):
+        monkeypatch.setenv("ISST_FUSE_ATTN_OPROJ", flag)
+        eng = make_engine(cfg, w, debug_taps=False, max_llm_cache_size=300, max_streams=1)
+        sid = eng.open_stream()
+        outs, logs, ckpts = [], [], []
+        for c in range(12):
+            seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+            o, l = eng.generate(gen, [sid], [seg], [synth.chunk_prompt_ids(cfg, 1, first=(c == 0))], [[]],
+                                system_prompt_size=sys_n if c == 0 else 0, return_logits=True)
+            outs.append(o[0])
+            logs.append(l[0][:len(o[0])].copy())
+            cur = eng.stream_info(sid)["llm_cache_len"]
+            ckpts.append(cur)
+            ev = oag.evict(ckpts, cur, 150, True, sys_n)
+            if ev is not None:
+                ckpts, new_size = ev
+                eng.kv_evict(sid, new_size, sys_n)
+        eng.close()
+        return outs, logs
+
+    (oa, la), (ob, lb) = run("1"), run("0")
+    assert oa == ob
+    for c, (x, y) in enumerate(zip(la, lb)):
+        assert np.array_equal(x, y), f"chunk {c}: logits differ between the fused launch and the three launches"
+
+
 def test_llm_embed_tap_equals_oracle_splice():
     """The `llm_embed` tap (decoder input rows after embedding lookup + speech splice, model/llm.py:86-113) against the oracle's splice of the
     oracle's own speech features: a pure row copy on the device, so token rows are bit-exact and speech rows carry only the encoder's error."""

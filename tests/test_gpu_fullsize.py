@@ -95,6 +95,30 @@ def test_full_size_replay_is_deterministic(full):
     eng.close_stream(b)
 
 
+def test_full_size_fused_attention_oproj_is_bit_identical_to_the_three_launches(full, monkeypatch):
+    """Llama-3.1-8B shapes: 256 workgroups (one per CU) hold the whole o_proj matrix in registers while 136 of them run the split-KV attention; head h's
+    slabs are merged by workgroup h, all 256 then read the 8 KB attention row (csrc/llm_attn.hip llm_attn_oproj_kernel).  The module's engine (fused, the
+    default) against a second engine created with ISST_FUSE_ATTN_OPROJ=0, same weights, two chunks of the same audio: every logit bit equal."""
+    cfg, w, eng, sys_n = full
+    gen = GenConfig(max_new_tokens=10)
+    monkeypatch.setenv("ISST_FUSE_ATTN_OPROJ", "0")
+    ref = Engine(cfg, max_streams=1, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n)
+    monkeypatch.delenv("ISST_FUSE_ATTN_OPROJ")
+    ref.load_weights(w)
+    a, b = eng.open_stream(), ref.open_stream()
+    audio = synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=3)
+    for c in range(2):
+        seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+        prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+        o1, l1 = eng.generate(gen, [a], [seg], [prompt], [[]], return_logits=True)
+        o2, l2 = ref.generate(gen, [b], [seg], [prompt], [[]], forced_tokens=[o1[0]], return_logits=True)
+        n = min(len(o1[0]), len(o2[0]))
+        assert n == len(o1[0]) and o1[0][:n] == o2[0][:n]
+        assert np.array_equal(l1[0][:n], l2[0][:n]), f"chunk {c}: the fused launch and the three launches must agree bit for bit"
+    eng.close_stream(a)
+    ref.close()
+
+
 @pytest.mark.parametrize("n", [4, 8, 14, 16])
 def test_full_size_multi_stream_batch_matches_single_stream(full, n):
     """(14 / 16 streams: the decode passes run on gemm_mid + split-K slabs with the reducing RMSNorm instead of the skinny kernel.  8 streams: prefill 176 rows -- q/k/v as K slices + slab reduce too.)  4 streams in one call take different kernels from one stream (prefill 88 rows: split-K slabs on the dense kernel, q/k/v on
