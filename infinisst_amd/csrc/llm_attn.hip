@@ -134,7 +134,9 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
                                                       Hook&& after_fetch, int* sync4 = nullptr) {
     // every mul and add below is rounded on its own, as written: the body is compiled into two kernels whose surrounding code differs, and with
     // contraction left to the compiler the two copies fused different mul/add pairs (a 1-ulp logit now and then between the two paths)
+#ifndef ATTN_CONTRACT_ON
 #pragma clang fp contract(off)
+#endif
     // arrive != null (one row group per launch, more than one split): the last workgroup of a kv head to arrive combines the splits itself
     // n_splits: partial slabs per (row, head) = gridDim.x; the last n_extra (> 0) of them are the per-beam workgroups of the shared-prefix form
     __shared__ float mS[4][CT * 16], lS[4][CT * 16];
@@ -144,7 +146,7 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
     const int2 grp = one.enabled ? one.grp : groups[zgrp];
     const int r0 = grp.x, nrows = grp.y, ncols = nrows * G;
     const LlmStreamView v = one.enabled ? one.v : sv[row_stream[r0]];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the tile walk below stays in scalar registers)
     const int fr = lane & 15, fq = lane >> 4;
     const int H = d.heads, KV = d.kv_heads;
     const long ldq = (long)(H + 2 * KV) * HD;
@@ -186,32 +188,29 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
     // own-key tiles of this wave: per-beam workgroup -- the wave-th tile of its beam; folded -- all of them for beams wave, wave + 4, ..
     const int n_own = tailwg ? (wave < n_tail ? 1 : 0) : fold ? n_tail * ((v.n_beams - wave + 3) >> 2) : 0;
     const int n_it = n_pref + n_own;
-    // the wave's i-th tile: (physical tile, beam whose arena holds it, own-key tile?), advanced incrementally
-    struct TileIt { int tp, beam, idx; bool own; };
+    // the wave's i-th tile: (physical tile, beam whose arena holds it, index -- compact prefix index or own-tile number --, own-key tile?), advanced
+    // incrementally with selects, no branches: the walk is wave-uniform and must not sit between a wave and its next loads
     auto phys_prefix = [&](int tc) -> int {  // compact index -> physical 16-slot tile
-        if (tc < sys_tiles) return tc;
         int r = ring_tile0 + (tc - sys_tiles);
-        if (r >= ring_tiles) r -= ring_tiles;
-        return (d.sys_cap >> 4) + r;
+        r = r >= ring_tiles ? r - ring_tiles : r;
+        return tc < sys_tiles ? tc : (d.sys_cap >> 4) + r;
     };
     auto phys_own = [&](int idx) -> int {
         int r = tail_first + idx;
-        if (r >= ring_tiles) r -= ring_tiles;
+        r = r >= ring_tiles ? r - ring_tiles : r;
         return (d.sys_cap >> 4) + r;
     };
-    auto first_own = [&]() -> TileIt {
-        const int idx = tailwg ? wave : 0;
-        return TileIt{phys_own(idx), tailwg ? wg_beam : wave, idx, true};
-    };
-    auto tile_at0 = [&]() -> TileIt { return n_pref > 0 ? TileIt{phys_prefix(tile_begin + wave), 0, tile_begin + wave, false} : first_own(); };
-    auto tile_next = [&](const TileIt& c, int i_next) -> TileIt {  // the tile after c, which is the wave's i_next-th (i_next < n_it)
-        if (!c.own) {
-            if (i_next < n_pref) return TileIt{phys_prefix(c.idx + 4), 0, c.idx + 4, false};
-            return first_own();
-        }
-        int idx = c.idx + 1, beam = c.beam;
-        if (idx >= n_tail) { idx = 0; beam += 4; }
-        return TileIt{phys_own(idx), beam, idx, true};
+    const int own_idx0 = tailwg ? wave : 0, own_beam0 = tailwg ? wg_beam : wave;
+    auto tile_next = [&](int& tp, int& beam, int& idx, bool& own, int i_next) {  // -> the wave's i_next-th tile (i_next < n_it), from its predecessor
+        const bool to_own = i_next >= n_pref;
+        const bool wrap = idx + 1 >= n_tail;
+        const int oidx = own ? (wrap ? 0 : idx + 1) : own_idx0;
+        const int obeam = own ? (wrap ? beam + 4 : beam) : own_beam0;
+        const int pidx = idx + 4;
+        tp = to_own ? phys_own(oidx) : phys_prefix(pidx);
+        beam = to_own ? obeam : 0;
+        idx = to_own ? oidx : pidx;
+        own = to_own;
     };
 
     // ---- rotated query fragments: B[k = dim][n = column c], c = ct*16 + fr -> (row r0 + c / G, head kvh*G + c % G) ----
@@ -245,13 +244,17 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
         for (int nt = 0; nt < 8; ++nt) o[ct][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
 
-    // this lane's key of tile `it` as an A-operand row (slot 16 tp + fr of the arena of it.beam): source row (arena, or the qkv rows for keys
-    // written by this launch) and logical position
-    auto key_src = [&](const TileIt& it, int& jk, bool& k_new) -> const bf16_t* {
-        jk = llm_logical(v, d, it.tp * 16 + fr, total);
+    // what a wave needs to put a tile in flight: this lane's key of the tile as an A-operand row (slot 16 tp + fr of the arena of `beam`) and its
+    // value row -- from the arena, or from the qkv rows for keys written by this launch -- and the key's logical position.  Computed one tile AHEAD
+    // of the loads (the walk is latency-bound with one tile in flight: every instruction between "the tile in hand has landed" and "the next
+    // loads are out" is paid once per tile; with the address arithmetic in that gap the 64-stream launch took 63.5 us instead of 52)
+    auto prep = [&](int tp, int beam, const bf16_t*& ks, const bf16_t*& vs, int& jk, bool& k_new) {
+        jk = llm_logical(v, d, tp * 16 + fr, total);
         k_new = jk >= 0 && jk >= v.new_start;
-        return k_new ? qkv + (long)(v.row0 + it.beam + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD
-                     : (rot ? kr : kb) + (long)it.beam * v.beam_stride + (long)(it.tp * 16 + fr) * HD;
+        const long boff = (long)beam * v.beam_stride + (long)(tp * 16 + fr) * HD;
+        const long qoff = (long)(v.row0 + beam + (jk - v.new_start)) * ldq + (long)(H + kvh) * HD;
+        ks = k_new ? qkv + qoff : (rot ? kr : kb) + boff;
+        vs = k_new ? qkv + qoff + (long)KV * HD : vb + boff;
     };
     // V tile staging: the lane's value row (16 B x 4, same lane -> (key, dims) map as K) goes to a wave-private LDS image
     // [16 keys][128 dims] (256-byte rows, 16-byte chunks XOR-swizzled so that row writes and transposed reads both spread over the
@@ -267,31 +270,37 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) vr_off[nt] = v_off(4 * fq + tq, 2 * nt + (tp >> 1)) + 8 * (tp & 1);
 
-    // the lane's value row of tile `it`: from the arena, or from the qkv row for a key written by this launch
-    auto val_src = [&](const TileIt& it, int jk, bool k_new) -> const bf16_t* {
-        return k_new ? qkv + (long)(v.row0 + it.beam + (jk - v.new_start)) * ldq + (long)(H + KV + kvh) * HD
-                     : vb + (long)it.beam * v.beam_stride + (long)(it.tp * 16 + fr) * HD;
-    };
     // MULTI: the next tile's key and value rows go in flight before this tile's arithmetic (one tile ahead; two measured no faster, see above).
     // The prefetch is unconditional, clamped to the wave's last tile: a conditional load makes hipcc branch around it and drain vmcnt(0).
     int jk_n = -1;
     bool knew_n = false;
     u32x4_t kraw_n[4], vraw_n[4];
-    TileIt cur = tile_at0(), nxt = cur;
-    auto fetch = [&](const TileIt& it) {
-        const bf16_t* src = key_src(it, jk_n, knew_n);
+    auto fetch = [&](const bf16_t* ks, const bf16_t* vs) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kraw_n[s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-        const bf16_t* vs = val_src(it, jk_n, knew_n);
+        for (int s = 0; s < 4; ++s) kraw_n[s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(ks + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(ks + 32 * s + 8 * fq);
 #pragma unroll
         for (int s = 0; s < 4; ++s) vraw_n[s] = (MULTI && ATTN_KV_NT) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq)) : *reinterpret_cast<const u32x4_t*>(vs + 32 * s + 8 * fq);
     };
-    if (n_it > 0) fetch(cur);
+    // cur_*: the tile whose rows are in (or on their way to) the prefetch registers; nxt_*: the tile to request next, with its sources
+    const bool pre0 = n_pref > 0;
+    int cur_tp = pre0 ? phys_prefix(tile_begin + wave) : phys_own(own_idx0), cur_beam = pre0 ? 0 : own_beam0, cur_idx = pre0 ? tile_begin + wave : own_idx0;
+    bool cur_own = !pre0;
+    const bf16_t *nks = nullptr, *nvs = nullptr;
+    int njk = -1;
+    bool nknew = false;
+    prep(cur_tp, cur_beam, nks, nvs, jk_n, knew_n);
+    if (n_it > 0) fetch(nks, nvs);
     after_fetch();
+    int nxt_tp = cur_tp, nxt_beam = cur_beam, nxt_idx = cur_idx;
+    bool nxt_own = cur_own;
+    if constexpr (MULTI) {
+        if (n_it > 1) tile_next(nxt_tp, nxt_beam, nxt_idx, nxt_own, 1);
+        prep(nxt_tp, nxt_beam, nks, nvs, njk, nknew);
+    }
     auto tile_body = [&](int i) {  // the wave's i-th tile (= cur, already in the prefetch registers)
-        const int t0 = cur.tp * 16;
-        const int beam = cur.beam;
-        const bool own = cur.own;
+        const int t0 = cur_tp * 16;
+        const int beam = cur_beam;
+        const bool own = cur_own;
         const long boff = (long)beam * v.beam_stride;
         const int jk = jk_n;
         const bool k_new = knew_n;
@@ -299,8 +308,13 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
 #pragma unroll
         for (int s = 0; s < 4; ++s) { kraw[s] = kraw_n[s]; vraw[s] = vraw_n[s]; }
         if constexpr (MULTI) {
-            nxt = i + 1 < n_it ? tile_next(cur, i + 1) : cur;
-            fetch(nxt);
+            fetch(nks, nvs);  // (addresses ready since the previous tile)
+            jk_n = njk;
+            knew_n = nknew;
+            __builtin_amdgcn_sched_barrier(0);
+            cur_tp = nxt_tp; cur_beam = nxt_beam; cur_idx = nxt_idx; cur_own = nxt_own;
+            if (i + 2 < n_it) tile_next(nxt_tp, nxt_beam, nxt_idx, nxt_own, i + 2);
+            prep(nxt_tp, nxt_beam, nks, nvs, njk, nknew);
         }
         const bool tile_live = __any(jk >= 0);
         if (!tile_live) return;
@@ -401,10 +415,7 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
         }
     };
     if constexpr (MULTI) {
-        for (int i = 0; i < n_it; ++i) {
-            tile_body(i);
-            cur = nxt;
-        }
+        for (int i = 0; i < n_it; ++i) tile_body(i);
     } else {
         if (n_it > 0) tile_body(0);
     }
