@@ -114,9 +114,13 @@ struct isst_handle {
     bool fuse_attn_oproj = true;  // one stream's decode step: attention + combine + o_proj + residual as ONE launch (llm_attn.hip llm_attn_oproj_kernel; needs the
                                   // device to itself: N / 16 workgroups resident at once).  ISST_FUSE_ATTN_OPROJ=0: the three launches.  Bit-identical either way.
     int fuse_ao_mode = 0;         // ISST_FUSE_ATTN_OPROJ=2 -> 1: the fused launch stops after the combine, o_proj is its own launch (bisecting aid)
+    bool fuse_ao_beams = false;   // ISST_FUSE_ATTN_OPROJ=3: also for the <= 4 beams of ONE stream (a shared-prefix group of B rows: 184 attention workgroups, one merging
+                                  // workgroup per (row, head), a B-row GEMV).  Built, bit-identical (tests/test_gpu_beam.py, test_gpu_fullsize.py) and measured: the launch ends
+                                  // 16.6 us after its first wave (12.5 at one row) and a beam-4 chunk takes 33.7-34.0 ms against 33.7 with three launches -- opt-in
+                                  // (profiles/r04/fused_attn_oproj_beam4_ab_v2.txt)
     bool fuse_ao_used = false;    // a fused launch was enqueued since the error word (tok_host[tok_cap + 8]) was last checked
     unsigned* fuse_bar = nullptr; // its hand-off counters (40 x 128 B, only ever grow)
-    unsigned fuse_phase = 0;      // fused launches enqueued so far (the launch's `phase` argument)
+    unsigned fuse_arrive_total = 0, fuse_merge_total = 0;  // what its counters will read once every enqueued launch has run (the next launch's targets start here)
     int fuse_ao_delay = 4;        // ISST_FUSE_AO_DELAY (swept 0..16: 0-4 equal within noise, 30.93-31.06 ms per chunk; 12: 31.5; 16: 32.0): x ~0.4 us the waves without attention work hold their weight loads back
     int n_cus = 0;                // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     bool fuse_reduce = true;      // 13..64 rows -- no rmsnorm_reduce launches: the last K-slice workgroup of o_proj / down_proj sums the slabs and writes x

@@ -126,6 +126,18 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
     return m;
 }
 
+// the fused attention + o_proj launches enqueued since the last check have run (call after a synchronisation point): a wait inside one of them that ran
+// out raised the (pinned) error word
+int check_fused_ao(isst_handle* h) {
+    if (!h->fuse_ao_used) return ISST_OK;
+    h->fuse_ao_used = false;
+    volatile int* ferr = h->tok_host + h->tok_cap + 8;
+    if (*ferr == 0) return ISST_OK;
+    *ferr = 0;
+    h->fuse_attn_oproj = false;  // (its counters are out of step now; the three launches from here on)
+    return h->fail(ISST_ERR_HIP, "the fused attention + o_proj launch timed out waiting for its own workgroups (is another process using this GPU?); set ISST_FUSE_ATTN_OPROJ=0");
+}
+
 // one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
 int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_groups, int max_group_rows, bool splice, const char* tap_prefix,
                 hipStream_t st, const StepMeta* hm = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0) {
@@ -135,12 +147,16 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
     LlmAttnOne one{};
     if (hm && n_groups == 1) {
         const int2 g0 = hm->groups[0];
-        bool consecutive = true;
-        for (int k = 1; k < g0.y; ++k) consecutive = consecutive && hm->row_pos[g0.x + k] == hm->row_pos[g0.x] + k;
-        if (consecutive) {
+        bool consecutive = true, same = true;  // (a prompt's rows / one decode row; the beams of a stream all sit at one position)
+        for (int k = 1; k < g0.y; ++k) {
+            consecutive = consecutive && hm->row_pos[g0.x + k] == hm->row_pos[g0.x] + k;
+            same = same && hm->row_pos[g0.x + k] == hm->row_pos[g0.x];
+        }
+        if (consecutive || same) {
             one.enabled = 1;
             one.grp = g0;
             one.pos0 = hm->row_pos[g0.x];
+            one.pos_step = consecutive ? 1 : 0;
             one.v = hm->views[hm->row_stream[g0.x]];
         }
     }
@@ -214,17 +230,16 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             }
         }
         // one stream's decode step: attention, combine and o_proj (+ residual) are ONE launch (llm_attn.hip llm_attn_oproj_kernel)
-        const bool fused_ao = h->fuse_attn_oproj && !h->fuse_combine && !h->inline_combine && so == 1 && n_units == 0 && n_beam_wgs == 0 && !tap_prefix &&
-                              L.o.n_valid == L.o.N && llm_attn_oproj_supported(h->adims, rows, n_groups, &one, L.o.N, L.o.K, h->n_cus) > 0;
+        const bool fused_ao = h->fuse_attn_oproj && (n_beam_wgs == 0 || h->fuse_ao_beams) && !h->fuse_combine && !h->inline_combine && so == 1 && n_units == 0 && !tap_prefix && L.o.n_valid == L.o.N &&
+                              llm_attn_oproj_supported(h->adims, rows, n_groups, &one, L.o.N, L.o.K, h->n_cus, n_beam_wgs) > 0;
         // one or two decode rows: no combine launch -- o_proj merges the split-KV partials while it stages its A row (gemm.hip AMODE 3)
         int merge_splits = 0;
         const bool merge_in_oproj = h->fuse_combine && !h->inline_combine && so == 1 && rows <= ATTN_MERGE_MAX_ROWS && n_units == 0 && n_beam_wgs == 0;
         if (fused_ao) {
             h->fuse_ao_used = true;
-            CHK(launch_llm_attn_oproj(h->lqkv, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->llm_v, h->lpartial, h->adims, l, one, L.o.wp, L.o.N, L.o.K,
-                                      L.o.n_valid, h->lx + (long)one.grp.x * DL, h->lx + (long)one.grp.x * DL, h->lattn + (long)one.grp.x * H * 128, h->fuse_bar,
-                                      h->tok_host + h->tok_cap + 8, h->n_cus, st, h->fuse_phase + 1, h->fuse_ao_mode, h->fuse_ao_delay));
-            ++h->fuse_phase;  // (counted once the launch is enqueued: the device-side counters advance with executed launches only)
+            CHK(launch_llm_attn_oproj(h->lqkv, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->llm_v, h->lpartial, h->adims, l, one, n_beam_wgs, L.o.wp, L.o.N, L.o.K,
+                                      L.o.n_valid, h->lx + (long)one.grp.x * DL, h->lx + (long)one.grp.x * DL, DL, h->lattn + (long)one.grp.x * H * 128, h->fuse_bar,
+                                      h->tok_host + h->tok_cap + 8, h->n_cus, st, &h->fuse_arrive_total, &h->fuse_merge_total, h->fuse_ao_mode, h->fuse_ao_delay));
         } else
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
@@ -504,6 +519,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
             // (the final selection stores its <= 32 candidates per row straight into the pinned host arrays: no device copy, no two D2H launches per step)
             CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val_host, h->top_idx_host, rows, st));
             HIPCHK(hipStreamSynchronize(st));
+            CHK(check_fused_ao(h));
             h->kv_ops_used = 0;  // every earlier copy batch has run
         }
 
@@ -980,15 +996,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         const int na = (int)active.size();
         if (g_ht.on) ht_a = std::chrono::steady_clock::now();
         CHK(wait_tokens());
-        if (h->fuse_ao_used) {  // the fused attention + o_proj launches of this pass: a wait inside one of them that ran out raised the (pinned) error word
-            h->fuse_ao_used = false;
-            volatile int* ferr = h->tok_host + h->tok_cap + 8;
-            if (*ferr != 0) {
-                *ferr = 0;
-                h->fuse_attn_oproj = false;  // (its counters are out of step now; the three launches from here on)
-                return h->fail(ISST_ERR_HIP, "the fused attention + o_proj launch timed out waiting for its own workgroups (is another process using this GPU?); set ISST_FUSE_ATTN_OPROJ=0");
-            }
-        }
+        CHK(check_fused_ao(h));
         if (g_ht.on) { ht_b = std::chrono::steady_clock::now(); g_ht.wait += HostTrace::us(ht_a, ht_b); g_ht.waits++; }
         if (p->do_sample)  // HF _sample with do_sample: warpers, softmax, one draw per row (patch_hf.py:606-624)
             for (int r = 0; r < na; ++r)

@@ -193,7 +193,7 @@ extern "C" int isst_op_llm_attention(const uint16_t* qkv, int rows, int pos0, ui
     if (rc == ISST_OK && rot_keys && pos0 > 0) rc = launch_llm_rope_cache(dv, 1, rope_cos, rope_sin, kpool, krpool, d, 1, st);
     if (rc == ISST_OK) {
         LlmAttnOne one{};
-        if (groups.size() == 1) { one.enabled = 1; one.grp = groups[0]; one.pos0 = pos0; one.v = v; }
+        if (groups.size() == 1) { one.enabled = 1; one.grp = groups[0]; one.pos0 = pos0; one.pos_step = 1; one.v = v; }
         rc = launch_llm_attention(qkv, reinterpret_cast<const int*>(meta), reinterpret_cast<const int*>(meta + off_pos), dv,
                                   reinterpret_cast<const int2*>(meta + off_groups), (int)groups.size(), gmax, rope_cos, rope_sin, kpool, krpool, vpool, partial, out, d,
                                   0, rows, st, &one, reinterpret_cast<const int2*>(meta + off_units), (int)units.size(), max_unit_groups, 0);

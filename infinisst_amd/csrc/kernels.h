@@ -74,7 +74,8 @@ void llm_attn_set_tuning(int target_wgs);  // workgroups wanted before slot span
 struct LlmAttnOne {
     int enabled;
     int2 grp;        // (first row, row count)
-    int pos0;        // position of the first row; the rows of a group are consecutive positions
+    int pos0;        // position of the first row
+    int pos_step;    // row k of the group sits at pos0 + k * pos_step: 1 = consecutive positions (a prompt, one decode row), 0 = all rows at pos0 (the beams of a stream)
     LlmStreamView v;
 };
 int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* row_pos, const LlmStreamView* sv, const int2* groups,
@@ -82,11 +83,12 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
                          float* partial, bf16_t* out, LlmAttnDims d, int layer, int rows, hipStream_t s, const LlmAttnOne* one = nullptr,
                          const int2* units = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0, int* defer_combine = nullptr,
                          int* arrive_counters = nullptr);
-// one stream's decode step, attention + combine + o_proj + residual in one launch: > 0 (the slot splits it will use) when the shape is covered
-int llm_attn_oproj_supported(const LlmAttnDims& d, int rows, int n_groups, const LlmAttnOne* one, int N, int K, int n_cus);
+// one stream's decode step (one row or <= 4 shared-prefix beams), attention + combine + o_proj + residual in one launch: > 0 (the prefix's slot splits) when covered
+int llm_attn_oproj_supported(const LlmAttnDims& d, int rows, int n_groups, const LlmAttnOne* one, int N, int K, int n_cus, int n_beam_wgs);
 int launch_llm_attn_oproj(const bf16_t* qkv, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool, float* partial,
-                          LlmAttnDims d, int layer, const LlmAttnOne& one, const bf16_t* Wp, int N, int K, int n_valid, const bf16_t* res, bf16_t* out,
-                          bf16_t* attn_row, unsigned* bar, int* err, int n_cus, hipStream_t s, unsigned phase, int mode = 0, int delay = 0);
+                          LlmAttnDims d, int layer, const LlmAttnOne& one, int n_beam_wgs, const bf16_t* Wp, int N, int K, int n_valid, const bf16_t* res,
+                          bf16_t* out, int ld, bf16_t* attn_row, unsigned* bar, int* err, int n_cus, hipStream_t s, unsigned* arrive_total,
+                          unsigned* merge_total, int mode = 0, int delay = 0);
                          // arrive_counters != null (>= kv_heads zeroed ints): a ONE-group launch combines its splits itself (last-arriver form, llm_attn.hip)
                          // defer_combine != null: more than one slot split -> NO combine launch, *defer_combine = the split count and `partial` holds the
                          // (max, sum, O) slabs for the consumer to merge (GemmArgs::attn_partial); one split -> *defer_combine = 0, `out` is written  // units[z] = (first group, groups <= 8) of ONE

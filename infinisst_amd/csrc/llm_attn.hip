@@ -166,7 +166,7 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
     bf16_t* const kr = krpool + base;   // [slots][128] the same keys rotated at their logical position of this chunk (LlmStreamView::rot_keys)
     const bool rot = v.rot_keys != 0;
     bf16_t* const vb = vtpool + base;   // [slots][128] row per key, like K
-    const int total = (one.enabled ? one.pos0 + nrows - 1 : row_pos[r0 + nrows - 1]) + 1;  // keys visible to the last row of the group
+    const int total = (one.enabled ? one.pos0 + (nrows - 1) * one.pos_step : row_pos[r0 + nrows - 1]) + 1;  // keys visible to the last row of the group
     const float scale = 0.08838834764831845f;       // 1/sqrt(128)
     // Tiles are walked in a COMPACT index space that holds only the tiles with a live slot: [pinned prefix tiles | ring tiles from the one that
     // holds ring_start on, as many as the live span touches].  The arena is sized for max_llm_cache_size + a chunk + slack, the steady-state
@@ -221,7 +221,7 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
         const int c = ct * 16 + fr;
         const bool cv = c < ncols;
         const int row = r0 + (cv ? c / G : 0);
-        cpos[ct] = cv ? (one.enabled ? one.pos0 + (row - r0) : row_pos[row]) : -1;
+        cpos[ct] = cv ? (one.enabled ? one.pos0 + (row - r0) * one.pos_step : row_pos[row]) : -1;
         const bf16_t* qh = qkv + (long)row * ldq + (long)(kvh * G + (cv ? c % G : 0)) * HD;
         u32x4_t qraw[4];
 #pragma unroll
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 //      vmcnt(KPW) then means "slabs in memory" while the weights stay in flight) and meet each other at LDS counters, not at the workgroup barrier.
 //      All other waves hold their loads back by `delay` x ~0.4 us: 33.5 MB requested at t = 0 put a 4 us queue in front of the attention's
 //      dependent round trips (queries rotated at 3.5 us instead of 1.0, profiles/r04/attn_oproj_trace_v*.txt).
-//   B  hand-off 1: an attention workgroup adds to ITS kv head's arrival count; workgroup h < heads polls the count of head h's kv head (on wave 4,
+//   B  hand-off 1: an attention workgroup adds to ITS kv head's arrival count; workgroup h < heads (x rows: one per (row, head)) polls the count of head h's kv head (on wave 4,
 //      whose own loads have landed: a poll is a load, and waiting for it waits for every older load), merges head h's slabs (common.h
 //      attn_merge_*, the combine kernel's arithmetic), stores the 128 outputs write-through and adds to the merge count (8 replicas);
 //   C  hand-off 2: every workgroup polls one replica for heads x phase merges, stages the 8 KB attention row in LDS and runs the skinny GEMV's
@@ -556,20 +556,24 @@ __device__ __forceinline__ bool fused_wait(const unsigned* bar, int line, unsign
     __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return false;
 }
+#define FUSED_MAX_ROWS 4
 template <int G, int KPW>  // KPW: k-tiles (32 deep) per wave: K = 32 * FUSED_WAVES * KPW
 __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ rope_cos,
                                                                               const bf16_t* __restrict__ rope_sin, bf16_t* kpool, bf16_t* krpool,
                                                                               bf16_t* vtpool, float* __restrict__ partial, LlmAttnDims d, int layer,
-                                                                              int n_splits, int tiles_per_split, LlmAttnOne one,
+                                                                              int n_splits, int n_extra, int tiles_per_split, LlmAttnOne one,
                                                                               const bf16_t* __restrict__ Wp, int n_valid, const bf16_t* res,
-                                                                              bf16_t* out, bf16_t* attn_row, unsigned* bar, int* err, int mode, unsigned phase, int delay) {
-    __shared__ __attribute__((aligned(16))) bf16_t xs[32 * FUSED_WAVES * KPW];
-    __shared__ float red[FUSED_WAVES][64];
+                                                                              bf16_t* out, int ld, bf16_t* attn_row, unsigned* bar, int* err, int mode,
+                                                                              unsigned arrive_target, unsigned merge_target, int delay) {
+    // n_splits: slabs per (row, head) = the attention workgroups of a kv head (n_extra of them the per-beam workgroups of a shared-prefix beam group);
+    // res / out / attn_row: row one.grp.x of the hidden state (row stride ld) and of the attention output (row stride K)
+    constexpr int K = 32 * FUSED_WAVES * KPW, KT = K / 32;
+    __shared__ __attribute__((aligned(16))) bf16_t xs[FUSED_MAX_ROWS * K];
+    __shared__ float red[FUSED_WAVES][FUSED_MAX_ROWS][16];
     __shared__ int s_sync[2];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int K = 32 * FUSED_WAVES * KPW, KT = K / 32;
-    const int H = d.heads;
+    const int H = d.heads, r0 = one.grp.x, rows = one.grp.y;
     ATTN_STAMP(0);
     if (tid == 0) { s_sync[0] = 0; s_sync[1] = 0; }
     __syncthreads();
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(con
             //  leaves exactly the KPW weight loads outstanding; asked for earlier, every wait of the attention itself would also wait for them.
             //  They meet each other at LDS counters, not at the workgroup barrier: waves 4-7 are busy getting their loads issued)
             llm_attn_partial_body<G, 1, false>(qkv, nullptr, nullptr, nullptr, nullptr, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer,
-                                               n_splits, tiles_per_split, one, nullptr, 0, nullptr, nullptr, b % n_splits, kvh, 0, true, [] {}, &s_sync[0]);
+                                               n_splits, tiles_per_split, one, nullptr, n_extra, nullptr, nullptr, b % n_splits, kvh, 0, true, [] {}, &s_sync[0]);
             issue_w();
             fused_wait_vmcnt<KPW>();  // this wave's slab stores (write-through) have completed
             lds_sync4(&s_sync[1], lane);
@@ -606,28 +610,29 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(con
         issue_w();
     }
     if (wave == 4) {  // (a wave whose weights went out early and have landed: every poll below is a load, and waiting for it waits for all older loads)
-        // ---- B: head b's merge, once the n_splits workgroups of its kv head have arrived ----
-        if (b < H) {
-            if (fused_wait(bar, b / G, (unsigned)n_splits * phase, err)) {
-                AttnMergeLoads<ATTN_MERGE_MAX_SPLITS> ld;
-                attn_merge_issue<ATTN_MERGE_MAX_SPLITS, 16>(partial + ((long)one.grp.x * H + b) * n_splits * ATTN_SLAB, n_splits, lane, ld);
-                const uint32_t v = attn_merge_finish<ATTN_MERGE_MAX_SPLITS>(ld, n_splits, lane);
-                const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(attn_row, 0, K * 2, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b32(v, ars, (unsigned)(b * 128 + 2 * lane) * 2u, 0, 16);
+        // ---- B: workgroup b merges (row r0 + b / heads, head b % heads), once the workgroups of that head's kv head have arrived ----
+        if (b < H * rows) {
+            const int mr = b / H, mh = b - mr * H;
+            if (fused_wait(bar, mh / G, arrive_target, err)) {
+                AttnMergeLoads<ATTN_MERGE_MAX_SPLITS> ldm;
+                attn_merge_issue<ATTN_MERGE_MAX_SPLITS, 16>(partial + ((long)(r0 + mr) * H + mh) * n_splits * ATTN_SLAB, n_splits, lane, ldm);
+                const uint32_t v = attn_merge_finish<ATTN_MERGE_MAX_SPLITS>(ldm, n_splits, lane);
+                const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(attn_row, 0, rows * K * 2, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(v, ars, (unsigned)(mr * K + mh * 128 + 2 * lane) * 2u, 0, 16);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (lane < 8) __hip_atomic_fetch_add(bar + (32 + lane) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (also after a timeout: the count stays in step)
             ATTN_STAMP_W4(5);
         }
-        // ---- C: wait for every head ----
-        fused_wait(bar, 32 + (b & 7), (unsigned)H * phase, err);
+        // ---- C: wait for every (row, head) ----
+        fused_wait(bar, 32 + (b & 7), merge_target, err);
     }
     __syncthreads();
     ATTN_STAMP(6);
     if (mode == 1) return;  // (bisecting aid, ISST_FUSE_ATTN_OPROJ=2: attention + combine only; the caller launches the o_proj GEMV)
-    {   // the merged attention row -> LDS (sc1 loads: other workgroups stored it)
-        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(attn_row, 0, K * 2, 0x00020000);
-        for (int c = tid * 8; c < K; c += FUSED_WAVES * 64 * 8)
+    {   // the merged attention rows -> LDS (sc1 loads: other workgroups stored them)
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(attn_row, 0, rows * K * 2, 0x00020000);
+        for (int c = tid * 8; c < rows * K; c += FUSED_WAVES * 64 * 8)
             *reinterpret_cast<u32x4_t*>(xs + c) = __builtin_amdgcn_raw_buffer_load_b128(ars, (unsigned)c * 2u, 0, 16);
     }
     __syncthreads();
@@ -637,17 +642,21 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(con
 #pragma unroll
     for (int j = 0; j < KPW; ++j) {
         const int kt = wave + FUSED_WAVES * j;
-        const u32x4_t a = arow == 0 ? *reinterpret_cast<const u32x4_t*>(xs + kt * 32 + kq) : zero4;
+        const u32x4_t a = arow < rows ? *reinterpret_cast<const u32x4_t*>(xs + arow * K + kt * 32 + kq) : zero4;
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, wreg[j]), acc, 0, 0, 0);
     }
-    if (lane < 16) red[wave][lane] = acc[0];  // row 0 of the tile: lanes 0..15, register 0
+    if (lane < 16) {  // rows 0..3 of the tile: lanes 0..15, registers 0..3
+#pragma unroll
+        for (int r = 0; r < FUSED_MAX_ROWS; ++r) red[wave][r][lane] = acc[r];
+    }
     __syncthreads();
-    if (tid < 16) {
+    if (tid < 16 * rows) {
+        const int r = tid >> 4, c = tid & 15;
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < FUSED_WAVES; ++w) sum += red[w][tid];
-        const int col = b * 16 + tid;
-        if (col < n_valid) out[col] = f2bf(bf2f(res[col]) + bfr(sum));
+        for (int w = 0; w < FUSED_WAVES; ++w) sum += red[w][r][c];
+        const int col = b * 16 + c;
+        if (col < n_valid) out[(long)r * ld + col] = f2bf(bf2f(res[(long)r * ld + col]) + bfr(sum));
     }
     ATTN_STAMP(7);
 }
@@ -1083,36 +1092,43 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
-// One stream's decode step: attention + combine + o_proj + residual in one launch (llm_attn_oproj_kernel).  ISST_ERR_UNSUPPORTED-style answer (1) when
-// the shape is outside what the launch covers; the caller then runs the three launches.
-int llm_attn_oproj_supported(const LlmAttnDims& d, int rows, int n_groups, const LlmAttnOne* one, int N, int K, int n_cus) {
-    if (!one || !one->enabled || n_groups != 1 || rows != 1 || one->grp.y != 1) return 0;
-    if (K != d.heads * HD || (K != 32 * FUSED_WAVES * 16 && K != 32 * FUSED_WAVES * 2) || N % 128 != 0) return 0;  // (4096: Llama-3.1-8B; 512: the test configs)
-    const int nwg = N / 16;
-    if (nwg > n_cus || nwg < d.heads || d.kv_heads > 32) return 0;
-    const int slots = d.sys_cap + d.ring_cap;
-    if (slots % 64 != 0 || d.sys_cap % 16 != 0) return 0;
+// One stream's decode step (one row, or the <= 4 beams of a shared-prefix beam group): attention + combine + o_proj + residual in one launch
+// (llm_attn_oproj_kernel).  > 0: the slot splits of the prefix it will use; 0: the shape is outside what the launch covers (the caller runs the three launches).
+int llm_attn_oproj_supported(const LlmAttnDims& d, int rows, int n_groups, const LlmAttnOne* one, int N, int K, int n_cus, int n_beam_wgs) {
+    if (!one || !one->enabled || n_groups != 1 || rows < 1 || rows > FUSED_MAX_ROWS || one->grp.y != rows) return 0;
     const int G = d.heads / d.kv_heads;
     if (G != 1 && G != 2 && G != 4) return 0;
-    int n_splits = nwg / d.kv_heads;  // 64-slot spans (one tile per wave) while they fit the launch
+    if (n_beam_wgs > 0 ? (n_beam_wgs != rows || rows * G > 16 || one->v.n_beams != rows || one->pos_step != 0) : rows != 1) return 0;
+    if (K != d.heads * HD || (K != 32 * FUSED_WAVES * 16 && K != 32 * FUSED_WAVES * 2) || N % 128 != 0) return 0;  // (4096: Llama-3.1-8B; 512: the test configs)
+    const int nwg = N / 16;
+    if (nwg > n_cus || nwg < d.heads * rows || d.kv_heads > 32) return 0;  // (one merging workgroup per (row, head))
+    const int slots = d.sys_cap + d.ring_cap;
+    if (slots % 64 != 0 || d.sys_cap % 16 != 0) return 0;
+    int n_splits = nwg / d.kv_heads - n_beam_wgs;  // 64-slot spans (one tile per wave) while they fit the launch
     if (n_splits > slots / 64) n_splits = slots / 64;
-    if (n_splits < 1 || n_splits > ATTN_MERGE_MAX_SPLITS) return 0;
+    if (n_splits < 1 || n_splits + n_beam_wgs > ATTN_MERGE_MAX_SPLITS) return 0;
     const int tiles_per_split = ((slots / 16 + n_splits - 1) / n_splits + 3) / 4 * 4;
     return tiles_per_split <= 4 ? n_splits : 0;  // (longer caches than 64 slots x the workgroups available: the three-launch path)
 }
 
+// arrive_total / merge_total: the handle's running totals of arrivals per kv head and of merges (the device-side counts only grow); advanced here once the
+// launch is enqueued
 int launch_llm_attn_oproj(const bf16_t* qkv, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool, float* partial,
-                          LlmAttnDims d, int layer, const LlmAttnOne& one, const bf16_t* Wp, int N, int K, int n_valid, const bf16_t* res, bf16_t* out,
-                          bf16_t* attn_row, unsigned* bar, int* err, int n_cus, hipStream_t s, unsigned phase, int mode, int delay) {
-    const int n_splits = llm_attn_oproj_supported(d, 1, 1, &one, N, K, n_cus);
-    if (n_splits <= 0) return ISST_ERR_ARG;
+                          LlmAttnDims d, int layer, const LlmAttnOne& one, int n_beam_wgs, const bf16_t* Wp, int N, int K, int n_valid, const bf16_t* res,
+                          bf16_t* out, int ld, bf16_t* attn_row, unsigned* bar, int* err, int n_cus, hipStream_t s, unsigned* arrive_total,
+                          unsigned* merge_total, int mode, int delay) {
+    const int rows = one.grp.y;
+    const int n_prefix = llm_attn_oproj_supported(d, rows, 1, &one, N, K, n_cus, n_beam_wgs);
+    if (n_prefix <= 0) return ISST_ERR_ARG;
     const int slots = d.sys_cap + d.ring_cap;
-    const int tiles_per_split = ((slots / 16 + n_splits - 1) / n_splits + 3) / 4 * 4;
+    const int tiles_per_split = ((slots / 16 + n_prefix - 1) / n_prefix + 3) / 4 * 4;
+    const int n_splits = n_prefix + n_beam_wgs;
+    const unsigned arrive_target = *arrive_total + (unsigned)n_splits, merge_target = *merge_total + (unsigned)(d.heads * rows);
     const int G = d.heads / d.kv_heads;
     dim3 grid(N / 16), block(FUSED_WAVES * 64);
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, block, 0, s, qkv, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, tiles_per_split, one, Wp, n_valid,
-                           res, out, attn_row, bar, err, mode, phase, delay);
+        hipLaunchKernelGGL(kern, grid, block, 0, s, qkv, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, n_beam_wgs, tiles_per_split, one, Wp,
+                           n_valid, res, out, ld, attn_row, bar, err, mode, arrive_target, merge_target, delay);
     };
     const bool big = K == 32 * FUSED_WAVES * 16;
     switch (G) {
@@ -1121,5 +1137,8 @@ int launch_llm_attn_oproj(const bf16_t* qkv, const bf16_t* rope_cos, const bf16_
         case 4: if (big) go(llm_attn_oproj_kernel<4, 16>); else go(llm_attn_oproj_kernel<4, 2>); break;
         default: return ISST_ERR_ARG;
     }
-    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+    if (hipGetLastError() != hipSuccess) return ISST_ERR_HIP;
+    *arrive_total = arrive_target;
+    *merge_total = merge_target;
+    return ISST_OK;
 }

@@ -10,8 +10,9 @@ import bench
 from infinisst_amd.config import GenConfig, full_config
 cfg = full_config().replace(eos_ids=())
 dev = torch.device("cuda:0")
-gen = GenConfig(max_new_tokens=4, max_llm_cache_size=1000)
-eng, weights, sys_n = bench.build_engine(cfg, 1, 4, dev, 1, None)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1  # argv: num_beams (1 = greedy)
+gen = GenConfig(max_new_tokens=4, max_llm_cache_size=1000, beam=B)
+eng, weights, sys_n = bench.build_engine(cfg, 1, 4, dev, B, None)
 loop = bench.ChunkLoop(eng, cfg, gen, [0], sys_n); loop.import_steady_state(dev)
 for _ in range(4): loop.step()
 torch.cuda.synchronize()
@@ -22,7 +23,7 @@ t0 = t[:, 0].min()
 names = ["entry", "queries rotated (attention wgs)", "tiles done (attention wgs)", "slab stored (attention wgs)", "arriving at barrier 1",
          "head merged + published (wgs < heads)", "all heads seen, workgroup released", "o_proj columns stored"]
 n_attn = int((t[:, 3] > t0).sum())
-print(f"256 workgroups, {n_attn} of them with attention stamps")
+print(f"num_beams {B}: 256 workgroups, {n_attn} of them with attention stamps")
 for i, n in enumerate(names):
     sel = t[:, i] >= t0
     if not sel.any(): continue

@@ -318,6 +318,54 @@ def test_beam_rotated_key_arena_is_bit_identical_to_rotate_on_read(monkeypatch):
             assert torch.equal(xa[b][0], xb[b][0]) and torch.equal(xa[b][1], xb[b][1]), f"chunk {c} beam {b}: KV differs between the two key schedules"
 
 
+def test_beam_fused_attention_oproj_is_bit_identical_to_the_three_launches(monkeypatch):
+    """The B beams of ONE stream are one shared-prefix attention group of B rows; their decode steps run attention + combine + o_proj (+ residual) as one
+    launch (csrc/llm_attn.hip llm_attn_oproj_kernel: prefix splits + one workgroup per beam, B merging waves per head, a B-row GEMV from registers).
+    (ISST_FUSE_ATTN_OPROJ=3: for beam groups the fused launch is opt-in.)  Against ISST_FUSE_ATTN_OPROJ=0 (three launches): the same outputs, the same candidate log-probs bit for bit, the same KV in every beam's arena,
+    across chunks, a pinned system prompt and evictions."""
+    from oracle import agent as oag
+    cfg = toy_config()
+    B = 3
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=45)
+    gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=100, always_cache_system_prompt=True)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 7, stream_id=13)
+    sys_n = len(synth.system_prompt_ids(cfg))
+
+    def run(flag):
+        monkeypatch.setenv("ISST_FUSE_ATTN_OPROJ", flag)
+        eng = Engine(cfg, max_streams=1, max_multiplier=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=100, max_system_prompt=64, max_beams=B)
+        eng.load_weights(w)
+        sid = eng.open_stream()
+        outs, kvs, traces, ckpts, prev = [], [], [], [], []
+        for c in range(7):
+            seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+            prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            eng.beam_trace_begin(B)
+            ids, _ = eng.generate(gen, [sid], [seg], [prompt], [prev[-100:]], system_prompt_size=sys_n if c == 0 else 0)
+            traces.append(eng.beam_trace_end())
+            outs.append(ids[0])
+            prev.extend(ids[0][:-1])
+            cur = eng.stream_info(sid)["llm_cache_len"]
+            kvs.append([kv_of(eng, sid, cur, beam=b) for b in range(B)])
+            ckpts.append(cur)
+            ev = oag.evict(ckpts, cur, gen.max_llm_cache_size, True, sys_n)
+            if ev is not None:
+                ckpts, new_size = ev
+                eng.kv_evict(sid, new_size, sys_n)
+        eng.close()
+        return outs, kvs, traces
+
+    (oa, ka, ta), (ob, kb, tb) = run("3"), run("0")  # 3: the fused launch for beam groups too (opt-in: measured no faster than the three launches)
+    assert oa == ob
+    for c, (xa, xb) in enumerate(zip(ta, tb)):
+        assert len(xa) == len(xb)
+        for step, ((va, ia, sa), (vb, ib, sb)) in enumerate(zip(xa, xb)):
+            assert np.array_equal(va, vb) and np.array_equal(ia, ib) and np.array_equal(sa, sb), f"chunk {c} step {step}: candidates differ between the fused launch and the three launches"
+    for c, (xa, xb) in enumerate(zip(ka, kb)):
+        for b in range(B):
+            assert torch.equal(xa[b][0], xb[b][0]) and torch.equal(xa[b][1], xb[b][1]), f"chunk {c} beam {b}: KV differs between the fused launch and the three launches"
+
+
 @pytest.mark.parametrize("target_wgs", [0, 8])
 def test_beam_shared_prefix_agrees_with_per_beam_arenas(monkeypatch, target_wgs):
     """The shared-prefix attention (one group per stream + one workgroup per beam) against one group per beam, three streams at once, with

@@ -675,6 +675,32 @@ def test_full_size_beam4_teacher_forced_candidates_match_oracle(beam4_ref):
     eng.close()
 
 
+def test_full_size_beam4_fused_launch_is_bit_identical_to_the_three_launches(beam4_ref, monkeypatch):
+    """One stream x beam 4 at Llama-3.1-8B shapes: (19 prefix splits + 4 per-beam workgroups) x 8 kv heads = 184 of the fused launch's 256 workgroups run the
+    shared-prefix attention, waves 4-7 of workgroup h merge head h of the four rows, the o_proj GEMV runs on four rows from registers.  Teacher-forced along
+    the oracle's choices on two engines (ISST_FUSE_ATTN_OPROJ=3 / 0): every candidate log-prob, index and beam score equal bit for bit."""
+    r = beam4_ref
+    B, cfg, sys_n, gen, prompt, ref = r["B"], r["cfg"], r["sys_n"], r["gen"], r["prompt"], r["ref"]
+    ring_cap = 64 * ((1000 + (sys_n + 32) + 10 + 8 + 63) // 64)
+
+    def run(flag):
+        monkeypatch.setenv("ISST_FUSE_ATTN_OPROJ", flag)
+        eng = Engine(cfg, max_streams=1, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=B)
+        eng.load_weights(r["w_dev"])
+        sid = eng.open_stream()
+        _import_state(eng, sid, cfg, sys_n, r["kv0"], r["enc0"], r["src0"], llm_ring_start=ring_cap - 300, enc_ring_start=560)
+        eng.beam_trace_begin(B, [st.next_tokens for st in ref.steps], [st.next_parents for st in ref.steps])
+        outs, _ = eng.generate(gen, [sid], [r["seg"]], [prompt], [r["prev"]], system_prompt_size=0)
+        trace = eng.beam_trace_end()
+        eng.close()
+        return outs, trace
+
+    (oa, ta), (ob, tb) = run("3"), run("0")  # 3: the fused launch for beam groups too (opt-in: measured no faster than the three launches at 4 beams)
+    assert oa == ob and len(ta) == len(tb) == gen.max_new_tokens
+    for step, ((va, ia, sa), (vb, ib, sb)) in enumerate(zip(ta, tb)):
+        assert np.array_equal(va, vb) and np.array_equal(ia, ib) and np.array_equal(sa, sb), f"step {step}: candidates differ between the fused launch and the three launches"
+
+
 @pytest.mark.parametrize("n_streams,folded", [(20, True), (20, False), (40, False)])
 def test_full_size_many_streams_beam4_match_oracle(beam4_ref, n_streams, folded):
     """The reference's production decoding (agents/infinisst.py:86 asserts beam > 1; scripts/infer/infinisst.sh:48) on MANY streams in one call at FULL
