@@ -3,10 +3,10 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04
+O=$R/gpurun_out/r04/${TAG:-collect}   # TAG=final: the re-collection on the last build of the round
 mkdir -p $O
 cd $R
-python3 bench.py > $O/bench_v2.json 2> $O/bench_v2.err
+python3 bench.py > $O/bench.json 2> $O/bench.err
 B="python3 bench.py --no-cpu-baseline --no-streams64 --no-beam4 --no-streams64-beam4 --no-multipliers --host-audio-steps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- $B > $O/prof1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof64 -- $B --no-roofline --streams 64 --steps 16 --warmup 4 --spinup 4 > $O/prof64.log 2>&1
@@ -32,10 +32,14 @@ for f, k, o in (("$F", "gemm_skinny_kernel<1, 2, 5", "gemv_pmc_fetch_size.csv"),
 PY
 rm -rf $O/prof1 $O/prof64 $O/prof128 $O/prof64x4 $O/pmc_fetch $O/pmc_write
 : > $O/streams_sweep.txt
-for n in 1 2 4 8 16 32 48 64 96 128 192 256; do
+for n in 1 2 4 8 16 32 48 64 96 128 192 256; do  # (greedy)
   timeout 600 $B --no-roofline --streams $n --steps 12 --warmup 4 2>/dev/null | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); c=j['config']; print(f\"$n streams: {j['ms_per_step']} ms per chunk, {j['value']} xRT, p50 {j['p50_chunk_latency_ms']} p95 {j['p95_chunk_latency_ms']} host {j['host_ms_per_step']} ms kv {c.get('llm_kv_entries')} evictions {c.get('evictions_per_stream')}\")" >> $O/streams_sweep.txt
 done
 cat $O/streams_sweep.txt
+for n in 4 8 16 32 64 128; do
+  timeout 600 $B --no-roofline --streams $n --beam 4 --steps 8 --warmup 3 2>/dev/null | tail -1 | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print(f\"$n streams x beam 4: {j['ms_per_step']} ms per chunk, {j['value']} xRT, p50 {j['p50_chunk_latency_ms']} p95 {j['p95_chunk_latency_ms']} host {j['host_ms_per_step']} ms\")" >> $O/streams_sweep_beam4.txt
+done
+cat $O/streams_sweep_beam4.txt
 timeout 400 $B --no-roofline --beam 4 > $O/bench_beam4.log 2>&1; tail -1 $O/bench_beam4.log | cut -c1-260
 timeout 600 $B --no-roofline --steps 1875 --warmup 8 > $O/bench_30min_stream.log 2>&1; tail -1 $O/bench_30min_stream.log | cut -c1-400
 ls -la $O
