@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 // count.  Both only grow (wrap-safe compares): launch number `phase` (1, 2, .. counted by the host: the handle's launches are stream-ordered) waits
 // for n_splits x phase arrivals and heads x phase merges.
 // delay: x ~0.4 us that the waves WITHOUT attention work hold their weight loads back -- all 33.5 MB requested at t = 0 put the attention's
-// dependent round trips (queries, keys, values) behind a 4 us queue (profiles/r04/attn_oproj_trace_v1.txt)
+// dependent round trips (queries, keys, values) behind a 4 us queue (profiles/r04/attn_oproj_trace_v2.txt)
 // ------------------------------------------------------------------------------------------------------------------------
 #define FUSED_WAVES 8
 template <int N>

@@ -1,3 +1,6 @@
+"""Bisecting aid for the fused attention + combine + o_proj launch: the same 12 toy-size chunks (free-running, evictions) through engines created with
+ISST_FUSE_ATTN_OPROJ = 1 / 0 / 1 / 2 -- fused against three launches, fused against itself (a race would differ from run to run), and fused attention +
+combine with a separate o_proj (which half differs?).  This is how the 1-ulp differences from compiler-chosen fma contraction were found."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from infinisst_amd import synth
