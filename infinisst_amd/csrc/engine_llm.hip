@@ -394,6 +394,7 @@ struct BeamHyps {  // BeamHypotheses, patch_hf.py:278-302 + [3P] is_done (early_
 
 struct BeamStream {  // host state of one stream during a beam call
     std::vector<std::vector<int>> seq;  // per beam: prompt + generated
+    std::vector<std::vector<int>> seq_next;  // (scratch of the scorer, kept across steps: 64 streams x 4 beams made the scorer's allocations a 270 us GPU-idle gap per step)
     std::vector<float> score;
     BeamHyps hyps;
     bool done = false;
@@ -465,8 +466,16 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], rows_len[i], true);
     CHK(flush_copies(h, ops, mh, md, st));
 
+    // ISST_HOST_TRACE=2: where the host's time between two forward passes of a beam step goes (one line per call)
+    static const bool bt_on = std::getenv("ISST_HOST_TRACE") && std::atoi(std::getenv("ISST_HOST_TRACE")) == 2;
+    using bclock = std::chrono::steady_clock;
+    double bt_tail = 0, bt_sync = 0, bt_score = 0, bt_copies = 0, bt_meta = 0, bt_enq = 0;
+    auto bt_us = [](bclock::time_point a, bclock::time_point b2) { return std::chrono::duration<double, std::micro>(b2 - a).count(); };
+    bclock::time_point bt0 = bclock::now(), bt1;
+    auto bt_lap = [&](double& acc) { if (bt_on) { bt1 = bclock::now(); acc += bt_us(bt0, bt1); bt0 = bt1; } };
     int step = 0;  // tokens already chosen per beam
     while (true) {
+        if (bt_on) bt0 = bclock::now();
         const int rows_per = step == 0 ? 1 : B;  // step 0: only beam 0 carries a finite score (:767-771)
         const int rows = n * rows_per;
         // ---- log_softmax -> processors (on log-probs) -> per-row top-k ----
@@ -518,7 +527,9 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         } else {
             // (the final selection stores its <= 32 candidates per row straight into the pinned host arrays: no device copy, no two D2H launches per step)
             CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val_host, h->top_idx_host, rows, st));
+            bt_lap(bt_tail);
             HIPCHK(hipStreamSynchronize(st));
+            bt_lap(bt_sync);
             CHK(check_fused_ao(h));
             h->kv_ops_used = 0;  // every earlier copy batch has run
         }
@@ -526,6 +537,11 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         // ---- scorer (beam_search_process, :43-157) ----
         bool all_done = true;
         std::vector<std::vector<int>> parents(n), next_tok(n);
+        struct Cand { float val; long flat; };
+        std::vector<Cand> cands;
+        std::vector<float> nscore;
+        cands.reserve((size_t)rows_per * n_keep);
+        nscore.reserve(B);
         for (int i = 0; i < n; ++i) {
             BeamStream& S = bs[i];
             const int prompt_len = prompt_lens[i];
@@ -541,8 +557,9 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 S.score.assign(B, 0.f);
                 continue;
             }
-            struct Cand { float val; long flat; };
-            std::vector<Cand> cands;
+            ntok.reserve(B);
+            npar.reserve(B);
+            cands.clear();
             for (int b = 0; b < rows_per; ++b)
                 for (int j = 0; j < n_keep; ++j) {
                     const int r = i * rows_per + b;
@@ -562,10 +579,10 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 }
                 h->btrace.push_back(std::move(ts));
             }
-            std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b2) { return a.val > b2.val || (a.val == b2.val && a.flat < b2.flat); });
+            std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b2) { return a.val > b2.val || (a.val == b2.val && a.flat < b2.flat); });  // (a strict total order: flat indices are distinct -- no stable_sort, which allocates a buffer per call)
             if ((int)cands.size() > n_keep) cands.resize(n_keep);
             const int cur_len = (int)S.seq[0].size() + 1;
-            std::vector<float> nscore;
+            nscore.clear();
             for (size_t rank = 0; rank < cands.size(); ++rank) {
                 const int b = (int)(cands[rank].flat / V), tok = (int)(cands[rank].flat % V);
                 bool is_eos = false;
@@ -608,12 +625,19 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 }
             }
             // input_ids = cat(input_ids[beam_idx], tokens)  (:899)
-            std::vector<std::vector<int>> nseq(B);
-            for (int b = 0; b < B; ++b) { nseq[b] = S.seq[npar[b]]; nseq[b].push_back(ntok[b]); }
+            std::vector<std::vector<int>>& nseq = S.seq_next;  // (capacity survives the swap below: no allocation after the first steps)
+            nseq.resize(B);
+            for (int b = 0; b < B; ++b) {
+                const std::vector<int>& src = S.seq[npar[b]];
+                nseq[b].reserve(src.size() + 1 + p->max_new_tokens);
+                nseq[b].assign(src.begin(), src.end());
+                nseq[b].push_back(ntok[b]);
+            }
             S.seq.swap(nseq);
             S.score = nscore;
             all_done = all_done && S.done;
         }
+        bt_lap(bt_score);
         CHK(flush_copies(h, ops, mh, md, st));  // hypothesis tails first: the reorder below overwrites arenas
         ++step;
         // ---- reorder the tails (:910-913): new beam b continues parent npar[b].  Like the reference this happens BEFORE
@@ -632,6 +656,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
             }
             CHK(flush_copies(h, ops, mh, md, st));
         }
+        bt_lap(bt_copies);
         if (all_done || step >= p->max_new_tokens) break;  // :920
         // ---- next forward pass: one row per (stream, beam).  Shared-prefix form (llm_attn.hip, LlmStreamView::n_beams): the B rows of a
         //      stream are ONE attention group over arena 0 for everything older than this chunk's generated tokens (identical in all
@@ -664,9 +689,14 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                 }
             }
         }
+        bt_lap(bt_meta);
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
         CHK(llm_forward(h, md, nr, nr, shared ? n : nr, shared ? B : 1, false, nullptr, st, &mh, 0, 0, shared ? B : 0));
+        bt_lap(bt_enq);
     }
+    if (bt_on)
+        std::fprintf(stderr, "[isst beam host] %d streams x %d beams, %d steps: us per step -- sampling tail enqueue %.0f, wait for the candidates %.0f, scorer %.0f, KV copies %.0f, metadata %.0f, forward enqueue %.0f\n",
+                     n, B, step, bt_tail / step, bt_sync / step, bt_score / step, bt_copies / step, bt_meta / step, bt_enq / step);
 
     // ---- finalize (:159-275): open beams become hypotheses, the best one wins ----
     for (int i = 0; i < n; ++i) {
