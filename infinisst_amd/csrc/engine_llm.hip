@@ -699,10 +699,10 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
                      n, B, step, bt_tail / step, bt_sync / step, bt_score / step, bt_copies / step, bt_meta / step, bt_enq / step);
 
     // ---- finalize (:159-275): open beams become hypotheses, the best one wins ----
+    std::vector<size_t> best_of(n);
     for (int i = 0; i < n; ++i) {
         BeamStream& S = bs[i];
         const int prompt_len = prompt_lens[i];
-        const int P0 = total0[i] + rows_len[i];
         if (!S.done)
             for (int b = 0; b < B; ++b) {
                 BeamHyp hyp;
@@ -716,21 +716,28 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         size_t best = 0;
         for (size_t q = 1; q < S.hyps.beams.size(); ++q)
             if (S.hyps.beams[q].score >= S.hyps.beams[best].score) best = q;  // sorted(...).pop(): the last of equal scores
-        const BeamHyp& win = S.hyps.beams[best];
-        // make every arena of the stream hold the winner's tail
-        if (win.fed > 0) {
-            int src_buf = win.buf;
-            int skip_beam = -1;
-            if (win.buf < 0) {  // still in an arena: stage it through temporary 0
-                skip_beam = -1 - win.buf;
-                push_copy(h, ops, stream_ids[i], skip_beam, 0, P0, win.fed, false);
-                CHK(flush_copies(h, ops, mh, md, st));
-                src_buf = 0;
-            }
-            for (int b = 0; b < B; ++b)
-                if (b != skip_beam) push_copy(h, ops, stream_ids[i], b, src_buf, P0, win.fed, true);
-            CHK(flush_copies(h, ops, mh, md, st));
-        }
+        best_of[i] = best;
+    }
+    // make every arena of a stream hold its winner's tail -- TWO copy launches for the whole call (all streams' "winner still in an arena: stage it
+    // through temporary 0", then all streams' "temporary / hypothesis buffer -> the arenas"), not two per stream: at 64 streams those were 128 launches of
+    // 27 us + a 13 us gap each per chunk, 4.5 % of the step (profiles/r04/trace_busy_prof64x4.txt)
+    for (int i = 0; i < n; ++i) {
+        const BeamHyp& win = bs[i].hyps.beams[best_of[i]];
+        if (win.fed > 0 && win.buf < 0) push_copy(h, ops, stream_ids[i], -1 - win.buf, 0, total0[i] + rows_len[i], win.fed, false);
+    }
+    CHK(flush_copies(h, ops, mh, md, st));
+    for (int i = 0; i < n; ++i) {
+        const BeamHyp& win = bs[i].hyps.beams[best_of[i]];
+        if (win.fed <= 0) continue;
+        const int skip_beam = win.buf < 0 ? -1 - win.buf : -1, src_buf = win.buf < 0 ? 0 : win.buf;
+        for (int b = 0; b < B; ++b)
+            if (b != skip_beam) push_copy(h, ops, stream_ids[i], b, src_buf, total0[i] + rows_len[i], win.fed, true);
+    }
+    CHK(flush_copies(h, ops, mh, md, st));
+    for (int i = 0; i < n; ++i) {
+        const BeamHyp& win = bs[i].hyps.beams[best_of[i]];
+        const int prompt_len = prompt_lens[i];
+        const int P0 = total0[i] + rows_len[i];
         StreamState& ss = h->streams[stream_ids[i]];
         ss.llm_total = P0 + win.fed;
         ss.chunks++;
