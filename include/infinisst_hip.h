@@ -245,7 +245,9 @@ int isst_op_gemm_splitk_layernorm(const uint16_t* A, int64_t lda, const uint16_t
                                   int ksplit, float eps, void* hip_stream);
 /* profiling aid: override the GEMM launch heuristic (waves per workgroup, 16-row n-tiles per workgroup); 0 = automatic */
 int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block);
-/* profiling aid: workgroups the decoder attention wants chip-wide before a workgroup's slot span grows beyond 64; 0 = default */
+/* profiling / test aid: workgroups the decoder attention wants chip-wide before a workgroup's slot span grows beyond 64; 0 = default.  1 = one span per
+ * (stream, kv head), which also folds a shared-prefix beam group's per-beam keys into that workgroup (what 16+ streams x beams select by themselves);
+ * n < 0 = the target -n - 1 with the beams' per-beam workgroups kept at any stream count (A/B runs).  Bits 16.. : the same target for the prefill form. */
 int isst_op_set_attn_tuning(int target_workgroups);
 int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps,
                       int gelu, void* hip_stream);

@@ -366,10 +366,11 @@ def test_beam_fused_attention_oproj_is_bit_identical_to_the_three_launches(monke
             assert torch.equal(xa[b][0], xb[b][0]) and torch.equal(xa[b][1], xb[b][1]), f"chunk {c} beam {b}: KV differs between the fused launch and the three launches"
 
 
-@pytest.mark.parametrize("target_wgs", [0, 8])
+@pytest.mark.parametrize("target_wgs", [0, 8, 1])
 def test_beam_shared_prefix_agrees_with_per_beam_arenas(monkeypatch, target_wgs):
     """The shared-prefix attention (one group per stream + one workgroup per beam) against one group per beam, three streams at once, with
-    the default slot splits and with long multi-tile spans (target 8 workgroups: the running-softmax form of the kernel).  The two cut the
+    the default slot splits, with long multi-tile spans (target 8 workgroups: the running-softmax form of the kernel) and FOLDED (target 1: one span per
+    (stream, kv head), whose waves walk the beams' own tiles behind the prefix and write the output themselves -- what 16+ streams select by default).  The two cut the
     softmax differently, so a sequence may part at a near-tie (random toy weights give flat distributions: the engine and the oracle part in 2 of 8
     cases too): 18 independent cases, a clear majority must be identical -- a wrong mask or tile would leave none."""
     from infinisst_amd.engine import load_library
@@ -404,19 +405,23 @@ def test_beam_shared_prefix_agrees_with_per_beam_arenas(monkeypatch, target_wgs)
     assert len(a) == 18 and same >= 11
 
 
-def test_beam_shared_prefix_survives_evictions_and_ring_wrap():
+@pytest.mark.parametrize("folded,new_tokens", [(False, 7), (True, 7), (True, 20)])
+def test_beam_shared_prefix_survives_evictions_and_ring_wrap(folded, new_tokens):
     """Shared-prefix beam attention over a small, wrapping KV ring: 10 chunks with an eviction after most of them, so that the per-beam
-    tail tiles straddle the ring's end and the pinned system prompt.  After every chunk each beam's arena must hold the KV of the winner
+    tail tiles straddle the ring's end and the pinned system prompt.  `folded`: the form in which ONE workgroup per (stream, kv head) walks the prefix and
+    then the beams' own tiles (forced through the span knob; 20 new tokens: own keys over two or three tiles, some of them wrapping).  After every chunk each beam's arena must hold the KV of the winner
     path -- compared (within two bf16 roundings of a row's largest element, see test_beam_kv_bookkeeping_is_exact) with a greedy stream
     that is teacher-forced along the same path and evicted in lockstep."""
     from oracle import agent as oag
     cfg = toy_config().replace(eos_ids=())
     B = 4
-    gen_b = GenConfig(max_new_tokens=7, beam=B, max_llm_cache_size=150, always_cache_system_prompt=True)
-    gen_g = GenConfig(max_new_tokens=7, beam=1, max_llm_cache_size=150, always_cache_system_prompt=True)
+    from infinisst_amd.engine import load_library
+    gen_b = GenConfig(max_new_tokens=new_tokens, beam=B, max_llm_cache_size=150, always_cache_system_prompt=True)
+    gen_g = GenConfig(max_new_tokens=new_tokens, beam=1, max_llm_cache_size=150, always_cache_system_prompt=True)
     w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=46)
-    eng = Engine(cfg, max_streams=2, max_multiplier=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=150, max_system_prompt=64, max_beams=B)
+    eng = Engine(cfg, max_streams=2, max_multiplier=1, max_prompt_len=96, max_new_tokens=max(8, new_tokens), max_llm_cache_size=150, max_system_prompt=64, max_beams=B)
     eng.load_weights(w)
+    lib = load_library()
     a, g = eng.open_stream(), eng.open_stream()
     audio = synth.synthetic_audio(cfg.chunk_samples * 10, stream_id=21)
     sys_n = len(synth.system_prompt_ids(cfg))
@@ -425,7 +430,11 @@ def test_beam_shared_prefix_survives_evictions_and_ring_wrap():
         seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
         prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
         pin = sys_n if c == 0 else 0
-        outs, _ = eng.generate(gen_b, [a], [seg], [prompt], [prev[-100:]], system_prompt_size=pin)
+        lib.isst_op_set_attn_tuning(1 if folded else 0)
+        try:
+            outs, _ = eng.generate(gen_b, [a], [seg], [prompt], [prev[-100:]], system_prompt_size=pin)
+        finally:
+            lib.isst_op_set_attn_tuning(0)
         win = outs[0]
         outs_g, _ = eng.generate(gen_g, [g], [seg], [prompt], [prev[-100:]], system_prompt_size=pin, forced_tokens=[win])
         assert outs_g[0] == win
