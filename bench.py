@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
     ap.add_argument("--cpu-chunks", type=int, default=4, help="steady-state chunks the CPU baseline runs")
     ap.add_argument("--attn-target-wgs", type=int, default=0, help="profiling aid: isst_op_set_attn_tuning (0 = library default)")
+    ap.add_argument("--gemm-tuning", type=int, default=0, help="profiling aid: isst_op_set_gemm_tuning(w, 0) (0 = library default; e.g. 900010 + variant: gemm_wide.hip's A/B variants)")
     ap.add_argument("--cpu-layers", type=int, default=32, help="Llama layers actually run by the CPU baseline (time is scaled to all layers)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py starts the ranks itself (0 = pick a free one)")
     ap.add_argument("--dry-run", action="store_true",
@@ -712,6 +713,9 @@ def main():
     if args.attn_target_wgs:
         from infinisst_amd.engine import load_library
         load_library().isst_op_set_attn_tuning(args.attn_target_wgs)
+    if args.gemm_tuning:
+        from infinisst_amd.engine import load_library
+        load_library().isst_op_set_gemm_tuning(args.gemm_tuning, 0)
     mine = S.assign_streams(args.streams * world, rank, world)  # global stream ids of this rank: stream_id mod n_gpu
     loop = ChunkLoop(eng, cfg, gen, mine, sys_n, host_audio=args.host_audio)
     if not args.cold_start:

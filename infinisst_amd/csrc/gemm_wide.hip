@@ -434,6 +434,16 @@ template <int EPI>
 static int launch_wide_epi(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 64) return launch_wide_cfg<4, 4, 6, EPI>(g, stream);
     if (g.M <= 128) return launch_wide_cfg<8, 4, 6, EPI>(g, stream);
+    // 129..256 rows: one 256-row workgroup per (column block, K slice) -- or two 128-row ones where BOTH row blocks still fit the chip in one round
+    // (o_proj: 32 column blocks x 4 slices x 2 = 256 workgroups).  A 256-row workgroup is bound by its own matrix pipes (one consumer wave per SIMD:
+    // 16 x 8 MFMAs per k-step), and with 128 workgroups half the CUs idle; the twin row blocks read the same weights at the same time on the same XCD
+    // (their linear ids differ by a multiple of 8).  GEMM + reducing norm, us, one 256-row / two 128-row workgroups: o_proj 27.5 / 23.7 (192 rows: 26.2 /
+    // 22.8); q/k/v 30.1 / 31.6 and down_proj 46.0 / 46.1 at their best slice counts -- no gain, they keep the 256-row form (profiles/r04/wide_probe_row_blocks.txt).
+    // (variant bit 0: two row blocks for every K-sliced launch, bit 1: for every launch, bit 2: never -- A/B runs)
+    const int ks = g.epi == EPI_PARTIAL && g.ksplit > 1 ? g.ksplit : 1;
+    const bool twin = (g_wide_variant & 2) || ((g_wide_variant & 1) && EPI == EPI_PARTIAL) ||
+                      (!(g_wide_variant & 4) && EPI == EPI_PARTIAL && (long)((g.N / 16 + WIDE_NT - 1) / WIDE_NT) * ks * 2 <= 256);
+    if (twin) return launch_wide_cfg<8, 4, 6, EPI>(g, stream);
     return launch_wide_cfg<16, 2, 4, EPI>(g, stream);
 }
 
