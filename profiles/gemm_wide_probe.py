@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from infinisst_amd import engine as E
-dev = "cuda"; lib = E.load_library(); P = E._ptr
+dev = "cuda"; lib = E.load_library(os.environ.get("LIB")); E._lib = lib; P = E._ptr  # LIB=path: a variant build of the library
 ROWS = [int(x) for x in os.environ.get("ROWS", "128,256,96,192").split(",")]
 VARIANTS = [int(x) for x in os.environ.get("VARIANTS", "0,1,2,3").split(",")]
 SH = {"qkv": (6144, 4096, "none", (1, 2, 4, 8)), "o_proj": (4096, 4096, "res", (4, 8)), "gate_up": (28672, 4096, "swiglu", (1,)), "down": (4096, 14336, "res", (4, 8)),
