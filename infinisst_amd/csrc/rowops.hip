@@ -219,6 +219,37 @@ int launch_conv0(const bf16_t* audio, long audio_batch, const bf16_t* w, const b
 // ------------------------------------------------------------------------------------------------
 // Optional split-K prologue (slabs != null; encoder out_proj / fc2 at 65..1024 rows): x = bf16(x + bf16(sum of slabs + bias)) is
 // written back first -- the residual update of the projection whose K slices the dense kernel left as fp32 slabs -- then normalised.
+// acc[0..7] = sum over the K slices' fp32 slabs, ascending slice order (the order every reducer of this library uses), of the 8 elements at `off`.
+// Up to 8 slices: every load is issued before the first add (the runtime-bounded loop below waits for each slice's round trip in turn: at 256 rows one
+// workgroup per row then sits through 4-8 serial round trips); slices past n_slabs re-read slice 0 and are dropped by a select AFTER the add, so the
+// arithmetic is exactly the loop's.  rmsnorm_reduce_kernel: 7.08 -> 6.05 us per launch over a 128-stream step (A/B of library builds, same box).
+__device__ __forceinline__ void slab_sum8(const float* __restrict__ slabs, long slab_stride, int n_slabs, long off, float (&acc)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (n_slabs <= 8) {
+        f32x4_t a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float* sp = slabs + (long)(k < n_slabs ? k : 0) * slab_stride + off;
+            a[k] = *reinterpret_cast<const f32x4_t*>(sp);
+            b[k] = *reinterpret_cast<const f32x4_t*>(sp + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool on = k < n_slabs;
+            acc[0] = on ? acc[0] + a[k].x : acc[0]; acc[1] = on ? acc[1] + a[k].y : acc[1]; acc[2] = on ? acc[2] + a[k].z : acc[2]; acc[3] = on ? acc[3] + a[k].w : acc[3];
+            acc[4] = on ? acc[4] + b[k].x : acc[4]; acc[5] = on ? acc[5] + b[k].y : acc[5]; acc[6] = on ? acc[6] + b[k].z : acc[6]; acc[7] = on ? acc[7] + b[k].w : acc[7];
+        }
+        return;
+    }
+    for (int k = 0; k < n_slabs; ++k) {
+        const float* sp = slabs + (long)k * slab_stride + off;
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), b = *reinterpret_cast<const f32x4_t*>(sp + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    }
+}
+
 template <int STEPS>
 __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ b, bf16_t* out, long ldo,
@@ -238,7 +269,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
             unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
             if (slabs) {
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pb[8];
-                for (int k = 0; k < n_slabs; ++k) {
+                for (int k = 0; k < n_slabs; ++k) {  // (slab_sum8's loads-first form measured SLOWER here at many rows -- 16.4 -> 20.5 us at 128 streams: one wave per row, registers)
                     const float* sp = slabs + (long)k * slab_stride + row * C + c;
                     const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), a2 = *reinterpret_cast<const f32x4_t*>(sp + 4);
                     acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
@@ -384,13 +415,8 @@ __global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(const float* __rest
     for (int s = 0; s < STEPS; ++s) {
         const int c = (threadIdx.x + 256 * s) * 8;
         if (c < D) {
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < n_slabs; ++k) {
-                const float* sp = slabs + (long)k * slab_stride + row * D + c;
-                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), b = *reinterpret_cast<const f32x4_t*>(sp + 4);
-                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-            }
+            float acc[8];
+            slab_sum8(slabs, slab_stride, n_slabs, row * D + c, acc);
             unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + bfr(acc[j]));
@@ -441,7 +467,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (c >= N) return;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < n_slabs; ++k) {
+    for (int k = 0; k < n_slabs; ++k) {  // (768+ small workgroups: the loads-first form of slab_sum8 changes nothing here, 5.1 us either way)
         const float* sp = slabs + (long)k * slab_stride + row * N + c;
         const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), b = *reinterpret_cast<const f32x4_t*>(sp + 4);
         acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
