@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 //   B  hand-off 1: an attention workgroup adds to ITS kv head's arrival count; workgroup h < heads (x rows: one per (row, head)) polls the count of head h's kv head (on wave 4,
 //      whose own loads have landed: a poll is a load, and waiting for it waits for every older load), merges head h's slabs (common.h
 //      attn_merge_*, the combine kernel's arithmetic), stores the 128 outputs write-through and adds to the merge count (8 replicas);
-//   C  hand-off 2: every workgroup polls one replica for heads x phase merges, stages the 8 KB attention row in LDS and runs the skinny GEMV's
+//   C  hand-off 2: every workgroup polls one replica of the merge count for this launch's total, stages the 8 KB attention row in LDS and runs the skinny GEMV's
 //      arithmetic from registers: wave w multiplies k-tiles w, w + 8, .. in ascending order, the eight partial tiles are summed in wave order,
 //      out = res + bf16(sum) -- the operations of gemm_skinny_kernel<1, 1, EPI_RES, nt, AMODE 0> at 8 waves in the same order, so the result is
 //      bit-identical to the three-launch path (tests/test_gpu_engine.py, test_gpu_fullsize.py).
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 // in its first form against 17.7 us + two boundaries for the three launches); one stream 31.8 -> 30.95 ms per chunk.  What is left is a chain of
 // ~6 memory round trips behind the attention (store ack, count, slabs, store ack, count, row), each 0.6-1 us while the weights stream.
 // bar: 40 x 128-byte lines of unsigned -- [0..31] one arrival count per kv head (the attention workgroups of that head), [32..39] replicas of the merge
-// count.  Both only grow (wrap-safe compares): launch number `phase` (1, 2, .. counted by the host: the handle's launches are stream-ordered) waits
-// for n_splits x phase arrivals and heads x phase merges.
+// count.  Both only grow (wrap-safe compares): the host keeps the totals every enqueued launch will have brought them to (the handle's launches are
+// stream-ordered) and passes a launch its own: arrive_target = arrivals per kv head so far + this launch's splits, merge_target = merges so far + heads x rows.
 // delay: x ~0.4 us that the waves WITHOUT attention work hold their weight loads back -- all 33.5 MB requested at t = 0 put the attention's
 // dependent round trips (queries, keys, values) behind a 4 us queue (profiles/r04/attn_oproj_trace_v2.txt)
 // ------------------------------------------------------------------------------------------------------------------------
