@@ -249,6 +249,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->ltickets_n = std::max(DL, (H + 2 * KV) * 128) / 32 + 16;  // a ticketed launch indexes tickets[blockIdx.x]; its narrowest workgroup spans 32 columns (gemm_mid NP = 1)
     h->ltickets = h->dalloc<int>((size_t)h->ltickets_n, true);
     h->fuse_bar = h->dalloc<unsigned>(40 * 32, true);
+    h->fuse_row = h->dalloc<unsigned>((size_t)4 * H * 64 * 2, true);
     h->attn_cnt = h->dalloc<int>(64, true);  // arrival counters of the in-kernel split-KV combine (llm_attn.hip), one per kv head; zero between launches
     h->lslab_elems = (long)LLM_SLAB_ROWS * std::max(DL, (H + 2 * KV) * 128);
     h->lslab = h->dalloc<float>((size_t)h->lslab_elems);

@@ -120,6 +120,7 @@ struct isst_handle {
                                   // (profiles/r04/fused_attn_oproj_beam4_ab_v2.txt)
     bool fuse_ao_used = false;    // a fused launch was enqueued since the error word (tok_host[tok_cap + 8]) was last checked
     unsigned* fuse_bar = nullptr; // its hand-off counters (40 x 128 B, only ever grow)
+    unsigned* fuse_row = nullptr; // its merged attention rows as {two bf16, tag} words: [4 rows][heads x 64] x 8 B
     unsigned fuse_arrive_total = 0, fuse_merge_total = 0;  // what its counters will read once every enqueued launch has run (the next launch's targets start here)
     int fuse_ao_delay = 4;        // ISST_FUSE_AO_DELAY (swept 0..16: 0-4 equal within noise, 30.93-31.06 ms per chunk; 12: 31.5; 16: 32.0): x ~0.4 us the waves without attention work hold their weight loads back
     int n_cus = 0;                // compute units of the device (hipDeviceProp_t::multiProcessorCount)

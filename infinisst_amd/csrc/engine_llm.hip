@@ -238,7 +238,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
         if (fused_ao) {
             h->fuse_ao_used = true;
             CHK(launch_llm_attn_oproj(h->lqkv, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->llm_v, h->lpartial, h->adims, l, one, n_beam_wgs, L.o.wp, L.o.N, L.o.K,
-                                      L.o.n_valid, h->lx + (long)one.grp.x * DL, h->lx + (long)one.grp.x * DL, DL, h->lattn + (long)one.grp.x * H * 128, h->fuse_bar,
+                                      L.o.n_valid, h->lx + (long)one.grp.x * DL, h->lx + (long)one.grp.x * DL, DL, h->lattn + (long)one.grp.x * H * 128, h->fuse_row, h->fuse_bar,
                                       h->tok_host + h->tok_cap + 8, h->n_cus, st, &h->fuse_arrive_total, &h->fuse_merge_total, h->fuse_ao_mode, h->fuse_ao_delay));
         } else
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,

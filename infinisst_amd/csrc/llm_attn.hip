@@ -519,22 +519,25 @@ __global__ __launch_bounds__(256, MULTI ? 2 : 1) void llm_attn_partial_kernel(co
 //      vmcnt(KPW) then means "slabs in memory" while the weights stay in flight) and meet each other at LDS counters, not at the workgroup barrier.
 //      All other waves hold their loads back by `delay` x ~0.4 us: 33.5 MB requested at t = 0 put a 4 us queue in front of the attention's
 //      dependent round trips (queries rotated at 3.5 us instead of 1.0, profiles/r04/attn_oproj_trace_v*.txt).
-//   B  hand-off 1: an attention workgroup adds to ITS kv head's arrival count; workgroup h < heads (x rows: one per (row, head)) polls the count of head h's kv head (on wave 4,
-//      whose own loads have landed: a poll is a load, and waiting for it waits for every older load), merges head h's slabs (common.h
-//      attn_merge_*, the combine kernel's arithmetic), stores the 128 outputs write-through and adds to the merge count (8 replicas);
-//   C  hand-off 2: every workgroup polls one replica of the merge count for this launch's total, stages the 8 KB attention row in LDS and runs the skinny GEMV's
-//      arithmetic from registers: wave w multiplies k-tiles w, w + 8, .. in ascending order, the eight partial tiles are summed in wave order,
-//      out = res + bf16(sum) -- the operations of gemm_skinny_kernel<1, 1, EPI_RES, nt, AMODE 0> at 8 waves in the same order, so the result is
-//      bit-identical to the three-launch path (tests/test_gpu_engine.py, test_gpu_fullsize.py).
+//   B  hand-off 1: an attention workgroup adds to ITS kv head's arrival count; workgroup h < heads (x rows: one per (row, head)) polls the count of head h's
+//      kv head (on wave 4, whose own loads have landed: a poll is a load, and waiting for it waits for every older load), merges head h's slabs (common.h
+//      attn_merge_*, the combine kernel's arithmetic) and stores the 128 outputs write-through as 8-byte words {two bf16 outputs, tag};
+//   C  hand-off 2 carries its own validity: tag = the handle's running total of merges after this launch, so a word is either this launch's or it is read
+//      again -- no store acknowledgement, no counter.  Wave 4 of every workgroup polls ONE word as a gate, then all threads read the row (8 KB of outputs
+//      = 16 KB of words) until every word carries the tag, stage it in LDS and run the skinny GEMV's arithmetic from registers: wave w multiplies
+//      k-tiles w, w + 8, .. in ascending order, the eight partial tiles are summed in wave order, out = res + bf16(sum) -- the operations of
+//      gemm_skinny_kernel<1, 1, EPI_RES, nt, AMODE 0> at 8 waves in the same order, so the result is bit-identical to the three-launch path
+//      (tests/test_gpu_engine.py, test_gpu_fullsize.py).
 // Memory ordering across workgroups is the protocol of the in-launch combine above: sc1 stores, a counted wait for them, relaxed agent-scope
 // counter adds, sc1 loads on the reading side.  The launch needs every workgroup resident at once (the host checks N / 16 <= CU count; the device must
 // not be shared with another process' kernels); every wait is bounded and raises *err (pinned host memory) instead of hanging.
-// Measured (profiles/r04/attn_oproj_trace_v4.txt, fused_attn_oproj_ab_v4.txt): the launch ends 12.0 us after its first wave starts (rocprofv3: 15.2 us
-// in its first form against 17.7 us + two boundaries for the three launches); one stream 31.8 -> 30.95 ms per chunk.  What is left is a chain of
-// ~6 memory round trips behind the attention (store ack, count, slabs, store ack, count, row), each 0.6-1 us while the weights stream.
-// bar: 40 x 128-byte lines of unsigned -- [0..31] one arrival count per kv head (the attention workgroups of that head), [32..39] replicas of the merge
-// count.  Both only grow (wrap-safe compares): the host keeps the totals every enqueued launch will have brought them to (the handle's launches are
-// stream-ordered) and passes a launch its own: arrive_target = arrivals per kv head so far + this launch's splits, merge_target = merges so far + heads x rows.
+// Measured (profiles/r04/attn_oproj_trace_v4.txt, _v5_tagged_row.txt, fused_attn_oproj_ab_v4.txt, _v5_tagged_row.txt): the launch ends 11.8 us after its first wave
+// starts (12.9 before the tagged row; rocprofv3: 15.2 us in its first form against 17.7 us + two boundaries for the three launches); one stream 31.8 -> 30.9 ms per
+// chunk.  What is left is a chain of memory round trips behind the attention (store ack, count, slabs, tagged row), each 0.6-1 us while the weights stream.
+// bar: 40 x 128-byte lines of unsigned -- [0..31] one arrival count per kv head (the attention workgroups of that head) ([32..39]: unused since the merged row
+// carries tags).  The counts only grow (wrap-safe compares): the host keeps the totals every enqueued launch will have brought them to (the handle's launches
+// are stream-ordered) and passes a launch its own: arrive_target = arrivals per kv head so far + this launch's splits; merge_target = merges so far + heads x
+// rows, used as the tag of this launch's row words.
 // delay: x ~0.4 us that the waves WITHOUT attention work hold their weight loads back -- all 33.5 MB requested at t = 0 put the attention's
 // dependent round trips (queries, keys, values) behind a 4 us queue (profiles/r04/attn_oproj_trace_v2.txt)
 // ------------------------------------------------------------------------------------------------------------------------
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(con
                                                                               bf16_t* vtpool, float* __restrict__ partial, LlmAttnDims d, int layer,
                                                                               int n_splits, int n_extra, int tiles_per_split, LlmAttnOne one,
                                                                               const bf16_t* __restrict__ Wp, int n_valid, const bf16_t* res,
-                                                                              bf16_t* out, int ld, bf16_t* attn_row, unsigned* bar, int* err, int mode,
+                                                                              bf16_t* out, int ld, bf16_t* attn_row, unsigned* trow, unsigned* bar, int* err, int mode,
                                                                               unsigned arrive_target, unsigned merge_target, int delay) {
     // n_splits: slabs per (row, head) = the attention workgroups of a kv head (n_extra of them the per-beam workgroups of a shared-prefix beam group);
     // res / out / attn_row: row one.grp.x of the hidden state (row stride ld) and of the attention output (row stride K)
@@ -609,6 +612,11 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(con
         hold();
         issue_w();
     }
+    // hand-off 2 carries its own validity: the merged row travels as 8-byte words {two bf16 outputs, tag}, tag = merge_target (unique per launch: the
+    // running total of merges, which also makes stale words from any earlier launch recognisable).  A reader needs no count and the writer no store
+    // acknowledgement and no atomic: a word is either this launch's or it is read again (saves the ack wait + the counter's propagation, ~1 us).
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(trow, 0, rows * K * 4, 0x00020000);  // [rows][K / 2] words
+    const unsigned tag = merge_target;
     if (wave == 4) {  // (a wave whose weights went out early and have landed: every poll below is a load, and waiting for it waits for all older loads)
         // ---- B: workgroup b merges (row r0 + b / heads, head b % heads), once the workgroups of that head's kv head have arrived ----
         if (b < H * rows) {
@@ -616,26 +624,48 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(con
             if (fused_wait(bar, mh / G, arrive_target, err)) {
                 AttnMergeLoads<ATTN_MERGE_MAX_SPLITS> ldm;
                 attn_merge_issue<ATTN_MERGE_MAX_SPLITS, 16>(partial + ((long)(r0 + mr) * H + mh) * n_splits * ATTN_SLAB, n_splits, lane, ldm);
-                const uint32_t v = attn_merge_finish<ATTN_MERGE_MAX_SPLITS>(ldm, n_splits, lane);
-                const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(attn_row, 0, rows * K * 2, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b32(v, ars, (unsigned)(mr * K + mh * 128 + 2 * lane) * 2u, 0, 16);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                u32x2_t wv;
+                wv.x = attn_merge_finish<ATTN_MERGE_MAX_SPLITS>(ldm, n_splits, lane);
+                wv.y = tag;
+                __builtin_amdgcn_raw_buffer_store_b64(wv, trs, (unsigned)(mr * (K / 2) + mh * 64 + lane) * 8u, 0, 16);
             }
-            if (lane < 8) __hip_atomic_fetch_add(bar + (32 + lane) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (also after a timeout: the count stays in step)
             ATTN_STAMP_W4(5);
         }
-        // ---- C: wait for every (row, head) ----
-        fused_wait(bar, 32 + (b & 7), merge_target, err);
+        // ---- C: a cheap gate before everybody reads: ONE word of head b % heads (the heads finish within ~0.4 us of each other) ----
+        {
+            bool seen = false;
+            for (int it = 0; it < FUSED_SPIN && !seen; ++it) {
+                const u32x2_t gw = __builtin_amdgcn_raw_buffer_load_b64(trs, (unsigned)((b % H) * 64) * 8u, 0, 16);
+                seen = gw.y == tag;
+                if (!seen) {
+                    if ((it & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
     }
     __syncthreads();
     ATTN_STAMP(6);
-    if (mode == 1) return;  // (bisecting aid, ISST_FUSE_ATTN_OPROJ=2: attention + combine only; the caller launches the o_proj GEMV)
-    {   // the merged attention rows -> LDS (sc1 loads: other workgroups stored them)
-        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(attn_row, 0, rows * K * 2, 0x00020000);
-        for (int c = tid * 8; c < rows * K; c += FUSED_WAVES * 64 * 8)
-            *reinterpret_cast<u32x4_t*>(xs + c) = __builtin_amdgcn_raw_buffer_load_b128(ars, (unsigned)c * 2u, 0, 16);
+    // the merged rows -> LDS: every thread takes runs of four words (= 8 consecutive outputs) and re-reads a run until all four carry this launch's tag
+    for (int p4 = tid; p4 < rows * K / 8; p4 += FUSED_WAVES * 64) {
+        u32x4_t a, c;
+        bool ok = false;
+        for (int it = 0; it < FUSED_SPIN && !ok; ++it) {
+            a = __builtin_amdgcn_raw_buffer_load_b128(trs, (unsigned)p4 * 32u, 0, 16);
+            c = __builtin_amdgcn_raw_buffer_load_b128(trs, (unsigned)p4 * 32u + 16u, 0, 16);
+            ok = a.y == tag && a.w == tag && c.y == tag && c.w == tag;
+            if (!ok && (it & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+        }
+        if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const u32x4_t dv = {a.x, a.z, c.x, c.z};
+        *reinterpret_cast<u32x4_t*>(xs + p4 * 8) = dv;
     }
     __syncthreads();
+    if (mode == 1) {  // (bisecting aid, ISST_FUSE_ATTN_OPROJ=2: attention + combine only; the caller launches the o_proj GEMV on the plain rows)
+        if (b == 0)
+            for (int c8 = tid * 8; c8 < rows * K; c8 += FUSED_WAVES * 64 * 8) *reinterpret_cast<u32x4_t*>(attn_row + c8) = *reinterpret_cast<const u32x4_t*>(xs + c8);
+        return;
+    }
     const int arow = lane & 15, kq = (lane >> 4) * 8;
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -1115,7 +1145,7 @@ int llm_attn_oproj_supported(const LlmAttnDims& d, int rows, int n_groups, const
 // launch is enqueued
 int launch_llm_attn_oproj(const bf16_t* qkv, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool, float* partial,
                           LlmAttnDims d, int layer, const LlmAttnOne& one, int n_beam_wgs, const bf16_t* Wp, int N, int K, int n_valid, const bf16_t* res,
-                          bf16_t* out, int ld, bf16_t* attn_row, unsigned* bar, int* err, int n_cus, hipStream_t s, unsigned* arrive_total,
+                          bf16_t* out, int ld, bf16_t* attn_row, unsigned* trow, unsigned* bar, int* err, int n_cus, hipStream_t s, unsigned* arrive_total,
                           unsigned* merge_total, int mode, int delay) {
     const int rows = one.grp.y;
     const int n_prefix = llm_attn_oproj_supported(d, rows, 1, &one, N, K, n_cus, n_beam_wgs);
@@ -1128,7 +1158,7 @@ int launch_llm_attn_oproj(const bf16_t* qkv, const bf16_t* rope_cos, const bf16_
     dim3 grid(N / 16), block(FUSED_WAVES * 64);
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, grid, block, 0, s, qkv, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer, n_splits, n_beam_wgs, tiles_per_split, one, Wp,
-                           n_valid, res, out, ld, attn_row, bar, err, mode, arrive_target, merge_target, delay);
+                           n_valid, res, out, ld, attn_row, trow, bar, err, mode, arrive_target, merge_target, delay);
     };
     const bool big = K == 32 * FUSED_WAVES * 16;
     switch (G) {
