@@ -114,10 +114,9 @@ struct isst_handle {
     bool fuse_attn_oproj = true;  // one stream's decode step: attention + combine + o_proj + residual as ONE launch (llm_attn.hip llm_attn_oproj_kernel; needs the
                                   // device to itself: N / 16 workgroups resident at once).  ISST_FUSE_ATTN_OPROJ=0: the three launches.  Bit-identical either way.
     int fuse_ao_mode = 0;         // ISST_FUSE_ATTN_OPROJ=2 -> 1: the fused launch stops after the combine, o_proj is its own launch (bisecting aid)
-    bool fuse_ao_beams = false;   // ISST_FUSE_ATTN_OPROJ=3: also for the <= 4 beams of ONE stream (a shared-prefix group of B rows: 184 attention workgroups, one merging
-                                  // workgroup per (row, head), a B-row GEMV).  Built, bit-identical (tests/test_gpu_beam.py, test_gpu_fullsize.py) and measured: the launch ends
-                                  // 16.6 us after its first wave (12.5 at one row) and a beam-4 chunk takes 33.7-34.0 ms against 33.7 with three launches -- opt-in
-                                  // (profiles/r04/fused_attn_oproj_beam4_ab_v2.txt)
+    bool fuse_ao_beams = true;    // ... also for the <= 4 beams of ONE stream (a shared-prefix group of B rows: 184 attention workgroups, one merging workgroup per (row, head), a
+                                  // B-row GEMV).  Bit-identical (tests/test_gpu_beam.py, test_gpu_fullsize.py).  With the counted second hand-off it bought nothing (33.7-34.0 ms per
+                                  // beam-4 chunk either way); with the tagged row 33.39 against 33.60 ms (profiles/r04/fused_attn_oproj_beam4_ab_v3.txt).  ISST_FUSE_ATTN_OPROJ=1: greedy only
     bool fuse_ao_used = false;    // a fused launch was enqueued since the error word (tok_host[tok_cap + 8]) was last checked
     unsigned* fuse_bar = nullptr; // its hand-off counters (40 x 128 B, only ever grow)
     unsigned* fuse_row = nullptr; // its merged attention rows as {two bf16, tag} words: [4 rows][heads x 64] x 8 B

@@ -321,7 +321,7 @@ def test_beam_rotated_key_arena_is_bit_identical_to_rotate_on_read(monkeypatch):
 def test_beam_fused_attention_oproj_is_bit_identical_to_the_three_launches(monkeypatch):
     """The B beams of ONE stream are one shared-prefix attention group of B rows; their decode steps run attention + combine + o_proj (+ residual) as one
     launch (csrc/llm_attn.hip llm_attn_oproj_kernel: prefix splits + one workgroup per beam, B merging waves per head, a B-row GEMV from registers).
-    (ISST_FUSE_ATTN_OPROJ=3: for beam groups the fused launch is opt-in.)  Against ISST_FUSE_ATTN_OPROJ=0 (three launches): the same outputs, the same candidate log-probs bit for bit, the same KV in every beam's arena,
+    Against ISST_FUSE_ATTN_OPROJ=0 (three launches): the same outputs, the same candidate log-probs bit for bit, the same KV in every beam's arena,
     across chunks, a pinned system prompt and evictions."""
     from oracle import agent as oag
     cfg = toy_config()
@@ -355,7 +355,7 @@ def test_beam_fused_attention_oproj_is_bit_identical_to_the_three_launches(monke
         eng.close()
         return outs, kvs, traces
 
-    (oa, ka, ta), (ob, kb, tb) = run("3"), run("0")  # 3: the fused launch for beam groups too (opt-in: measured no faster than the three launches)
+    (oa, ka, ta), (ob, kb, tb) = run("3"), run("0")  # 3: the fused launch for beam groups too (= the default)
     assert oa == ob
     for c, (xa, xb) in enumerate(zip(ta, tb)):
         assert len(xa) == len(xb)

@@ -695,7 +695,7 @@ def test_full_size_beam4_fused_launch_is_bit_identical_to_the_three_launches(bea
         eng.close()
         return outs, trace
 
-    (oa, ta), (ob, tb) = run("3"), run("0")  # 3: the fused launch for beam groups too (opt-in: measured no faster than the three launches at 4 beams)
+    (oa, ta), (ob, tb) = run("3"), run("0")  # 3: the fused launch for beam groups too (= the default)
     assert oa == ob and len(ta) == len(tb) == gen.max_new_tokens
     for step, ((va, ia, sa), (vb, ib, sb)) in enumerate(zip(ta, tb)):
         assert np.array_equal(va, vb) and np.array_equal(ia, ib) and np.array_equal(sa, sb), f"step {step}: candidates differ between the fused launch and the three launches"
