@@ -128,6 +128,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_ATTN_OPROJ")) { h->fuse_attn_oproj = e[0] && e[0] != '0'; h->fuse_ao_mode = e[0] == '2' ? 1 : 0; h->fuse_ao_beams = e[0] != '1' && e[0] != '2'; }  // 0: three launches; 1: one row only; 2: bisecting aid; 3 (= default): beam groups too
+    if (const char* e = getenv("ISST_FUSE_AO_TEST_TIMEOUT")) h->fuse_ao_test_timeout = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_AO_DELAY")) h->fuse_ao_delay = atoi(e) >= 0 && atoi(e) <= 64 ? atoi(e) : 0;
     {
         int dev = 0;

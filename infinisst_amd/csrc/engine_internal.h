@@ -117,6 +117,7 @@ struct isst_handle {
     bool fuse_ao_beams = true;    // ... also for the <= 4 beams of ONE stream (a shared-prefix group of B rows: 184 attention workgroups, one merging workgroup per (row, head), a
                                   // B-row GEMV).  Bit-identical (tests/test_gpu_beam.py, test_gpu_fullsize.py).  With the counted second hand-off it bought nothing (33.7-34.0 ms per
                                   // beam-4 chunk either way); with the tagged row 33.39 against 33.60 ms (profiles/r04/fused_attn_oproj_beam4_ab_v3.txt).  ISST_FUSE_ATTN_OPROJ=1: greedy only
+    bool fuse_ao_test_timeout = false;  // ISST_FUSE_AO_TEST_TIMEOUT=1 (test aid): the launch waits for an arrival count that is never reached -- exercises the bounded waits and the error path
     bool fuse_ao_used = false;    // a fused launch was enqueued since the error word (tok_host[tok_cap + 8]) was last checked
     unsigned* fuse_bar = nullptr; // its hand-off counters (40 x 128 B, only ever grow)
     unsigned* fuse_row = nullptr; // its merged attention rows as {two bf16, tag} words: [4 rows][heads x 64] x 8 B

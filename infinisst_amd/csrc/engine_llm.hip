@@ -239,7 +239,7 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             h->fuse_ao_used = true;
             CHK(launch_llm_attn_oproj(h->lqkv, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->llm_v, h->lpartial, h->adims, l, one, n_beam_wgs, L.o.wp, L.o.N, L.o.K,
                                       L.o.n_valid, h->lx + (long)one.grp.x * DL, h->lx + (long)one.grp.x * DL, DL, h->lattn + (long)one.grp.x * H * 128, h->fuse_row, h->fuse_bar,
-                                      h->tok_host + h->tok_cap + 8, h->n_cus, st, &h->fuse_arrive_total, &h->fuse_merge_total, h->fuse_ao_mode, h->fuse_ao_delay));
+                                      h->tok_host + h->tok_cap + 8, h->n_cus, st, &h->fuse_arrive_total, &h->fuse_merge_total, h->fuse_ao_mode, h->fuse_ao_delay, h->fuse_ao_test_timeout ? 1000000u : 0u));
         } else
         CHK(launch_llm_attention(h->lqkv, d.row_stream, d.row_pos, d.views, d.groups, n_groups, max_group_rows, h->llm_cos, h->llm_sin, h->llm_k,
                                  h->llm_kr, h->llm_v, h->lpartial, h->lattn, h->adims, l, rows, st, &one, n_units > 0 ? d.units : nullptr, n_units,
@@ -530,7 +530,7 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
             bt_lap(bt_tail);
             HIPCHK(hipStreamSynchronize(st));
             bt_lap(bt_sync);
-            CHK(check_fused_ao(h));
+            if (const int rc_f = check_fused_ao(h)) return rc_f;  // (not through CHK: the message names the cause)
             h->kv_ops_used = 0;  // every earlier copy batch has run
         }
 
@@ -1033,7 +1033,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         const int na = (int)active.size();
         if (g_ht.on) ht_a = std::chrono::steady_clock::now();
         CHK(wait_tokens());
-        CHK(check_fused_ao(h));
+        if (const int rc_f = check_fused_ao(h)) return rc_f;  // (not through CHK: the message names the cause)
         if (g_ht.on) { ht_b = std::chrono::steady_clock::now(); g_ht.wait += HostTrace::us(ht_a, ht_b); g_ht.waits++; }
         if (p->do_sample)  // HF _sample with do_sample: warpers, softmax, one draw per row (patch_hf.py:606-624)
             for (int r = 0; r < na; ++r)

@@ -88,7 +88,7 @@ int llm_attn_oproj_supported(const LlmAttnDims& d, int rows, int n_groups, const
 int launch_llm_attn_oproj(const bf16_t* qkv, const bf16_t* rope_cos, const bf16_t* rope_sin, bf16_t* kpool, bf16_t* krpool, bf16_t* vtpool, float* partial,
                           LlmAttnDims d, int layer, const LlmAttnOne& one, int n_beam_wgs, const bf16_t* Wp, int N, int K, int n_valid, const bf16_t* res,
                           bf16_t* out, int ld, bf16_t* attn_row, unsigned* trow, unsigned* bar, int* err, int n_cus, hipStream_t s, unsigned* arrive_total,
-                          unsigned* merge_total, int mode = 0, int delay = 0);
+                          unsigned* merge_total, int mode = 0, int delay = 0, unsigned arrive_bias = 0);
                          // arrive_counters != null (>= kv_heads zeroed ints): a ONE-group launch combines its splits itself (last-arriver form, llm_attn.hip)
                          // defer_combine != null: more than one slot split -> NO combine launch, *defer_combine = the split count and `partial` holds the
                          // (max, sum, O) slabs for the consumer to merge (GemmArgs::attn_partial); one split -> *defer_combine = 0, `out` is written  // units[z] = (first group, groups <= 8) of ONE

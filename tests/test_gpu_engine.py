@@ -589,6 +589,47 @@ def test_fused_attention_combine_oproj_is_bit_identical_to_the_three_launches(mo
         assert np.array_equal(x, y), f"chunk {c}: logits differ between the fused launch and the three launches"
 
 
+def test_fused_launch_that_cannot_complete_fails_loudly_and_the_handle_recovers(monkeypatch):
+    """The fused attention + o_proj launch needs all of its workgroups resident and fed; a device shared with another process' kernels could starve it.
+    ISST_FUSE_AO_TEST_TIMEOUT=1 makes every launch wait for an arrival count that never comes: the bounded waits must run out (no hang), isst_generate must
+    return an error that names the cause, and the SAME handle must then carry on with the three launches -- bit-identical to an engine that never fused."""
+    import time
+    from infinisst_amd.engine import IsstError
+    cfg = toy_config()
+    gen = GenConfig(max_new_tokens=6, max_llm_cache_size=300)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=73)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=8)
+    sys_n = len(synth.system_prompt_ids(cfg))
+
+    def chunks(eng, sid):
+        outs, logs = [], []
+        for c in range(2):
+            seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+            o, l = eng.generate(gen, [sid], [seg], [synth.chunk_prompt_ids(cfg, 1, first=(c == 0))], [[]], system_prompt_size=sys_n if c == 0 else 0, return_logits=True)
+            outs.append(o[0])
+            logs.append(l[0][:len(o[0])].copy())
+        return outs, logs
+
+    monkeypatch.setenv("ISST_FUSE_ATTN_OPROJ", "0")
+    ref = make_engine(cfg, w, debug_taps=False, max_llm_cache_size=300, max_streams=1)
+    want = chunks(ref, ref.open_stream())
+    ref.close()
+    monkeypatch.setenv("ISST_FUSE_ATTN_OPROJ", "1")
+    monkeypatch.setenv("ISST_FUSE_AO_TEST_TIMEOUT", "1")
+    eng = make_engine(cfg, w, debug_taps=False, max_llm_cache_size=300, max_streams=2)
+    bad = eng.open_stream()
+    t0 = time.time()
+    with pytest.raises(IsstError, match="timed out"):
+        eng.generate(gen, [bad], [audio[:cfg.chunk_samples]], [synth.chunk_prompt_ids(cfg, 1, first=True)], [[]], system_prompt_size=sys_n)
+    assert time.time() - t0 < 30.0, "the bounded waits took too long"
+    eng.close_stream(bad)  # (its cache holds a pass that was computed on garbage)
+    got = chunks(eng, eng.open_stream())  # the handle has switched itself to the three launches
+    eng.close()
+    assert got[0] == want[0]
+    for c, (x, y) in enumerate(zip(got[1], want[1])):
+        assert np.array_equal(x, y), f"chunk {c}: the handle did not recover to the three-launch path's bits"
+
+
 def test_llm_embed_tap_equals_oracle_splice():
     """The `llm_embed` tap (decoder input rows after embedding lookup + speech splice, model/llm.py:86-113) against the oracle's splice of the
     oracle's own speech features: a pure row copy on the device, so token rows are bit-exact and speech rows carry only the encoder's error."""
