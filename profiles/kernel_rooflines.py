@@ -60,6 +60,7 @@ s = stats("64x4")
 print("64 streams x beam 4 (the reference's production decoding), decode pass (256 rows):")
 line(s, "gate/up (gemm_wide)", r"gemm_wide_kernel<16, 2, 4, 5", W["gateup"])
 line(s, "gate/up (gemm_wide), as flops", r"gemm_wide_kernel<16, 2, 4, 5", flops=2.0 * 256 * 28672 * 4096)
-line(s, "q/k/v + o_proj + down avg (gemm_wide)", r"gemm_wide_kernel<16, 2, 4, 7", (W["qkv"] + W["o"] + W["down"]) / 3)
-line(s, "q/k/v + o_proj + down avg, as flops", r"gemm_wide_kernel<16, 2, 4, 7", flops=2.0 * 256 * (6144 * 4096 + 4096 * 4096 + 4096 * 14336) / 3)
+line(s, "q/k/v + down avg (gemm_wide, one 256-row wg)", r"gemm_wide_kernel<16, 2, 4, 7", (W["qkv"] + W["down"]) / 2)
+line(s, "q/k/v + down avg, as flops", r"gemm_wide_kernel<16, 2, 4, 7", flops=2.0 * 256 * (6144 * 4096 + 4096 * 14336) / 2)
+line(s, "o_proj (gemm_wide, two 128-row wgs)", r"gemm_wide_kernel<8, 4, 6, 7", W["o"])
 line(s, "decode attention (shared prefix, folded)", r"llm_attn_partial_kernel<4, 1, true", 64 * KV1)
