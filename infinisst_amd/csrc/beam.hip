@@ -10,39 +10,48 @@
 #define HD 128
 
 // ---- copy `count` logical positions starting at p0 between an arena (K [slots][128], V [slots][128]) and a buffer
-//      (K [layers][kv][tcap][128], V [layers][kv][tcap][128], both row-major).  grid = (count, kv_heads, layers * n_ops)
-__global__ __launch_bounds__(128) void kv_positions_copy_kernel(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf,
+//      (K [layers][kv][tcap][128], V [layers][kv][tcap][128], both row-major).  grid = (kv_heads, layers * n_ops): one workgroup moves all positions of
+//      its (kv head, layer, op) as 16-byte chunks, the three pools' loads in flight together.  (One 128-thread workgroup per (position, kv head, layer, op)
+//      moving 2 bytes per thread was 414 k workgroups per launch at 64 streams x 4 beams: 152 us per launch, 1.2 TB/s -- profiles/r04/trace_busy_prof64x4.txt.)
+__global__ __launch_bounds__(256) void kv_positions_copy_kernel(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf,
                                                                const KvCopyOp* __restrict__ ops, LlmAttnDims d, int layers, int tcap) {
-    const int t = blockIdx.x, kvh = blockIdx.y;
-    const int layer = blockIdx.z % layers;
-    const KvCopyOp op = ops[blockIdx.z / layers];
-    if (t >= op.count) return;
-    const int dd = threadIdx.x;
+    const int kvh = blockIdx.x;
+    const int layer = blockIdx.y % layers;
+    const KvCopyOp op = ops[blockIdx.y / layers];
     const int slots = d.sys_cap + d.ring_cap;
-    const int p = op.p0 + t;
-    long slot;
-    if (p < op.sys_len) slot = p;
-    else { int x = op.ring_start + (p - op.sys_len); x %= d.ring_cap; slot = (long)d.sys_cap + x; }
     const long abase = op.arena_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
-    const long bidx = op.buf_offset + (((long)layer * d.kv_heads + kvh) * tcap + t) * HD + dd;
+    const long bbase = op.buf_offset + ((long)layer * d.kv_heads + kvh) * tcap * HD;
     // (krpool: the keys rotated at their position of this chunk, LlmStreamView::rot_keys -- travels with K so that the beams' arenas
     //  can be read through it like a greedy stream's)
-    if (op.to_arena) {
-        kpool[abase + slot * HD + dd] = kbuf[bidx];
-        vtpool[abase + slot * HD + dd] = vbuf[bidx];
-        if (krpool) krpool[abase + slot * HD + dd] = krbuf[bidx];
-    } else {
-        kbuf[bidx] = kpool[abase + slot * HD + dd];
-        vbuf[bidx] = vtpool[abase + slot * HD + dd];
-        if (krpool) krbuf[bidx] = krpool[abase + slot * HD + dd];
+    for (int e = threadIdx.x; e < op.count * (HD / 8); e += 256) {
+        const int t = e / (HD / 8), ch = e % (HD / 8);
+        const int p = op.p0 + t;
+        long slot;
+        if (p < op.sys_len) slot = p;
+        else { int x = op.ring_start + (p - op.sys_len); x %= d.ring_cap; slot = (long)d.sys_cap + x; }
+        const long ai = abase + slot * HD + ch * 8, bi = bbase + (long)t * HD + ch * 8;
+        if (op.to_arena) {
+            const u32x4_t k = *reinterpret_cast<const u32x4_t*>(kbuf + bi), v = *reinterpret_cast<const u32x4_t*>(vbuf + bi);
+            u32x4_t kr = {0u, 0u, 0u, 0u};
+            if (krpool) kr = *reinterpret_cast<const u32x4_t*>(krbuf + bi);
+            *reinterpret_cast<u32x4_t*>(kpool + ai) = k;
+            *reinterpret_cast<u32x4_t*>(vtpool + ai) = v;
+            if (krpool) *reinterpret_cast<u32x4_t*>(krpool + ai) = kr;
+        } else {
+            const u32x4_t k = *reinterpret_cast<const u32x4_t*>(kpool + ai), v = *reinterpret_cast<const u32x4_t*>(vtpool + ai);
+            u32x4_t kr = {0u, 0u, 0u, 0u};
+            if (krpool) kr = *reinterpret_cast<const u32x4_t*>(krpool + ai);
+            *reinterpret_cast<u32x4_t*>(kbuf + bi) = k;
+            *reinterpret_cast<u32x4_t*>(vbuf + bi) = v;
+            if (krpool) *reinterpret_cast<u32x4_t*>(krbuf + bi) = kr;
+        }
     }
 }
 
 int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf, const KvCopyOp* ops, int n_ops, int max_count,
                              LlmAttnDims d, int layers, int tcap, hipStream_t s) {
     if (n_ops <= 0 || max_count <= 0) return ISST_OK;
-    hipLaunchKernelGGL(kv_positions_copy_kernel, dim3(max_count, d.kv_heads, layers * n_ops), dim3(HD), 0, s, kpool, vtpool, krpool, kbuf, vbuf, krbuf, ops,
-                       d, layers, tcap);
+    hipLaunchKernelGGL(kv_positions_copy_kernel, dim3(d.kv_heads, layers * n_ops), dim3(256), 0, s, kpool, vtpool, krpool, kbuf, vbuf, krbuf, ops, d, layers, tcap);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
