@@ -104,34 +104,68 @@ __device__ __forceinline__ void amax_merge(float& bv, int& bi, float ov, int oi)
     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
 }
 __device__ void block_topk(float* vals, const int* idx, int n, int k, float* out_val, int* out_idx) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    for (int it = 0; it < k; ++it) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff, bpos = -1;
+    // Two levels, one barrier: every WAVE finds the top k of its own threads' elements with wave-level reductions (a thread keeps the best of ITS elements
+    // e = tid, tid + blockDim, .. in registers; a round is one shuffle reduction, and only the winner's owner rescans its handful of elements), then wave 0
+    // takes the top k of the waves' k-lists.  The top k of a union of per-wave top-k lists is the global top k under the same total order (value, then
+    // lowest index), so the results are those of k block-wide argmax rounds -- which cost 2 barriers and n LDS reads per round (the 64-part stage at 256 rows:
+    // 16 384 workgroups, 195 us).
+    __shared__ float wv[4 * BEAM_TOPK];
+    __shared__ int wi[4 * BEAM_TOPK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float mv;
+    int mi, mpos;
+    auto rescan = [&]() {
+        mv = -INFINITY; mi = 0x7fffffff; mpos = -1;
         for (int e = threadIdx.x; e < n; e += blockDim.x) {
             const float x = vals[e];
             const int id = idx ? idx[e] : e;
-            if (x > bv || (x == bv && id < bi)) { bv = x; bi = id; bpos = e; }
+            if (x > mv || (x == mv && id < mi)) { mv = x; mi = id; mpos = e; }
         }
+    };
+    rescan();
+    for (int it = 0; it < k; ++it) {
+        float bv = mv;
+        int bi = mi, bpos = mpos;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o, WAVE);
             const int oi = __shfl_xor(bi, o, WAVE), op = __shfl_xor(bpos, o, WAVE);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bpos = op; }
         }
-        __shared__ int sp[4];
-        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; sp[threadIdx.x >> 6] = bpos; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; bpos = sp[w]; }
-            out_val[it] = bv;
-            out_idx[it] = bi;
-            if (bpos >= 0) vals[bpos] = -INFINITY;  // NaN-free inputs: -inf entries simply never win again
-            sp[0] = bpos;
+        if (lane == 0) { wv[wave * BEAM_TOPK + it] = bv; wi[wave * BEAM_TOPK + it] = bi; }
+        if (bpos >= 0 && bpos == mpos) {  // the owner retires the winner (NaN-free inputs: -inf entries never win again) and finds its next best
+            vals[bpos] = -INFINITY;
+            rescan();
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // wave 0: the same procedure over the nw * k candidates (candidate c = entry c % k of wave c / k; lane l owns c = l, l + 64, ..)
+    const int nc = nw * k;
+    float cv;
+    int ci, cpos;
+    auto rescan2 = [&]() {
+        cv = -INFINITY; ci = 0x7fffffff; cpos = -1;
+        for (int c = lane; c < nc; c += 64) {
+            const int q = (c / k) * BEAM_TOPK + c % k;
+            if (wv[q] > cv || (wv[q] == cv && wi[q] < ci)) { cv = wv[q]; ci = wi[q]; cpos = q; }
+        }
+    };
+    rescan2();
+    for (int it = 0; it < k; ++it) {
+        float bv = cv;
+        int bi = ci, bpos = cpos;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, WAVE);
+            const int oi = __shfl_xor(bi, o, WAVE), op = __shfl_xor(bpos, o, WAVE);
+            if (ov > bv || (ov == bv && oi < bi) || (ov == bv && oi == bi && op >= 0 && (bpos < 0 || op < bpos))) { bv = ov; bi = oi; bpos = op; }
+        }
+        if (lane == 0) { out_val[it] = bv; out_idx[it] = bi; }
+        if (bpos >= 0 && bpos == cpos) {  // the one owner of the winning entry retires it
+            wv[bpos] = -INFINITY;
+            rescan2();
+        }
     }
 }
 #define TOPK_SLICE 2048
@@ -169,10 +203,136 @@ int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* ps
     hipLaunchKernelGGL(lse_apply_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, logits, ld, vocab, pmax, psum);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
+// ---- stage 1, many rows (beam search over many streams): a (part, row) workgroup SCANS its slice once -- every thread keeps the best KR of its elements in
+//      registers (an unsorted list and its worst entry: a new element replaces the worst one) -- and the lists are then drained like block_topk's: a wave round is
+//      one shuffle reduction over the lanes' current bests, the winner's owner drops that entry; wave 0 merges the waves' lists.  One pass over the scores, no
+//      per-slice LDS image: 256 rows x 64 slices of 2 005 elements through block_topk took 195-212 us, whatever its rounds cost (profiles/r04/topk_scan_ab.txt). ----
+__device__ __forceinline__ bool topk_better(float x, int i, float y, int j) { return x > y || (x == y && i < j); }
+template <int KR>
+__global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict__ scores, long ld, int vocab, int k, int parts, float* __restrict__ cval,
+                                                        int* __restrict__ cidx) {
+    __shared__ float wv[4 * BEAM_TOPK];
+    __shared__ int wi[4 * BEAM_TOPK];
+    const float* L = scores + (long)blockIdx.y * ld;
+    const int per = ((vocab + parts - 1) / parts + 3) & ~3;  // (slices start at multiples of 4 elements: 16-byte loads; rows are 64-byte aligned, ld % 16 == 0)
+    const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float tv[KR];
+    int ti[KR];
+#pragma unroll
+    for (int j = 0; j < KR; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+    float wv_ = -INFINITY;  // the list's worst entry (the one a better element replaces) ...
+    int wi_ = 0x7fffffff;
+    for (int v4 = lo + (int)threadIdx.x * 4; v4 < hi; v4 += 1024) {
+        const f32x4_t q = *reinterpret_cast<const f32x4_t*>(L + v4);  // (the row's padding up to ld is readable; elements at or past `hi` are skipped below)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+        const float x = q[u];
+        const int v0 = v4 + u;
+        if (v0 < hi && topk_better(x, v0, wv_, wi_)) {
+            bool done = false;
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {  // replace the (first) worst entry
+                const bool here = !done && tv[j] == wv_ && ti[j] == wi_;
+                tv[j] = here ? x : tv[j];
+                ti[j] = here ? v0 : ti[j];
+                done = done || here;
+            }
+            wv_ = tv[0]; wi_ = ti[0];
+#pragma unroll
+            for (int j = 1; j < KR; ++j)
+                if (topk_better(wv_, wi_, tv[j], ti[j])) { wv_ = tv[j]; wi_ = ti[j]; }
+        }
+        }
+    }
+    // drain: lane's current best of its list
+    float mv;
+    int mi;
+    auto rescan = [&]() {
+        mv = tv[0]; mi = ti[0];
+#pragma unroll
+        for (int j = 1; j < KR; ++j)
+            if (topk_better(tv[j], ti[j], mv, mi)) { mv = tv[j]; mi = ti[j]; }
+    };
+    rescan();
+    for (int it = 0; it < k; ++it) {
+        float bv = mv;
+        int bi = mi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, WAVE);
+            const int oi = __shfl_xor(bi, o, WAVE);
+            if (topk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { wv[wave * BEAM_TOPK + it] = bv; wi[wave * BEAM_TOPK + it] = bi; }
+        if (bi == mi && bi != 0x7fffffff) {  // (real indices are distinct: exactly one lane owns the winner)
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const bool here = ti[j] == bi;
+                tv[j] = here ? -INFINITY : tv[j];
+                ti[j] = here ? 0x7fffffff : ti[j];
+            }
+            rescan();
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int nc = 4 * k;
+    float cv;
+    int ci, cpos;
+    auto rescan2 = [&]() {
+        cv = -INFINITY; ci = 0x7fffffff; cpos = -1;
+        for (int c = lane; c < nc; c += 64) {
+            const int q = (c / k) * BEAM_TOPK + c % k;
+            if (topk_better(wv[q], wi[q], cv, ci) || cpos < 0) { cv = wv[q]; ci = wi[q]; cpos = q; }
+        }
+    };
+    rescan2();
+    float* oc = cval + ((long)blockIdx.y * parts + blockIdx.x) * BEAM_TOPK;
+    int* oi_ = cidx + ((long)blockIdx.y * parts + blockIdx.x) * BEAM_TOPK;
+    for (int it = 0; it < k; ++it) {
+        float bv = cv;
+        int bi = ci, bpos = cpos;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, WAVE);
+            const int oi = __shfl_xor(bi, o, WAVE), op = __shfl_xor(bpos, o, WAVE);
+            if (op >= 0 && (bpos < 0 || topk_better(ov, oi, bv, bi) || (ov == bv && oi == bi && op < bpos))) { bv = ov; bi = oi; bpos = op; }
+        }
+        if (lane == 0) { oc[it] = bv; oi_[it] = bi; }
+        if (bpos >= 0 && bpos == cpos) {
+            wv[bpos] = -INFINITY;
+            wi[bpos] = 0x7fffffff;
+            rescan2();
+        }
+    }
+}
+// stage 2 over `parts` lists of k
+__global__ __launch_bounds__(256) void topk_final_parts_kernel(const float* __restrict__ cval, const int* __restrict__ cidx, int k, int parts,
+                                                               float* __restrict__ out_val, int* __restrict__ out_idx) {
+    __shared__ float vals[LSE_PARTS * BEAM_TOPK];
+    __shared__ int ids[LSE_PARTS * BEAM_TOPK];
+    for (int e = threadIdx.x; e < parts * k; e += blockDim.x) {
+        const int part = e / k, j = e % k;
+        vals[e] = cval[((long)blockIdx.x * parts + part) * BEAM_TOPK + j];
+        ids[e] = cidx[((long)blockIdx.x * parts + part) * BEAM_TOPK + j];
+    }
+    __syncthreads();
+    block_topk(vals, ids, parts * k, k, out_val + (long)blockIdx.x * BEAM_TOPK, out_idx + (long)blockIdx.x * BEAM_TOPK);
+}
+
 int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
                      hipStream_t s) {
     if (rows <= 0) return ISST_OK;
     if (k < 1 || k > BEAM_TOPK || (vocab + LSE_PARTS - 1) / LSE_PARTS > TOPK_SLICE) return ISST_ERR_ARG;
+    if (rows >= 16 && k <= 16 && ld % 16 == 0 && (reinterpret_cast<uintptr_t>(scores) & 63) == 0) {  // many rows: one scan per (part, row) with the candidates in registers; enough parts for ~1024 workgroups
+        int parts = 1024 / rows;
+        parts = parts < 1 ? 1 : (parts > LSE_PARTS ? LSE_PARTS : parts);
+        if (k <= 8) hipLaunchKernelGGL(topk_scan_kernel<8>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx);
+        else hipLaunchKernelGGL(topk_scan_kernel<16>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx);
+        hipLaunchKernelGGL(topk_final_parts_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, parts, out_val, out_idx);
+        return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+    }
     hipLaunchKernelGGL(topk_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, scores, ld, vocab, k, cval, cidx);
     hipLaunchKernelGGL(topk_final_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, out_val, out_idx);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;

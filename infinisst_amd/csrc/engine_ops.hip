@@ -103,6 +103,20 @@ extern "C" int isst_op_set_attn_tuning(int target_workgroups) {
     llm_attn_set_tuning(target_workgroups);
     return ISST_OK;
 }
+extern "C" int isst_op_topk_rows(const float* scores, long ld, int vocab, int k, int rows, float* out_val, int* out_idx, void* hip_stream) {
+    // test entry of beam.hip's per-row top-k (ties -> lowest index): out_val / out_idx are [rows][32] device arrays, the first k entries of a row are filled
+    if (!scores || !out_val || !out_idx || rows < 1 || vocab < 1 || k < 1 || k > BEAM_TOPK || ld < vocab) return ISST_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    float* cv = nullptr;
+    int* ci = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&cv), sizeof(float) * (size_t)rows * 64 * BEAM_TOPK) != hipSuccess) return ISST_ERR_NOMEM;
+    if (hipMalloc(reinterpret_cast<void**>(&ci), sizeof(int) * (size_t)rows * 64 * BEAM_TOPK) != hipSuccess) { (void)hipFree(cv); return ISST_ERR_NOMEM; }
+    int rc = launch_topk_rows(scores, ld, vocab, k, cv, ci, out_val, out_idx, rows, st);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == ISST_OK) rc = ISST_ERR_HIP;
+    (void)hipFree(cv);
+    (void)hipFree(ci);
+    return rc;
+}
 extern "C" int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps, int gelu,
                                  void* hip_stream) {
     return launch_layernorm(x, C, w, b, out, C, rows, C, eps, gelu, reinterpret_cast<hipStream_t>(hip_stream));

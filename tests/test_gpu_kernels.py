@@ -571,3 +571,31 @@ def test_split_kv_merge_fused_into_oproj_equals_combine_then_gemm():
         assert lib.isst_op_gemm_attn_merge(P(part), S, P(packed), P(res), N, P(fused), N, M, N, K, E._stream_ptr()) == 0
         torch.cuda.synchronize()
         assert torch.equal(sep, fused), f"M={M}: merge-on-load differs from combine + GEMV"
+
+
+@pytest.mark.parametrize("rows,k", [(4, 8), (16, 8), (80, 16), (256, 8), (256, 16)])
+def test_topk_rows_matches_a_sort_with_ties_to_the_lowest_index(rows, k):
+    """csrc/beam.hip: the beam search's candidate selection (reference: torch.topk over the processed scores, patch_hf.py:871-879).  Few rows take the
+    slice-in-LDS kernel, 16+ rows the one-pass scan with the candidates in registers; both must return exactly the k best (value, lowest index first on ties)
+    -- checked on scores quantised so coarsely that ties are everywhere, with -inf entries (suppressed tokens) mixed in."""
+    from infinisst_amd.engine import load_library, _ptr, _stream_ptr
+    lib = load_library()
+    V, ld = 128263, 128272
+    g = torch.Generator(device="cuda").manual_seed(rows * 31 + k)
+    sc = torch.randn(rows, ld, device="cuda", generator=g)
+    sc = torch.round(sc * 3.0) / 3.0  # ~20 distinct values: the top k are all ties
+    sc[:, ::7] = float("-inf")
+    sc[rows // 2, :V - 5] = float("-inf")  # a row with five finite entries
+    out_val = torch.full((rows, 32), float("nan"), device="cuda")
+    out_idx = torch.full((rows, 32), -7, device="cuda", dtype=torch.int32)
+    rc = lib.isst_op_topk_rows(_ptr(sc), ld, V, k, rows, _ptr(out_val), _ptr(out_idx), _stream_ptr())
+    assert rc == 0
+    s = sc[:, :V].cpu().numpy()
+    gv, gi = out_val.cpu().numpy(), out_idx.cpu().numpy()
+    for r in range(rows):
+        finite = int(np.isfinite(s[r]).sum())
+        order = np.lexsort((np.arange(V), -s[r]))[:k]  # value descending, index ascending
+        n = min(k, finite)  # (below that, -inf candidates: which of them come back is not specified)
+        assert np.array_equal(gi[r, :n], order[:n]), f"row {r}: indices {gi[r, :k]} vs {order}"
+        assert np.array_equal(gv[r, :n], s[r][order[:n]])
+        assert np.all(np.isneginf(gv[r, n:k]))
