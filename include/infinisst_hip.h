@@ -250,7 +250,7 @@ int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block);
  * n < 0 = the target -n - 1 with the beams' per-beam workgroups kept at any stream count (A/B runs).  Bits 16.. : the same target for the prefill form. */
 int isst_op_set_attn_tuning(int target_workgroups);
 /* test entry: the beam search's per-row top-k over the processed log-probs (csrc/beam.hip; replaces torch.topk(next_token_scores, ...) of the reference's
- * _beam_search, patch_hf.py:871-879): scores [rows][ld] fp32 on the device, out_val / out_idx [rows][32]; ties go to the lowest index */
+ * _beam_search, patch_hf.py:863-879): scores [rows][ld] fp32 on the device, out_val / out_idx [rows][32]; ties go to the lowest index */
 int isst_op_topk_rows(const float* scores, long ld, int vocab, int k, int rows, float* out_val, int* out_idx, void* hip_stream);
 int isst_op_layernorm(const uint16_t* x, const uint16_t* w, const uint16_t* b, uint16_t* out, int rows, int C, float eps,
                       int gelu, void* hip_stream);

@@ -575,7 +575,7 @@ def test_split_kv_merge_fused_into_oproj_equals_combine_then_gemm():
 
 @pytest.mark.parametrize("rows,k", [(4, 8), (16, 8), (80, 16), (256, 8), (256, 16)])
 def test_topk_rows_matches_a_sort_with_ties_to_the_lowest_index(rows, k):
-    """csrc/beam.hip: the beam search's candidate selection (reference: torch.topk over the processed scores, patch_hf.py:871-879).  Few rows take the
+    """csrc/beam.hip: the beam search's candidate selection (reference: torch.topk over the processed scores, patch_hf.py:877-879).  Few rows take the
     slice-in-LDS kernel, 16+ rows the one-pass scan with the candidates in registers; both must return exactly the k best (value, lowest index first on ties)
     -- checked on scores quantised so coarsely that ties are everywhere, with -inf entries (suppressed tokens) mixed in."""
     from infinisst_amd.engine import load_library, _ptr, _stream_ptr
