@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="LAUNCHER SELF-TEST, no compute and no GPU: every rank sleeps instead of stepping the engine and the ranks meet over gloo; "
                          "the JSON line is marked dry_run and is not a measurement (tests/test_streams_gloo.py)")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="--dry-run only: this rank reports a failed set-up of the 64-streams-per-GPU leg (every rank must then skip it)")
     return ap.parse_args()
 
 
@@ -379,13 +380,24 @@ def run_streams64_all_ranks(cfg, gen, weights, device, args, tg, world, rank):
     """BASELINE.json configs[3]: 64 concurrent streams on EVERY GPU of the node (512 on 8), independent -- no data-path collective.  Every rank builds its
     64-stream engine, imports the steady state and times the same K steps between barriers; time = max over ranks, audio = sum over ranks.  The
     reference runs one GPU per SLURM array task (scripts/infer/infinisst.sh:5-13)."""
-    eng, _, sys_n = build_engine(cfg, 64, args.gen_tokens, device, gen.beam, weights)
+    # set-up (engine, steady state, warm-up) can fail on ONE rank: the ranks agree on the host before the first timed barrier, so that a local failure makes
+    # every rank skip the leg instead of leaving the healthy ones inside a collective until the launcher's timeout (TimingGroup.all_ok)
+    eng = loop = None
     mine = S.assign_streams(64 * world, rank, world)
-    loop = ChunkLoop(eng, cfg, gen, mine, sys_n, host_audio=False)
-    loop.import_steady_state(device)
-    for _ in range(8):
-        loop.step()
-    torch.cuda.synchronize()
+    err = None
+    try:
+        eng, _, sys_n = build_engine(cfg, 64, args.gen_tokens, device, gen.beam, weights)
+        loop = ChunkLoop(eng, cfg, gen, mine, sys_n, host_audio=False)
+        loop.import_steady_state(device)
+        for _ in range(8):
+            loop.step()
+        torch.cuda.synchronize()
+    except Exception as e:  # report, never hide
+        err = f"{type(e).__name__}: {e}"
+    if not tg.all_ok(err is None):
+        if eng is not None:
+            eng.close()
+        return {"failed": err or "another rank failed while setting the leg up; skipped on every rank"}
     tg.barrier()
     torch.cuda.synchronize()
     steps = args.streams64_steps
@@ -664,6 +676,9 @@ def dry_run(args, world, rank, cores=None):
         mine64 = S.assign_streams(64 * world, rank, world)
         b64 = S.StreamBatch(DryEngine(rank, args.gen_tokens), gen, sys_n, lambda first, m: synth.chunk_prompt_ids(cfg, m, first=first))
         idx64 = [b64.open() for _ in mine64]
+    if world > 1 and not args.no_streams64 and not tg.all_ok(rank != args.dry_fail_rank):  # (run_streams64_all_ranks: a failed set-up is agreed on before the timed barrier)
+        s64 = {"failed": "a rank failed while setting the leg up; skipped on every rank", "ranks_seen": dist.get_world_size()}
+    elif world > 1 and not args.no_streams64:
         tg.barrier()
         t1 = time.perf_counter()
         for _ in range(4):
@@ -762,7 +777,7 @@ def main():
             s64 = run_streams64_all_ranks(cfg, gen, weights, device, args, tg, world, rank)
             if rank == 0:
                 log(f"64-streams-per-GPU leg done on {world} ranks: {s64['xrt']} xRT aggregate, {s64['ms_per_step']} ms per step")
-        except Exception as e:  # report, never hide (a rank that fails here leaves the others at the barrier: the launcher's timeout ends the job)
+        except Exception as e:  # report, never hide (set-up failures are agreed on and skipped by all ranks inside; what lands here failed in the timed part)
             s64 = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if not args.host_audio and args.host_audio_steps > 0:

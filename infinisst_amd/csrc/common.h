@@ -157,7 +157,7 @@ bool gemm_dense_preferred(const GemmArgs& g);
 bool gemm_dense_would_run(int M, int N, int K);                   // ... as a function of the shape alone (the engine picks its K slices by it)
 int launch_gemm_dense(const GemmArgs& g, hipStream_t stream);
 void gemm_dense_set(int mode);                                     // profiling aid: 0 never, 1 heuristic, 2 wherever supported
-bool gemm_wide_supported(const GemmArgs& g);                       // gemm_wide.hip: 65..256 rows, weights read once (4 waves, one per SIMD, register rings)
+bool gemm_wide_supported(const GemmArgs& g);                       // gemm_wide.hip: 65..256 rows, weights read once (8 waves: 4 consumers with the W ring in registers + 4 LDS-DMA loaders for the A ring)
 bool gemm_wide_preferred(const GemmArgs& g);
 int launch_gemm_wide(const GemmArgs& g, hipStream_t stream);
 bool gemm_wide_enabled();

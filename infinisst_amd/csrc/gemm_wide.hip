@@ -7,22 +7,27 @@
 // ~32 KB in flight per CU: 3.3 TB/s on gate/up at 128 rows (profiles/r03/trace_busy_prof128.txt), and at 129..256 rows it read the weights twice.
 //
 // Structure -- gemm_tiled's dataflow (bit-identical results: same MFMA, same ascending K order per accumulator, same epilogue arithmetic)
-// rebuilt around what a weight stream needs on this part, ~100+ KB in flight per CU (MI355X_MICROARCH.md: ~25 GB/s per CU x 3-4 us loaded latency):
-//   * workgroup = 4 waves = ONE wave per SIMD, so a wave may hold up to 512 registers (unified VGPR + AGPR file): the accumulators of
-//     ALL rows (MT m-tiles x 2 n-tiles: 64 registers at 128 rows, 128 at 256 rows) plus two statically indexed register RINGS;
-//   * wave w owns n-tiles 2w, 2w+1 of the workgroup's 8 (128 columns; the (gate, up) pair of SwiGLU sits in one wave) x all rows x all of
-//     K: no K split across waves, no cross-wave reduction, one accumulation chain per output element in ascending K;
-//   * W ring: the wave's weight fragments stream straight from the fragment-major packed layout into VGPRs (1 KiB coalesced per load,
-//     non-temporal), DW K-steps (64 deep each: 4 KiB per wave and step) ahead -- 96 KB per CU at DW = 6;
-//   * A ring: activations (L2-resident, shared by every workgroup) are loaded in full 128-byte lines (8 rows x 128 B per wave-load), DA
-//     K-steps ahead in registers, and written to LDS one step ahead of use as ready-made MFMA A fragments ([k-step][m-tile][lane] x 16 B:
-//     conflict-free ds_write_b128 / ds_read_b128), double buffered, one barrier per K-step; every wave reads all rows' fragments and feeds
-//     two MFMAs from each;
-//   * every load is an unconditional bounds-checked buffer load through a descriptor covering exactly the slice: steps past the end and
-//     rows past M read zeros without traffic, so the loop has no branch around a load and hipcc emits counted s_waitcnt vmcnt(n)
-//     (program order of the prologue pinned with sched_barrier: left alone hipcc fills a ring back to front and the first wait drains it);
+// rebuilt around what a weight stream needs on this part, ~100 KB in flight per CU (MI355X_MICROARCH.md: ~25 GB/s per CU x 3-4 us loaded latency):
+//   * workgroup = 8 waves (512 threads, __launch_bounds__(512, 2): at most 256 registers per wave), one per CU in practice, in two ROLES -- the two kinds
+//     of load must not share a wave's in-order vmcnt queue (a wait for an L2-resident activation line would also wait for every weight fragment
+//     issued before it: the first form of this kernel, 4 waves with both rings in registers, ran 56 us on gate/up at 128 rows for that reason);
+//   * CONSUMER waves 0-3, one per SIMD: wave w owns n-tiles 2w, 2w+1 of the workgroup's 8 (128 columns; the (gate, up) pair of SwiGLU sits in one
+//     wave) x ALL rows (MT m-tiles: 64 / 128 / 256 rows = 32 / 64 / 128 accumulator registers) x all of K: no K split across waves, no cross-wave
+//     reduction, one accumulation chain per output element in ascending K.  W ring: the wave's weight fragments stream straight from the
+//     fragment-major packed layout into a statically indexed register ring (1 KiB coalesced per load, non-temporal), DW K-steps (64 deep each: 4 KiB
+//     per wave and step) ahead.  A fragments come from LDS in groups of 8 through two register sets, the next group requested under the MFMAs of
+//     the current one; every MFMA (inline asm, accumulator tied) is followed by at most one filler instruction, pinned pair by pair;
+//   * LOADER waves 4-7: the activation ring, NS stages of one K-step each ([m-tiles][16 rows][128 B], 16-byte chunks XOR-swizzled on the SOURCE
+//     side), filled by LDS-DMA (global_load_lds_dwordx4: full 128-byte lines, no registers, no ds_write) with a hand-counted vmcnt in front of the
+//     one barrier per K-step that publishes step t+2 while steps t+3 .. t+NS-1 stay in flight.  NORM: the loaders also RMS-normalise every staged
+//     step in place (1/rms from the producer's sums of squares, GemmArgs::ssq);
+//   * every load is unconditional: weight steps past the slice read zeros through a descriptor that covers exactly the slice, activation steps
+//     past it re-read the last step into a stage nobody reads -- the loop has no branch around a load, every wait is counted, and both roles pass
+//     the same number of barriers;
+//   * epilogue through the idle ring: every value is written once into a [rows][workgroup columns] LDS image and stored as whole row segments;
 //   * narrow outputs (q/k/v, o_proj, down_proj: 32..48 column blocks) split K over blockIdx.y into fp32 slabs (EPI_PARTIAL) that the
-//     residual + RMSNorm kernel (or launch_slab_reduce) sums in slice order, exactly as gemm_tiled's split-K does.
+//     residual + RMSNorm kernel (or launch_slab_reduce) sums in slice order, exactly as gemm_tiled's split-K does; a K-sliced launch that would
+//     leave half the CUs idle runs as two 128-row workgroups per (column block, slice) (blockIdx.z).
 #include "common.h"
 
 #define WIDE_TK 64          // K elements per step (two MFMA k-steps); one barrier per step

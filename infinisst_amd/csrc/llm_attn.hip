@@ -598,6 +598,10 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(con
             //  They meet each other at LDS counters, not at the workgroup barrier: waves 4-7 are busy getting their loads issued)
             llm_attn_partial_body<G, 1, false>(qkv, nullptr, nullptr, nullptr, nullptr, rope_cos, rope_sin, kpool, krpool, vtpool, partial, d, layer,
                                                n_splits, tiles_per_split, one, nullptr, n_extra, nullptr, nullptr, b % n_splits, kvh, 0, true, [] {}, &s_sync[0]);
+            // (compiler fence: fused_wait_vmcnt<KPW> below reads "all but the KPW youngest vector-memory operations are done" as "the slab stores have
+            //  landed", which holds only if the KPW weight loads are issued AFTER the body's last slab store and nothing else in between.  sched_barrier
+            //  pins the machine schedule, not IR-level motion of a load through another descriptor; this does.)
+            asm volatile("" ::: "memory");
             issue_w();
             fused_wait_vmcnt<KPW>();  // this wave's slab stores (write-through) have completed
             lds_sync4(&s_sync[1], lane);

@@ -37,10 +37,44 @@ def _parse_cpulist(text: str) -> List[int]:
     return cpus
 
 
-def local_cores_of_rank(local_rank: int, local_world: int, sysfs: str = "/sys/class/drm", allowed: Optional[Sequence[int]] = None) -> List[int]:
+def _kfd_gpu_order(kfd: str) -> Optional[List[str]]:
+    """PCI addresses (`dddd:bb:dd.f`) of the GPU agents in KFD topology order -- the order ROCr enumerates them in, hence the HIP device index
+    of an unmasked process (the amdgpu cards sorted by PCI address need not be in that order).  Read from
+    `<kfd>/topology/nodes/<n>/properties` (`simd_count` > 0: a GPU; `domain` and `location_id` = bus << 8 | device << 3 | function).
+    None when the tree is absent or unreadable.  Touches no GPU."""
+    import os
+    nodes = os.path.join(kfd, "topology", "nodes")
+    try:
+        names = sorted((n for n in os.listdir(nodes) if n.isdigit()), key=int)
+    except OSError:
+        return None
+    out: List[str] = []
+    for n in names:
+        props = {}
+        try:
+            with open(os.path.join(nodes, n, "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    if v.strip().lstrip("-").isdigit():
+                        props[k] = int(v)
+        except OSError:
+            return None  # (a node the process may not read: the order of the others is not the device order)
+        if props.get("simd_count", 0) <= 0:
+            continue
+        loc = props.get("location_id")
+        if loc is None:
+            return None
+        out.append("%04x:%02x:%02x.%x" % (props.get("domain", 0) & 0xFFFF, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+    return out or None
+
+
+def local_cores_of_rank(local_rank: int, local_world: int, sysfs: str = "/sys/class/drm", allowed: Optional[Sequence[int]] = None,
+                        kfd: str = "/sys/class/kfd/kfd") -> List[int]:
     """Host cores rank `local_rank` of `local_world` ranks on this node should run on: the cores local to its GPU's NUMA node (sysfs:
-    the amdgpu cards in PCI order, `local_cpulist`), shared evenly with the other ranks on that node; an even split of the allowed
-    cores when sysfs does not answer (no GPUs here, a visibility mask, fewer cards than ranks).  The reference runs one GPU per SLURM
+    the amdgpu cards' `local_cpulist`), shared evenly with the other ranks on that node; an even split of the allowed cores when sysfs
+    does not answer (no GPUs here, a visibility mask, fewer cards than ranks).  HIP device i is the i-th GPU agent of the KFD topology
+    (`_kfd_gpu_order`), so the cards are taken in THAT order; when the KFD tree is absent they are taken in PCI address order, and when
+    it names a GPU that has no amdgpu card here the two views disagree and the even split is used.  The reference runs one GPU per SLURM
     array task (scripts/infer/infinisst.sh:5-13) and leaves placement to the scheduler; one process per GPU on one node has to do
     it itself -- eight Python hosts on the cores of one socket would time each other, not the GPUs.  Touches no GPU."""
     import os
@@ -69,6 +103,10 @@ def local_cores_of_rank(local_rank: int, local_world: int, sysfs: str = "/sys/cl
     except OSError:
         cards = []
     cards.sort()
+    order = _kfd_gpu_order(kfd) if cards else None
+    if order is not None:
+        by_bdf = dict(cards)
+        cards = [(b, by_bdf[b]) for b in order] if all(b in by_bdf for b in order) else []
     if len(cards) >= local_world and 0 <= local_rank < len(cards) and cards[local_rank][1]:
         mine = cards[local_rank][1]
         peers = [i for i in range(local_world) if cards[i][1] == mine]
@@ -79,7 +117,9 @@ def local_cores_of_rank(local_rank: int, local_world: int, sysfs: str = "/sys/cl
 def pin_rank_to_local_cores(local_rank: int, local_world: int) -> List[int]:
     """Set this process's affinity (before anything touches the GPU) and return the cores chosen."""
     import os
-    cores = local_cores_of_rank(local_rank, local_world)
+    # (ISST_SYSFS_DRM / ISST_SYSFS_KFD: other roots for the two sysfs trees -- containers that mount the host's elsewhere, and the launcher's CPU test)
+    cores = local_cores_of_rank(local_rank, local_world, sysfs=os.environ.get("ISST_SYSFS_DRM", "/sys/class/drm"),
+                                kfd=os.environ.get("ISST_SYSFS_KFD", "/sys/class/kfd/kfd"))
     try:
         os.sched_setaffinity(0, cores)
     except OSError:
@@ -358,6 +398,18 @@ class TimingGroup:
 
     def barrier(self):
         self._reduce([0.0], dist.ReduceOp.SUM)
+
+    def all_ok(self, ok: bool) -> bool:
+        """Whether EVERY rank says ok (a MIN over the ranks, on the host: the gloo side group when there is one).  A leg whose set-up can fail on one
+        rank (engine build, import, warm-up) asks this before its first timed barrier, so that a local failure makes all ranks skip the leg together
+        instead of leaving the healthy ones inside a collective until the launcher's timeout."""
+        if not self._active():
+            return bool(ok)
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        if self.gloo is not None or self.device is None:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.gloo)
+            return float(flag.item()) >= 1.0
+        return self._reduce([float(flag.item())], dist.ReduceOp.MIN)[0] >= 1.0
 
     def max(self, value: float) -> float:
         return self._reduce([value], dist.ReduceOp.MAX)[0]

@@ -92,16 +92,93 @@ def test_local_cores_follow_the_gpus_numa_node(tmp_path):
         os.symlink(dev, tmp_path / name / "device")
     (tmp_path / "card0-DP-1").mkdir()
     allowed = list(range(16))
-    got = [streams.local_cores_of_rank(r, 4, sysfs=str(tmp_path), allowed=allowed) for r in range(4)]
+    nokfd = str(tmp_path / "no-kfd")  # no KFD topology: the cards count in PCI address order
+    got = [streams.local_cores_of_rank(r, 4, sysfs=str(tmp_path), allowed=allowed, kfd=nokfd) for r in range(4)]
     assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
-    assert streams.local_cores_of_rank(1, 2, sysfs=str(tmp_path), allowed=allowed) == [4, 5, 6, 7]      # two ranks: both GPUs sit on node 0
-    assert streams.local_cores_of_rank(5, 8, sysfs=str(tmp_path), allowed=allowed) == [10, 11]           # more ranks than cards: even split
-    assert streams.local_cores_of_rank(0, 1, sysfs=str(tmp_path / "missing"), allowed=allowed) == allowed
+    assert streams.local_cores_of_rank(1, 2, sysfs=str(tmp_path), allowed=allowed, kfd=nokfd) == [4, 5, 6, 7]      # two ranks: both GPUs sit on node 0
+    assert streams.local_cores_of_rank(5, 8, sysfs=str(tmp_path), allowed=allowed, kfd=nokfd) == [10, 11]           # more ranks than cards: even split
+    assert streams.local_cores_of_rank(0, 1, sysfs=str(tmp_path / "missing"), allowed=allowed, kfd=nokfd) == allowed
     os.environ["HIP_VISIBLE_DEVICES"] = "3"
     try:
-        assert streams.local_cores_of_rank(1, 4, sysfs=str(tmp_path), allowed=allowed) == [4, 5, 6, 7]  # masked: the card order is unknown -> even split
+        assert streams.local_cores_of_rank(1, 4, sysfs=str(tmp_path), allowed=allowed, kfd=nokfd) == [4, 5, 6, 7]  # masked: the card order is unknown -> even split
     finally:
         del os.environ["HIP_VISIBLE_DEVICES"]
+    # HIP device i = the i-th GPU agent of the KFD topology, which need not be PCI order: here KFD lists the node-1 GPUs first
+    _fake_kfd(tmp_path / "kfd", ["0000:85:00.0", "0000:95:00.0", "0000:05:00.0", "0000:15:00.0"])
+    got = [streams.local_cores_of_rank(r, 4, sysfs=str(tmp_path), allowed=allowed, kfd=str(tmp_path / "kfd")) for r in range(4)]
+    assert got == [[8, 9, 10, 11], [12, 13, 14, 15], [0, 1, 2, 3], [4, 5, 6, 7]]
+    # a KFD GPU without an amdgpu card in this tree: the two views disagree -> even split, not a guess
+    _fake_kfd(tmp_path / "kfd2", ["0000:85:00.0", "0000:a5:00.0", "0000:05:00.0", "0000:15:00.0"])
+    assert streams.local_cores_of_rank(1, 4, sysfs=str(tmp_path), allowed=allowed, kfd=str(tmp_path / "kfd2")) == [4, 5, 6, 7]
+
+
+def _fake_kfd(root, bdfs):
+    """A KFD topology tree: node 0 a CPU agent (no SIMDs), then one GPU agent per PCI address in the given order."""
+    def node(i, simd, loc, domain=0):
+        d = root / "topology" / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 8}\nsimd_count {simd}\ndomain {domain}\nlocation_id {loc}\ndrm_render_minor {128 + i}\n")
+    node(0, 0, 0)
+    for i, bdf in enumerate(bdfs):
+        dom, bus, devfn = bdf.split(":")
+        dev, fn = devfn.split(".")
+        node(i + 1, 1024, (int(bus, 16) << 8) | (int(dev, 16) << 3) | int(fn), int(dom, 16))
+
+
+def _fake_drm(root, cards):
+    """cards: {name: (pci address, local_cpulist)} of amdgpu cards under a fake /sys/class/drm."""
+    for name, (bdf, cpus) in cards.items():
+        dev = root / "pci" / bdf
+        dev.mkdir(parents=True)
+        (dev / "vendor").write_text("0x1002\n")
+        (dev / "local_cpulist").write_text(cpus + "\n")
+        (dev / "mem_info_vram_total").write_text("1\n")
+        (root / name).mkdir()
+        os.symlink(dev, root / name / "device")
+
+
+def test_bench_dry_run_on_eight_ranks(tmp_path):
+    """BASELINE.json configs[3] as the launcher will see it on an 8-GPU node (none is in the pool): `bench.py --dry-run --gpus 8` -- eight ranks over gloo,
+    512 streams dealt 64 per rank, the `streams64` block present, and every rank pinned to its own cores out of a fake sysfs with eight amdgpu cards on two
+    NUMA nodes whose KFD order differs from their PCI order (scripts/infer/infinisst.sh:5-13: the reference runs one GPU per SLURM array task)."""
+    import json
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu < 8:
+        import pytest
+        pytest.skip("needs 8 host cores for eight disjoint core sets")
+    cpus = sorted(os.sched_getaffinity(0))[:8]
+    node = [f"{cpus[0]}-{cpus[3]}" if cpus[3] - cpus[0] == 3 else ",".join(map(str, cpus[:4])),
+            f"{cpus[4]}-{cpus[7]}" if cpus[7] - cpus[4] == 3 else ",".join(map(str, cpus[4:]))]
+    bdfs = [f"0000:{b:02x}:00.0" for b in (0x05, 0x15, 0x25, 0x35, 0x85, 0x95, 0xa5, 0xb5)]
+    _fake_drm(tmp_path / "drm", {f"card{i}": (bdfs[i], node[i // 4]) for i in range(8)})
+    _fake_kfd(tmp_path / "kfd", [bdfs[i] for i in (4, 5, 6, 7, 0, 1, 2, 3)])
+    os.environ["ISST_SYSFS_DRM"], os.environ["ISST_SYSFS_KFD"] = str(tmp_path / "drm"), str(tmp_path / "kfd")
+    try:
+        r = _run_bench("--dry-run", "--gpus", "8", "--steps", "6", "--streams", "2", timeout=600)
+    finally:
+        del os.environ["ISST_SYSFS_DRM"], os.environ["ISST_SYSFS_KFD"]
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["n_gpus"] == 8 and j["ranks_seen"] == 8
+    assert j["streams_of_rank0"] == [0, 8] and j["latencies_gathered"] == 48
+    s64 = j["streams64"]
+    assert s64["ranks_seen"] == 8 and s64["streams_per_gpu"] == 64 and s64["streams_total"] == 512
+    assert s64["ms_per_step"] >= 16.0 and s64["xrt"] > 0          # the slowest rank (rank 7 sleeps 16 ms per step) sets the time
+    assert s64["cores_pinned_all_ranks"] == s64["cores_pinned_distinct"] == 8  # eight disjoint core sets
+    assert j["host_cores_of_rank0"] == [cpus[4]]                   # rank 0 = KFD GPU 0 = the first card of NUMA node 1, first of its four sharers
+
+
+def test_bench_skips_the_64_stream_leg_on_every_rank_when_one_rank_fails_to_set_it_up():
+    """a rank that fails while building the configs[3] leg must not strand the others at the timed barrier -- the ranks agree
+    (TimingGroup.all_ok) and every one of them skips the leg; the job ends normally and says so."""
+    import json
+    r = _run_bench("--dry-run", "--gpus", "2", "--steps", "4", "--streams", "1", "--dry-fail-rank", "1", timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "failed" in j["streams64"] and j["streams64"]["ranks_seen"] == 2
+    assert j["ranks_seen"] == 2 and j["latencies_gathered"] == 8  # the headline leg ran to the end on both ranks
 
 
 def test_bench_parent_reports_a_failing_rank():
