@@ -273,7 +273,8 @@ def run_leg(cfg, gen, weights, device, args, n_streams, steps, workload, extra_e
                 os.environ[k] = v
     loop = ChunkLoop(eng, cfg, gen, list(range(n_streams)), sys_n, host_audio=False)
     loop.import_steady_state(device)
-    for _ in range(8):
+    first = first_step_record(loop, eng, gen)  # (the first warm-up step, with stream 0's logits / candidate lists kept for the self-check below)
+    for _ in range(7):
         loop.step()
     dt, lat, host_s = timed_steps(loop, steps)
     info = eng.stream_info(loop.sids[0])
@@ -286,7 +287,78 @@ def run_leg(cfg, gen, weights, device, args, n_streams, steps, workload, extra_e
                                   "per-stream checkpoint walk and isst_kv_evict)",
            "llm_kv_entries": info["llm_cache_len"], "encoder_window": info["enc_cache_len"], "evictions_per_stream": loop.evictions // n_streams,
            "roofline": whole_step_roofline(cfg, n_streams, gen.max_new_tokens, info["llm_cache_len"], ms)}
+    try:  # untimed: what this leg computed, held against another dispatch path of the library (never against the oracle: that is the tests' job)
+        out["self_check"] = leg_self_check(cfg, gen, weights, device, n_streams, first)
+        out["checked"] = bool(out["self_check"]["ok"])
+    except Exception as e:  # report, never hide
+        out["self_check"] = {"failed": f"{type(e).__name__}: {e}"}
+        out["checked"] = False
     return out, loop, eng
+
+
+def first_step_record(loop, eng, gen):
+    """One step of `loop` that keeps what stream 0 computed: greedy -- its sampled ids and the raw logits of every pass; beam search -- its winner and the
+    per-step candidate lists (isst_debug_beam_trace_*: top log-probs, ids, running beam scores)."""
+    if gen.beam > 1:
+        eng.beam_trace_begin(gen.beam)
+        loop.step()
+        trace = eng.beam_trace_end()
+        return {"tokens": list(loop.batch.slots[loop.idx[0]].last_generated), "trace": trace}
+    outs, logits = loop.batch.step(loop.segs[loop.c % loop.n_chunks], return_logits=True)
+    loop.c += 1
+    toks = list(loop.batch.slots[loop.idx[0]].last_generated)
+    return {"tokens": toks, "logits": np.array(logits[0][:len(toks)], dtype=np.float32)}
+
+
+SELF_CHECK_TOL = 0.5  # |difference| of bf16-path logits / log-probs between two dispatch paths of the library on the same inputs (measured: < 0.1)
+
+
+def leg_self_check(cfg, gen, weights, device, n_streams, first):
+    """Untimed sanity check of an extra bench leg: stream 0's first step is recomputed on a SECOND engine that takes another dispatch path from the same
+    imported state and the same audio, and the two are compared.
+      * greedy, many streams: a one-stream engine (GEMV kernels, fused attention + o_proj instead of the batched forms), teacher-forced along the leg's ids:
+        every pass's raw logits within SELF_CHECK_TOL;
+      * beam search, one stream: the same search with the scorer on the HOST and attention / combine / o_proj as three launches
+        (ISST_BEAM_DEVICE=0, ISST_FUSE_ATTN_OPROJ=0): winner and every candidate list must be bit-identical;
+      * beam search, many streams: a one-stream beam engine: the candidates of the step behind the prefill (independent of later choices) within
+        SELF_CHECK_TOL, and whether the winners agree (a near-tie may part them: reported, not required)."""
+    import dataclasses
+    env = {"ISST_BEAM_DEVICE": "0", "ISST_FUSE_ATTN_OPROJ": "0"} if (gen.beam > 1 and n_streams == 1) else {}
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        eng, _, sys_n = build_engine(cfg, 1, gen.max_new_tokens, device, gen.beam, weights, gen.latency_multiplier)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        loop = ChunkLoop(eng, cfg, gen, [0], sys_n, host_audio=False)
+        loop.import_steady_state(device)
+        if gen.beam == 1:
+            outs, logits = loop.batch.step(loop.segs[0], forced_tokens=[first["tokens"]], return_logits=True)
+            toks = list(loop.batch.slots[loop.idx[0]].last_generated)
+            k = len(first["tokens"])
+            diff = float(np.abs(np.array(logits[0][:k], dtype=np.float32) - first["logits"]).max())
+            ok = toks == first["tokens"] and diff <= SELF_CHECK_TOL
+            return {"what": f"stream 0, first step: {k} passes recomputed by a one-stream engine, teacher-forced along the leg's ids", "passes": k,
+                    "max_abs_logit_diff": round(diff, 4), "tolerance": SELF_CHECK_TOL, "ok": bool(ok)}
+        again = first_step_record(loop, eng, gen)
+        t0, t1 = first["trace"], again["trace"]
+        if n_streams == 1:
+            same = len(t0) == len(t1) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) for a, b in zip(t0, t1))
+            ok = same and again["tokens"] == first["tokens"]
+            return {"what": "first step recomputed with the scorer on the host and attention / combine / o_proj as three launches: bit-identical candidates and winner required",
+                    "scorer_steps": len(t0), "candidates_bit_identical": bool(same), "winner_equal": again["tokens"] == first["tokens"], "ok": bool(ok)}
+        diff = float(np.abs(t0[0][0] - t1[0][0]).max())
+        ids_equal = float(np.mean(t0[0][1] == t1[0][1]))
+        return {"what": "stream 0, first step recomputed by a one-stream beam engine: the candidates of the step behind the prefill",
+                "max_abs_logprob_diff": round(diff, 4), "candidate_ids_equal_fraction": round(ids_equal, 3), "tolerance": SELF_CHECK_TOL,
+                "winner_equal": again["tokens"] == first["tokens"], "ok": bool(diff <= SELF_CHECK_TOL)}
+    finally:
+        eng.close()
 
 
 def run_streams64(cfg, gen, weights, device, args):
@@ -334,7 +406,7 @@ def run_multipliers(cfg, gen, weights, device, args, b4):
     rows = []
     if b4 and "xrt" in b4:
         rows.append({"multiplier": 1, "chunk_ms": 960, "max_new_tokens": 10, "xrt": b4["xrt"], "ms_per_step": b4["ms_per_step"], "p50_chunk_latency_ms": b4["p50_chunk_latency_ms"],
-                     "rtf": round(1.0 / b4["xrt"], 4)})
+                     "rtf": round(1.0 / b4["xrt"], 4), "checked": b4.get("checked")})
     for m in (2, 3, 4):
         g = dataclasses.replace(gen, beam=4, latency_multiplier=m, max_new_tokens=10 * m)
         out, loop, eng = run_leg(cfg, g, weights, device, args, 1, args.multiplier_steps, f"1 stream, num_beams 4, latency multiplier {m}")
@@ -342,9 +414,9 @@ def run_multipliers(cfg, gen, weights, device, args, b4):
         del loop, eng
         rows.append({"multiplier": m, "chunk_ms": 960 * m, "max_new_tokens": 10 * m, "xrt": out["xrt"], "ms_per_step": out["ms_per_step"],
                      "p50_chunk_latency_ms": out["p50_chunk_latency_ms"], "rtf": round(1.0 / out["xrt"], 4), "llm_kv_entries": out["llm_kv_entries"],
-                     "evictions_per_stream": out["evictions_per_stream"]})
+                     "evictions_per_stream": out["evictions_per_stream"], "checked": out.get("checked"), "self_check": out.get("self_check")})
     return {"workload": "InfiniSST en-de, wav2vec2-large + Llama-3.1-8B bf16, 1 stream on 1 MI355X, num_beams 4, chunks of m x 960 ms, max_new_tokens 10 m",
-            "rows": rows, "reference_published": {"what": "RTF at m = 1..4 (L40S, inferred)", "source": "plots/plot.ipynb:528-531"}}
+            "rows": rows, "checked": all(bool(r.get("checked")) for r in rows), "reference_published": {"what": "RTF at m = 1..4 (L40S, inferred)", "source": "plots/plot.ipynb:528-531"}}
 
 
 def run_streams64_beam4(cfg, gen, weights, device, args):

@@ -55,6 +55,241 @@ int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
+// ---- the same copies from an op list written on the device (beam_select_kernel): the host knows only an upper bound of the op count, so a workgroup
+//      (kv head, layer, lane z) walks ops z, z + Z, ... of the *count listed ----
+__global__ __launch_bounds__(256) void kv_positions_copy_list_kernel(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf,
+                                                                    const KvCopyOp* __restrict__ ops, const int* __restrict__ count, LlmAttnDims d, int tcap) {
+    const int kvh = blockIdx.x, layer = blockIdx.y;
+    const int n_ops = *count;
+    const int slots = d.sys_cap + d.ring_cap;
+    for (int o = blockIdx.z; o < n_ops; o += gridDim.z) {
+        const KvCopyOp op = ops[o];
+        const long abase = op.arena_offset + (long)layer * d.layer_stride + (long)kvh * slots * HD;
+        const long bbase = op.buf_offset + ((long)layer * d.kv_heads + kvh) * tcap * HD;
+        for (int e = threadIdx.x; e < op.count * (HD / 8); e += 256) {
+            const int t = e / (HD / 8), ch = e % (HD / 8);
+            const int p = op.p0 + t;
+            long slot;
+            if (p < op.sys_len) slot = p;
+            else { int x = op.ring_start + (p - op.sys_len); x %= d.ring_cap; slot = (long)d.sys_cap + x; }
+            const long ai = abase + slot * HD + ch * 8, bi = bbase + (long)t * HD + ch * 8;
+            if (op.to_arena) {
+                const u32x4_t k = *reinterpret_cast<const u32x4_t*>(kbuf + bi), v = *reinterpret_cast<const u32x4_t*>(vbuf + bi);
+                u32x4_t kr = {0u, 0u, 0u, 0u};
+                if (krpool) kr = *reinterpret_cast<const u32x4_t*>(krbuf + bi);
+                *reinterpret_cast<u32x4_t*>(kpool + ai) = k;
+                *reinterpret_cast<u32x4_t*>(vtpool + ai) = v;
+                if (krpool) *reinterpret_cast<u32x4_t*>(krpool + ai) = kr;
+            } else {
+                const u32x4_t k = *reinterpret_cast<const u32x4_t*>(kpool + ai), v = *reinterpret_cast<const u32x4_t*>(vtpool + ai);
+                u32x4_t kr = {0u, 0u, 0u, 0u};
+                if (krpool) kr = *reinterpret_cast<const u32x4_t*>(krpool + ai);
+                *reinterpret_cast<u32x4_t*>(kbuf + bi) = k;
+                *reinterpret_cast<u32x4_t*>(vbuf + bi) = v;
+                if (krpool) *reinterpret_cast<u32x4_t*>(krbuf + bi) = kr;
+            }
+        }
+    }
+}
+int launch_kv_positions_copy_list(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf, const KvCopyOp* ops, const int* count,
+                                  int max_ops, LlmAttnDims d, int layers, int tcap, hipStream_t s) {
+    if (max_ops <= 0) return ISST_OK;
+    // op lanes: enough workgroups to fill the chip (kv heads x layers x Z >= ~2048), never more lanes than ops
+    int z = 2048 / (d.kv_heads * layers) + 1;
+    z = z > max_ops ? max_ops : z;
+    hipLaunchKernelGGL(kv_positions_copy_list_kernel, dim3(d.kv_heads, layers, z), dim3(256), 0, s, kpool, vtpool, krpool, kbuf, vbuf, krbuf, ops, count, d, tcap);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
+// ---- the beam scorer of one step, on the device: one wave per stream.  It restates engine_llm.hip's host scorer (the `follower` there, which is pinned to
+//      the reference's beam_search_process / BeamHypotheses.add through beam_scorer.npz / beam_loop.npz) operation for operation -- fp32 `candidate + beam
+//      score`, the (value desc, flat index asc) order, double `sum / len^penalty` with len^penalty from a HOST-filled table -- so that both reach the same
+//      decisions bit for bit; the host re-derives every step from the logged candidates and fails the call if the two ever differ.  What it buys: the next
+//      forward pass's token ids, the reordered tails and the sequences the processors read exist on the device the moment the candidates do; the host
+//      scorer (172 us of GPU-idle time per step at 64 streams x 4 beams, 40 + 37 us at one stream: profiles/r04/trace_busy_prof64x4.txt, _beam4.txt) is off
+//      the critical path. ----
+__global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
+    __shared__ float cval[BEAM_MAX_B * BEAM_TOPK];
+    __shared__ int cflat[BEAM_MAX_B * BEAM_TOPK];
+    __shared__ float sval[BEAM_TOPK];
+    __shared__ int sflat[BEAM_TOPK];
+    __shared__ BeamDevStream S;
+    __shared__ int ntok[BEAM_MAX_B], npar[BEAM_MAX_B];
+    __shared__ float nscore[BEAM_MAX_B], nflp[BEAM_MAX_B];
+    __shared__ KvCopyOp l1[2 * BEAM_MAX_B], l2[BEAM_MAX_B];
+    __shared__ int n1, n2, base1, base2, status;
+    const int i = blockIdx.x, lane = threadIdx.x, B = a.B;
+    BeamDevStream* gS = a.st + i;
+    for (int w = lane; w < (int)(sizeof(BeamDevStream) / 4); w += 64) reinterpret_cast<int*>(&S)[w] = reinterpret_cast<const int*>(gS)[w];
+    if (lane == 0) { n1 = 0; n2 = 0; status = 0; }
+    __syncthreads();
+    const bool upstream_failed = a.err_word && *reinterpret_cast<const volatile int*>(a.err_word) != 0;
+    const int len = S.prompt_len + a.step;  // tokens of every beam's sequence before this step
+    auto op = [&](int beam, int buf, int count, int to_arena) {
+        KvCopyOp o;
+        o.arena_offset = ((long)S.sid * a.max_beams + beam) * a.stream_stride;
+        o.buf_offset = ((long)S.sid * a.nbuf + buf) * a.tbuf_stride;
+        o.p0 = S.P0; o.count = count; o.sys_len = S.sys_len; o.ring_start = S.ring_start; o.to_arena = to_arena; o.pad = 0;
+        return o;
+    };
+    if (upstream_failed) {
+        if (lane == 0) status = -1;  // the state stays as it is: the host re-issues the pass on the three-launch path and this step runs again
+    } else if (S.done) {
+        // a finished batch entry (patch_hf.py:83-92): pad tokens, zero scores, hypotheses untouched; its rows still ride through the forward pass
+        if (lane < B) { ntok[lane] = a.pad_tok; npar[lane] = lane; nscore[lane] = 0.f; nflp[lane] = 0.f; }
+        if (lane == 0) status = 1;
+    } else {
+        // ---- candidates: processed log-prob + beam score (fp32 add), flat index = beam * V + token; invalid slots are left out ----
+        const int N = a.rows_per * a.n_keep;
+        for (int c = lane; c < N; c += 64) {
+            const int b = c / a.n_keep, j = c - b * a.n_keep;
+            const int r = i * a.rows_per + b;
+            const int idx = a.top_idx[r * BEAM_TOPK + j];
+            const bool valid = idx >= 0 && idx < a.V;
+            cval[c] = valid ? a.top_val[r * BEAM_TOPK + j] + S.score[b] : 0.f;
+            cflat[c] = valid ? b * a.V + idx : -1;
+        }
+        __syncthreads();
+        // ---- rank = number of valid candidates that come first under (value desc, flat asc): a strict total order (flat indices are distinct) ----
+        int valid_total = 0;
+        for (int c = lane; c < N; c += 64) {
+            const int fc = cflat[c];
+            if (fc < 0) continue;
+            const float vc = cval[c];
+            int rank = 0;
+            for (int q = 0; q < N; ++q) {
+                const int fq = cflat[q];
+                rank += (fq >= 0 && (cval[q] > vc || (cval[q] == vc && fq < fc))) ? 1 : 0;
+            }
+            if (rank < a.n_keep && rank < BEAM_TOPK) { sval[rank] = vc; sflat[rank] = fc; }
+        }
+        for (int c = lane; c < N; c += 64) valid_total += cflat[c] >= 0 ? 1 : 0;
+        valid_total = (int)wave_sum((float)valid_total);  // (<= 256: exact in fp32)
+        __syncthreads();
+        if (lane == 0) {
+            const int ns = valid_total < a.n_keep ? valid_total : a.n_keep;
+            const int gen_len = a.step + 1;  // cur_len - prompt_len: the hypothesis length an EOS candidate of this step closes
+            int chosen = 0, st = 0;
+            for (int rank = 0; rank < ns && chosen < B; ++rank) {
+                const int b = sflat[rank] / a.V, tok = sflat[rank] - b * a.V;
+                bool is_eos = false;
+                for (int e = 0; e < a.n_eos; ++e) is_eos = is_eos || tok == a.eos[e];
+                if (is_eos) {
+                    if (rank >= B) continue;
+                    int buf = -1;
+                    if (a.step > 0) {  // the hypothesis keeps a copy of that beam's tail (the reference clones the whole KV cache, :113-120)
+                        if (S.n_free == 0) { st = -2; break; }
+                        buf = S.free_bufs[--S.n_free];
+                        l1[n1++] = op(b, buf, a.step, 0);
+                    }
+                    // BeamHypotheses.add (:278-302)
+                    const double hs = (double)sval[rank] / a.powtab[gen_len];
+                    int freed = -1;
+                    if (S.hyp_n < B || hs > S.worst) {
+                        S.hyp_score[S.hyp_n] = hs; S.hyp_buf[S.hyp_n] = buf; ++S.hyp_n;
+                        if (S.hyp_n > B) {  // drop the worst: sorted((score, index))[0]; worst_score = the next one's
+                            int w0 = 0;
+                            for (int q = 1; q < S.hyp_n; ++q) if (S.hyp_score[q] < S.hyp_score[w0]) w0 = q;
+                            freed = S.hyp_buf[w0];
+                            for (int q = w0; q + 1 < S.hyp_n; ++q) { S.hyp_score[q] = S.hyp_score[q + 1]; S.hyp_buf[q] = S.hyp_buf[q + 1]; }
+                            --S.hyp_n;
+                            int w1 = 0;
+                            for (int q = 1; q < S.hyp_n; ++q) if (S.hyp_score[q] < S.hyp_score[w1]) w1 = q;
+                            S.worst = S.hyp_score[w1];
+                        } else {
+                            S.worst = hs < S.worst ? hs : S.worst;
+                        }
+                    } else {
+                        freed = buf;
+                    }
+                    if (freed >= B) S.free_bufs[S.n_free++] = freed;
+                } else {
+                    nscore[chosen] = sval[rank]; ntok[chosen] = tok; npar[chosen] = b; nflp[chosen] = 0.f;
+                    ++chosen;
+                }
+            }
+            if (st == 0 && chosen < B) st = -3;
+            if (st == 0 && ns > 0 && !S.done && S.hyp_n >= B) {  // BeamHypotheses.is_done, early_stopping = False [3P]
+                const double highest = (double)sval[0] / a.powtab[gen_len];
+                if (S.worst >= highest) S.done = 1;
+            }
+            if (st == 0 && i == 0 && a.step < a.force_steps) {  // teacher forcing (test aid): the caller's (token, parent) choices; score = parent's + the token's processed log-prob
+                for (int b = 0; b < B; ++b) {
+                    const int tok = a.force_tok[a.step * B + b], par = a.force_par[a.step * B + b];
+                    if (tok < 0 || tok >= a.V || par < 0 || par >= a.rows_per) { st = -4; break; }
+                    const float lp = a.logits[(long)(i * a.rows_per + par) * a.ld_logits + tok];
+                    ntok[b] = tok; npar[b] = par; nscore[b] = S.score[par] + lp; nflp[b] = lp;
+                }
+            }
+            if (st == 0 && a.step > 0) {  // reorder the tails (:910-913): new beam b continues parent npar[b] -- parents staged through temporaries 0..B-1
+                unsigned need = 0;
+                for (int b = 0; b < B; ++b) if (npar[b] != b) need |= 1u << npar[b];
+                for (int src = 0; src < B; ++src) if (need >> src & 1u) l1[n1++] = op(src, src, a.step, 0);
+                for (int b = 0; b < B; ++b) if (npar[b] != b) l2[n2++] = op(b, npar[b], a.step, 1);
+            }
+            if (st != 0) { n1 = 0; n2 = 0; }
+            status = st != 0 ? st : (S.done ? 1 : 0);
+            if (st == 0) for (int b = 0; b < B; ++b) S.score[b] = nscore[b];
+        }
+    }
+    __syncthreads();
+    const int st = status;
+    if (st >= 0) {
+        // ---- sequences (the processors' ids of the next step): row i * B + b = parent's tokens + the chosen one ----
+        for (int b = 0; b < B; ++b) {
+            const int* src = a.seq_in + (long)(i * a.seq_in_rows_per + (a.seq_in_rows_per == 1 ? 0 : npar[b])) * a.max_ids;
+            int* dst = a.seq_out + (long)(i * B + b) * a.max_ids;
+            for (int t = lane; t < len; t += 64) dst[t] = src[t];
+            if (lane == 0) dst[len] = ntok[b];
+        }
+        // ---- the next forward pass's rows ----
+        if (lane < B) {
+            const int r = i * B + lane;
+            a.ids[r] = ntok[lane];
+            a.row_pos[r] = S.P0 + a.step;
+            a.views[r].new_start = S.P0 + a.step;
+            a.samp[r].n_ids = len + 1;
+        }
+        // ---- position copies: reserve this stream's share of the two lists ----
+        if (lane == 0) {
+            base1 = n1 ? atomicAdd(a.op_counts, n1) : 0;
+            base2 = n2 ? atomicAdd(a.op_counts + 1, n2) : 0;
+        }
+        __syncthreads();
+        for (int q = lane; q < n1; q += 64) a.ops1[base1 + q] = l1[q];
+        for (int q = lane; q < n2; q += 64) a.ops2[base2 + q] = l2[q];
+        // ---- state back to memory ----
+        for (int w = lane; w < (int)(sizeof(BeamDevStream) / 4); w += 64) reinterpret_cast<int*>(gS)[w] = reinterpret_cast<const int*>(&S)[w];
+    }
+    // ---- log to the host: candidates as the top-k left them, the choices, the stream's status ----
+    for (int e = lane; e < a.rows_per * BEAM_TOPK; e += 64) {
+        const int b = e / BEAM_TOPK, j = e - b * BEAM_TOPK;
+        a.log_val[(long)(i * B + b) * BEAM_TOPK + j] = a.top_val[(long)(i * a.rows_per + b) * BEAM_TOPK + j];
+        a.log_idx[(long)(i * B + b) * BEAM_TOPK + j] = a.top_idx[(long)(i * a.rows_per + b) * BEAM_TOPK + j];
+    }
+    if (lane < B && st >= 0) {
+        BeamDecision dcs;
+        dcs.tok = ntok[lane]; dcs.par = npar[lane]; dcs.score = nscore[lane]; dcs.forced_lp = nflp[lane];
+        a.log_dec[i * B + lane] = dcs;
+    }
+    if (lane == 0) a.log_done[i] = st;
+    __threadfence_system();  // every lane: its part of the log is in host memory before this stream's ticket is drawn
+    if (lane == 0) {
+        const int t = atomicAdd(a.ticket, 1);
+        if (t == a.n - 1) {
+            *a.ticket = 0;  // re-armed (launch boundary = visibility)
+            __threadfence_system();
+            *reinterpret_cast<volatile int*>(a.log_seq) = a.seq_value;
+        }
+    }
+}
+int launch_beam_select(const BeamSelArgs& a, hipStream_t s) {
+    if (a.n <= 0) return ISST_OK;
+    if (a.B < 1 || a.B > BEAM_MAX_B || a.n_keep < 1 || a.n_keep > BEAM_TOPK || a.rows_per < 1 || a.rows_per > a.B || a.n_eos < 0 || a.n_eos > 8) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(beam_select_kernel, dim3(a.n), dim3(64), 0, s, a);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
 // ---- log_softmax, stage 1: per (part, row) running max and sum of exp ----
 #define LSE_PARTS 64
 __global__ __launch_bounds__(256) void lse_part_kernel(const float* __restrict__ logits, long ld, int vocab, float* __restrict__ pmax,

@@ -103,6 +103,11 @@ extern "C" void isst_destroy(isst_handle* h) {
     if (h->pcm_host) (void)hipHostFree(h->pcm_host);
     if (h->top_val_host) (void)hipHostFree(h->top_val_host);
     if (h->top_idx_host) (void)hipHostFree(h->top_idx_host);
+    if (h->meta_host2) (void)hipHostFree(h->meta_host2);
+    if (h->bst_host) (void)hipHostFree(h->bst_host);
+    if (h->bpow_host) (void)hipHostFree(h->bpow_host);
+    if (h->bforce_host) (void)hipHostFree(h->bforce_host);
+    if (h->blog) (void)hipHostFree(h->blog);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->side_ev) (void)hipEventDestroy(h->side_ev);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -274,13 +279,27 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         h->cand_idx = h->dalloc<int>(NB * 64 * BEAM_TOPK);
         h->top_val = h->dalloc<float>(NB * BEAM_TOPK);
         h->top_idx = h->dalloc<int>(NB * BEAM_TOPK);
-        if (!h->tbuf_k || !h->tbuf_v || !h->tbuf_kr || !h->lse_max || !h->lse_sum || !h->cand_val || !h->cand_idx || !h->top_val || !h->top_idx) {
+        h->bseq[0] = h->dalloc<int>(NB * h->max_ids);
+        h->bseq[1] = h->dalloc<int>(NB * h->max_ids);
+        h->bst_dev = h->dalloc<BeamDevStream>(ns);
+        h->bpow_dev = h->dalloc<double>((size_t)c.max_new_tokens + 2);
+        h->bops_dev[0] = h->dalloc<KvCopyOp>(NB * 2);
+        h->bops_dev[1] = h->dalloc<KvCopyOp>(NB);
+        h->bop_counts_dev = h->dalloc<int>(((size_t)c.max_new_tokens + 1) * 2, true);
+        h->bticket_dev = h->dalloc<int>(4, true);
+        h->bforce_dev = h->dalloc<int>((size_t)2 * c.max_new_tokens * h->max_beams);
+        if (!h->tbuf_k || !h->tbuf_v || !h->tbuf_kr || !h->lse_max || !h->lse_sum || !h->cand_val || !h->cand_idx || !h->top_val || !h->top_idx || !h->bseq[0] || !h->bseq[1] ||
+            !h->bst_dev || !h->bpow_dev || !h->bops_dev[0] || !h->bops_dev[1] || !h->bop_counts_dev || !h->bticket_dev || !h->bforce_dev) {
             h->fail(ISST_ERR_NOMEM, "beam search allocation failed"); return die(ISST_ERR_NOMEM);
         }
     }
     h->meta_bytes = (size_t)LR * 8 * sizeof(int) + NB * (sizeof(int) + sizeof(LlmStreamView) + sizeof(SampleStream) + sizeof(EncStreamView)) +
                     NB * (h->max_ids + h->max_enc_ids) * sizeof(int) + NB * 4 * sizeof(KvCopyOp) * KV_OPS_SLOTS + 65536 * sizeof(int) + 8192;
     h->meta_dev = h->dalloc<unsigned char>(h->meta_bytes);
+    if (h->max_beams > 1) {
+        h->meta_dev2 = h->dalloc<unsigned char>(h->meta_bytes);
+        if (!h->meta_dev2) { h->fail(ISST_ERR_NOMEM, "beam search allocation failed"); return die(ISST_ERR_NOMEM); }
+    }
     const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->llm_kr, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
                           h->window, h->act_a, h->act_b, h->ex, h->exn, h->eqkv, h->eattn, h->effn, h->speech, h->lx, h->lxn, h->lqkv, h->lqrot,
                           h->lattn, h->lact, h->llast, h->lpartial, h->lslab, h->logits, h->out_tok, h->samp_val, h->samp_idx, h->meta_dev};
@@ -293,6 +312,21 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         hipHostMalloc(reinterpret_cast<void**>(&h->top_idx_host), sizeof(int) * NB * BEAM_TOPK, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
         h->fail(ISST_ERR_NOMEM, "pinned host allocation failed"); return die(ISST_ERR_NOMEM);
     }
+    if (h->max_beams > 1) {
+        // per-step slot of the pinned beam log: candidates [NB][BEAM_TOPK] (values, ids), decisions [NB], status per stream; behind the slots one 64-byte line
+        // with the sequence number of the last beam_select launch that has published
+        h->blog_steps = c.max_new_tokens + 1;
+        h->blog_slot_bytes = (NB * BEAM_TOPK * 8 + NB * sizeof(BeamDecision) + (size_t)ns * sizeof(int) + 63) / 64 * 64;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->meta_host2), h->meta_bytes) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&h->bst_host), sizeof(BeamDevStream) * ns) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&h->bpow_host), sizeof(double) * ((size_t)c.max_new_tokens + 2)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&h->bforce_host), sizeof(int) * 2 * c.max_new_tokens * h->max_beams) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&h->blog), h->blog_slot_bytes * h->blog_steps + 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+            h->fail(ISST_ERR_NOMEM, "pinned host allocation failed (beam search)"); return die(ISST_ERR_NOMEM);
+        }
+        std::memset(h->blog, 0, h->blog_slot_bytes * h->blog_steps + 64);
+    }
+    if (const char* e = getenv("ISST_BEAM_DEVICE")) h->beam_device = e[0] && e[0] != '0';
     std::memset(h->tok_host, 0, sizeof(int) * (NB + 16));  // the published sequence number starts at 0 = "no fused tail yet" (samp_seq_expected counts from 1)
     if (hipDeviceSynchronize() != hipSuccess) { h->fail(ISST_ERR_HIP, "device sync after allocation failed"); return die(ISST_ERR_HIP); }
     *out = h;

@@ -221,6 +221,27 @@ struct isst_handle {
     float* top_val_host = nullptr;
     int* top_idx_host = nullptr;
 
+    // beam search with the scorer on the device (beam.hip beam_select_kernel; engine_llm.hip beam_decode_device): the state of a call's streams, the n x B-row
+    // metadata of its decode passes, the beams' token sequences (double buffered), the op lists of the position copies, and the pinned per-step log the
+    // host follows the search through
+    bool beam_device = true;                 // ISST_BEAM_DEVICE=0: the host scorer decides every step (the stream drains twice per step)
+    unsigned char* meta_dev2 = nullptr;      // second metadata block (same carving as meta_dev)
+    unsigned char* meta_host2 = nullptr;     // pinned
+    int* bseq[2] = {nullptr, nullptr};       // [max_streams * max_beams][max_ids]
+    BeamDevStream* bst_dev = nullptr;        // [max_streams]
+    BeamDevStream* bst_host = nullptr;       // pinned staging of the same
+    double* bpow_dev = nullptr;              // [max_new_tokens + 2] len^length_penalty, from the host's libm
+    double* bpow_host = nullptr;             // pinned
+    KvCopyOp* bops_dev[2] = {nullptr, nullptr};  // [2 NB], [NB]
+    int* bop_counts_dev = nullptr;           // [max_new_tokens + 1][2]
+    int* bticket_dev = nullptr;
+    int* bforce_dev = nullptr;               // forced (token, parent) choices of stream 0 (test aid): [2][max_new_tokens * max_beams]
+    int* bforce_host = nullptr;              // pinned
+    unsigned char* blog = nullptr;           // pinned log, blog_steps slots of blog_slot_bytes + the sequence word
+    size_t blog_slot_bytes = 0;
+    int blog_steps = 0;
+    int bsel_seq = 0;                        // beam_select launches enqueued so far = the sequence number the last one publishes
+
     // beam-search test aid (isst_debug_beam_trace_*): per-step candidate lists of a ONE-stream call and optional teacher forcing
     struct BeamTraceStep { int rows, n_keep; std::vector<float> val; std::vector<int> idx; std::vector<float> score; };
     bool btrace_on = false;

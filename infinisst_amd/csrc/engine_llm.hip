@@ -126,18 +126,6 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
     return m;
 }
 
-// the fused attention + o_proj launches enqueued since the last check have run (call after a synchronisation point): a wait inside one of them that ran
-// out raised the (pinned) error word
-int check_fused_ao(isst_handle* h) {
-    if (!h->fuse_ao_used) return ISST_OK;
-    h->fuse_ao_used = false;
-    volatile int* ferr = h->tok_host + h->tok_cap + 8;
-    if (*ferr == 0) return ISST_OK;
-    *ferr = 0;
-    h->fuse_attn_oproj = false;  // (its counters are out of step now; the three launches from here on)
-    return h->fail(ISST_ERR_HIP, "the fused attention + o_proj launch timed out waiting for its own workgroups (is another process using this GPU?); set ISST_FUSE_ATTN_OPROJ=0");
-}
-
 // one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
 int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_groups, int max_group_rows, bool splice, const char* tap_prefix,
                 hipStream_t st, const StepMeta* hm = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0) {
@@ -363,12 +351,12 @@ struct BeamHyp {
 };
 struct BeamHyps {  // BeamHypotheses, patch_hf.py:278-302 + [3P] is_done (early_stopping = False)
     int num_beams;
-    double length_penalty;
+    const double* powtab;  // powtab[l] = pow((double)l, length_penalty): ONE table per call for this scorer and the device's (beam.hip beam_select_kernel)
     std::vector<BeamHyp> beams;
     double worst = 1e9;
     // returns the buffer slot freed by an evicted (or rejected) hypothesis, or -1
     int add(BeamHyp hyp, double sum_logprobs, int generated_len) {
-        hyp.score = sum_logprobs / std::pow((double)generated_len, length_penalty);
+        hyp.score = sum_logprobs / powtab[generated_len];
         if ((int)beams.size() < num_beams || hyp.score > worst) {
             beams.push_back(std::move(hyp));
             if ((int)beams.size() > num_beams) {
@@ -387,7 +375,7 @@ struct BeamHyps {  // BeamHypotheses, patch_hf.py:278-302 + [3P] is_done (early_
     }
     bool is_done(double best_sum_logprobs, int cur_len, int prompt_len) const {
         if ((int)beams.size() < num_beams) return false;
-        const double highest = best_sum_logprobs / std::pow((double)(cur_len - prompt_len), length_penalty);
+        const double highest = best_sum_logprobs / powtab[cur_len - prompt_len];
         return worst >= highest;
     }
 };
@@ -436,269 +424,132 @@ int flush_copies(isst_handle* h, std::vector<KvCopyOp>& ops, const StepMeta& mh,
     return ISST_OK;
 }
 
-// decode phase of a beam call; the prefill (on arena 0 of every stream) has already produced h->logits rows 0..n-1
-int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const int* const* prompt_ids, const int* prompt_lens,
-                const std::vector<int>& rows_len /* KV entries the prompt wrote (<= prompt_lens after a short splice) */, const int* const* prev_target_ids, const int* n_prev, const std::vector<int>& total0, int* const* out_ids, int* out_lens,
-                StepMeta& mh, StepMeta& md, hipStream_t st) {
+// One step of the scorer for stream i of a beam call (beam_search_process, patch_hf.py:43-157): merges the rows' top-k candidates, walks them in rank order
+// (EOS candidates inside the top B ranks become hypotheses that keep a copy of their beam's tail), decides (token, parent) of the B next beams, updates the
+// stream's sequences / scores / done flag.  val / idx: the candidates of the stream's rows_per rows, [rows_per][BEAM_TOPK].  `ops` != null: the tail copies of new
+// hypotheses are appended to it (the host drives the search); null: bookkeeping only -- the device scorer issues the copies (beam_decode_device) and this run
+// follows it.  forced_lp(b, parent, token, &lp): the processed log-prob of a teacher-forced choice (test aid).
+template <typename ForcedLp>
+int scorer_step(isst_handle* h, const isst_gen_params* p, BeamStream& S, int i, int sid, int rows_per, int n_keep, int B, int step, int prompt_len, int P0,
+                const float* val, const int* idx, std::vector<int>& ntok, std::vector<int>& npar, std::vector<KvCopyOp>* ops, ForcedLp forced_lp) {
     const isst_config& c = h->cfg;
-    const int B = p->num_beams, V = c.vocab;
-    const int n_keep = std::max(2, 1 + c.n_eos) * B;
-    if (n_keep > BEAM_TOPK) return h->fail(ISST_ERR_ARG, "beam search keeps %d candidates per step, at most %d are supported", n_keep, BEAM_TOPK);
-    const double lp = p->length_penalty == 0.f ? 1.0 : (double)p->length_penalty;
-    std::vector<BeamStream> bs(n);
-    std::vector<KvCopyOp> ops;
-    if (h->kv_ops_used) {  // batches of an earlier call that ended without a synchronisation in between (finalize)
-        HIPCHK(hipStreamSynchronize(st));
-        h->kv_ops_used = 0;
+    const int V = c.vocab;
+    ntok.clear();
+    npar.clear();
+    if (S.done) {
+        // a finished batch entry is skipped by the scorer (patch_hf.py:83-92: pad tokens, zero scores, its hypotheses untouched)
+        // while the other streams of the call go on; its rows still ride through the forward pass (their KV beyond the
+        // winner's tail is never read: llm_total is set from the winning hypothesis)
+        const int pad = c.n_eos ? c.eos_ids[0] : 0;
+        for (int b = 0; b < B; ++b) { ntok.push_back(pad); npar.push_back(b); S.seq[b].push_back(pad); }
+        S.score.assign(B, 0.f);
+        return ISST_OK;
     }
-    for (int i = 0; i < n; ++i) {
-        bs[i].seq.assign(B, std::vector<int>(prompt_ids[i], prompt_ids[i] + prompt_lens[i]));
-        bs[i].score.assign(B, -1e9f);
-        bs[i].score[0] = 0.f;
-        bs[i].hyps.num_beams = B;
-        bs[i].hyps.length_penalty = lp;
-        for (int b = B; b < h->nbuf; ++b) bs[i].free_bufs.push_back(b);  // slots 0..B-1 are reorder temporaries
-        // the prompt's KV was written to arena 0: replicate it into the other beams' arenas (they are identical before it)
-        push_copy(h, ops, stream_ids[i], 0, 0, total0[i], rows_len[i], false);
+    struct Cand { float val; long flat; };
+    static thread_local std::vector<Cand> cands;
+    static thread_local std::vector<float> nscore;
+    cands.clear();
+    nscore.clear();
+    ntok.reserve(B);
+    npar.reserve(B);
+    for (int b = 0; b < rows_per; ++b)
+        for (int j = 0; j < n_keep; ++j) {
+            const int id = idx[b * BEAM_TOPK + j];
+            if (id < 0 || id >= V) continue;
+            cands.push_back({val[b * BEAM_TOPK + j] + S.score[b], (long)b * V + id});
+        }
+    if (h->btrace_on && i == 0) {
+        isst_handle::BeamTraceStep ts;
+        ts.rows = rows_per; ts.n_keep = n_keep;
+        for (int b = 0; b < rows_per; ++b) {
+            for (int j = 0; j < n_keep; ++j) {
+                ts.val.push_back(val[b * BEAM_TOPK + j]);
+                ts.idx.push_back(idx[b * BEAM_TOPK + j]);
+            }
+            ts.score.push_back(S.score[b]);
+        }
+        h->btrace.push_back(std::move(ts));
     }
-    CHK(flush_copies(h, ops, mh, md, st));
-    for (int i = 0; i < n; ++i)
-        for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], rows_len[i], true);
-    CHK(flush_copies(h, ops, mh, md, st));
-
-    // ISST_HOST_TRACE=2: where the host's time between two forward passes of a beam step goes (one line per call)
-    static const bool bt_on = std::getenv("ISST_HOST_TRACE") && std::atoi(std::getenv("ISST_HOST_TRACE")) == 2;
-    using bclock = std::chrono::steady_clock;
-    double bt_tail = 0, bt_sync = 0, bt_score = 0, bt_copies = 0, bt_meta = 0, bt_enq = 0;
-    auto bt_us = [](bclock::time_point a, bclock::time_point b2) { return std::chrono::duration<double, std::micro>(b2 - a).count(); };
-    bclock::time_point bt0 = bclock::now(), bt1;
-    auto bt_lap = [&](double& acc) { if (bt_on) { bt1 = bclock::now(); acc += bt_us(bt0, bt1); bt0 = bt1; } };
-    int step = 0;  // tokens already chosen per beam
-    while (true) {
-        if (bt_on) bt0 = bclock::now();
-        const int rows_per = step == 0 ? 1 : B;  // step 0: only beam 0 carries a finite score (:767-771)
-        const int rows = n * rows_per;
-        // ---- log_softmax -> processors (on log-probs) -> per-row top-k ----
-        for (int i = 0; i < n; ++i)
-            for (int b = 0; b < rows_per; ++b) {
-                const int r = i * rows_per + b;
-                const std::vector<int>& sq = bs[i].seq[b];
-                std::memcpy(mh.ids_pool + (size_t)r * h->max_ids, sq.data(), sq.size() * 4);
-                const int ne = n_prev ? n_prev[i] : 0;
-                if (b == 0 && ne) std::memcpy(mh.enc_pool + (size_t)i * h->max_enc_ids, prev_target_ids[i], (size_t)ne * 4);
-                mh.samp[r].n_ids = (int)sq.size(); mh.samp[r].n_enc = ne;
-                mh.samp[r].ids_off = r * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
+    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b2) { return a.val > b2.val || (a.val == b2.val && a.flat < b2.flat); });  // (a strict total order: flat indices are distinct -- no stable_sort, which allocates a buffer per call)
+    if ((int)cands.size() > n_keep) cands.resize(n_keep);
+    const int cur_len = (int)S.seq[0].size() + 1;
+    for (size_t rank = 0; rank < cands.size(); ++rank) {
+        const int b = (int)(cands[rank].flat / V), tok = (int)(cands[rank].flat % V);
+        bool is_eos = false;
+        for (int e = 0; e < c.n_eos; ++e) is_eos = is_eos || tok == c.eos_ids[e];
+        if (is_eos) {
+            if ((int)rank >= B) continue;
+            BeamHyp hyp;
+            hyp.tokens = S.seq[b];
+            hyp.fed = step;
+            hyp.buf = -1;
+            if (step > 0) {  // keep a copy of that beam's tail (the reference clones the whole KV cache, :113-120)
+                if (S.free_bufs.empty()) return h->fail(ISST_ERR_STATE, "beam search ran out of hypothesis buffers");
+                hyp.buf = S.free_bufs.back();
+                S.free_bufs.pop_back();
+                if (ops) push_copy(h, *ops, sid, b, hyp.buf, P0, step, false);
+            } else {
+                hyp.buf = -1 - 0;  // empty tail: nothing to keep
             }
-        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-        CHK(launch_log_softmax(h->logits, h->vocab_pad, V, h->lse_max, h->lse_sum, rows, st));
-        CHK(launch_sample_process(h->logits, h->vocab_pad, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
-                                  p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, rows, st));
-        if (p->do_sample) {
-            // beam SAMPLE (:871-875): the processed log-probs of every row come to the host; there the warpers (part of the processor list under do_sample),
-            // + beam score, softmax over a stream's rows_per x V scores, n_keep draws without replacement (warp.hip) -- written into the same candidate
-            // arrays the top-k fills below (value = warped log-prob of the drawn token, so that value + beam score is the reference's gathered score)
-            HIPCHK(hipMemcpyAsync(h->samp_host, h->logits, (size_t)rows * h->vocab_pad * sizeof(float), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            h->kv_ops_used = 0;
-            std::vector<float> flat((size_t)rows_per * V);
-            std::vector<double> us(n_keep);
-            std::vector<long> picked(n_keep);
-            for (int i = 0; i < n; ++i) {
-                for (int b = 0; b < rows_per; ++b) {
-                    float* row = h->samp_host + (size_t)(i * rows_per + b) * h->vocab_pad;
-                    warp_scores(row, V, p->temperature, p->top_k, p->top_p, p->epsilon_cutoff, c.n_eos + 1);  // min_tokens_to_keep of beam methods
-                    const float bsc = bs[i].score[b];
-                    for (int v2 = 0; v2 < V; ++v2) flat[(size_t)b * V + v2] = row[v2] + bsc;
-                }
-                for (int j = 0; j < n_keep; ++j) us[j] = sample_uniform(p->seed, stream_ids[i], h->streams[stream_ids[i]].chunks, 64 * step + j);
-                if (multinomial_without_replacement(flat.data(), (long)rows_per * V, n_keep, us.data(), picked.data()) != ISST_OK)
-                    return h->fail(ISST_ERR_STATE, "beam sample: fewer than %d tokens with non-zero probability at step %d (torch.multinomial raises here too)", n_keep, step);
-                // candidate j of the stream goes to the slot (row of its beam, next free column); unused slots are marked invalid
-                std::vector<int> used(rows_per, 0);
-                for (int b = 0; b < rows_per; ++b)
-                    for (int j = 0; j < BEAM_TOPK; ++j) h->top_idx_host[(i * rows_per + b) * BEAM_TOPK + j] = -1;
-                for (int j = 0; j < n_keep; ++j) {
-                    const int b = (int)(picked[j] / V), tok = (int)(picked[j] % V);
-                    const int r = i * rows_per + b, slot = used[b]++;
-                    h->top_val_host[r * BEAM_TOPK + slot] = h->samp_host[(size_t)r * h->vocab_pad + tok];
-                    h->top_idx_host[r * BEAM_TOPK + slot] = tok;
-                }
-            }
+            const int freed = S.hyps.add(std::move(hyp), (double)cands[rank].val, cur_len - prompt_len);
+            if (freed >= B) S.free_bufs.push_back(freed);
         } else {
-            // (the final selection stores its <= 32 candidates per row straight into the pinned host arrays: no device copy, no two D2H launches per step)
-            CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val_host, h->top_idx_host, rows, st));
-            bt_lap(bt_tail);
-            HIPCHK(hipStreamSynchronize(st));
-            bt_lap(bt_sync);
-            if (const int rc_f = check_fused_ao(h)) return rc_f;  // (not through CHK: the message names the cause)
-            h->kv_ops_used = 0;  // every earlier copy batch has run
+            nscore.push_back(cands[rank].val);
+            ntok.push_back(tok);
+            npar.push_back(b);
         }
-
-        // ---- scorer (beam_search_process, :43-157) ----
-        bool all_done = true;
-        std::vector<std::vector<int>> parents(n), next_tok(n);
-        struct Cand { float val; long flat; };
-        std::vector<Cand> cands;
-        std::vector<float> nscore;
-        cands.reserve((size_t)rows_per * n_keep);
-        nscore.reserve(B);
-        for (int i = 0; i < n; ++i) {
-            BeamStream& S = bs[i];
-            const int prompt_len = prompt_lens[i];
-            const int P0 = total0[i] + rows_len[i];  // first position written by the decode phase
-            std::vector<int>& ntok = next_tok[i];
-            std::vector<int>& npar = parents[i];
-            if (S.done) {
-                // a finished batch entry is skipped by the scorer (patch_hf.py:83-92: pad tokens, zero scores, its hypotheses untouched)
-                // while the other streams of the call go on; its rows still ride through the forward pass (their KV beyond the
-                // winner's tail is never read: llm_total is set from the winning hypothesis)
-                const int pad = c.n_eos ? c.eos_ids[0] : 0;
-                for (int b = 0; b < B; ++b) { ntok.push_back(pad); npar.push_back(b); S.seq[b].push_back(pad); }
-                S.score.assign(B, 0.f);
-                continue;
-            }
-            ntok.reserve(B);
-            npar.reserve(B);
-            cands.clear();
-            for (int b = 0; b < rows_per; ++b)
-                for (int j = 0; j < n_keep; ++j) {
-                    const int r = i * rows_per + b;
-                    const int idx = h->top_idx_host[r * BEAM_TOPK + j];
-                    if (idx < 0 || idx >= V) continue;
-                    cands.push_back({h->top_val_host[r * BEAM_TOPK + j] + S.score[b], (long)b * V + idx});
-                }
-            if (h->btrace_on && i == 0) {
-                isst_handle::BeamTraceStep ts;
-                ts.rows = rows_per; ts.n_keep = n_keep;
-                for (int b = 0; b < rows_per; ++b) {
-                    for (int j = 0; j < n_keep; ++j) {
-                        ts.val.push_back(h->top_val_host[b * BEAM_TOPK + j]);
-                        ts.idx.push_back(h->top_idx_host[b * BEAM_TOPK + j]);
-                    }
-                    ts.score.push_back(S.score[b]);
-                }
-                h->btrace.push_back(std::move(ts));
-            }
-            std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b2) { return a.val > b2.val || (a.val == b2.val && a.flat < b2.flat); });  // (a strict total order: flat indices are distinct -- no stable_sort, which allocates a buffer per call)
-            if ((int)cands.size() > n_keep) cands.resize(n_keep);
-            const int cur_len = (int)S.seq[0].size() + 1;
-            nscore.clear();
-            for (size_t rank = 0; rank < cands.size(); ++rank) {
-                const int b = (int)(cands[rank].flat / V), tok = (int)(cands[rank].flat % V);
-                bool is_eos = false;
-                for (int e = 0; e < c.n_eos; ++e) is_eos = is_eos || tok == c.eos_ids[e];
-                if (is_eos) {
-                    if ((int)rank >= B) continue;
-                    BeamHyp hyp;
-                    hyp.tokens = S.seq[b];
-                    hyp.fed = step;
-                    hyp.buf = -1;
-                    if (step > 0) {  // keep a copy of that beam's tail (the reference clones the whole KV cache, :113-120)
-                        if (S.free_bufs.empty()) return h->fail(ISST_ERR_STATE, "beam search ran out of hypothesis buffers");
-                        hyp.buf = S.free_bufs.back();
-                        S.free_bufs.pop_back();
-                        push_copy(h, ops, stream_ids[i], b, hyp.buf, P0, step, false);
-                    } else {
-                        hyp.buf = -1 - 0;  // empty tail: nothing to keep
-                    }
-                    const int freed = S.hyps.add(std::move(hyp), (double)cands[rank].val, cur_len - prompt_len);
-                    if (freed >= B) S.free_bufs.push_back(freed);
-                } else {
-                    nscore.push_back(cands[rank].val);
-                    ntok.push_back(tok);
-                    npar.push_back(b);
-                }
-                if ((int)ntok.size() == B) break;
-            }
-            if ((int)ntok.size() < B) return h->fail(ISST_ERR_STATE, "beam search: fewer than %d non-EOS candidates", B);
-            if (!cands.empty()) S.done = S.done || S.hyps.is_done((double)cands[0].val, cur_len, prompt_len);
-            if (h->btrace_on && i == 0 && (size_t)(step + 1) * B <= h->bforce_tok.size()) {
-                // teacher forcing (test aid): continue with the caller's (token, parent) choices; a beam's score is its parent's score plus
-                // the processed log-prob of the forced token, read back from the device's score row
-                for (int b = 0; b < B; ++b) {
-                    const int tok = h->bforce_tok[(size_t)step * B + b], par = h->bforce_par[(size_t)step * B + b];
-                    if (tok < 0 || tok >= V || par < 0 || par >= rows_per) return h->fail(ISST_ERR_ARG, "forced beam choice (%d, %d) out of range at step %d", tok, par, step);
-                    float lp = 0.f;
-                    if (p->do_sample) lp = h->samp_host[(size_t)(i * rows_per + par) * h->vocab_pad + tok];  // (the warped row is on the host)
-                    else HIPCHK(hipMemcpy(&lp, h->logits + (size_t)(i * rows_per + par) * h->vocab_pad + tok, sizeof(float), hipMemcpyDeviceToHost));
-                    ntok[b] = tok; npar[b] = par; nscore[b] = S.score[par] + lp;
-                }
-            }
-            // input_ids = cat(input_ids[beam_idx], tokens)  (:899)
-            std::vector<std::vector<int>>& nseq = S.seq_next;  // (capacity survives the swap below: no allocation after the first steps)
-            nseq.resize(B);
-            for (int b = 0; b < B; ++b) {
-                const std::vector<int>& src = S.seq[npar[b]];
-                nseq[b].reserve(src.size() + 1 + p->max_new_tokens);
-                nseq[b].assign(src.begin(), src.end());
-                nseq[b].push_back(ntok[b]);
-            }
-            S.seq.swap(nseq);
-            S.score = nscore;
-            all_done = all_done && S.done;
-        }
-        bt_lap(bt_score);
-        CHK(flush_copies(h, ops, mh, md, st));  // hypothesis tails first: the reorder below overwrites arenas
-        ++step;
-        // ---- reorder the tails (:910-913): new beam b continues parent npar[b].  Like the reference this happens BEFORE
-        //      the stop test, so that finalize sees arena b == beam b ----
-        if (step - 1 > 0) {
-            for (int i = 0; i < n; ++i) {
-                const int P0 = total0[i] + rows_len[i];
-                std::set<int> needed;
-                for (int b = 0; b < B; ++b) if (parents[i][b] != b) needed.insert(parents[i][b]);
-                for (int src : needed) push_copy(h, ops, stream_ids[i], src, src, P0, step - 1, false);
-            }
-            CHK(flush_copies(h, ops, mh, md, st));
-            for (int i = 0; i < n; ++i) {
-                const int P0 = total0[i] + rows_len[i];
-                for (int b = 0; b < B; ++b) if (parents[i][b] != b) push_copy(h, ops, stream_ids[i], b, parents[i][b], P0, step - 1, true);
-            }
-            CHK(flush_copies(h, ops, mh, md, st));
-        }
-        bt_lap(bt_copies);
-        if (all_done || step >= p->max_new_tokens) break;  // :920
-        // ---- next forward pass: one row per (stream, beam).  Shared-prefix form (llm_attn.hip, LlmStreamView::n_beams): the B rows of a
-        //      stream are ONE attention group over arena 0 for everything older than this chunk's generated tokens (identical in all
-        //      arenas) plus one workgroup per beam for the <= 4 tiles that differ; otherwise every beam is its own group over its arena ----
-        const int nr = n * B;
-        const bool shared = h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;  // (isst_generate's `beams_share_prefix`: the pre-pass relies on it)
-        for (int i = 0; i < n; ++i) {
-            const StreamState& ss = h->streams[stream_ids[i]];
-            for (int b = 0; b < B; ++b) {
-                const int r = i * B + b;
-                mh.row_stream[r] = shared ? i * B : r;  // view index
-                mh.row_pos[r] = total0[i] + rows_len[i] + step - 1;
-                mh.ids[r] = bs[i].seq[b].back();
-                mh.last_rows[r] = r;
-                mh.views[r].sys_len = ss.llm_sys;
-                mh.views[r].ring_start = ss.llm_ring_start;
-                mh.views[r].kv_offset = h->arena_off(stream_ids[i], b);
-                mh.views[r].new_start = mh.row_pos[r];
-                mh.views[r].row0 = shared ? i * B : r;
-                mh.views[r].rot_keys = h->rot_keys ? 1 : 0;  // every beam's arena carries its rotated keys (pre-pass over all arenas + position copies)
-                mh.views[r].n_beams = shared ? B : 0;
-                mh.views[r].tail_start = total0[i] + rows_len[i];
-                mh.views[r].beam_stride = h->llm_stream_stride;
-                if (shared) {
-                    mh.groups[i].x = i * B;
-                    mh.groups[i].y = B;
-                } else {
-                    mh.groups[r].x = r;
-                    mh.groups[r].y = 1;
-                }
-            }
-        }
-        bt_lap(bt_meta);
-        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-        CHK(llm_forward(h, md, nr, nr, shared ? n : nr, shared ? B : 1, false, nullptr, st, &mh, 0, 0, shared ? B : 0));
-        bt_lap(bt_enq);
+        if ((int)ntok.size() == B) break;
     }
-    if (bt_on)
-        std::fprintf(stderr, "[isst beam host] %d streams x %d beams, %d steps: us per step -- sampling tail enqueue %.0f, wait for the candidates %.0f, scorer %.0f, KV copies %.0f, metadata %.0f, forward enqueue %.0f\n",
-                     n, B, step, bt_tail / step, bt_sync / step, bt_score / step, bt_copies / step, bt_meta / step, bt_enq / step);
+    if ((int)ntok.size() < B) return h->fail(ISST_ERR_STATE, "beam search: fewer than %d non-EOS candidates", B);
+    if (!cands.empty()) S.done = S.done || S.hyps.is_done((double)cands[0].val, cur_len, prompt_len);
+    if (h->btrace_on && i == 0 && (size_t)(step + 1) * B <= h->bforce_tok.size()) {
+        // teacher forcing (test aid): continue with the caller's (token, parent) choices; a beam's score is its parent's score plus
+        // the processed log-prob of the forced token, read back from the device's score row
+        for (int b = 0; b < B; ++b) {
+            const int tok = h->bforce_tok[(size_t)step * B + b], par = h->bforce_par[(size_t)step * B + b];
+            if (tok < 0 || tok >= V || par < 0 || par >= rows_per) return h->fail(ISST_ERR_ARG, "forced beam choice (%d, %d) out of range at step %d", tok, par, step);
+            float lp = 0.f;
+            if (const int rc = forced_lp(b, par, tok, &lp)) return rc;
+            ntok[b] = tok; npar[b] = par; nscore[b] = S.score[par] + lp;
+        }
+    }
+    // input_ids = cat(input_ids[beam_idx], tokens)  (:899)
+    std::vector<std::vector<int>>& nseq = S.seq_next;  // (capacity survives the swap below: no allocation after the first steps)
+    nseq.resize(B);
+    for (int b = 0; b < B; ++b) {
+        const std::vector<int>& src = S.seq[npar[b]];
+        nseq[b].reserve(src.size() + 1 + p->max_new_tokens);
+        nseq[b].assign(src.begin(), src.end());
+        nseq[b].push_back(ntok[b]);
+    }
+    S.seq.swap(nseq);
+    S.score = nscore;
+    return ISST_OK;
+}
 
-    // ---- finalize (:159-275): open beams become hypotheses, the best one wins ----
+// the per-call table both scorers divide by: powtab[l] = l ^ length_penalty (host libm)
+void fill_powtab(std::vector<double>& t, int max_new, double lp) {
+    t.resize((size_t)max_new + 2);
+    for (size_t l = 0; l < t.size(); ++l) t[l] = std::pow((double)l, lp);
+}
+
+// the fused attention + o_proj launch timed out (another process on the GPU, a CU mask: its workgroups were not all resident): from here on this handle
+// runs the three launches -- said once, on stderr -- and the caller re-issues the pass (nothing of the step was committed)
+void latch_three_launch_path(isst_handle* h) {
+    volatile int* ferr = h->tok_host + h->tok_cap + 8;
+    *ferr = 0;
+    h->fuse_ao_used = false;
+    h->fuse_attn_oproj = false;
+    if (h->dgraph.exec) { (void)hipGraphExecDestroy(h->dgraph.exec); h->dgraph.exec = nullptr; }
+    std::fprintf(stderr, "[isst] the fused attention + o_proj launch timed out waiting for its own workgroups (is another process using this GPU, or a CU mask set?): "
+                         "this handle runs attention, combine and o_proj as three launches from now on (ISST_FUSE_ATTN_OPROJ=0 selects that from the start)\n");
+}
+
+// finalize (:159-275): open beams become hypotheses, the best one wins; every arena of a stream ends up holding its winner's tail; outputs + stream lengths
+int beam_finalize(isst_handle* h, const isst_gen_params* p, int n, int B, const int* stream_ids, const int* prompt_lens, const std::vector<int>& rows_len,
+                  const std::vector<int>& total0, std::vector<BeamStream>& bs, int* const* out_ids, int* out_lens, StepMeta& mh, StepMeta& md, hipStream_t st) {
+    const isst_config& c = h->cfg;
+    std::vector<KvCopyOp> ops;
     std::vector<size_t> best_of(n);
     for (int i = 0; i < n; ++i) {
         BeamStream& S = bs[i];
@@ -748,7 +599,410 @@ int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stre
         out_lens[i] = (int)outv.size();
     }
     HIPCHK(hipStreamSynchronize(st));
+    h->kv_ops_used = 0;
     return ISST_OK;
+}
+
+// the metadata of one decode pass of a beam call: one row per (stream, beam).  Shared-prefix form (llm_attn.hip, LlmStreamView::n_beams): the B rows of a
+// stream are ONE attention group over arena 0 for everything older than this chunk's generated tokens (identical in all arenas) plus one workgroup per beam
+// for the <= 4 tiles that differ; otherwise every beam is its own group over its arena.  `fed`: generated tokens already in the caches (the rows sit at P0 + fed)
+void beam_pass_rows(isst_handle* h, StepMeta& m, int n, int B, bool shared, const int* stream_ids, const std::vector<int>& total0, const std::vector<int>& rows_len, int fed) {
+    for (int i = 0; i < n; ++i) {
+        const StreamState& ss = h->streams[stream_ids[i]];
+        for (int b = 0; b < B; ++b) {
+            const int r = i * B + b;
+            m.row_stream[r] = shared ? i * B : r;  // view index
+            m.row_pos[r] = total0[i] + rows_len[i] + fed;
+            m.last_rows[r] = r;
+            m.views[r].sys_len = ss.llm_sys;
+            m.views[r].ring_start = ss.llm_ring_start;
+            m.views[r].kv_offset = h->arena_off(stream_ids[i], b);
+            m.views[r].new_start = m.row_pos[r];
+            m.views[r].row0 = shared ? i * B : r;
+            m.views[r].rot_keys = h->rot_keys ? 1 : 0;  // every beam's arena carries its rotated keys (pre-pass over all arenas + position copies)
+            m.views[r].n_beams = shared ? B : 0;
+            m.views[r].tail_start = total0[i] + rows_len[i];
+            m.views[r].beam_stride = h->llm_stream_stride;
+            if (shared) {
+                m.groups[i].x = i * B;
+                m.groups[i].y = B;
+            } else {
+                m.groups[r].x = r;
+                m.groups[r].y = 1;
+            }
+        }
+    }
+}
+
+// decode phase of a beam call, the HOST deciding every step (do_sample: the warpers and the draws without replacement run on the host; ISST_BEAM_DEVICE=0);
+// the prefill (on arena 0 of every stream) has already produced h->logits rows 0..n-1
+int beam_decode(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const int* const* prompt_ids, const int* prompt_lens,
+                const std::vector<int>& rows_len /* KV entries the prompt wrote (<= prompt_lens after a short splice) */, const int* const* prev_target_ids, const int* n_prev, const std::vector<int>& total0, int* const* out_ids, int* out_lens,
+                StepMeta& mh, StepMeta& md, hipStream_t st) {
+    const isst_config& c = h->cfg;
+    const int B = p->num_beams, V = c.vocab;
+    const int n_keep = std::max(2, 1 + c.n_eos) * B;
+    if (n_keep > BEAM_TOPK) return h->fail(ISST_ERR_ARG, "beam search keeps %d candidates per step, at most %d are supported", n_keep, BEAM_TOPK);
+    const double lp = p->length_penalty == 0.f ? 1.0 : (double)p->length_penalty;
+    std::vector<double> powtab;
+    fill_powtab(powtab, p->max_new_tokens, lp);
+    std::vector<BeamStream> bs(n);
+    std::vector<KvCopyOp> ops;
+    if (h->kv_ops_used) {  // batches of an earlier call that ended without a synchronisation in between (finalize)
+        HIPCHK(hipStreamSynchronize(st));
+        h->kv_ops_used = 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        bs[i].seq.assign(B, std::vector<int>(prompt_ids[i], prompt_ids[i] + prompt_lens[i]));
+        bs[i].score.assign(B, -1e9f);
+        bs[i].score[0] = 0.f;
+        bs[i].hyps.num_beams = B;
+        bs[i].hyps.powtab = powtab.data();
+        for (int b = B; b < h->nbuf; ++b) bs[i].free_bufs.push_back(b);  // slots 0..B-1 are reorder temporaries
+        // the prompt's KV was written to arena 0: replicate it into the other beams' arenas (they are identical before it)
+        push_copy(h, ops, stream_ids[i], 0, 0, total0[i], rows_len[i], false);
+    }
+    CHK(flush_copies(h, ops, mh, md, st));
+    for (int i = 0; i < n; ++i)
+        for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], rows_len[i], true);
+    CHK(flush_copies(h, ops, mh, md, st));
+
+    // ISST_HOST_TRACE=2: where the host's time between two forward passes of a beam step goes (one line per call)
+    static const bool bt_on = std::getenv("ISST_HOST_TRACE") && std::atoi(std::getenv("ISST_HOST_TRACE")) == 2;
+    using bclock = std::chrono::steady_clock;
+    double bt_tail = 0, bt_sync = 0, bt_score = 0, bt_copies = 0, bt_meta = 0, bt_enq = 0;
+    auto bt_us = [](bclock::time_point a, bclock::time_point b2) { return std::chrono::duration<double, std::micro>(b2 - a).count(); };
+    bclock::time_point bt0 = bclock::now(), bt1;
+    auto bt_lap = [&](double& acc) { if (bt_on) { bt1 = bclock::now(); acc += bt_us(bt0, bt1); bt0 = bt1; } };
+    int step = 0;  // tokens already chosen per beam
+    bool relaunched = false;  // the pass whose logits are being scored was re-issued on the three-launch path
+    const bool shared = h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;  // (isst_generate's `beams_share_prefix`: the pre-pass relies on it)
+    while (true) {
+        if (bt_on) bt0 = bclock::now();
+        const int rows_per = step == 0 ? 1 : B;  // step 0: only beam 0 carries a finite score (:767-771)
+        const int rows = n * rows_per;
+        // ---- log_softmax -> processors (on log-probs) -> per-row top-k ----
+        for (int i = 0; i < n; ++i)
+            for (int b = 0; b < rows_per; ++b) {
+                const int r = i * rows_per + b;
+                const std::vector<int>& sq = bs[i].seq[b];
+                std::memcpy(mh.ids_pool + (size_t)r * h->max_ids, sq.data(), sq.size() * 4);
+                const int ne = n_prev ? n_prev[i] : 0;
+                if (b == 0 && ne) std::memcpy(mh.enc_pool + (size_t)i * h->max_enc_ids, prev_target_ids[i], (size_t)ne * 4);
+                mh.samp[r].n_ids = (int)sq.size(); mh.samp[r].n_enc = ne;
+                mh.samp[r].ids_off = r * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
+            }
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+        CHK(launch_log_softmax(h->logits, h->vocab_pad, V, h->lse_max, h->lse_sum, rows, st));
+        CHK(launch_sample_process(h->logits, h->vocab_pad, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
+                                  p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, rows, st));
+        if (p->do_sample) {
+            // beam SAMPLE (:871-875): the processed log-probs of every row come to the host; there the warpers (part of the processor list under do_sample),
+            // + beam score, softmax over a stream's rows_per x V scores, n_keep draws without replacement (warp.hip) -- written into the same candidate
+            // arrays the top-k fills below (value = warped log-prob of the drawn token, so that value + beam score is the reference's gathered score)
+            HIPCHK(hipMemcpyAsync(h->samp_host, h->logits, (size_t)rows * h->vocab_pad * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h->kv_ops_used = 0;
+        } else {
+            // (the final selection stores its <= 32 candidates per row straight into the pinned host arrays: no device copy, no two D2H launches per step)
+            CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val_host, h->top_idx_host, rows, st));
+            bt_lap(bt_tail);
+            HIPCHK(hipStreamSynchronize(st));
+            bt_lap(bt_sync);
+            h->kv_ops_used = 0;  // every earlier copy batch has run
+        }
+        if (h->fuse_ao_used) {  // the fused launches of the pass that produced these logits have run: did one of them give up waiting?
+            h->fuse_ao_used = false;
+            if (*reinterpret_cast<volatile int*>(h->tok_host + h->tok_cap + 8) != 0) {
+                if (relaunched || step == 0) return h->fail(ISST_ERR_HIP, "the fused attention + o_proj launch timed out and the pass could not be re-issued");
+                latch_three_launch_path(h);
+                relaunched = true;  // nothing of this step is committed (the host's state moves below): the same pass once more, attention / combine / o_proj as three launches
+                beam_pass_rows(h, mh, n, B, shared, stream_ids, total0, rows_len, step - 1);
+                for (int i = 0; i < n; ++i)
+                    for (int b = 0; b < B; ++b) mh.ids[i * B + b] = bs[i].seq[b].back();
+                HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+                CHK(llm_forward(h, md, n * B, n * B, shared ? n : n * B, shared ? B : 1, false, nullptr, st, &mh, 0, 0, shared ? B : 0));
+                continue;
+            }
+        }
+        relaunched = false;
+        if (p->do_sample) {
+            std::vector<float> flat((size_t)rows_per * V);
+            std::vector<double> us(n_keep);
+            std::vector<long> picked(n_keep);
+            for (int i = 0; i < n; ++i) {
+                for (int b = 0; b < rows_per; ++b) {
+                    float* row = h->samp_host + (size_t)(i * rows_per + b) * h->vocab_pad;
+                    warp_scores(row, V, p->temperature, p->top_k, p->top_p, p->epsilon_cutoff, c.n_eos + 1);  // min_tokens_to_keep of beam methods
+                    const float bsc = bs[i].score[b];
+                    for (int v2 = 0; v2 < V; ++v2) flat[(size_t)b * V + v2] = row[v2] + bsc;
+                }
+                for (int j = 0; j < n_keep; ++j) us[j] = sample_uniform(p->seed, stream_ids[i], h->streams[stream_ids[i]].chunks, 64 * step + j);
+                if (multinomial_without_replacement(flat.data(), (long)rows_per * V, n_keep, us.data(), picked.data()) != ISST_OK)
+                    return h->fail(ISST_ERR_STATE, "beam sample: fewer than %d tokens with non-zero probability at step %d (torch.multinomial raises here too)", n_keep, step);
+                // candidate j of the stream goes to the slot (row of its beam, next free column); unused slots are marked invalid
+                std::vector<int> used(rows_per, 0);
+                for (int b = 0; b < rows_per; ++b)
+                    for (int j = 0; j < BEAM_TOPK; ++j) h->top_idx_host[(i * rows_per + b) * BEAM_TOPK + j] = -1;
+                for (int j = 0; j < n_keep; ++j) {
+                    const int b = (int)(picked[j] / V), tok = (int)(picked[j] % V);
+                    const int r = i * rows_per + b, slot = used[b]++;
+                    h->top_val_host[r * BEAM_TOPK + slot] = h->samp_host[(size_t)r * h->vocab_pad + tok];
+                    h->top_idx_host[r * BEAM_TOPK + slot] = tok;
+                }
+            }
+        }
+
+        // ---- scorer (beam_search_process, :43-157) ----
+        bool all_done = true;
+        std::vector<std::vector<int>> parents(n), next_tok(n);
+        for (int i = 0; i < n; ++i) {
+            const int P0 = total0[i] + rows_len[i];  // first position written by the decode phase
+            auto forced_lp = [&](int, int par, int tok, float* out) -> int {
+                if (p->do_sample) *out = h->samp_host[(size_t)(i * rows_per + par) * h->vocab_pad + tok];  // (the warped row is on the host)
+                else HIPCHK(hipMemcpy(out, h->logits + (size_t)(i * rows_per + par) * h->vocab_pad + tok, sizeof(float), hipMemcpyDeviceToHost));
+                return ISST_OK;
+            };
+            if (const int rc = scorer_step(h, p, bs[i], i, stream_ids[i], rows_per, n_keep, B, step, prompt_lens[i], P0, h->top_val_host + (size_t)i * rows_per * BEAM_TOPK,
+                                           h->top_idx_host + (size_t)i * rows_per * BEAM_TOPK, next_tok[i], parents[i], &ops, forced_lp))
+                return rc;
+            all_done = all_done && bs[i].done;
+        }
+        bt_lap(bt_score);
+        CHK(flush_copies(h, ops, mh, md, st));  // hypothesis tails first: the reorder below overwrites arenas
+        ++step;
+        // ---- reorder the tails (:910-913): new beam b continues parent npar[b].  Like the reference this happens BEFORE
+        //      the stop test, so that finalize sees arena b == beam b ----
+        if (step - 1 > 0) {
+            for (int i = 0; i < n; ++i) {
+                const int P0 = total0[i] + rows_len[i];
+                std::set<int> needed;
+                for (int b = 0; b < B; ++b) if (parents[i][b] != b) needed.insert(parents[i][b]);
+                for (int src : needed) push_copy(h, ops, stream_ids[i], src, src, P0, step - 1, false);
+            }
+            CHK(flush_copies(h, ops, mh, md, st));
+            for (int i = 0; i < n; ++i) {
+                const int P0 = total0[i] + rows_len[i];
+                for (int b = 0; b < B; ++b) if (parents[i][b] != b) push_copy(h, ops, stream_ids[i], b, parents[i][b], P0, step - 1, true);
+            }
+            CHK(flush_copies(h, ops, mh, md, st));
+        }
+        bt_lap(bt_copies);
+        if (all_done || step >= p->max_new_tokens) break;  // :920
+        // ---- next forward pass: one row per (stream, beam) ----
+        const int nr = n * B;
+        beam_pass_rows(h, mh, n, B, shared, stream_ids, total0, rows_len, step - 1);
+        for (int i = 0; i < n; ++i)
+            for (int b = 0; b < B; ++b) mh.ids[i * B + b] = bs[i].seq[b].back();
+        bt_lap(bt_meta);
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+        CHK(llm_forward(h, md, nr, nr, shared ? n : nr, shared ? B : 1, false, nullptr, st, &mh, 0, 0, shared ? B : 0));
+        bt_lap(bt_enq);
+    }
+    if (bt_on)
+        std::fprintf(stderr, "[isst beam host] %d streams x %d beams, %d steps: us per step -- sampling tail enqueue %.0f, wait for the candidates %.0f, scorer %.0f, KV copies %.0f, metadata %.0f, forward enqueue %.0f\n",
+                     n, B, step, bt_tail / step, bt_sync / step, bt_score / step, bt_copies / step, bt_meta / step, bt_enq / step);
+    return beam_finalize(h, p, n, B, stream_ids, prompt_lens, rows_len, total0, bs, out_ids, out_lens, mh, md, st);
+}
+
+// decode phase of a beam call with the SCORER ON THE DEVICE (the default; beam.hip beam_select_kernel).  Per step the stream carries
+//     log-softmax -> processors -> per-row top-k -> beam_select (decides, reorders the beams' sequences, writes the next pass's token ids / positions and the
+//     position-copy lists, logs candidates + choices to pinned memory, publishes a sequence number) -> the two copy launches -> the next forward pass
+// and never waits for the host: the host waits for the sequence number (it arrives while the copies still run), reads the done flags, enqueues the next pass --
+// whose one-group attention metadata it knows without the tokens -- and only then re-derives the step from the logged candidates with the scorer above
+// (the state finalize needs: sequences, hypotheses, their buffers), checking every choice against the device's.  The reference's beam_search_process is a
+// host round trip per step by construction (patch_hf.py:43-157 runs in Python between two forward passes).
+int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const int* stream_ids, const int* const* prompt_ids, const int* prompt_lens,
+                       const std::vector<int>& rows_len, const int* const* prev_target_ids, const int* n_prev, const std::vector<int>& total0, int* const* out_ids,
+                       int* out_lens, StepMeta& mh, StepMeta& md, hipStream_t st) {
+    const isst_config& c = h->cfg;
+    const int B = p->num_beams, V = c.vocab;
+    const int n_keep = std::max(2, 1 + c.n_eos) * B;
+    if (n_keep > BEAM_TOPK) return h->fail(ISST_ERR_ARG, "beam search keeps %d candidates per step, at most %d are supported", n_keep, BEAM_TOPK);
+    if (B > BEAM_MAX_B || p->max_new_tokens + 1 > h->blog_steps) return h->fail(ISST_ERR_ARG, "beam search: %d beams / %d new tokens exceed the configured capacity", B, p->max_new_tokens);
+    const double lp = p->length_penalty == 0.f ? 1.0 : (double)p->length_penalty;
+    std::vector<double> powtab;
+    fill_powtab(powtab, p->max_new_tokens, lp);
+    std::vector<BeamStream> bs(n);
+    std::vector<KvCopyOp> ops;
+    if (h->kv_ops_used) {  // batches of an earlier call that ended without a synchronisation in between
+        HIPCHK(hipStreamSynchronize(st));
+        h->kv_ops_used = 0;
+    }
+    for (int i = 0; i < n; ++i) {
+        bs[i].seq.assign(B, std::vector<int>(prompt_ids[i], prompt_ids[i] + prompt_lens[i]));
+        bs[i].score.assign(B, -1e9f);
+        bs[i].score[0] = 0.f;
+        bs[i].hyps.num_beams = B;
+        bs[i].hyps.powtab = powtab.data();
+        for (int b = B; b < h->nbuf; ++b) bs[i].free_bufs.push_back(b);  // slots 0..B-1 are reorder temporaries
+        // the prompt's KV was written to arena 0: replicate it into the other beams' arenas (they are identical before it)
+        push_copy(h, ops, stream_ids[i], 0, 0, total0[i], rows_len[i], false);
+    }
+    CHK(flush_copies(h, ops, mh, md, st));
+    for (int i = 0; i < n; ++i)
+        for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], rows_len[i], true);
+    CHK(flush_copies(h, ops, mh, md, st));
+
+    // ---- the device's copy of the search state (the stream was idle when this call began: the pinned staging blocks are free) ----
+    const bool shared = h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;  // (isst_generate's `beams_share_prefix`: the pre-pass relies on it)
+    const int nr = n * B;
+    std::memcpy(h->bpow_host, powtab.data(), sizeof(double) * powtab.size());
+    HIPCHK(hipMemcpyAsync(h->bpow_dev, h->bpow_host, sizeof(double) * powtab.size(), hipMemcpyHostToDevice, st));
+    for (int i = 0; i < n; ++i) {
+        BeamDevStream& D = h->bst_host[i];
+        std::memset(&D, 0, sizeof D);
+        for (int b = 0; b < BEAM_MAX_B; ++b) D.score[b] = b == 0 ? 0.f : -1e9f;
+        D.worst = 1e9;
+        for (int b = B; b < h->nbuf; ++b) D.free_bufs[D.n_free++] = b;  // (the order of bs[i].free_bufs: both scorers hand out the same slots)
+        const StreamState& ss = h->streams[stream_ids[i]];
+        D.prompt_len = prompt_lens[i];
+        D.P0 = total0[i] + rows_len[i];
+        D.sid = stream_ids[i];
+        D.sys_len = ss.llm_sys;
+        D.ring_start = ss.llm_ring_start;
+        D.n_enc = n_prev ? n_prev[i] : 0;
+    }
+    HIPCHK(hipMemcpyAsync(h->bst_dev, h->bst_host, sizeof(BeamDevStream) * n, hipMemcpyHostToDevice, st));
+    const int force_steps = h->btrace_on ? (int)(h->bforce_tok.size() / (size_t)B) : 0;
+    if (force_steps > 0) {
+        if (force_steps > c.max_new_tokens) return h->fail(ISST_ERR_ARG, "more forced beam steps (%d) than max_new_tokens", force_steps);
+        std::memcpy(h->bforce_host, h->bforce_tok.data(), sizeof(int) * force_steps * B);
+        std::memcpy(h->bforce_host + (size_t)c.max_new_tokens * h->max_beams, h->bforce_par.data(), sizeof(int) * force_steps * B);
+        HIPCHK(hipMemcpyAsync(h->bforce_dev, h->bforce_host, sizeof(int) * 2 * c.max_new_tokens * h->max_beams, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemsetAsync(h->bop_counts_dev, 0, sizeof(int) * 2 * ((size_t)c.max_new_tokens + 1), st));
+    // the decode passes' rows (static part; token ids, positions and sequence lengths are written by beam_select step by step)
+    StepMeta bh = carve(h, h->meta_host2), bd = carve(h, h->meta_dev2);
+    beam_pass_rows(h, bh, n, B, shared, stream_ids, total0, rows_len, 0);
+    for (int i = 0; i < n; ++i) {
+        const int ne = n_prev ? n_prev[i] : 0;
+        if (ne) std::memcpy(bh.enc_pool + (size_t)i * h->max_enc_ids, prev_target_ids[i], (size_t)ne * 4);
+        for (int b = 0; b < B; ++b) {
+            const int r = i * B + b;
+            bh.ids[r] = 0;
+            bh.speech_row[r] = -1;
+            bh.samp[r].n_ids = 0; bh.samp[r].n_enc = ne;
+            bh.samp[r].ids_off = r * h->max_ids; bh.samp[r].enc_off = i * h->max_enc_ids; bh.samp[r].logits_row = r;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(h->meta_dev2 + 4096, h->meta_host2 + 4096, bh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+
+    const size_t NB = (size_t)c.max_streams * h->max_beams;
+    auto slot_val = [&](int s) { return reinterpret_cast<float*>(h->blog + (size_t)s * h->blog_slot_bytes); };
+    auto slot_idx = [&](int s) { return reinterpret_cast<int*>(h->blog + (size_t)s * h->blog_slot_bytes + NB * BEAM_TOPK * 4); };
+    auto slot_dec = [&](int s) { return reinterpret_cast<BeamDecision*>(h->blog + (size_t)s * h->blog_slot_bytes + NB * BEAM_TOPK * 8); };
+    auto slot_done = [&](int s) { return reinterpret_cast<int*>(h->blog + (size_t)s * h->blog_slot_bytes + NB * BEAM_TOPK * 8 + NB * sizeof(BeamDecision)); };
+    volatile int* seq_word = reinterpret_cast<volatile int*>(h->blog + (size_t)h->blog_steps * h->blog_slot_bytes);
+    volatile int* ferr = h->tok_host + h->tok_cap + 8;
+
+    // the host's re-derivation of step s from the log (after the next pass is enqueued: it overlaps the GPU's work)
+    std::vector<int> f_tok, f_par;
+    auto follow = [&](int s) -> int {
+        const int rows_per = s == 0 ? 1 : B;
+        const BeamDecision* dec = slot_dec(s);
+        const int* dn = slot_done(s);
+        for (int i = 0; i < n; ++i) {
+            auto forced_lp = [&](int b, int, int, float* out) -> int { *out = dec[i * B + b].forced_lp; return ISST_OK; };
+            if (const int rc = scorer_step(h, p, bs[i], i, stream_ids[i], rows_per, n_keep, B, s, prompt_lens[i], total0[i] + rows_len[i], slot_val(s) + (size_t)i * B * BEAM_TOPK,
+                                           slot_idx(s) + (size_t)i * B * BEAM_TOPK, f_tok, f_par, nullptr, forced_lp))
+                return rc;
+            if (dn[i] < 0) return h->fail(ISST_ERR_STATE, "beam search: the device scorer failed at step %d of stream %d (status %d) where the host scorer did not", s, stream_ids[i], dn[i]);
+            for (int b = 0; b < B; ++b) {
+                const BeamDecision& d = dec[i * B + b];
+                if (d.tok != f_tok[b] || d.par != f_par[b] || std::memcmp(&d.score, &bs[i].score[b], sizeof(float)) != 0 || (dn[i] != 0) != bs[i].done)
+                    return h->fail(ISST_ERR_STATE, "beam search: device and host scorers disagree at step %d, stream %d, beam %d (device token %d parent %d score %.9g done %d, host token %d parent %d score %.9g done %d)",
+                                   s, stream_ids[i], b, d.tok, d.par, (double)d.score, dn[i], f_tok[b], f_par[b], (double)bs[i].score[b], (int)bs[i].done);
+            }
+        }
+        return ISST_OK;
+    };
+
+    static const bool bt_on = std::getenv("ISST_HOST_TRACE") && std::atoi(std::getenv("ISST_HOST_TRACE")) == 2;
+    using bclock = std::chrono::steady_clock;
+    double bt_tail = 0, bt_wait = 0, bt_enq = 0, bt_follow = 0;
+    bclock::time_point bt0 = bclock::now(), bt1;
+    auto bt_lap = [&](double& acc) { if (bt_on) { bt1 = bclock::now(); acc += std::chrono::duration<double, std::micro>(bt1 - bt0).count(); bt0 = bt1; } };
+    int step = 0;            // tokens already chosen per beam
+    bool relaunched = false; // the pass whose logits are being scored was re-issued on the three-launch path
+    while (true) {
+        if (bt_on) bt0 = bclock::now();
+        const int rows_per = step == 0 ? 1 : B;  // step 0: only beam 0 carries a finite score (:767-771)
+        const int rows = n * rows_per;
+        // ---- log_softmax -> processors (on log-probs) -> per-row top-k, all on device-resident sequences ----
+        const SampleStream* samp = step == 0 ? md.samp : bd.samp;
+        const int* ids_pool = step == 0 ? md.ids_pool : h->bseq[step & 1];
+        const int* enc_pool = step == 0 ? md.enc_pool : bd.enc_pool;
+        CHK(launch_log_softmax(h->logits, h->vocab_pad, V, h->lse_max, h->lse_sum, rows, st));
+        CHK(launch_sample_process(h->logits, h->vocab_pad, samp, ids_pool, enc_pool, md.suppress, p->n_suppress, p->repetition_penalty, p->no_repeat_ngram_size,
+                                  p->encoder_no_repeat_ngram_size, rows, st));
+        CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val, h->top_idx, rows, st));
+        // ---- the scorer + the reorder ----
+        BeamSelArgs a{};
+        a.n = n; a.B = B; a.n_keep = n_keep; a.V = V; a.step = step; a.rows_per = rows_per; a.max_ids = h->max_ids; a.max_enc_ids = h->max_enc_ids;
+        a.n_eos = c.n_eos; a.pad_tok = c.n_eos ? c.eos_ids[0] : 0;
+        for (int e = 0; e < 8; ++e) a.eos[e] = e < c.n_eos ? c.eos_ids[e] : -1;
+        a.top_val = h->top_val; a.top_idx = h->top_idx; a.st = h->bst_dev; a.powtab = h->bpow_dev;
+        a.seq_in = ids_pool; a.seq_in_rows_per = step == 0 ? 1 : B; a.seq_out = h->bseq[(step + 1) & 1];
+        a.ids = bd.ids; a.row_pos = bd.row_pos; a.views = bd.views; a.samp = bd.samp;
+        a.ops1 = h->bops_dev[0]; a.ops2 = h->bops_dev[1]; a.op_counts = h->bop_counts_dev + 2 * step;
+        a.stream_stride = h->llm_stream_stride; a.tbuf_stride = h->tbuf_stride; a.max_beams = h->max_beams; a.nbuf = h->nbuf;
+        a.log_val = slot_val(step); a.log_idx = slot_idx(step); a.log_dec = slot_dec(step); a.log_done = slot_done(step);
+        a.log_seq = const_cast<int*>(seq_word); a.seq_value = ++h->bsel_seq; a.ticket = h->bticket_dev;
+        a.err_word = const_cast<const int*>(ferr);
+        a.force_tok = h->bforce_dev; a.force_par = h->bforce_dev + (size_t)c.max_new_tokens * h->max_beams; a.force_steps = force_steps;
+        a.logits = h->logits; a.ld_logits = h->vocab_pad;
+        CHK(launch_beam_select(a, st));
+        if (step > 0) {  // (step 0: every beam descends from beam 0 and no tail exists yet -- nothing to copy)
+            bf16_t* kr = h->rot_keys ? h->llm_kr : nullptr;
+            CHK(launch_kv_positions_copy_list(h->llm_k, h->llm_v, kr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, a.ops1, a.op_counts, 2 * nr, h->adims, c.llm_layers, h->tcap, st));
+            CHK(launch_kv_positions_copy_list(h->llm_k, h->llm_v, kr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, a.ops2, a.op_counts + 1, nr, h->adims, c.llm_layers, h->tcap, st));
+        }
+        bt_lap(bt_tail);
+        // ---- the step's sequence number (published by the scorer while the copies still run) ----
+        for (unsigned long spins = 1; *seq_word != a.seq_value; ++spins) {
+            if ((spins & 0x3FFFF) == 0) {  // every ~quarter million polls: has the stream drained without the number arriving?
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {
+                    if (*seq_word == a.seq_value) break;
+                    return h->fail(ISST_ERR_HIP, "beam step %d did not publish its choices", step);
+                }
+                if (q != hipErrorNotReady) return h->fail(ISST_ERR_HIP, "hipStreamQuery: %s", hipGetErrorString(q));
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        bt_lap(bt_wait);
+        h->fuse_ao_used = false;
+        bool all_done = true, upstream_failed = false;
+        const int* dn = slot_done(step);
+        for (int i = 0; i < n; ++i) { all_done = all_done && dn[i] == 1; upstream_failed = upstream_failed || dn[i] == -1; }
+        if (upstream_failed || *ferr != 0) {
+            // a fused attention + o_proj launch of the pass behind these logits gave up waiting: the scorer left its state alone.  Latch the three-launch
+            // path and run the same pass and the same step again (the KV appends and the hidden state are rewritten from the token ids)
+            if (relaunched || step == 0 || !upstream_failed) return h->fail(ISST_ERR_HIP, "the fused attention + o_proj launch timed out and the pass could not be re-issued");
+            latch_three_launch_path(h);
+            relaunched = true;
+            beam_pass_rows(h, bh, n, B, shared, stream_ids, total0, rows_len, step - 1);
+            CHK(llm_forward(h, bd, nr, nr, shared ? n : nr, shared ? B : 1, false, nullptr, st, &bh, 0, 0, shared ? B : 0));
+            continue;
+        }
+        relaunched = false;
+        ++step;
+        if (all_done || step >= p->max_new_tokens) {  // :920
+            if (const int rc = follow(step - 1)) return rc;
+            break;
+        }
+        // ---- the next forward pass (its rows' ids / positions are on the device already; the host needs the positions for the one-group launch forms) ----
+        beam_pass_rows(h, bh, n, B, shared, stream_ids, total0, rows_len, step - 1);
+        CHK(llm_forward(h, bd, nr, nr, shared ? n : nr, shared ? B : 1, false, nullptr, st, &bh, 0, 0, shared ? B : 0));
+        bt_lap(bt_enq);
+        if (const int rc = follow(step - 1)) return rc;
+        bt_lap(bt_follow);
+    }
+    if (bt_on)
+        std::fprintf(stderr, "[isst beam host] %d streams x %d beams, %d steps, scorer on the device: us per step -- tail + scorer + copies enqueue %.0f, wait for the step's number %.0f, forward enqueue %.0f, host follower (beside the GPU) %.0f\n",
+                     n, B, step, bt_tail / step, bt_wait / step, bt_enq / step, bt_follow / step);
+    return beam_finalize(h, p, n, B, stream_ids, prompt_lens, rows_len, total0, bs, out_ids, out_lens, mh, md, st);
 }
 
 }  // namespace
@@ -919,8 +1173,11 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         if (h->rot_keys && any_cached) CHK(launch_llm_rope_cache(md.views, rope_views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
     }
     CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh, n_units, max_unit_groups));
-    if (B > 1)
+    if (B > 1) {
+        if (h->beam_device && !p->do_sample)
+            return beam_decode_device(h, p, n, stream_ids, prompt_ids, prompt_lens, rows_len, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);
         return beam_decode(h, p, n, stream_ids, prompt_ids, prompt_lens, rows_len, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);
+    }
 
     // ---- 3. greedy loop (patch_hf.py:606-624 -> HF _sample) ----
     std::vector<int> active(n);
@@ -1027,13 +1284,27 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     };
 
     if (const int rc = sample_tail(n)) return rc;
+    int last_nr = 0;          // rows of the decode pass whose tokens are being waited for (0: the prefill, which never takes the fused launch)
+    bool relaunched = false;  // ... and that pass is already the re-issue on the three-launch path
     std::chrono::steady_clock::time_point ht_a, ht_b;
     if (g_ht.on) { ht_a = std::chrono::steady_clock::now(); g_ht.enq_first = HostTrace::us(g_ht.t_entry, ht_a); }
     while (true) {
         const int na = (int)active.size();
         if (g_ht.on) ht_a = std::chrono::steady_clock::now();
         CHK(wait_tokens());
-        if (const int rc_f = check_fused_ao(h)) return rc_f;  // (not through CHK: the message names the cause)
+        if (h->fuse_ao_used) {  // the fused attention + o_proj launches of the pass behind these tokens have run: did one of them give up waiting for its own workgroups?
+            h->fuse_ao_used = false;
+            if (*reinterpret_cast<volatile int*>(h->tok_host + h->tok_cap + 8) != 0) {
+                // nothing of the step is committed yet (the tokens above are discarded, the stream lengths move at the end of the call): latch the three-launch
+                // path and run the SAME pass again -- its metadata is still in the pinned block, its KV appends and hidden state are rewritten from the token ids
+                if (relaunched || last_nr == 0) return h->fail(ISST_ERR_HIP, "the fused attention + o_proj launch timed out and the pass could not be re-issued on the three-launch path");
+                latch_three_launch_path(h);
+                relaunched = true;
+                if (const int rc = decode_step(last_nr)) return rc;
+                continue;
+            }
+        }
+        relaunched = false;
         if (g_ht.on) { ht_b = std::chrono::steady_clock::now(); g_ht.wait += HostTrace::us(ht_a, ht_b); g_ht.waits++; }
         if (p->do_sample)  // HF _sample with do_sample: warpers, softmax, one draw per row (patch_hf.py:606-624)
             for (int r = 0; r < na; ++r)
@@ -1074,6 +1345,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             mh.samp[r].ids_off = i * h->max_ids; mh.samp[r].enc_off = i * h->max_enc_ids; mh.samp[r].logits_row = r;
         }
         if (g_ht.on) { ht_a = std::chrono::steady_clock::now(); g_ht.between += HostTrace::us(ht_b, ht_a); }
+        last_nr = nr;
         if (const int rc = decode_step(nr)) return rc;  // (the failing call has already recorded its message)
         if (g_ht.on) g_ht.enq_pass += HostTrace::us(ht_a, std::chrono::steady_clock::now());
     }

@@ -126,7 +126,68 @@ struct KvCopyOp {
 };
 int launch_kv_positions_copy(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf, const KvCopyOp* ops, int n_ops, int max_count,
                              LlmAttnDims d, int layers, int tcap, hipStream_t s);
+// the same copies from op lists that a kernel wrote (beam_select_kernel): `*count` ops, known only on the device; grid (kv heads, layers, op lanes)
+int launch_kv_positions_copy_list(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf, const KvCopyOp* ops, const int* count,
+                                  int max_ops, LlmAttnDims d, int layers, int tcap, hipStream_t s);
 int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* psum, int rows, hipStream_t s);
+
+// ---- the beam scorer on the device (beam.hip beam_select_kernel; reference patch_hf.py:43-157 beam_search_process + :278-302 BeamHypotheses.add + [3P]
+//      is_done + the cache reorder of :910-913) ----
+#define BEAM_MAX_B 8
+struct BeamDevStream {           // one per stream of a beam call; written by the host before the loop, kept up to date by the kernel
+    float score[BEAM_MAX_B];     // beam scores (running sums of log-probs)
+    double hyp_score[BEAM_MAX_B + 1];  // BeamHypotheses: score of every kept hypothesis, in insertion order (the order decides ties)
+    int hyp_buf[BEAM_MAX_B + 1]; // tail buffer slot holding its KV, or < 0
+    int hyp_n;
+    int done;
+    double worst;
+    int free_bufs[2 * BEAM_MAX_B + 1];
+    int n_free;
+    int prompt_len;              // tokens of the prompt (the processors' ids: patch tokens included)
+    int P0;                      // first logical KV position written by the decode phase
+    int sid;                     // library stream id (arena / buffer offsets)
+    int sys_len, ring_start;
+    int n_enc;
+    int pad;
+};
+struct BeamDecision {            // per (stream, beam) and step, in the pinned host log
+    int tok, par;
+    float score;
+    float forced_lp;
+};
+struct BeamSelArgs {
+    int n, B, n_keep, V, step, rows_per, max_ids, max_enc_ids;
+    int n_eos, pad_tok;
+    int eos[8];
+    const float* top_val;        // [rows][BEAM_TOPK] candidates of this step (processed log-probs, before the beam score is added)
+    const int* top_idx;
+    BeamDevStream* st;           // [n]
+    const double* powtab;        // powtab[l] = pow((double)l, length_penalty), filled by the HOST (one libm for both scorers)
+    const int* seq_in;           // token sequences of the beams before this step: row (i * seq_in_rows_per + parent) x max_ids
+    int seq_in_rows_per;
+    int* seq_out;                // ... and after it: row i * B + b
+    int *ids, *row_pos;          // metadata of the NEXT forward pass (rows i * B + b)
+    LlmStreamView* views;
+    SampleStream* samp;
+    KvCopyOp *ops1, *ops2;       // position copies of this step: arena -> buffer (hypothesis tails, parents staged), then buffer -> arena
+    int* op_counts;              // [2], zero before the launch
+    long stream_stride, tbuf_stride;
+    int max_beams, nbuf;
+    float* log_val;              // pinned host log of this step: the candidates ...
+    int* log_idx;
+    BeamDecision* log_dec;       // ... the choices [n * B] ...
+    int* log_done;               // ... per stream: 0 / 1 = BeamSearchScorer done flag, < 0 = failure (-1: an earlier launch of the pass raised the error word,
+                                 //     -2: out of hypothesis buffers, -3: fewer than B non-EOS candidates, -4: forced choice out of range)
+    int* log_seq;                // ... and the launch's sequence number, stored once every stream's part is in host memory
+    int seq_value;
+    int* ticket;                 // device counter, zero between launches
+    const int* err_word;         // pinned error word of the fused attention launch (0 = fine)
+    const int *force_tok, *force_par;  // teacher forcing of stream 0 (test aid): [force_steps][B]
+    int force_steps;
+    const float* logits;         // processed log-probs of this step's rows (forced choices read theirs here)
+    long ld_logits;
+};
+int launch_beam_select(const BeamSelArgs& a, hipStream_t s);
 int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
                      hipStream_t s);
 // the same in ONE launch; the tokens also go to the pinned array `host_tokens`, and `*host_seq` receives the launch's sequence number (tickets[1], kept on

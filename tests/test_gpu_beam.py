@@ -526,3 +526,59 @@ def test_beam_sample_is_seeded_reproducible_and_refuses_what_torch_refuses():
     with pytest.raises(IsstError, match="non-zero probability"):
         eng.generate(GenConfig(max_new_tokens=6, beam=B, do_sample=True, top_k=1, seed=1), [sid], [audio], [prompt], [[]])
     eng.close()
+
+
+@pytest.mark.parametrize("B,n_streams", [(4, 1), (3, 3), (4, 6)])
+def test_beam_device_scorer_is_bit_identical_to_the_host_scorer(monkeypatch, B, n_streams):
+    """The scorer of a beam step runs on the device (csrc/beam.hip beam_select_kernel: merge of the rows' candidates, EOS hypotheses with their tail
+    copies, BeamHypotheses.add / is_done, the reorder of tails and token sequences, the next pass's rows) and the stream never waits for the host; the
+    host re-derives every step from the logged candidates and fails the call on any disagreement.  Against ISST_BEAM_DEVICE=0 -- the host deciding every
+    step between two stream synchronisations, the round-1..4 loop that beam_scorer.npz / beam_loop.npz pin to patch_hf.py:43-157,278-302 -- the same
+    tokens, the same candidate lists bit for bit, the same cache lengths and the same KV in EVERY beam's arena: over chunks, many EOS ids (hypotheses
+    close early, their tails travel through buffers, streams finish at different steps and ride along), a pinned system prompt and evictions."""
+    from oracle import agent as oag
+    cfg = toy_config().replace(eos_ids=(1001, 1008, 1009, 7, 8, 9) if B == 4 else (1001, 7))
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=51)
+    w["lm_head.weight"][list(cfg.eos_ids)] *= 2.0  # EOS among the leading candidates often enough that hypotheses close
+    gen = GenConfig(max_new_tokens=7, beam=B, max_llm_cache_size=110, always_cache_system_prompt=True, no_repeat_ngram_size=3, repetition_penalty=1.2)
+    audio = [synth.synthetic_audio(cfg.chunk_samples * 6, stream_id=30 + i) for i in range(n_streams)]
+    sys_n = len(synth.system_prompt_ids(cfg))
+
+    def run(flag):
+        monkeypatch.setenv("ISST_BEAM_DEVICE", flag)
+        eng = Engine(cfg, max_streams=n_streams, max_multiplier=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=110, max_system_prompt=64, max_beams=B)
+        eng.load_weights(w)
+        sids = [eng.open_stream() for _ in range(n_streams)]
+        outs, kvs, traces, lens = [], [], [], []
+        ckpts = [[] for _ in sids]
+        prev = [[] for _ in sids]
+        for c in range(6):
+            segs = [a[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples] for a in audio]
+            prompt = synth.chunk_prompt_ids(cfg, 1, first=(c == 0))
+            eng.beam_trace_begin(B)
+            ids, _ = eng.generate(gen, sids, segs, [prompt] * n_streams, [p[-100:] for p in prev], system_prompt_size=sys_n if c == 0 else 0)
+            traces.append(eng.beam_trace_end())
+            outs.append(ids)
+            for i, sid in enumerate(sids):
+                prev[i].extend(ids[i][:-1])
+                cur = eng.stream_info(sid)["llm_cache_len"]
+                lens.append(cur)
+                kvs.append([kv_of(eng, sid, cur, beam=b) for b in range(B)])
+                ckpts[i].append(cur)
+                ev = oag.evict(ckpts[i], cur, gen.max_llm_cache_size, True, sys_n)
+                if ev is not None:
+                    ckpts[i], new_size = ev
+                    eng.kv_evict(sid, new_size, sys_n)
+        eng.close()
+        return outs, kvs, traces, lens
+
+    (oa, ka, ta, la), (ob, kb, tb, lb) = run("1"), run("0")
+    assert oa == ob and la == lb, "the device scorer and the host scorer chose different tokens / cache lengths"
+    assert any(len(x) < gen.max_new_tokens for chunk in oa for x in chunk), "no hypothesis was closed by EOS: the tail buffers were not exercised"
+    for c, (xa, xb) in enumerate(zip(ta, tb)):
+        assert len(xa) == len(xb), f"chunk {c}: {len(xa)} scorer steps on the device against {len(xb)} on the host"
+        for step, ((va, ia, sa), (vb, ib, sb)) in enumerate(zip(xa, xb)):
+            assert np.array_equal(va, vb) and np.array_equal(ia, ib) and np.array_equal(sa, sb), f"chunk {c} step {step}: candidates / beam scores differ"
+    for q, (xa, xb) in enumerate(zip(ka, kb)):
+        for b in range(B):
+            assert torch.equal(xa[b][0], xb[b][0]) and torch.equal(xa[b][1], xb[b][1]), f"state {q} beam {b}: KV differs between the device scorer and the host scorer"

@@ -256,11 +256,11 @@ def test_full_size_steady_state_matches_oracle(full, steady):
     eng.close_stream(sid)
 
 
-@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("m", [2, 3, 4])
 def test_full_size_latency_multipliers_match_oracle(full, m):
-    """Latency multipliers 2 and 4 at FULL size (agents/infinisst.py:125-128,245; scripts/infer/infinisst.sh:42-47 -- the settings besides m = 1 the
+    """Latency multipliers 2, 3 and 4 at FULL size (agents/infinisst.py:125-128,245; scripts/infer/infinisst.sh:42-47 -- the settings besides m = 1 the
     reference publishes numbers for, plots/plot.ipynb:528-531), where they take other dispatch paths than m = 1: a chunk of m x 960 ms is 48 m encoder
-    frames (Q = 96 / 192 over a window of 672 / 768 keys), 12 m speech tokens in a 34 / 58-row prompt (prefill on gemm_mid), max_new_tokens = 10 m.
+    frames (Q = 96 / 144 / 192 over a window of 672 / 720 / 768 keys), 12 m speech tokens in a 34 / 46 / 58-row prompt (prefill on gemm_mid), max_new_tokens = 10 m.
     One steady-state chunk (1020 cached LLM entries, full encoder window, wrapping rings), teacher-forced along the fp32 oracle's tokens, every pass's
     logits under the noise-floor criterion of the m = 1 tests, speech features and cache counters equal to the oracle's."""
     cfg, w_dev, _, sys_n = full
@@ -362,7 +362,7 @@ def test_full_size_64_streams_steady_state(full, steady):
 # ------------------------------------------------------------------------------------------------------------------------
 # Greedy TOKEN IDS at full size: free-running, steady state, an eviction after every chunk.
 # ------------------------------------------------------------------------------------------------------------------------
-PEAKED_CHUNKS = 16
+PEAKED_CHUNKS = 12
 DECISIVE_MARGIN = 1.0     # a step is decisive when the bf16 oracle's top-2 margin of the PROCESSED scores exceeds this ...
 LOGIT_TOLERANCE = 0.45    # ... which is > 2 x the stated logit tolerance of the HIP path against the bf16 oracle under this recipe
 
@@ -376,7 +376,7 @@ def test_full_size_free_running_ids_with_peaked_logits():
     checkpoint walk, whole-chunk eviction after every chunk) from the imported steady state (KV = 45 pinned + 975 ring entries, encoder
     window full, both rings about to wrap) for PEAKED_CHUNKS chunks x 10 passes.  The bf16 oracle follows the SAME token history
     (teacher-forced with the engine's tokens, same eviction) and judges every step: where its processed top-2 margin exceeds
-    DECISIVE_MARGIN the engine's token must be the oracle's argmax.  Required: 0 mismatches, decisive fraction >= 90 %, >= 130 decisive
+    DECISIVE_MARGIN the engine's token must be the oracle's argmax.  Required: 0 mismatches, decisive fraction >= 90 %, >= 100 decisive
     steps, every raw logit within LOGIT_TOLERANCE, cache counters equal after every chunk."""
     from infinisst_amd.streams import StreamBatch
     from oracle import agent as oag
@@ -453,7 +453,7 @@ def test_full_size_free_running_ids_with_peaked_logits():
           f"taken {n_first} / {n_second} times; oracle margin median {np.median(margins):.2f}; worst |logit - oracle| {worst:.3f}; "
           f"evictions {batch.evictions}", flush=True)
     assert n_mismatch == 0
-    assert frac >= 0.90 and n_decisive >= 130
+    assert frac >= 0.90 and n_decisive >= 100  # (12 chunks x 10 passes; 16 chunks gave 154 of 160 in rounds 3-4 -- shortened to keep the GPU suite inside its step limit)
     assert worst <= LOGIT_TOLERANCE
     assert batch.evictions == PEAKED_CHUNKS
     eng.close()
@@ -701,17 +701,18 @@ def test_full_size_beam4_fused_launch_is_bit_identical_to_the_three_launches(bea
         assert np.array_equal(va, vb) and np.array_equal(ia, ib) and np.array_equal(sa, sb), f"step {step}: candidates differ between the fused launch and the three launches"
 
 
-@pytest.mark.parametrize("n_streams,folded", [(20, True), (20, False), (40, False)])
+@pytest.mark.parametrize("n_streams,folded", [(20, True), (20, False), (64, None)])
 def test_full_size_many_streams_beam4_match_oracle(beam4_ref, n_streams, folded):
     """The reference's production decoding (agents/infinisst.py:86 asserts beam > 1; scripts/infer/infinisst.sh:48) on MANY streams in one call at FULL
-    size: n streams x 4 beams = 80 / 160 decode rows per pass -- the row counts that run on gemm_wide.hip (128- and 256-row workgroups; round 4), with
-    a 440 / 880-row prefill.  Every stream is handed the SAME steady state (1020 cached entries, wrapping rings) and the same audio.  Stream 0 is
+    size: n streams x 4 beams = 80 / 256 decode rows per pass -- the row counts that run on gemm_wide.hip (128-row workgroups; at 256 rows -- BASELINE.json
+    configs[2] in the production decoding, the shape the `streams64_beam4` bench leg times -- one 256-row workgroup per column block and the twin 128-row
+    blocks of o_proj; round 4), with a 440 / 1408-row prefill.  Every stream is handed the SAME steady state (1020 cached entries, wrapping rings) and the same audio.  Stream 0 is
     teacher-forced along the ORACLE's (token, parent) choices and its candidates are held to the oracle step by step (as in the one-stream test);
     the other streams search freely: identical inputs through row-independent kernels must give them identical results, equal to the oracle's
     sequence unless its final hypotheses tie; cache lengths equal the reference's.
     `folded`: the decode attention in the form 64+ streams x beams select by themselves (llm_attn.hip: one workgroup per (stream, kv head) walks the
     shared prefix AND the beams' own keys and writes the output itself), forced here at 20 streams through the span-size knob; otherwise the form
-    with one more workgroup per beam and a combine launch."""
+    with one more workgroup per beam and a combine launch; None: whatever the library selects by itself (64 streams: folded)."""
     r = beam4_ref
     B, cfg, sys_n, gen, prompt, ref = r["B"], r["cfg"], r["sys_n"], r["gen"], r["prompt"], r["ref"]
     eng = Engine(cfg, max_streams=n_streams, max_prompt_len=sys_n + 32, max_new_tokens=10, max_llm_cache_size=1000, max_system_prompt=sys_n, max_beams=B)
@@ -722,7 +723,7 @@ def test_full_size_many_streams_beam4_match_oracle(beam4_ref, n_streams, folded)
         _import_state(eng, sid, cfg, sys_n, r["kv0"], r["enc0"], r["src0"], llm_ring_start=ring_cap - 300, enc_ring_start=560)
     eng.beam_trace_begin(B, [st.next_tokens for st in ref.steps], [st.next_parents for st in ref.steps])
     lib = load_library()
-    lib.isst_op_set_attn_tuning(1 if folded else 0)  # 1 workgroup wanted chip-wide: every (stream, kv head) is one span
+    lib.isst_op_set_attn_tuning(1 if folded else 0)  # 1 workgroup wanted chip-wide: every (stream, kv head) is one span (None / False: the library's own choice)
     try:
         outs, _ = eng.generate(gen, sids, [r["seg"]] * n_streams, [prompt] * n_streams, [r["prev"]] * n_streams, system_prompt_size=0)
     finally:
@@ -745,15 +746,15 @@ def test_full_size_many_streams_beam4_match_oracle(beam4_ref, n_streams, folded)
 # ------------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[4]: an unbounded stream at FULL size -- rolling whole-chunk eviction for hundreds of chunks.
 # ------------------------------------------------------------------------------------------------------------------------
-LONG_CHUNKS = 640
+LONG_CHUNKS = 1875
 
 
 def test_full_size_long_stream_is_bounded_and_flat(full):
-    """640 consecutive chunks (10.2 minutes of audio; 1875 = 30 minutes run the same loop in bench.py --steps 1875) of one stream at full size through
-    streams.StreamBatch from the imported steady state: an eviction after every chunk (agents/infinisst.py:340-361), the LLM ring wrapping ~17 times and the
+    """BASELINE.json configs[4] at its real length: 1875 consecutive chunks (30 minutes of audio) of one stream at full size through
+    streams.StreamBatch from the imported steady state: an eviction after every chunk (agents/infinisst.py:340-361), the LLM ring wrapping ~50 times and the
     encoder ring every 13 chunks (patch_speech_encoder.py:516-520, 259-262).  Size-independent properties: the caches stay bounded (LLM <= budget + one
     chunk, encoder window == 576 before / 624 inside a chunk), the logits of sampled chunks are finite, per-chunk latency is flat (p95 / p50 <= 1.03 over the
-    last 500 chunks: O(1) cost in stream length) and device memory does not grow."""
+    last 1500 chunks: O(1) cost in stream length) and device memory does not grow."""
     import time
     from infinisst_amd.streams import StreamBatch
     cfg, w_dev, _, sys_n = full
@@ -787,7 +788,7 @@ def test_full_size_long_stream_is_bounded_and_flat(full):
         if c == 40:
             free0 = torch.cuda.mem_get_info()[0]
     free1 = torch.cuda.mem_get_info()[0]
-    tail = np.array(lat[-500:])
+    tail = np.array(lat[-1500:])
     p50, p95 = float(np.percentile(tail, 50)), float(np.percentile(tail, 95))
     print(f"long stream: {LONG_CHUNKS} chunks, {batch.evictions} evictions, KV {min(lens)}..{max(lens)} entries, p50 {1e3 * p50:.2f} ms, p95 {1e3 * p95:.2f} ms, "
           f"free memory {free0 / 2**30:.2f} -> {free1 / 2**30:.2f} GiB")
