@@ -310,7 +310,11 @@ def first_step_record(loop, eng, gen):
     return {"tokens": toks, "logits": np.array(logits[0][:len(toks)], dtype=np.float32)}
 
 
-SELF_CHECK_TOL = 0.5  # |difference| of bf16-path logits / log-probs between two dispatch paths of the library on the same inputs (measured: < 0.1)
+# |difference| of bf16-path logits / log-probs between two dispatch paths of the library on the same inputs.  With the plain N(0, 0.02^2) init the residual stream
+# reaches |x| ~ 60 and bf16 rounding alone moves a logit by 0.07 on average and 0.4-0.6 at worst (the bf16 oracle against the same math in fp32), so two
+# bf16 paths with different summation orders may differ by twice that at their worst element: the check bounds the MEAN tightly and the maximum loosely.
+SELF_CHECK_TOL = 1.0
+SELF_CHECK_MEAN_TOL = 0.15
 
 
 def leg_self_check(cfg, gen, weights, device, n_streams, first):
@@ -341,10 +345,12 @@ def leg_self_check(cfg, gen, weights, device, n_streams, first):
             outs, logits = loop.batch.step(loop.segs[0], forced_tokens=[first["tokens"]], return_logits=True)
             toks = list(loop.batch.slots[loop.idx[0]].last_generated)
             k = len(first["tokens"])
-            diff = float(np.abs(np.array(logits[0][:k], dtype=np.float32) - first["logits"]).max())
-            ok = toks == first["tokens"] and diff <= SELF_CHECK_TOL
+            d = np.abs(np.array(logits[0][:k], dtype=np.float32) - first["logits"])
+            diff, mean = float(d.max()), float(d.mean())
+            ok = toks == first["tokens"] and diff <= SELF_CHECK_TOL and mean <= SELF_CHECK_MEAN_TOL
             return {"what": f"stream 0, first step: {k} passes recomputed by a one-stream engine, teacher-forced along the leg's ids", "passes": k,
-                    "max_abs_logit_diff": round(diff, 4), "tolerance": SELF_CHECK_TOL, "ok": bool(ok)}
+                    "max_abs_logit_diff": round(diff, 4), "mean_abs_logit_diff": round(mean, 4), "tolerance_max": SELF_CHECK_TOL, "tolerance_mean": SELF_CHECK_MEAN_TOL,
+                    "ok": bool(ok)}
         again = first_step_record(loop, eng, gen)
         t0, t1 = first["trace"], again["trace"]
         if n_streams == 1:
@@ -355,7 +361,7 @@ def leg_self_check(cfg, gen, weights, device, n_streams, first):
         diff = float(np.abs(t0[0][0] - t1[0][0]).max())
         ids_equal = float(np.mean(t0[0][1] == t1[0][1]))
         return {"what": "stream 0, first step recomputed by a one-stream beam engine: the candidates of the step behind the prefill",
-                "max_abs_logprob_diff": round(diff, 4), "candidate_ids_equal_fraction": round(ids_equal, 3), "tolerance": SELF_CHECK_TOL,
+                "max_abs_logprob_diff": round(diff, 4), "candidate_ids_equal_fraction": round(ids_equal, 3), "tolerance_max": SELF_CHECK_TOL,
                 "winner_equal": again["tokens"] == first["tokens"], "ok": bool(diff <= SELF_CHECK_TOL)}
     finally:
         eng.close()

@@ -101,6 +101,8 @@ int launch_kv_positions_copy_list(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool,
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
+__device__ __forceinline__ float beam_score_of(float x, int v, float lz, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side);  // (below, with beam_process_kernel)
+
 // ---- the beam scorer of one step, on the device: one wave per stream.  It restates engine_llm.hip's host scorer (the `follower` there, which is pinned to
 //      the reference's beam_search_process / BeamHypotheses.add through beam_scorer.npz / beam_loop.npz) operation for operation -- fp32 `candidate + beam
 //      score`, the (value desc, flat index asc) order, double `sum / len^penalty` with len^penalty from a HOST-filled table -- so that both reach the same
@@ -217,7 +219,10 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
                 for (int b = 0; b < B; ++b) {
                     const int tok = a.force_tok[a.step * B + b], par = a.force_par[a.step * B + b];
                     if (tok < 0 || tok >= a.V || par < 0 || par >= a.rows_per) { st = -4; break; }
-                    const float lp = a.logits[(long)(i * a.rows_per + par) * a.ld_logits + tok];
+                    const int fr_ = i * a.rows_per + par;
+                    const float raw = a.logits[(long)fr_ * a.ld_logits + tok];
+                    const float lp = a.view.logz ? beam_score_of(raw, tok, a.view.logz[fr_], a.view.side_tok + (long)fr_ * a.view.side_cap, a.view.side_val + (long)fr_ * a.view.side_cap,
+                                                                 a.view.side_n[fr_]) : raw;
                     ntok[b] = tok; npar[b] = par; nscore[b] = S.score[par] + lp; nflp[b] = lp;
                 }
             }
@@ -290,47 +295,157 @@ int launch_beam_select(const BeamSelArgs& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
-// ---- log_softmax, stage 1: per (part, row) running max and sum of exp ----
+// ---- log_softmax, stage 1: per (part, row) max and sum of exp.  One pass over memory: a thread's (at most LSE_PT) 16-byte pieces of the slice are all in
+//      flight before the first use and stay in registers for the sum (the first form read the slice twice with 4-byte loads: 51 us at 256 rows, 2.5 TB/s).
+//      Slices start at multiples of 4 elements (rows are 64-byte aligned, ld % 4 == 0 is checked by the launcher). ----
 #define LSE_PARTS 64
+#define LSE_PT 4
+__device__ __forceinline__ int lse_per(int vocab) { return (((vocab + LSE_PARTS - 1) / LSE_PARTS) + 3) & ~3; }
 __global__ __launch_bounds__(256) void lse_part_kernel(const float* __restrict__ logits, long ld, int vocab, float* __restrict__ pmax,
                                                        float* __restrict__ psum) {
     __shared__ float sm[4], ss[4];
     const float* L = logits + (long)blockIdx.y * ld;
-    const int per = (vocab + LSE_PARTS - 1) / LSE_PARTS;
+    const int per = lse_per(vocab);
     const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
-    float m = -INFINITY;
-    for (int v = lo + threadIdx.x; v < hi; v += blockDim.x) m = fmaxf(m, L[v]);
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    float m = -INFINITY, s = 0.f;
+    for (int v0 = lo; v0 < hi; v0 += 1024 * LSE_PT) {  // (one trip for every vocabulary up to 64 x 4096 entries)
+        f32x4_t q[LSE_PT];
+#pragma unroll
+        for (int u = 0; u < LSE_PT; ++u) {
+            const int v4 = v0 + (u * 256 + (int)threadIdx.x) * 4;
+            q[u] = v4 < hi ? *reinterpret_cast<const f32x4_t*>(L + v4) : (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // (the row's padding up to ld is readable)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (v4 + e >= hi) q[u][e] = -INFINITY;
+        }
+        float m2 = m;
+#pragma unroll
+        for (int u = 0; u < LSE_PT; ++u) m2 = fmaxf(fmaxf(fmaxf(q[u][0], q[u][1]), fmaxf(q[u][2], q[u][3])), m2);
+        if (m2 > -INFINITY) {
+            s = s * expf(m - m2);  // (m == -inf: s is 0 and exp(-inf) = 0)
+#pragma unroll
+            for (int u = 0; u < LSE_PT; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += expf(q[u][e] - m2);
+            m = m2;
+        }
+    }
+    const float wm = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = wm;
     __syncthreads();
-    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-    float s = 0.f;
-    if (m > -INFINITY)
-        for (int v = lo + threadIdx.x; v < hi; v += blockDim.x) s += expf(L[v] - m);
+    const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    s = (m > -INFINITY) ? s * expf(m - M) : 0.f;
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) ss[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        pmax[blockIdx.y * LSE_PARTS + blockIdx.x] = m;
+        pmax[blockIdx.y * LSE_PARTS + blockIdx.x] = M;
         psum[blockIdx.y * LSE_PARTS + blockIdx.x] = ss[0] + ss[1] + ss[2] + ss[3];
     }
+}
+// log Z of a row from its LSE_PARTS partial results: one wave, every lane ends up with the value
+__device__ __forceinline__ float lse_logz(const float* __restrict__ pmax, const float* __restrict__ psum, int row, int lane) {
+    const float m = pmax[row * LSE_PARTS + lane];
+    const float M = wave_max(m);
+    const float s = (m == -INFINITY) ? 0.f : psum[row * LSE_PARTS + lane] * expf(m - M);
+    const float S = wave_sum(s);
+    return M + logf(S);
 }
 // ---- stage 2: logits <- logits - logZ (in place) ----
 __global__ __launch_bounds__(256) void lse_apply_kernel(float* __restrict__ logits, long ld, int vocab, const float* __restrict__ pmax,
                                                         const float* __restrict__ psum) {
     __shared__ float logz;
     if (threadIdx.x < 64) {
-        const float m = pmax[blockIdx.y * LSE_PARTS + threadIdx.x];
-        const float M = wave_max(m);
-        const float s = (m == -INFINITY) ? 0.f : psum[blockIdx.y * LSE_PARTS + threadIdx.x] * expf(m - M);
-        const float S = wave_sum(s);
-        if (threadIdx.x == 0) logz = M + logf(S);
+        const float z = lse_logz(pmax, psum, blockIdx.y, threadIdx.x);
+        if (threadIdx.x == 0) logz = z;
     }
     __syncthreads();
     float* L = logits + (long)blockIdx.y * ld;
-    const int per = (vocab + LSE_PARTS - 1) / LSE_PARTS;
+    const int per = lse_per(vocab);
     const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
     for (int v = lo + threadIdx.x; v < hi; v += blockDim.x) L[v] -= logz;
+}
+
+// ---- the beam step's processors WITHOUT the in-place log-softmax sweep (beam_decode_device): one block per row.  The row keeps its RAW logits; what the
+//      processors change is recorded so that a reader can reproduce `processors(log_softmax(row))` element by element, bit for bit:
+//        * log Z of the row -> logz[row] (the same arithmetic as lse_apply_kernel's): an untouched entry is  raw - logz;
+//        * repetition penalty (first occurrence of every distinct id): the penalised log-prob goes to the row's SIDE list (token, value) and the entry
+//          becomes NaN -- "look me up" (logits of a bf16 path are never NaN; a reader that finds no side entry treats the NaN as -inf);
+//        * n-gram bans, suppressed tokens: the entry becomes -inf (-inf - logz = -inf), over a NaN too: penalised AND banned is banned.
+//      The order is the reference's (RepetitionPenalty -> NoRepeatNGram -> EncoderNoRepeatNGram -> SuppressTokens, sample.hip).  Two sweeps over the
+//      rows x vocab fp32 scores of a step remain (lse_part, the top-k scan) instead of four; 256 rows x 128 263: 524 MB -> 262 MB. ----
+__global__ __launch_bounds__(256) void beam_process_kernel(float* __restrict__ logits, long ld, const SampleStream* __restrict__ ss, const int* __restrict__ ids_pool,
+                                                           const int* __restrict__ enc_pool, const int* __restrict__ suppress, int n_suppress, float pen, int ngram,
+                                                           int enc_ngram, const float* __restrict__ pmax, const float* __restrict__ psum, float* __restrict__ logz_out,
+                                                           int* __restrict__ side_tok, float* __restrict__ side_val, int* __restrict__ side_n, int side_cap) {
+    __shared__ float s_logz;
+    __shared__ int s_cnt;
+    const SampleStream st = ss[blockIdx.x];
+    const int row = st.logits_row;
+    float* L = logits + (long)row * ld;
+    const int* ids = ids_pool + st.ids_off;
+    const int* enc = enc_pool + st.enc_off;
+    const int n = st.n_ids, tid = threadIdx.x;
+    if (tid < 64) {
+        const float z = lse_logz(pmax, psum, row, tid);
+        if (tid == 0) { s_logz = z; s_cnt = 0; logz_out[row] = z; }
+    }
+    __syncthreads();
+    const float lz = s_logz;
+    if (pen != 1.0f) {
+        for (int i = tid; i < n; i += blockDim.x) {
+            const int t = ids[i];
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && (ids[j] != t);
+            if (first) {
+                const float v = L[t] - lz;
+                const int k = atomicAdd(&s_cnt, 1);
+                if (k < side_cap) {
+                    side_tok[(long)row * side_cap + k] = t;
+                    side_val[(long)row * side_cap + k] = v < 0.f ? v * pen : v / pen;
+                    L[t] = __int_as_float(0x7fc00000);
+                } else {
+                    L[t] = v < 0.f ? v * pen : v / pen;  // (cannot happen: the list holds one entry per id of the sequence) -- degrade to an in-place value
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) side_n[row] = s_cnt < side_cap ? s_cnt : side_cap;
+    if (ngram > 0 && n + 1 >= ngram) {
+        const int* key = ids + n - (ngram - 1);
+        for (int p = tid; p + ngram <= n; p += blockDim.x) {
+            bool eq = true;
+            for (int q = 0; q < ngram - 1; ++q) eq = eq && (ids[p + q] == key[q]);
+            if (eq) L[ids[p + ngram - 1]] = -INFINITY;
+        }
+    }
+    if (enc_ngram > 0 && n + 1 >= enc_ngram) {
+        const int* key = ids + n - (enc_ngram - 1);
+        for (int p = tid; p + enc_ngram <= st.n_enc; p += blockDim.x) {
+            bool eq = true;
+            for (int q = 0; q < enc_ngram - 1; ++q) eq = eq && (enc[p + q] == key[q]);
+            if (eq) L[enc[p + enc_ngram - 1]] = -INFINITY;
+        }
+    }
+    for (int i = tid; i < n_suppress; i += blockDim.x) L[suppress[i]] = -INFINITY;
+}
+// the processed log-prob of entry v of a row prepared by beam_process_kernel (x = its stored value)
+__device__ __forceinline__ float beam_score_of(float x, int v, float lz, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side) {
+    if (x == x) return x - lz;
+    for (int k = 0; k < n_side; ++k)
+        if (side_tok[k] == v) return side_val[k];
+    return -INFINITY;
+}
+struct TopkView {  // how a top-k kernel reads a score row: as it stands (lz == null), or through beam_process_kernel's encoding
+    const float* logz;
+    const int* side_tok;
+    const float* side_val;
+    const int* side_n;
+    int side_cap;
+};
+__device__ __forceinline__ float topk_view(const TopkView& tv, int row, float x, int v) {
+    if (!tv.logz) return x;
+    return beam_score_of(x, v, tv.logz[row], tv.side_tok + (long)row * tv.side_cap, tv.side_val + (long)row * tv.side_cap, tv.side_n[row]);
 }
 
 // ---- top-k (k <= BEAM_TOPK), ties -> lowest index.  Stage 1: the slice of a (part, row) is copied to LDS and the
@@ -405,14 +520,14 @@ __device__ void block_topk(float* vals, const int* idx, int n, int k, float* out
 }
 #define TOPK_SLICE 2048
 __global__ __launch_bounds__(256) void topk_part_kernel(const float* __restrict__ scores, long ld, int vocab, int k,
-                                                        float* __restrict__ cval, int* __restrict__ cidx) {
+                                                        float* __restrict__ cval, int* __restrict__ cidx, TopkView view) {
     __shared__ float vals[TOPK_SLICE];
     __shared__ int ids[TOPK_SLICE];
     const float* L = scores + (long)blockIdx.y * ld;
     const int per = (vocab + LSE_PARTS - 1) / LSE_PARTS;  // <= TOPK_SLICE (checked by the launcher)
     const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
     const int n = max(hi - lo, 0);
-    for (int e = threadIdx.x; e < n; e += blockDim.x) { vals[e] = L[lo + e]; ids[e] = lo + e; }
+    for (int e = threadIdx.x; e < n; e += blockDim.x) { vals[e] = topk_view(view, blockIdx.y, L[lo + e], lo + e); ids[e] = lo + e; }
     __syncthreads();
     block_topk(vals, ids, n, k, cval + ((long)blockIdx.y * LSE_PARTS + blockIdx.x) * BEAM_TOPK,
                cidx + ((long)blockIdx.y * LSE_PARTS + blockIdx.x) * BEAM_TOPK);
@@ -434,6 +549,7 @@ __global__ __launch_bounds__(256) void topk_final_kernel(const float* __restrict
 
 int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* psum, int rows, hipStream_t s) {
     if (rows <= 0) return ISST_OK;
+    if (ld % 4 != 0 || (reinterpret_cast<uintptr_t>(logits) & 15) != 0 || vocab > LSE_PARTS * 4096) return ISST_ERR_ARG;  // (lse_part_kernel: 16-byte loads, one trip)
     hipLaunchKernelGGL(lse_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, logits, ld, vocab, pmax, psum);
     hipLaunchKernelGGL(lse_apply_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, logits, ld, vocab, pmax, psum);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
@@ -445,7 +561,7 @@ int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* ps
 __device__ __forceinline__ bool topk_better(float x, int i, float y, int j) { return x > y || (x == y && i < j); }
 template <int KR>
 __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict__ scores, long ld, int vocab, int k, int parts, float* __restrict__ cval,
-                                                        int* __restrict__ cidx) {
+                                                        int* __restrict__ cidx, TopkView view) {
     __shared__ float wv[4 * BEAM_TOPK];
     __shared__ int wi[4 * BEAM_TOPK];
     const float* L = scores + (long)blockIdx.y * ld;
@@ -458,12 +574,21 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict_
     for (int j = 0; j < KR; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
     float wv_ = -INFINITY;  // the list's worst entry (the one a better element replaces) ...
     int wi_ = 0x7fffffff;
-    for (int v4 = lo + (int)threadIdx.x * 4; v4 < hi; v4 += 1024) {
-        const f32x4_t q = *reinterpret_cast<const f32x4_t*>(L + v4);  // (the row's padding up to ld is readable; elements at or past `hi` are skipped below)
+    // (four 16-byte loads in flight per thread: with one, a (slice, row) workgroup's scan was a chain of ~30 dependent round trips -- 110 us for 256 rows x 128 263)
+    for (int vb = lo + (int)threadIdx.x * 4; vb < hi; vb += 4096) {
+        f32x4_t qq[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int v4 = vb + w * 1024;
+            qq[w] = v4 < hi ? *reinterpret_cast<const f32x4_t*>(L + v4) : (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // (the row's padding up to ld is readable; elements at or past `hi` are skipped below)
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+        const int v4 = vb + w * 1024;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-        const float x = q[u];
         const int v0 = v4 + u;
+        const float x = topk_view(view, blockIdx.y, qq[w][u], v0);
         if (v0 < hi && topk_better(x, v0, wv_, wi_)) {
             bool done = false;
 #pragma unroll
@@ -477,6 +602,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 1; j < KR; ++j)
                 if (topk_better(wv_, wi_, tv[j], ti[j])) { wv_ = tv[j]; wi_ = ti[j]; }
+        }
         }
         }
     }
@@ -556,19 +682,36 @@ __global__ __launch_bounds__(256) void topk_final_parts_kernel(const float* __re
     block_topk(vals, ids, parts * k, k, out_val + (long)blockIdx.x * BEAM_TOPK, out_idx + (long)blockIdx.x * BEAM_TOPK);
 }
 
-int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
-                     hipStream_t s) {
+static int launch_topk_rows_view(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows, const TopkView& view,
+                                 hipStream_t s) {
     if (rows <= 0) return ISST_OK;
     if (k < 1 || k > BEAM_TOPK || (vocab + LSE_PARTS - 1) / LSE_PARTS > TOPK_SLICE) return ISST_ERR_ARG;
     if (rows >= 16 && k <= 16 && ld % 16 == 0 && (reinterpret_cast<uintptr_t>(scores) & 63) == 0) {  // many rows: one scan per (part, row) with the candidates in registers; enough parts for ~1024 workgroups
         int parts = 1024 / rows;
         parts = parts < 1 ? 1 : (parts > LSE_PARTS ? LSE_PARTS : parts);
-        if (k <= 8) hipLaunchKernelGGL(topk_scan_kernel<8>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx);
-        else hipLaunchKernelGGL(topk_scan_kernel<16>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx);
+        if (k <= 8) hipLaunchKernelGGL(topk_scan_kernel<8>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
+        else hipLaunchKernelGGL(topk_scan_kernel<16>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
         hipLaunchKernelGGL(topk_final_parts_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, parts, out_val, out_idx);
         return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
     }
-    hipLaunchKernelGGL(topk_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, scores, ld, vocab, k, cval, cidx);
+    hipLaunchKernelGGL(topk_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, scores, ld, vocab, k, cval, cidx, view);
     hipLaunchKernelGGL(topk_final_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, out_val, out_idx);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
+                     hipStream_t s) {
+    return launch_topk_rows_view(scores, ld, vocab, k, cval, cidx, out_val, out_idx, rows, TopkView{}, s);
+}
+// the scoring tail of a beam step without the in-place log-softmax: lse_part -> beam_process (log Z, side lists, bans) -> top-k through the view
+int launch_beam_scores(float* logits, long ld, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool, const int* suppress, int n_suppress,
+                       float rep_penalty, int ngram, int enc_ngram, float* pmax, float* psum, const BeamScoreView& v, int k, float* cval, int* cidx,
+                       float* out_val, int* out_idx, int rows, hipStream_t s) {
+    if (rows <= 0) return ISST_OK;
+    if (ld % 4 != 0 || (reinterpret_cast<uintptr_t>(logits) & 15) != 0 || vocab > LSE_PARTS * 4096 || !v.logz || !v.side_tok || !v.side_val || !v.side_n || v.side_cap < 1) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(lse_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, logits, ld, vocab, pmax, psum);
+    hipLaunchKernelGGL(beam_process_kernel, dim3(rows), dim3(256), 0, s, logits, ld, ss, ids_pool, enc_pool, suppress, n_suppress, rep_penalty, ngram, enc_ngram, pmax, psum,
+                       v.logz, v.side_tok, v.side_val, v.side_n, v.side_cap);
+    if (hipGetLastError() != hipSuccess) return ISST_ERR_HIP;
+    TopkView tv{v.logz, v.side_tok, v.side_val, v.side_n, v.side_cap};
+    return launch_topk_rows_view(logits, ld, vocab, k, cval, cidx, out_val, out_idx, rows, tv, s);
 }

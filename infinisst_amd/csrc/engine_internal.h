@@ -208,6 +208,7 @@ struct isst_handle {
     int* samp_tickets = nullptr;  // sample_fused_kernel's counters (device): [0] streams done, [1] sequence number, [2 + stream] parts done
     int tok_cap = 0;
     int samp_seq_expected = 0;  // fused tails launched so far (the device keeps the same count in samp_tickets[1])
+    bool tail_advance = true;   // ISST_TAIL_ADVANCE=0: one stream's decode step uploads its metadata block and launches the embedding kernel, as before round 5
     bool fused_sample = true;   // ISST_FUSED_SAMPLE=0: three launches + D2H copy + stream synchronisation per token instead of one launch + a wait on pinned memory
     float* samp_host = nullptr;  // pinned [rows][vocab_pad]: processed scores of a sampling step (allocated on the first do_sample call)
     size_t samp_host_rows = 0;
@@ -241,6 +242,8 @@ struct isst_handle {
     size_t blog_slot_bytes = 0;
     int blog_steps = 0;
     int bsel_seq = 0;                        // beam_select launches enqueued so far = the sequence number the last one publishes
+    bool beam_lean_tail = true;              // ISST_BEAM_LEAN_TAIL=0: log-softmax applied in place + processors + top-k (four sweeps over the step's fp32 scores instead of two)
+    BeamScoreView bview{};                   // log Z per row + the penalised entries' side lists (beam.hip beam_process_kernel)
 
     // beam-search test aid (isst_debug_beam_trace_*): per-step candidate lists of a ONE-stream call and optional teacher forcing
     struct BeamTraceStep { int rows, n_keep; std::vector<float> val; std::vector<int> idx; std::vector<float> score; };

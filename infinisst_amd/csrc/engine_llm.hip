@@ -128,7 +128,7 @@ StepMeta carve(isst_handle* h, unsigned char* base) {
 
 // one forward pass of the decoder stack over `rows` token rows, logits for `n_last` rows
 int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_groups, int max_group_rows, bool splice, const char* tap_prefix,
-                hipStream_t st, const StepMeta* hm = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0) {
+                hipStream_t st, const StepMeta* hm = nullptr, int n_units = 0, int max_unit_groups = 0, int n_beam_wgs = 0, bool rows_embedded = false) {
     const isst_config& c = h->cfg;
     const int DL = c.llm_dim, H = c.llm_heads, KV = c.llm_kv_heads;
     // one group (one stream's decode step): its metadata travels in the kernel arguments (llm_attn.hip LlmAttnOne)
@@ -148,7 +148,8 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             one.v = hm->views[hm->row_stream[g0.x]];
         }
     }
-    CHK(launch_embed_splice(d.ids, splice ? d.speech_row : nullptr, h->embed, h->speech, h->lx, rows, DL, st));
+    // (rows_embedded: h->lx already holds the rows -- one stream's decode step, whose sampling tail copied the new token's embedding there)
+    if (!rows_embedded) CHK(launch_embed_splice(d.ids, splice ? d.speech_row : nullptr, h->embed, h->speech, h->lx, rows, DL, st));
     if (tap_prefix) CHK(tap(h, std::string(tap_prefix) + "embed", h->lx, (int64_t)rows * DL, st));
     // 17..64 rows (one stream's prefill, a 64-stream decode pass): o_proj and down_proj split K over workgroups and the
     // residual + RMSNorm kernel that follows reduces the slabs (gemm_mid.hip); `pending`: lx still lacks the previous
@@ -933,10 +934,15 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
         const SampleStream* samp = step == 0 ? md.samp : bd.samp;
         const int* ids_pool = step == 0 ? md.ids_pool : h->bseq[step & 1];
         const int* enc_pool = step == 0 ? md.enc_pool : bd.enc_pool;
-        CHK(launch_log_softmax(h->logits, h->vocab_pad, V, h->lse_max, h->lse_sum, rows, st));
-        CHK(launch_sample_process(h->logits, h->vocab_pad, samp, ids_pool, enc_pool, md.suppress, p->n_suppress, p->repetition_penalty, p->no_repeat_ngram_size,
-                                  p->encoder_no_repeat_ngram_size, rows, st));
-        CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val, h->top_idx, rows, st));
+        if (h->beam_lean_tail) {  // two sweeps over the rows' fp32 scores: lse_part, then the top-k scan reading `raw - log Z` through beam_process_kernel's encoding
+            CHK(launch_beam_scores(h->logits, h->vocab_pad, V, samp, ids_pool, enc_pool, md.suppress, p->n_suppress, p->repetition_penalty, p->no_repeat_ngram_size,
+                                   p->encoder_no_repeat_ngram_size, h->lse_max, h->lse_sum, h->bview, n_keep, h->cand_val, h->cand_idx, h->top_val, h->top_idx, rows, st));
+        } else {
+            CHK(launch_log_softmax(h->logits, h->vocab_pad, V, h->lse_max, h->lse_sum, rows, st));
+            CHK(launch_sample_process(h->logits, h->vocab_pad, samp, ids_pool, enc_pool, md.suppress, p->n_suppress, p->repetition_penalty, p->no_repeat_ngram_size,
+                                      p->encoder_no_repeat_ngram_size, rows, st));
+            CHK(launch_topk_rows(h->logits, h->vocab_pad, V, n_keep, h->cand_val, h->cand_idx, h->top_val, h->top_idx, rows, st));
+        }
         // ---- the scorer + the reorder ----
         BeamSelArgs a{};
         a.n = n; a.B = B; a.n_keep = n_keep; a.V = V; a.step = step; a.rows_per = rows_per; a.max_ids = h->max_ids; a.max_enc_ids = h->max_enc_ids;
@@ -952,6 +958,7 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
         a.err_word = const_cast<const int*>(ferr);
         a.force_tok = h->bforce_dev; a.force_par = h->bforce_dev + (size_t)c.max_new_tokens * h->max_beams; a.force_steps = force_steps;
         a.logits = h->logits; a.ld_logits = h->vocab_pad;
+        if (h->beam_lean_tail) a.view = h->bview;
         CHK(launch_beam_select(a, st));
         if (step > 0) {  // (step 0: every beam descends from beam 0 and no tail exists yet -- nothing to copy)
             bf16_t* kr = h->rot_keys ? h->llm_kr : nullptr;
@@ -1183,6 +1190,14 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     std::vector<int> active(n);
     for (int i = 0; i < n; ++i) active[i] = i;
 
+    // One stream (BASELINE.json configs[1]): the fused sampling tail also prepares the next pass on the device -- the sampled id appended to the id list the
+    // processors read, its embedding row copied to the decoder's input row -- so a decode step is neither preceded by a metadata upload (a 3 us copy kernel
+    // with a 13 us dependency gap behind it) nor opened by the embedding launch: 31 + 3 + 13 + 5 + 6 us between the last kernel of a pass and the first
+    // projection of the next became the token poll + one launch (profiles/r04/trace_busy_prof1.txt).  The attention metadata of a one-group launch travels
+    // in the kernel arguments already.  (Forced tokens -- a test aid -- replace the sampled id on the host, the sample branch draws on the host, a captured
+    // graph replays frozen arguments: those keep the upload.)
+    const bool advance_on_device = n == 1 && h->fused_sample && h->tail_advance && !any_forced && !p->do_sample && !h->use_graphs && !c.debug_taps && !h->prof_on;
+    const SampleAdvance adv{advance_on_device ? 1 : 0, md.ids, md.ids_pool, md.samp, h->embed, h->lx, c.llm_dim};
     // sampling tail of a pass over `na` rows: (test aid: logits download) -> processors + argmax -> token ids to the host
     bool tail_fused = false;  // the tail enqueued last went the fused way (wait_tokens then waits on pinned memory)
     auto sample_tail = [&](int na) -> int {
@@ -1202,7 +1217,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         if (tail_fused) {  // one launch: processors, argmax, the tokens straight into pinned host memory, then the tail's sequence number behind them
             CHK(launch_sample_fused(h->logits, h->vocab_pad, c.vocab, md.samp, md.ids_pool, md.enc_pool, md.suppress, p->n_suppress, p->repetition_penalty,
                                     p->no_repeat_ngram_size, p->encoder_no_repeat_ngram_size, h->out_tok, h->samp_val, h->samp_idx, h->samp_tickets, h->tok_host,
-                                    h->tok_host + h->tok_cap, na, st));
+                                    h->tok_host + h->tok_cap, na, st, &adv));
             ++h->samp_seq_expected;
             return ISST_OK;
         }
@@ -1244,11 +1259,13 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     // one decode step over nr rows: metadata upload -> decoder stack -> sampling tail.  Every pointer and dimension in it is
     // the same from step to step (the per-step values live in the metadata block), so it is captured once per row count and
     // replayed: ~230 launches become one graph launch
-    auto decode_step = [&](int nr) -> int {
+    auto decode_step = [&](int nr, bool restore = false) -> int {
         const bool graph_ok = h->use_graphs && st != nullptr && !logits_out && !c.debug_taps && !h->prof_on && !p->do_sample;  // (the NULL stream cannot be captured)
         if (!graph_ok) {
-            HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
-            CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st, &mh));
+            // (restore: the pass is being re-issued after a failed one whose tail advanced the device's copies on garbage -- the host's block is the truth)
+            const bool on_device = advance_on_device && !restore;
+            if (!on_device) HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+            CHK(llm_forward(h, md, nr, nr, nr, 1, false, nullptr, st, &mh, 0, 0, 0, on_device));
             return sample_tail(nr);
         }
         isst_handle::DecodeGraph& g = h->dgraph;
@@ -1300,7 +1317,7 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
                 if (relaunched || last_nr == 0) return h->fail(ISST_ERR_HIP, "the fused attention + o_proj launch timed out and the pass could not be re-issued on the three-launch path");
                 latch_three_launch_path(h);
                 relaunched = true;
-                if (const int rc = decode_step(last_nr)) return rc;
+                if (const int rc = decode_step(last_nr, true)) return rc;
                 continue;
             }
         }

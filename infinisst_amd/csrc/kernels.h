@@ -131,6 +131,18 @@ int launch_kv_positions_copy_list(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool,
                                   int max_ops, LlmAttnDims d, int layers, int tcap, hipStream_t s);
 int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* psum, int rows, hipStream_t s);
 
+// the score rows of a beam step as beam_process_kernel leaves them (beam.hip): raw logits + log Z per row + the penalised entries in a side list
+struct BeamScoreView {
+    float* logz;       // [rows]
+    int* side_tok;     // [rows][side_cap]
+    float* side_val;
+    int* side_n;       // [rows]
+    int side_cap;
+};
+int launch_beam_scores(float* logits, long ld, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool, const int* suppress, int n_suppress,
+                       float rep_penalty, int ngram, int enc_ngram, float* pmax, float* psum, const BeamScoreView& v, int k, float* cval, int* cidx,
+                       float* out_val, int* out_idx, int rows, hipStream_t s);
+
 // ---- the beam scorer on the device (beam.hip beam_select_kernel; reference patch_hf.py:43-157 beam_search_process + :278-302 BeamHypotheses.add + [3P]
 //      is_done + the cache reorder of :910-913) ----
 #define BEAM_MAX_B 8
@@ -184,17 +196,30 @@ struct BeamSelArgs {
     const int* err_word;         // pinned error word of the fused attention launch (0 = fine)
     const int *force_tok, *force_par;  // teacher forcing of stream 0 (test aid): [force_steps][B]
     int force_steps;
-    const float* logits;         // processed log-probs of this step's rows (forced choices read theirs here)
-    long ld_logits;
+    const float* logits;         // the score rows of this step (forced choices read theirs here): processed log-probs, or -- view.logz != null -- rows as
+    long ld_logits;              //     beam_process_kernel leaves them
+    BeamScoreView view;
 };
 int launch_beam_select(const BeamSelArgs& a, hipStream_t s);
 int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
                      hipStream_t s);
 // the same in ONE launch; the tokens also go to the pinned array `host_tokens`, and `*host_seq` receives the launch's sequence number (tickets[1], kept on
 // the device) once every stream's token is there.  tickets: 2 + max streams ints, zero before the first launch
+// adv (one stream's greedy loop): the launch also PREPARES THE NEXT PASS on the device -- the sampled id appended to the stream's id list (ids_pool, ss[0].n_ids),
+// written to ids[0], and its embedding row copied to `lx` (the decoder's input row: model/llm.py:114-115 embeds the last token only) -- so that the host
+// neither uploads a metadata block nor launches the embedding kernel between two passes
+struct SampleAdvance {
+    int enabled;
+    int* ids;              // [0] <- the sampled id
+    int* ids_pool;         // the stream's id list (same memory as the const view the processors read)
+    SampleStream* ss;      // [0].n_ids += 1
+    const bf16_t* embed;   // [vocab][D]
+    bf16_t* lx;            // [D] <- embed[id]
+    int D;
+};
 int launch_sample_fused(float* logits, long ld_logits, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool, const int* suppress,
                         int n_suppress, float rep_penalty, int ngram, int enc_ngram, int* out_tokens, float* scratch_val, int* scratch_idx, int* tickets,
-                        int* host_tokens, int* host_seq, int n_streams, hipStream_t s);
+                        int* host_tokens, int* host_seq, int n_streams, hipStream_t s, const SampleAdvance* adv = nullptr);
 // processors only (stage 1 of launch_sample), in place on the rows named by ss[]
 // warp.hip (host): HF's logits warpers (Temperature -> TopK -> TopP -> Epsilon) on one row of processed scores, then an inverse-CDF draw at `u`
 int warp_and_sample(float* scores, int n, float temperature, int top_k, float top_p, float epsilon, double u);

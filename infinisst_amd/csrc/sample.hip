@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void sample_fused_kernel(float* __restrict__ l
                                                            const int* __restrict__ ids_pool, const int* __restrict__ enc_pool,
                                                            const int* __restrict__ suppress, int n_suppress, float pen, int ngram, int enc_ngram,
                                                            float* __restrict__ pval, int* __restrict__ pidx, int* __restrict__ tickets /* [0] streams done, [1] sequence number, [2 + stream] parts done */,
-                                                           int* __restrict__ out_tokens, int* host_tokens, int* host_seq) {
+                                                           int* __restrict__ out_tokens, int* host_tokens, int* host_seq, SampleAdvance adv) {
     __shared__ float sval[4];
     __shared__ int sidx[4];
     __shared__ int s_last;
@@ -179,6 +179,17 @@ __global__ __launch_bounds__(256) void sample_fused_kernel(float* __restrict__ l
     if (!all_done) return;
     __threadfence();
     for (int i = tid; i < n_streams; i += 64) host_tokens[i] = __hip_atomic_load(out_tokens + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (adv.enabled) {  // one stream: the next pass's inputs, on the device (the launch boundary makes them visible to it)
+        const int tok = bi;  // (this wave merged stream 0 itself: the reduction left the argmax in every lane)
+        if (tid == 0) {
+            const SampleStream s0 = adv.ss[0];
+            adv.ids_pool[s0.ids_off + s0.n_ids] = tok;
+            adv.ss[0].n_ids = s0.n_ids + 1;
+            adv.ids[0] = tok;
+        }
+        const bf16_t* src = adv.embed + (long)tok * adv.D;
+        for (int c = tid * 8; c < adv.D; c += 512) *reinterpret_cast<u32x4_t*>(adv.lx + c) = *reinterpret_cast<const u32x4_t*>(src + c);
+    }
     __threadfence_system();  // every lane: its tokens are in host memory before the call's sequence number can be
     if (tid == 0) {
         tickets[0] = 0;
@@ -189,10 +200,15 @@ __global__ __launch_bounds__(256) void sample_fused_kernel(float* __restrict__ l
 
 int launch_sample_fused(float* logits, long ld_logits, int vocab, const SampleStream* ss, const int* ids_pool, const int* enc_pool, const int* suppress,
                         int n_suppress, float rep_penalty, int ngram, int enc_ngram, int* out_tokens, float* scratch_val, int* scratch_idx, int* tickets,
-                        int* host_tokens, int* host_seq, int n_streams, hipStream_t s) {
+                        int* host_tokens, int* host_seq, int n_streams, hipStream_t s, const SampleAdvance* adv) {
     if (n_streams <= 0) return ISST_OK;
+    SampleAdvance a{};
+    if (adv && adv->enabled) {
+        if (n_streams != 1 || adv->D % 8 != 0) return ISST_ERR_ARG;
+        a = *adv;
+    }
     hipLaunchKernelGGL(sample_fused_kernel, dim3(SAMPLE_PARTS, n_streams), dim3(256), 0, s, logits, ld_logits, vocab, ss, ids_pool, enc_pool, suppress, n_suppress,
-                       rep_penalty, ngram, enc_ngram, scratch_val, scratch_idx, tickets, out_tokens, host_tokens, host_seq);
+                       rep_penalty, ngram, enc_ngram, scratch_val, scratch_idx, tickets, out_tokens, host_tokens, host_seq, a);
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 

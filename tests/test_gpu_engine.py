@@ -456,6 +456,42 @@ def test_fused_sampling_tail_equals_the_three_launch_tail(monkeypatch, graph):
     assert len({tuple(t) for ids, _ in a for t in ids}) > 2
 
 
+def test_one_stream_decode_step_prepared_on_the_device_is_bit_identical(monkeypatch):
+    """One stream's greedy loop (BASELINE.json configs[1]): the fused sampling tail appends the sampled id to the id list the processors read and copies its
+    embedding row to the decoder's input row ON THE DEVICE, so a decode step is neither preceded by a metadata upload nor opened by the embedding launch
+    (engine_llm.hip `advance_on_device`; model/llm.py:114-115 embeds the last token only).  ISST_TAIL_ADVANCE=0 keeps upload + embedding launch.  Same
+    tokens, same raw logits bit for bit, same cache lengths over chunks with repeated tokens in the history (penalty / n-gram bans read the id list), a
+    previous-target window and evictions."""
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=43, recipe="peaked")
+    gen = GenConfig(max_new_tokens=7, max_llm_cache_size=150, no_repeat_ngram_size=3)
+    audio = synth.synthetic_audio(cfg.chunk_samples * 6, stream_id=27)
+
+    def run(flag):
+        monkeypatch.setenv("ISST_TAIL_ADVANCE", flag)
+        eng = make_engine(cfg, w, debug_taps=False, max_multiplier=1)
+        sid = eng.open_stream()
+        out, prev = [], []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for c in range(6):
+                seg = audio[c * cfg.chunk_samples:(c + 1) * cfg.chunk_samples]
+                ids, logits = eng.generate(gen, [sid], [seg], [synth.chunk_prompt_ids(cfg, 1, first=(c == 0))], [prev[-100:]], return_logits=(c % 2 == 0))
+                out.append((ids[0], eng.stream_info(sid)["llm_cache_len"], None if logits is None else logits[0][:len(ids[0])].copy()))
+                prev = prev + ids[0][:-1]
+                if eng.stream_info(sid)["llm_cache_len"] > 120:
+                    eng.kv_evict(sid, 60, 0)
+            torch.cuda.synchronize()
+        eng.close()
+        return out
+
+    a, b = run("1"), run("0")
+    assert [(x[0], x[1]) for x in a] == [(x[0], x[1]) for x in b]
+    for c, (x, y) in enumerate(zip(a, b)):
+        if x[2] is not None:
+            assert np.array_equal(x[2], y[2]), f"chunk {c}: logits differ between the device-prepared step and upload + embedding launch"
+    assert len({t for ids, _, _ in a for t in ids}) > 3
+
+
 @pytest.mark.parametrize("target_wgs", [1, 6])
 def test_attention_span_forms_match_oracle(target_wgs):
     """The many-stream forms of the decoder attention, forced on one stream through the tuning hook: target 1 = one workgroup per
@@ -638,7 +674,7 @@ def test_fused_launch_timeout_inside_a_beam_search_falls_back_too(monkeypatch, c
     lists and every arena's KV equal those of a handle that never fused."""
     cfg = toy_config()
     B = 3
-    gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=300)
+    gen = GenConfig(max_new_tokens=6, beam=B, max_llm_cache_size=100)  # (a cache short enough for the fused launch's 64-slot spans at toy width: llm_attn_oproj_supported)
     w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=74)
     audio = synth.synthetic_audio(cfg.chunk_samples * 2, stream_id=9)
     sys_n = len(synth.system_prompt_ids(cfg))
@@ -647,7 +683,7 @@ def test_fused_launch_timeout_inside_a_beam_search_falls_back_too(monkeypatch, c
     def run(fuse, starve):
         monkeypatch.setenv("ISST_FUSE_ATTN_OPROJ", fuse)
         monkeypatch.setenv("ISST_FUSE_AO_TEST_TIMEOUT", "1" if starve else "0")
-        eng = Engine(cfg, max_streams=1, max_multiplier=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=300, max_system_prompt=64, max_beams=B)
+        eng = Engine(cfg, max_streams=1, max_multiplier=1, max_prompt_len=96, max_new_tokens=8, max_llm_cache_size=100, max_system_prompt=64, max_beams=B)
         eng.load_weights(w)
         sid = eng.open_stream()
         outs, traces, kvs = [], [], []
