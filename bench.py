@@ -867,12 +867,13 @@ def main():
             roof["whole_step"] = whole_step_roofline(cfg, args.streams, args.gen_tokens, info["llm_cache_len"], 1e3 * elapsed / args.steps)
             log(f"roofline probe done: {roof['achieved']} GB/s, in-situ bracket {roof['in_situ_event_bracket_us']} us")
         legs = world == 1 and args.streams == 1 and args.beam == 1 and not args.toy
-        if legs and not args.no_streams64:
-            try:
-                s64 = run_streams64(cfg, gen, weights, device, args)
-                log(f"64-stream leg done: {s64['xrt']} xRT, {s64['ms_per_step']} ms per step")
-            except Exception as e:  # report, never hide
-                s64 = {"failed": f"{type(e).__name__}: {e}"}
+        if legs:
+            # Every leg below builds its own engine.  The headline engine is released first, and the one-stream legs run BEFORE the 64-stream ones: the same
+            # one-stream beam-4 configuration measured 33.13 ms as the first engine built after the headline one, 33.76 ms when its memory was carved out of
+            # what a 64-stream engine had just freed, and 34.77 ms next to a second live engine of its own size (profiles/r05/leg_order_probe.txt; rounds 3-4
+            # reported that leg ~0.9 ms above the same configuration run in a process of its own for this reason) -- placement of 17 GB of weights in
+            # recycled device memory is the driver's business, a leg should not be timed on its leftovers
+            eng.close()
         if legs and not args.no_beam4:
             try:
                 b4 = run_beam4(cfg, gen, weights, device, args)
@@ -885,6 +886,12 @@ def main():
                 log("latency-multiplier table done: " + ", ".join(f"m={r['multiplier']}: {r['xrt']} xRT" for r in mult["rows"]))
             except Exception as e:  # report, never hide
                 mult = {"failed": f"{type(e).__name__}: {e}"}
+        if legs and not args.no_streams64:
+            try:
+                s64 = run_streams64(cfg, gen, weights, device, args)
+                log(f"64-stream leg done: {s64['xrt']} xRT, {s64['ms_per_step']} ms per step")
+            except Exception as e:  # report, never hide
+                s64 = {"failed": f"{type(e).__name__}: {e}"}
         if legs and not args.no_streams64_beam4:
             try:
                 s64b4 = run_streams64_beam4(cfg, gen, weights, device, args)

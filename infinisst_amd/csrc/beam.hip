@@ -682,16 +682,67 @@ __global__ __launch_bounds__(256) void topk_final_parts_kernel(const float* __re
     block_topk(vals, ids, parts * k, k, out_val + (long)blockIdx.x * BEAM_TOPK, out_idx + (long)blockIdx.x * BEAM_TOPK);
 }
 
+// stage 2, one WAVE per row: the parts x k survivors of a row sit in registers (<= TFW_CPL per lane); a round is one shuffle reduction over the lanes'
+// current bests under the same total order (value desc, index asc) and the winner's owner drops that entry.  The block-wide form above (LDS image, two
+// levels, barriers) took 17.9 us for 4 rows x 512 candidates inside a one-stream beam step (profiles/r05/trace_busy_profb4_b.txt).
+#define TFW_CPL 16
+__global__ __launch_bounds__(256) void topk_final_wave_kernel(const float* __restrict__ cval, const int* __restrict__ cidx, int k, int parts, int rows,
+                                                              float* __restrict__ out_val, int* __restrict__ out_idx) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nc = parts * k;
+    float tv[TFW_CPL];
+    int ti[TFW_CPL];
+#pragma unroll
+    for (int j = 0; j < TFW_CPL; ++j) {
+        const int e = lane + 64 * j;
+        const bool in = e < nc;
+        const long q = ((long)row * parts + (in ? e / k : 0)) * BEAM_TOPK + (in ? e % k : 0);
+        tv[j] = in ? cval[q] : -INFINITY;
+        ti[j] = in ? cidx[q] : 0x7fffffff;
+    }
+    float mv;
+    int mi;
+    auto rescan = [&]() {
+        mv = tv[0]; mi = ti[0];
+#pragma unroll
+        for (int j = 1; j < TFW_CPL; ++j)
+            if (topk_better(tv[j], ti[j], mv, mi)) { mv = tv[j]; mi = ti[j]; }
+    };
+    rescan();
+    for (int it = 0; it < k; ++it) {
+        float bv = mv;
+        int bi = mi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, WAVE);
+            const int oi = __shfl_xor(bi, o, WAVE);
+            if (topk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { out_val[(long)row * BEAM_TOPK + it] = bv; out_idx[(long)row * BEAM_TOPK + it] = bi; }
+        if (bi == mi && bi != 0x7fffffff) {  // (token indices of a row's survivors are distinct: exactly one lane owns the winner)
+#pragma unroll
+            for (int j = 0; j < TFW_CPL; ++j) {
+                const bool here = ti[j] == bi;
+                tv[j] = here ? -INFINITY : tv[j];
+                ti[j] = here ? 0x7fffffff : ti[j];
+            }
+            rescan();
+        }
+    }
+}
+
 static int launch_topk_rows_view(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows, const TopkView& view,
                                  hipStream_t s) {
     if (rows <= 0) return ISST_OK;
     if (k < 1 || k > BEAM_TOPK || (vocab + LSE_PARTS - 1) / LSE_PARTS > TOPK_SLICE) return ISST_ERR_ARG;
-    if (rows >= 16 && k <= 16 && ld % 16 == 0 && (reinterpret_cast<uintptr_t>(scores) & 63) == 0) {  // many rows: one scan per (part, row) with the candidates in registers; enough parts for ~1024 workgroups
+    if (k <= 16 && ld % 16 == 0 && (reinterpret_cast<uintptr_t>(scores) & 63) == 0) {  // one scan per (part, row) with the candidates in registers; enough parts for ~1024 workgroups
         int parts = 1024 / rows;
         parts = parts < 1 ? 1 : (parts > LSE_PARTS ? LSE_PARTS : parts);
         if (k <= 8) hipLaunchKernelGGL(topk_scan_kernel<8>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
         else hipLaunchKernelGGL(topk_scan_kernel<16>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
-        hipLaunchKernelGGL(topk_final_parts_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, parts, out_val, out_idx);
+        if (parts * k <= 64 * TFW_CPL) hipLaunchKernelGGL(topk_final_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, cval, cidx, k, parts, rows, out_val, out_idx);
+        else hipLaunchKernelGGL(topk_final_parts_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, parts, out_val, out_idx);
         return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
     }
     hipLaunchKernelGGL(topk_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, scores, ld, vocab, k, cval, cidx, view);

@@ -110,6 +110,7 @@ extern "C" void isst_destroy(isst_handle* h) {
     if (h->blog) (void)hipHostFree(h->blog);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->side_ev) (void)hipEventDestroy(h->side_ev);
+    if (h->side_ev2) (void)hipEventDestroy(h->side_ev2);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->dgraph.exec) (void)hipGraphExecDestroy(h->dgraph.exec);
     delete h;
@@ -130,6 +131,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_ROPE_SIDE")) h->rope_side = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSED_SAMPLE")) h->fused_sample = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_TAIL_ADVANCE")) h->tail_advance = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_SYNC_AT_END")) h->sync_at_end = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_QKV_SLICES")) h->qkv_slices = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : 1;
     if (const char* e = getenv("ISST_INLINE_COMBINE")) h->inline_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_SHARED")) h->beam_shared = e[0] && e[0] != '0';
@@ -534,6 +536,7 @@ extern "C" int isst_stream_reset(isst_handle* h, int id) {
     h->streams[id] = StreamState();
     h->streams[id].open = true;
     // first-chunk offset: 79 + 320 zeros in front of the first samples (agents/infinisst.py:216-218)
+    HIPCHK(hipDeviceSynchronize());  // (isst_generate may return with the tail of its last kernel still running on the caller's stream)
     HIPCHK(hipMemsetAsync(h->audio_hist + (size_t)id * round_up(h->hist, 8), 0, (size_t)h->hist * 2, 0));
     HIPCHK(hipStreamSynchronize(0));
     return ISST_OK;

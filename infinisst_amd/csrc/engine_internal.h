@@ -136,7 +136,9 @@ struct isst_handle {
                                   // speech encoder (MFMA-bound at many streams) and joins before the prefill.  Measured, one box, ms per step: 64 streams
                                   // 90.96 / 90.90 without, 91.17 / 90.69 with; 16 streams 51.11 / 51.21 -- nothing, stays off
     hipStream_t side = nullptr;
-    hipEvent_t side_ev = nullptr;
+    hipEvent_t side_ev = nullptr, side_ev2 = nullptr;
+    bool sync_at_end = false;     // ISST_SYNC_AT_END=1: isst_generate drains the stream before it returns even when every token reached the host through a
+                                  // published sequence number (fused greedy tail, device beam scorer)
     bool use_graphs = false;  // ISST_GRAPH=1 enables.  Measured on MI355X (1 stream): 35.40 ms per chunk replayed vs 35.28 launched one by
                               // one -- the loop is GPU-bound, the host is ~0.6 ms ahead per pass, and a graph does not shorten the
                               // GPU-side kernel boundaries; it only saves host time (230 launches -> 1 per step)

@@ -548,7 +548,8 @@ void latch_three_launch_path(isst_handle* h) {
 
 // finalize (:159-275): open beams become hypotheses, the best one wins; every arena of a stream ends up holding its winner's tail; outputs + stream lengths
 int beam_finalize(isst_handle* h, const isst_gen_params* p, int n, int B, const int* stream_ids, const int* prompt_lens, const std::vector<int>& rows_len,
-                  const std::vector<int>& total0, std::vector<BeamStream>& bs, int* const* out_ids, int* out_lens, StepMeta& mh, StepMeta& md, hipStream_t st) {
+                  const std::vector<int>& total0, std::vector<BeamStream>& bs, int* const* out_ids, int* out_lens, StepMeta& mh, StepMeta& md, hipStream_t st,
+                  bool drain = true) {
     const isst_config& c = h->cfg;
     std::vector<KvCopyOp> ops;
     std::vector<size_t> best_of(n);
@@ -599,8 +600,12 @@ int beam_finalize(isst_handle* h, const isst_gen_params* p, int n, int B, const 
         for (size_t q = 0; q < outv.size(); ++q) out_ids[i][q] = outv[q];
         out_lens[i] = (int)outv.size();
     }
-    HIPCHK(hipStreamSynchronize(st));
-    h->kv_ops_used = 0;
+    // (drain == false: the caller has every token on the host already and nothing of the host's state depends on the copies above having run -- the next
+    //  call's work is ordered behind them on the stream, and the pinned op slots they were uploaded from are handed out in turn: flush_copies)
+    if (drain) {
+        HIPCHK(hipStreamSynchronize(st));
+        h->kv_ops_used = 0;
+    }
     return ISST_OK;
 }
 
@@ -826,10 +831,8 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
     fill_powtab(powtab, p->max_new_tokens, lp);
     std::vector<BeamStream> bs(n);
     std::vector<KvCopyOp> ops;
-    if (h->kv_ops_used) {  // batches of an earlier call that ended without a synchronisation in between
-        HIPCHK(hipStreamSynchronize(st));
-        h->kv_ops_used = 0;
-    }
+    // (copy batches of the previous call's finalize may still be in flight -- it does not drain the stream; flush_copies hands the pinned op slots out in turn
+    //  and synchronises by itself should they run out)
     for (int i = 0; i < n; ++i) {
         bs[i].seq.assign(B, std::vector<int>(prompt_ids[i], prompt_ids[i] + prompt_lens[i]));
         bs[i].score.assign(B, -1e9f);
@@ -980,6 +983,7 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         bt_lap(bt_wait);
         h->fuse_ao_used = false;
+        h->kv_ops_used = 0;  // (every copy batch enqueued before this step's scorer has run)
         bool all_done = true, upstream_failed = false;
         const int* dn = slot_done(step);
         for (int i = 0; i < n; ++i) { all_done = all_done && dn[i] == 1; upstream_failed = upstream_failed || dn[i] == -1; }
@@ -1009,7 +1013,7 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
     if (bt_on)
         std::fprintf(stderr, "[isst beam host] %d streams x %d beams, %d steps, scorer on the device: us per step -- tail + scorer + copies enqueue %.0f, wait for the step's number %.0f, forward enqueue %.0f, host follower (beside the GPU) %.0f\n",
                      n, B, step, bt_tail / step, bt_wait / step, bt_enq / step, bt_follow / step);
-    return beam_finalize(h, p, n, B, stream_ids, prompt_lens, rows_len, total0, bs, out_ids, out_lens, mh, md, st);
+    return beam_finalize(h, p, n, B, stream_ids, prompt_lens, rows_len, total0, bs, out_ids, out_lens, mh, md, st, h->sync_at_end);
 }
 
 }  // namespace
@@ -1169,6 +1173,9 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             HIPCHK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
             HIPCHK(hipEventCreateWithFlags(&h->side_ev, hipEventDisableTiming));
         }
+        if (!h->side_ev2) HIPCHK(hipEventCreateWithFlags(&h->side_ev2, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->side_ev2, st));  // (behind whatever the previous call left on the caller's stream: calls no longer end drained)
+        HIPCHK(hipStreamWaitEvent(h->side, h->side_ev2, 0));
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, h->side));
         CHK(launch_llm_rope_cache(md.views, rope_views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, h->side));
         HIPCHK(hipEventRecord(h->side_ev, h->side));
@@ -1366,9 +1373,13 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         if (const int rc = decode_step(nr)) return rc;  // (the failing call has already recorded its message)
         if (g_ht.on) g_ht.enq_pass += HostTrace::us(ht_a, std::chrono::steady_clock::now());
     }
-    // (every call still ENDS with the stream drained -- the side stream of the next call and the host-side eviction rely on it; with the fused tail the last
-    //  wait above returned on the published tokens, a few microseconds before the kernel's own completion)
-    if (tail_fused) HIPCHK(hipStreamSynchronize(st));
+    // (With the fused tail the last wait above returned on the published tokens, a few microseconds before the kernel's own completion -- every write of that
+    //  kernel to device state precedes the publication.  Nothing on the host depends on the stream being idle: the eviction that follows is a ring-start
+    //  advance in host state, the next call's work is ordered behind on the stream, the pinned staging blocks were consumed passes ago, and the entry points
+    //  that read device memory directly (debug reads, imports) synchronise the device themselves.  So the call returns without draining the stream -- the
+    //  completion round trip of hipStreamSynchronize was GPU-idle time between two chunks.  ISST_SYNC_AT_END=1 restores the drain; the side-stream
+    //  pre-pass (ISST_ROPE_SIDE, off by default) orders itself behind the caller's stream with an event.)
+    if (tail_fused && h->sync_at_end) HIPCHK(hipStreamSynchronize(st));
     // ---- 4. state: the cache holds the prompt and every generated token except the last one ----
     for (int i = 0; i < n; ++i) {
         StreamState& s = h->streams[stream_ids[i]];
