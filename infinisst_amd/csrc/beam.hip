@@ -313,9 +313,9 @@ __global__ __launch_bounds__(256) void lse_part_kernel(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < LSE_PT; ++u) {
             const int v4 = v0 + (u * 256 + (int)threadIdx.x) * 4;
-            q[u] = v4 < hi ? *reinterpret_cast<const f32x4_t*>(L + v4) : (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // (the row's padding up to ld is readable)
+            q[u] = *reinterpret_cast<const f32x4_t*>(L + (v4 < hi ? v4 : lo));  // UNCONDITIONAL load (a piece past the slice re-reads its first one and is masked below): a branch around a load makes hipcc drain the queue per load
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (v4 + e >= hi) q[u][e] = -INFINITY;
+            for (int e = 0; e < 4; ++e) q[u][e] = (v4 + e < hi) ? q[u][e] : -INFINITY;  // (the row's padding up to ld is readable; entries at or past `hi` do not count)
         }
         float m2 = m;
 #pragma unroll
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict_
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const int v4 = vb + w * 1024;
-            qq[w] = v4 < hi ? *reinterpret_cast<const f32x4_t*>(L + v4) : (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // (the row's padding up to ld is readable; elements at or past `hi` are skipped below)
+            qq[w] = *reinterpret_cast<const f32x4_t*>(L + (v4 < hi ? v4 : lo));  // UNCONDITIONAL (a piece past the slice re-reads its first one; its elements fail `v0 < hi` below): no branch around a load
         }
 #pragma unroll
         for (int w = 0; w < 4; ++w) {

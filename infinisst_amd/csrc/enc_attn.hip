@@ -56,6 +56,15 @@ __device__ __forceinline__ u32x4_t rot_frag(const bf16_t* p, int pos, int dim0, 
     return pack8(y);
 }
 
+// the same from registers: the raw 8 dims and the table entries were loaded earlier (several key tiles' loads in flight before the first rotation)
+__device__ __forceinline__ u32x4_t rot_frag_regs(const u32x4_t& raw, const f32x4_t& c, const f32x4_t& sn, int round_each) {
+    float x[8], y[8];
+    unpack8(raw, x);
+    const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+    rot8(x, cc, ss, round_each, y);
+    return pack8(y);
+}
+
 // -DISST_ENC_TRACE (make trace): wave 0 of every workgroup stamps the 100 MHz wall clock at entry / queries rotated / scores written / softmax done /
 // P.V done / stored (profiles/enc_attn_trace_probe.py)
 #ifdef ISST_ENC_TRACE
@@ -120,36 +129,60 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
 #endif
     ENC_STAMP(1);
     // ---- 1. scores ----
+    // One stream (QT == 1: 48 workgroups on 256 CUs, nothing else to hide a round trip behind) walks its 5 key tiles per wave with ALL their loads -- key rows and
+    // rotary table entries -- in flight before the first rotation: the phase was a chain of 5 dependent round trips, 9.0 of the launch's 18.4 us
+    // (profiles/r05/enc_attention_trace_1_stream.txt).  Many streams (QT == 3, two workgroups per CU, VALU-bound) keep one tile at a time and their registers.
+    constexpr int TCH = QT == 1 ? 5 : 1;
     const int n_tiles = cap >> 4;
-    for (int nt = wave; nt < n_tiles; nt += ENC_WAVES) {
-        const int cphys = nt * 16 + fr;       // physical slot of this lane's key
-        int j = cphys - start;                // logical index
-        if (j < 0) j += cap;
-        const bool live = j < K;
-        const int jpos = live ? j : 0;
-        const bool is_new = live && j >= len;  // written by this chunk: still only in the qkv rows
-        const bf16_t* krow = is_new ? knew + (long)(j - len) * 3 * D : kr + (long)cphys * ENC_HD;
-        if (is_new && qb == 0) {  // append the unrotated key to the ring (query block 0 owns the append)
+    for (int nt0 = wave; nt0 < n_tiles; nt0 += ENC_WAVES * TCH) {
+        u32x4_t kraw[TCH][2];
+        f32x4_t kc[TCH][2], ksn[TCH][2];
+        int jj[TCH], cph[TCH];
+        bool lv[TCH];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                *reinterpret_cast<u32x4_t*>(kr + (long)cphys * ENC_HD + ks * 32 + fq * 8) = *reinterpret_cast<const u32x4_t*>(krow + ks * 32 + fq * 8);
+        for (int t = 0; t < TCH; ++t) {
+            const int nt = min(nt0 + t * ENC_WAVES, n_tiles - 1);  // (a tile past the end re-reads the last one; it is not used)
+            const int cphys = nt * 16 + fr;       // physical slot of this lane's key
+            int j = cphys - start;                // logical index
+            if (j < 0) j += cap;
+            const bool live = j < K;
+            const int jpos = live ? j : 0;
+            const bool is_new = live && j >= len;  // written by this chunk: still only in the qkv rows
+            const bf16_t* krow = is_new ? knew + (long)(j - len) * 3 * D : kr + (long)cphys * ENC_HD;
+            jj[t] = j; cph[t] = cphys; lv[t] = live;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kraw[t][ks] = *reinterpret_cast<const u32x4_t*>(krow + ks * 32 + fq * 8);
+                kc[t][ks] = *reinterpret_cast<const f32x4_t*>(rope_cos + (long)jpos * 32 + ((ks * 32 + fq * 8) >> 1));
+                ksn[t][ks] = *reinterpret_cast<const f32x4_t*>(rope_sin + (long)jpos * 32 + ((ks * 32 + fq * 8) >> 1));
+            }
         }
-        u32x4_t kf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) kf[ks] = rot_frag(krow + ks * 32 + fq * 8, jpos, ks * 32 + fq * 8, rope_cos, rope_sin, round_each);
+        for (int t = 0; t < TCH; ++t) {
+            if (nt0 + t * ENC_WAVES >= n_tiles) break;  // (wave-uniform)
+            const int j = jj[t], cphys = cph[t];
+            const bool live = lv[t];
+            if (live && j >= len && qb == 0) {  // append the unrotated key to the ring (query block 0 owns the append)
 #pragma unroll
-        for (int mt = 0; mt < QT; ++mt) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<u32x4_t*>(kr + (long)cphys * ENC_HD + ks * 32 + fq * 8) = kraw[t][ks];
+            }
+            u32x4_t kf[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qf[mt][ks]), __builtin_bit_cast(bf16x8_t, kf[ks]), acc, 0, 0, 0);
-            // C layout: this lane holds column fr (its own key), rows 4 fq + r
+            for (int ks = 0; ks < 2; ++ks) kf[ks] = rot_frag_regs(kraw[t][ks], kc[t][ks], ksn[t][ks], round_each);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = live && j >= lo[mt][r] && j < hi[mt][r];
-                // q * head_dim^-0.5 (:768) is an exact power-of-two scaling, applied to the accumulated dot product
-                const bf16_t v = ok ? f2bf(0.125f * acc[r]) : (bf16_t)0xFF80;  // -inf
-                S[(long)(mt * 16 + fq * 4 + r) * ldS + cphys] = v;
+            for (int mt = 0; mt < QT; ++mt) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qf[mt][ks]), __builtin_bit_cast(bf16x8_t, kf[ks]), acc, 0, 0, 0);
+                // C layout: this lane holds column fr (its own key), rows 4 fq + r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = live && j >= lo[mt][r] && j < hi[mt][r];
+                    // q * head_dim^-0.5 (:768) is an exact power-of-two scaling, applied to the accumulated dot product
+                    const bf16_t v = ok ? f2bf(0.125f * acc[r]) : (bf16_t)0xFF80;  // -inf
+                    S[(long)(mt * 16 + fq * 4 + r) * ldS + cphys] = v;
+                }
             }
         }
     }
@@ -209,10 +242,11 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
     // physical slot range of the new keys: [nlo, nlo + Q) mod cap
     int nlo = start + len;
     if (nlo >= cap) nlo -= cap;
-    for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += 4) {
-        u32x4_t vf[4];
+    constexpr int VB = QT == 1 ? 10 : 4;  // V^T fragments in flight before the first use (one stream: the whole half of a full window in ONE round trip instead of three)
+    for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += VB) {
+        u32x4_t vf[VB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // four V^T fragments in flight before the first use
+        for (int u = 0; u < VB; ++u) {
             const int ks = ks0 + u < ks_hi ? ks0 + u : ks_hi - 1;
             const int t0 = ks * 32 + fq * 8;  // first of this lane's 8 slots
             int rel = t0 - nlo;
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < VB; ++u) {
             if (ks0 + u < ks_hi) {
 #pragma unroll
                 for (int mt = 0; mt < QT; ++mt) {
