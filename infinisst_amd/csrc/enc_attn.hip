@@ -77,11 +77,12 @@ extern "C" int isst_debug_enc_trace_read(void* dst, long bytes) {
 #define ENC_STAMP(i) do {} while (0)
 #endif
 
-template <int QT>  // m-tiles of 16 query rows per workgroup
+template <int QT, bool RND>  // QT: m-tiles of 16 query rows per workgroup; RND: every product of the rotation rounds to bf16 (enc_rope_mode "bf16": as a compile-time
+                              // constant -- as a runtime flag every rotated pair carried a branch, 160 of them per key tile in a phase that is bound by instruction issue)
 __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                                                             const EncStreamView* __restrict__ sv,
                                                             const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                                                            int round_each, bf16_t* __restrict__ out, int Q, int heads, int cap,
+                                                            int /*round_each: RND*/, bf16_t* __restrict__ out, int Q, int heads, int cap,
                                                             int C, int bs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ENC_STAMP(0);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
         const int qi = q0 + mt * 16 + fr;
         const bf16_t* qrow = qkv + ((long)s * Q + qi) * 3 * D + h * ENC_HD;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[mt][ks] = rot_frag(qrow + ks * 32 + fq * 8, K - Q + qi, ks * 32 + fq * 8, rope_cos, rope_sin, round_each);
+        for (int ks = 0; ks < 2; ++ks) qf[mt][ks] = rot_frag(qrow + ks * 32 + fq * 8, K - Q + qi, ks * 32 + fq * 8, rope_cos, rope_sin, RND ? 1 : 0);
     }
     // visible logical column range of the rows this lane holds in the C layout (rows 4 fq + r of each m-tile)
     // (patch_speech_encoder.py:30-77; P == 0 is the training mask)
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
             }
             u32x4_t kf[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kf[ks] = rot_frag_regs(kraw[t][ks], kc[t][ks], ksn[t][ks], round_each);
+            for (int ks = 0; ks < 2; ++ks) kf[ks] = rot_frag_regs(kraw[t][ks], kc[t][ks], ksn[t][ks], RND ? 1 : 0);
 #pragma unroll
             for (int mt = 0; mt < QT; ++mt) {
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -320,21 +321,18 @@ int launch_enc_attention(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long s
     const int QT = (Q % 48 == 0 && n_streams * (Q / 16) * heads >= 1024) ? 3 : 1;  // few streams: 16-row query blocks give 3x the workgroups (the K rotation is redone per block)
     const size_t lds = (size_t)QT * 16 * (cap + ENC_SPAD) * 2 + (size_t)QT * 16 * ENC_HD * sizeof(float);
     dim3 grid(heads, Q / (QT * 16), n_streams), block(ENC_WAVES * 64);
-    static size_t lds_set[2] = {0, 0};
-    if (QT == 3) {
-        if (lds > 64 * 1024 && lds > lds_set[0]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attention_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
-            lds_set[0] = lds;
+    auto go = [&](auto kern, size_t& lds_set) -> int {
+        if (lds > 64 * 1024 && lds > lds_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
+            lds_set = lds;
         }
-        hipLaunchKernelGGL(enc_attention_kernel<3>, grid, block, lds, s, qkv, kring, vring, stream_stride, sv, rope_cos, rope_sin,
-                           rope_round_each, out, Q, heads, cap, max_cache, blocksize);
-    } else {
-        if (lds > 64 * 1024 && lds > lds_set[1]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attention_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
-            lds_set[1] = lds;
-        }
-        hipLaunchKernelGGL(enc_attention_kernel<1>, grid, block, lds, s, qkv, kring, vring, stream_stride, sv, rope_cos, rope_sin,
-                           rope_round_each, out, Q, heads, cap, max_cache, blocksize);
-    }
+        hipLaunchKernelGGL(kern, grid, block, lds, s, qkv, kring, vring, stream_stride, sv, rope_cos, rope_sin, rope_round_each, out, Q, heads, cap, max_cache, blocksize);
+        return ISST_OK;
+    };
+    static size_t lds_set[4] = {0, 0, 0, 0};
+    int rc;
+    if (QT == 3) rc = rope_round_each ? go(enc_attention_kernel<3, true>, lds_set[0]) : go(enc_attention_kernel<3, false>, lds_set[1]);
+    else rc = rope_round_each ? go(enc_attention_kernel<1, true>, lds_set[2]) : go(enc_attention_kernel<1, false>, lds_set[3]);
+    if (rc != ISST_OK) return rc;
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }

@@ -129,6 +129,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_FUSE_COMBINE")) h->fuse_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_REDUCE")) h->fuse_reduce = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_ROPE_SIDE")) h->rope_side = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_ROPE_FUSE")) h->rope_fuse = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSED_SAMPLE")) h->fused_sample = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_TAIL_ADVANCE")) h->tail_advance = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_SYNC_AT_END")) h->sync_at_end = e[0] && e[0] != '0';

@@ -132,6 +132,8 @@ struct isst_handle {
     float* lssq = nullptr;        // [64][llm_dim / 32] sums of squares (GemmArgs::ssq)
     int* ltickets = nullptr;      // [ltickets_n] arrival counters (GemmArgs::tickets), one per 32-column block of the widest ticketed launch; zero between launches
     int ltickets_n = 0;
+    bool rope_fuse = true;        // ISST_ROPE_FUSE=0: the rotated-key arena of a chunk is filled by a pre-pass over every layer's keys (llm_rope_cache_kernel) instead of by
+                                  // the prefill attention's loader waves (LlmStreamView::rot_keys == 2)
     bool rope_side = false;       // ISST_ROPE_SIDE=1: the rotated-key pre-pass of a chunk (pure memory traffic) runs on a low-priority side stream beside the
                                   // speech encoder (MFMA-bound at many streams) and joins before the prefill.  Measured, one box, ms per step: 64 streams
                                   // 90.96 / 90.90 without, 91.17 / 90.69 with; 16 streams 51.11 / 51.21 -- nothing, stays off

@@ -1163,7 +1163,15 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
     }
     bool any_cached = false;
     for (int i = 0; i < n; ++i) any_cached = any_cached || total0[i] > 0;
-    if (h->rot_keys && any_cached && h->rope_side && st != nullptr) {
+    // The prefill attention fills the rotated-key arena itself (LlmStreamView::rot_keys == 2: its loader waves rotate every cached tile they stage and store
+    // it) wherever the prefill runs on llm_attn_prefill_kernel and only arena 0 of a stream is read through the arena below this chunk's tokens -- greedy, and
+    // beam search in the shared-prefix form.  ISST_ROPE_FUSE=0 (or one beam group per arena) keeps the pre-pass over all layers.
+    const bool fuse_rope = h->rot_keys && h->rope_fuse && gmax > 1 && (B == 1 || beams_share_prefix) && !h->rope_side;
+    if (fuse_rope)
+        for (int i = 0; i < n; ++i) mh.views[i].rot_keys = 2;
+    if (fuse_rope) {
+        HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
+    } else if (h->rot_keys && any_cached && h->rope_side && st != nullptr) {
         // The host is far ahead of the GPU here (the encoder above is milliseconds of queued work), so the metadata upload and the pre-pass, issued on
         // the side stream now, run BESIDE the encoder; the prefill waits for both.  (The caller's stream was idle when this call began -- every call ends
         // with a synchronisation -- so the pre-pass cannot overtake an earlier writer of the caches.)
@@ -1187,6 +1195,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         if (h->rot_keys && any_cached) CHK(launch_llm_rope_cache(md.views, rope_views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
     }
     CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh, n_units, max_unit_groups));
+    if (fuse_rope)  // (the decode passes read the arena the prefill has just filled: their views -- uploaded per step, or passed by value -- say 1)
+        for (int i = 0; i < n; ++i) mh.views[i].rot_keys = 1;
     if (B > 1) {
         if (h->beam_device && !p->do_sample)
             return beam_decode_device(h, p, n, stream_ids, prompt_ids, prompt_lens, rows_len, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);

@@ -734,7 +734,11 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
     bf16_t* kb = kpool + base;
     bf16_t* kr = krpool + base;
     bf16_t* vb = vpool + base;
-    const bool rot = v.rot_keys != 0;
+    // rot_keys 1: cached keys are read already rotated (the rotated-key arena was filled for this chunk).  2 ("fill", round 5): THIS launch fills it -- the
+    // loader waves read the unrotated keys, rotate them for the scores as the rotate-on-read schedule does, and store the rotated tile to the arena on their
+    // way to LDS, so the chunk needs no pre-pass over every layer's keys (llm_rope_cache_kernel: 8.4 GB of traffic, 1.8-1.95 ms per 64-stream chunk).  Every
+    // live cached tile of the stream is staged by exactly one loader wave per unit of the stream (same bits from every unit); the decode passes then read 1.
+    const bool rot = v.rot_keys == 1, fill = v.rot_keys == 2;
     const float scale = 0.08838834764831845f;
     // tiles are walked in the compact index space of the tiles that hold a live slot (see llm_attn_partial_kernel)
     const int sys_tiles = (v.sys_len + 15) >> 4, ring_tiles = d.ring_cap >> 4, ring_tile0 = v.ring_start >> 4;
@@ -825,8 +829,11 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     *reinterpret_cast<u32x4_t*>(kb + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = f.raw[s];
-                    if (rot) *reinterpret_cast<u32x4_t*>(kr + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
+                    if (rot || fill) *reinterpret_cast<u32x4_t*>(kr + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
                 }
+            } else if (fill && !f.is_new && f.jk >= 0) {  // a cached key: its rotation of this chunk goes to the arena for the decode passes
+#pragma unroll
+                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kr + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&kimg[buf][my_slot][rw_off[s]]) = kf[s];

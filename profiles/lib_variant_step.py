@@ -13,9 +13,10 @@ import bench
 from infinisst_amd.config import GenConfig, full_config
 cfg = full_config().replace(eos_ids=())
 dev = torch.device("cuda:0")
-gen = GenConfig(max_new_tokens=10, max_llm_cache_size=1000)
-eng, weights, sys_n = bench.build_engine(cfg, NS, 10, dev, 1, None)
+B = int(os.environ.get("AB_BEAM", "1"))  # num_beams (1 = greedy)
+gen = GenConfig(max_new_tokens=10, max_llm_cache_size=1000, beam=B)
+eng, weights, sys_n = bench.build_engine(cfg, NS, 10, dev, B, None)
 loop = bench.ChunkLoop(eng, cfg, gen, list(range(NS)), sys_n); loop.import_steady_state(dev)
 for _ in range(6): loop.step()
 dt, lat, _ = bench.timed_steps(loop, STEPS)
-print(f"{os.path.basename(sys.argv[1])}: {NS} streams {1e3 * dt / STEPS:.3f} ms per step, p50 {1e3 * float(np.percentile(lat, 50)):.3f}")
+print(f"{os.path.basename(sys.argv[1])}: {NS} streams x {B} beams {1e3 * dt / STEPS:.3f} ms per step, p50 {1e3 * float(np.percentile(lat, 50)):.3f}")

@@ -456,6 +456,61 @@ def test_fused_sampling_tail_equals_the_three_launch_tail(monkeypatch, graph):
     assert len({tuple(t) for ids, _ in a for t in ids}) > 2
 
 
+@pytest.mark.parametrize("m,beam,n_streams", [(1, 1, 1), (4, 1, 1), (1, 1, 3), (2, 3, 2)])
+def test_rotated_key_arena_filled_by_the_prefill_is_bit_identical_to_the_pre_pass(monkeypatch, m, beam, n_streams):
+    """The rotated-key arena of a chunk (the cached keys rotated at their logical position of THIS chunk: patch_llm.py:286-299 rotates every key on every pass)
+    is filled by the prefill attention's loader waves on their way to LDS (LlmStreamView::rot_keys == 2) instead of by a pre-pass over every layer's keys.
+    ISST_ROPE_FUSE=0 keeps the pre-pass.  Same tokens, same raw logits bit for bit, same cache lengths -- over chunks with evictions (every key re-indexes), a
+    pinned system prompt, prompts of one and of two attention units (m = 4: 58 rows = 15 row groups), several streams in a call, and the shared-prefix beam form
+    (whose decode passes read arena 0 through the rotated arena)."""
+    from oracle import agent as oag
+    cfg = toy_config()
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.05, norm_jitter=0.05, seed=61)
+    gen = GenConfig(latency_multiplier=m, max_new_tokens=6, beam=beam, max_llm_cache_size=160, always_cache_system_prompt=True)
+    audio = [synth.synthetic_audio(cfg.chunk_samples * m * 6, stream_id=40 + i) for i in range(n_streams)]
+    sys_n = len(synth.system_prompt_ids(cfg))
+
+    def run(flag):
+        monkeypatch.setenv("ISST_ROPE_FUSE", flag)
+        eng = Engine(cfg, max_streams=n_streams, max_multiplier=m, max_prompt_len=sys_n + 24 + 12 * m, max_new_tokens=8, max_llm_cache_size=160, max_system_prompt=64,
+                     max_beams=beam)
+        eng.load_weights(w)
+        sids = [eng.open_stream() for _ in range(n_streams)]
+        out = []
+        ckpts = [[] for _ in sids]
+        prev = [[] for _ in sids]
+        for c in range(6):
+            segs = [a[c * cfg.chunk_samples * m:(c + 1) * cfg.chunk_samples * m] for a in audio]
+            prompt = synth.chunk_prompt_ids(cfg, m, first=(c == 0))
+            ids, logits = eng.generate(gen, sids, segs, [prompt] * n_streams, [p[-100:] for p in prev], system_prompt_size=sys_n if c == 0 else 0,
+                                       return_logits=(beam == 1))
+            lens = []
+            for i, sid in enumerate(sids):
+                prev[i].extend(ids[i][:-1])
+                cur = eng.stream_info(sid)["llm_cache_len"]
+                lens.append(cur)
+                ckpts[i].append(cur)
+                ev = oag.evict(ckpts[i], cur, gen.max_llm_cache_size, True, sys_n)
+                if ev is not None:
+                    ckpts[i], new_size = ev
+                    eng.kv_evict(sid, new_size, sys_n)
+            kv = [[eng.read_kv(sid, p_, layer=1, kv_head=1, beam=b) for p_ in (0, sys_n, lens[i] - 1)] for i, sid in enumerate(sids) for b in range(beam)]
+            out.append((ids, lens, None if logits is None else [logits[i][:len(ids[i])].copy() for i in range(n_streams)], kv))
+        eng.close()
+        return out
+
+    a, b = run("1"), run("0")
+    for c, (x, y) in enumerate(zip(a, b)):
+        assert x[0] == y[0] and x[1] == y[1], f"chunk {c}: tokens / cache lengths differ"
+        if x[2] is not None:
+            for i in range(n_streams):
+                assert np.array_equal(x[2][i], y[2][i]), f"chunk {c} stream {i}: logits differ between the prefill-filled arena and the pre-pass"
+        for q, (ka, kb) in enumerate(zip(x[3], y[3])):
+            for (k1, v1), (k2, v2) in zip(ka, kb):
+                assert torch.equal(k1, k2) and torch.equal(v1, v2), f"chunk {c} arena {q}: KV differs"
+    assert any(len(set(x[1])) >= 1 for x in a)
+
+
 def test_one_stream_decode_step_prepared_on_the_device_is_bit_identical(monkeypatch):
     """One stream's greedy loop (BASELINE.json configs[1]): the fused sampling tail appends the sampled id to the id list the processors read and copies its
     embedding row to the decoder's input row ON THE DEVICE, so a decode step is neither preceded by a metadata upload nor opened by the embedding launch
