@@ -1195,8 +1195,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         if (h->rot_keys && any_cached) CHK(launch_llm_rope_cache(md.views, rope_views, h->llm_cos, h->llm_sin, h->llm_k, h->llm_kr, h->adims, c.llm_layers, st));
     }
     CHK(llm_forward(h, md, R, n, n_groups, gmax, true, "llm_", st, &mh, n_units, max_unit_groups));
-    if (fuse_rope)  // (the decode passes read the arena the prefill has just filled: their views -- uploaded per step, or passed by value -- say 1)
-        for (int i = 0; i < n; ++i) mh.views[i].rot_keys = 1;
+    // (the views keep rot_keys == 2 for the decode passes: every kernel but the prefill one reads "not 0" as "the arena is valid" -- and the pinned block must
+    //  not be touched here anyway: its upload above executes when the stream gets there, not when it was enqueued)
     if (B > 1) {
         if (h->beam_device && !p->do_sample)
             return beam_decode_device(h, p, n, stream_ids, prompt_ids, prompt_lens, rows_len, prev_target_ids, n_prev, total0, out_ids, out_lens, mh, md, st);

@@ -17,7 +17,8 @@ struct LlmStreamView {
     int row0;        // row of this launch that holds position new_start
     int rot_keys;    // 1: keys older than this launch are read ALREADY ROTATED from the rotated-key arena (filled for this chunk) and the launch's own
                      // keys are added to it; 0: rotate on read, as the reference does every pass; 2 (prefill launches only, llm_attn_prefill_kernel):
-                     // rotate on read AND store the rotated keys to the arena -- this launch is what fills it (no launch_llm_rope_cache pre-pass)
+                     // rotate on read AND store the rotated keys to the arena -- this launch is what fills it (no launch_llm_rope_cache pre-pass);
+                     // every other kernel reads 2 as 1
     // beam search, shared-prefix form (n_beams > 1): the group's rows are the B beams of ONE stream at the same position.  Their arenas
     // (kv_offset + b * beam_stride) are identical below logical position tail_start, so the ordinary slot-split workgroups read those
     // keys ONCE, from arena 0, for all beams' columns; keys >= tail_start (written during this chunk: per beam) and the step's own key

@@ -484,17 +484,16 @@ def test_rotated_key_arena_filled_by_the_prefill_is_bit_identical_to_the_pre_pas
             prompt = synth.chunk_prompt_ids(cfg, m, first=(c == 0))
             ids, logits = eng.generate(gen, sids, segs, [prompt] * n_streams, [p[-100:] for p in prev], system_prompt_size=sys_n if c == 0 else 0,
                                        return_logits=(beam == 1))
-            lens = []
+            lens = [eng.stream_info(sid)["llm_cache_len"] for sid in sids]
+            kv = [[eng.read_kv(sid, p_, layer=1, kv_head=1, beam=b) for p_ in (0, sys_n, lens[i] - 1)] for i, sid in enumerate(sids) for b in range(beam)]
             for i, sid in enumerate(sids):
                 prev[i].extend(ids[i][:-1])
-                cur = eng.stream_info(sid)["llm_cache_len"]
-                lens.append(cur)
+                cur = lens[i]
                 ckpts[i].append(cur)
                 ev = oag.evict(ckpts[i], cur, gen.max_llm_cache_size, True, sys_n)
                 if ev is not None:
                     ckpts[i], new_size = ev
                     eng.kv_evict(sid, new_size, sys_n)
-            kv = [[eng.read_kv(sid, p_, layer=1, kv_head=1, beam=b) for p_ in (0, sys_n, lens[i] - 1)] for i, sid in enumerate(sids) for b in range(beam)]
             out.append((ids, lens, None if logits is None else [logits[i][:len(ids[i])].copy() for i in range(n_streams)], kv))
         eng.close()
         return out
