@@ -102,6 +102,7 @@ int launch_kv_positions_copy_list(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool,
 }
 
 __device__ __forceinline__ float beam_score_of(float x, int v, float lz, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side);  // (below, with beam_process_kernel)
+__device__ __noinline__ float beam_score_side(int v, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side);
 
 // ---- the beam scorer of one step, on the device: one wave per stream.  It restates engine_llm.hip's host scorer (the `follower` there, which is pinned to
 //      the reference's beam_search_process / BeamHypotheses.add through beam_scorer.npz / beam_loop.npz) operation for operation -- fp32 `candidate + beam
@@ -429,12 +430,16 @@ __global__ __launch_bounds__(256) void beam_process_kernel(float* __restrict__ l
     }
     for (int i = tid; i < n_suppress; i += blockDim.x) L[suppress[i]] = -INFINITY;
 }
-// the processed log-prob of entry v of a row prepared by beam_process_kernel (x = its stored value)
-__device__ __forceinline__ float beam_score_of(float x, int v, float lz, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side) {
-    if (x == x) return x - lz;
+// the processed log-prob of entry v of a row prepared by beam_process_kernel (x = its stored value).  The NaN path -- a handful of entries per row -- is a CALL:
+// inlined into the top-k kernels' unrolled element loops (16-64 copies of a search loop) it made them several times their size.
+__device__ __noinline__ float beam_score_side(int v, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side) {
     for (int k = 0; k < n_side; ++k)
         if (side_tok[k] == v) return side_val[k];
     return -INFINITY;
+}
+__device__ __forceinline__ float beam_score_of(float x, int v, float lz, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side) {
+    if (x == x) return x - lz;
+    return beam_score_side(v, side_tok, side_val, n_side);
 }
 struct TopkView {  // how a top-k kernel reads a score row: as it stands (lz == null), or through beam_process_kernel's encoding
     const float* logz;
@@ -447,6 +452,16 @@ __device__ __forceinline__ float topk_view(const TopkView& tv, int row, float x,
     if (!tv.logz) return x;
     return beam_score_of(x, v, tv.logz[row], tv.side_tok + (long)row * tv.side_cap, tv.side_val + (long)row * tv.side_cap, tv.side_n[row]);
 }
+struct TopkRowView {  // one row's view with its per-row values loaded ONCE (the element loops call this per entry)
+    bool on;
+    float lz;
+    const int* side_tok;
+    const float* side_val;
+    int n_side;
+    __device__ __forceinline__ TopkRowView(const TopkView& tv, int row) : on(tv.logz != nullptr), lz(on ? tv.logz[row] : 0.f),
+        side_tok(on ? tv.side_tok + (long)row * tv.side_cap : nullptr), side_val(on ? tv.side_val + (long)row * tv.side_cap : nullptr), n_side(on ? tv.side_n[row] : 0) {}
+    __device__ __forceinline__ float operator()(float x, int v) const { return on ? beam_score_of(x, v, lz, side_tok, side_val, n_side) : x; }
+};
 
 // ---- top-k (k <= BEAM_TOPK), ties -> lowest index.  Stage 1: the slice of a (part, row) is copied to LDS and the
 //      block argmax is taken k times; stage 2: the same over the LSE_PARTS * k survivors of a row. ----
@@ -475,16 +490,11 @@ __device__ void block_topk(float* vals, const int* idx, int n, int k, float* out
     rescan();
     for (int it = 0; it < k; ++it) {
         float bv = mv;
-        int bi = mi, bpos = mpos;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, WAVE);
-            const int oi = __shfl_xor(bi, o, WAVE), op = __shfl_xor(bpos, o, WAVE);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bpos = op; }
-        }
+        int bi = mi;
+        wave_argmax_all(bv, bi);  // (DPP: common.h)
         if (lane == 0) { wv[wave * BEAM_TOPK + it] = bv; wi[wave * BEAM_TOPK + it] = bi; }
-        if (bpos >= 0 && bpos == mpos) {  // the owner retires the winner (NaN-free inputs: -inf entries never win again) and finds its next best
-            vals[bpos] = -INFINITY;
+        if (mpos >= 0 && mv == bv && mi == bi) {  // the owner retires the winner (indices are distinct but for the -inf sentinels: every holder of one retires it) and finds its next best
+            vals[mpos] = -INFINITY;
             rescan();
         }
     }
@@ -504,16 +514,12 @@ __device__ void block_topk(float* vals, const int* idx, int n, int k, float* out
     rescan2();
     for (int it = 0; it < k; ++it) {
         float bv = cv;
-        int bi = ci, bpos = cpos;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, WAVE);
-            const int oi = __shfl_xor(bi, o, WAVE), op = __shfl_xor(bpos, o, WAVE);
-            if (ov > bv || (ov == bv && oi < bi) || (ov == bv && oi == bi && op >= 0 && (bpos < 0 || op < bpos))) { bv = ov; bi = oi; bpos = op; }
-        }
+        int bi = ci;
+        wave_argmax_all(bv, bi);
         if (lane == 0) { out_val[it] = bv; out_idx[it] = bi; }
-        if (bpos >= 0 && bpos == cpos) {  // the one owner of the winning entry retires it
-            wv[bpos] = -INFINITY;
+        if (cpos >= 0 && cv == bv && ci == bi) {  // the owner of the winning entry retires it
+            wv[cpos] = -INFINITY;
+            wi[cpos] = 0x7fffffff;
             rescan2();
         }
     }
@@ -560,14 +566,14 @@ int launch_log_softmax(float* logits, long ld, int vocab, float* pmax, float* ps
 //      per-slice LDS image: 256 rows x 64 slices of 2 005 elements through block_topk took 195-212 us, whatever its rounds cost (profiles/r04/topk_scan_ab.txt). ----
 __device__ __forceinline__ bool topk_better(float x, int i, float y, int j) { return x > y || (x == y && i < j); }
 template <int KR>
-__global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict__ scores, long ld, int vocab, int k, int parts, float* __restrict__ cval,
-                                                        int* __restrict__ cidx, TopkView view) {
+__device__ void topk_scan_body(const float* __restrict__ scores, long ld, int vocab, int k, int parts, float* __restrict__ cval, int* __restrict__ cidx, const TopkView& view) {
     __shared__ float wv[4 * BEAM_TOPK];
     __shared__ int wi[4 * BEAM_TOPK];
     const float* L = scores + (long)blockIdx.y * ld;
     const int per = ((vocab + parts - 1) / parts + 3) & ~3;  // (slices start at multiples of 4 elements: 16-byte loads; rows are 64-byte aligned, ld % 16 == 0)
     const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TopkRowView rv(view, blockIdx.y);
     float tv[KR];
     int ti[KR];
 #pragma unroll
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
         const int v0 = v4 + u;
-        const float x = topk_view(view, blockIdx.y, qq[w][u], v0);
+        const float x = rv(qq[w][u], v0);
         if (v0 < hi && topk_better(x, v0, wv_, wi_)) {
             bool done = false;
 #pragma unroll
@@ -619,12 +625,7 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict_
     for (int it = 0; it < k; ++it) {
         float bv = mv;
         int bi = mi;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, WAVE);
-            const int oi = __shfl_xor(bi, o, WAVE);
-            if (topk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-        }
+        wave_argmax_all(bv, bi);  // (DPP: common.h)
         if (lane == 0) { wv[wave * BEAM_TOPK + it] = bv; wi[wave * BEAM_TOPK + it] = bi; }
         if (bi == mi && bi != 0x7fffffff) {  // (real indices are distinct: exactly one lane owns the winner)
 #pragma unroll
@@ -652,21 +653,91 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict_
     float* oc = cval + ((long)blockIdx.y * parts + blockIdx.x) * BEAM_TOPK;
     int* oi_ = cidx + ((long)blockIdx.y * parts + blockIdx.x) * BEAM_TOPK;
     for (int it = 0; it < k; ++it) {
-        float bv = cv;
-        int bi = ci, bpos = cpos;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, WAVE);
-            const int oi = __shfl_xor(bi, o, WAVE), op = __shfl_xor(bpos, o, WAVE);
-            if (op >= 0 && (bpos < 0 || topk_better(ov, oi, bv, bi) || (ov == bv && oi == bi && op < bpos))) { bv = ov; bi = oi; bpos = op; }
-        }
+        float bv = cpos >= 0 ? cv : -INFINITY;
+        int bi = cpos >= 0 ? ci : 0x7fffffff;
+        wave_argmax_all(bv, bi);
         if (lane == 0) { oc[it] = bv; oi_[it] = bi; }
-        if (bpos >= 0 && bpos == cpos) {
-            wv[bpos] = -INFINITY;
-            wi[bpos] = 0x7fffffff;
+        if (cpos >= 0 && cv == bv && ci == bi) {  // the owner of the winning entry retires it (sentinels: every holder of one)
+            wv[cpos] = -INFINITY;
+            wi[cpos] = 0x7fffffff;
             rescan2();
         }
     }
+}
+template <int KR>
+__global__ __launch_bounds__(256) void topk_scan_kernel(const float* __restrict__ scores, long ld, int vocab, int k, int parts, float* __restrict__ cval,
+                                                        int* __restrict__ cidx, TopkView view) {
+    topk_scan_body<KR>(scores, ld, vocab, k, parts, cval, cidx, view);
+}
+// ---- stage 1 by THRESHOLD (round 5): the scan above keeps a candidate list per thread, and with 64 lanes per wave SOME lane inserts at nearly every element, so
+//      the whole wave walks the insertion code every time -- ~64 instructions per element, 125 us for 256 rows x 128 263 (22.8 us for 4 rows), twice the time of
+//      the memory pass (profiles/r05/final/trace_busy_prof64x4.txt).  Here a thread keeps its NF4 16-byte pieces of the slice in registers and only their maximum;
+//      the k-th largest of the workgroup's 256 thread maxima is a lower bound T of the slice's k-th largest entry (k entries >= T exist), so every entry of the
+//      slice's top k is >= T: the threads append their entries >= T (a handful) to an LDS list and block_topk takes the k best of it under the same total order
+//      (value desc, index asc).  Ties or bans can make that list long (all entries equal; fewer than k finite ones: T = -inf): past TS_CAP entries the workgroup
+//      falls back to the exact scan above. ----
+#define TS_CAP 1024
+template <int KR, int NF4>
+__global__ __launch_bounds__(256) void topk_thresh_kernel(const float* __restrict__ scores, long ld, int vocab, int k, int parts, float* __restrict__ cval,
+                                                          int* __restrict__ cidx, TopkView view) {
+    __shared__ float tmax[256];
+    __shared__ float lv[TS_CAP];
+    __shared__ int li[TS_CAP];
+    __shared__ int s_cnt;
+    __shared__ float s_T;
+    const float* L = scores + (long)blockIdx.y * ld;
+    const int per = ((vocab + parts - 1) / parts + 3) & ~3;
+    const int lo = blockIdx.x * per, hi = min(lo + per, vocab);
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_cnt = 0; s_T = INFINITY; }
+    const TopkRowView rv(view, blockIdx.y);
+    f32x4_t q[NF4];
+#pragma unroll
+    for (int u = 0; u < NF4; ++u) {
+        const int v4 = lo + (u * 256 + tid) * 4;
+        q[u] = *reinterpret_cast<const f32x4_t*>(L + (v4 < hi ? v4 : lo));  // unconditional load; a piece past the slice is masked below
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NF4; ++u) {
+        const int v4 = lo + (u * 256 + tid) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v4 + e < hi ? rv(q[u][e], v4 + e) : -INFINITY;
+            q[u][e] = x;
+            m = fmaxf(m, x);
+        }
+    }
+    tmax[tid] = m;
+    __syncthreads();
+    {   // rank of this thread's maximum among the 256 (ties by thread id): the one of rank k - 1 is the threshold
+        int rank = 0;
+        for (int j = 0; j < 256; ++j) {
+            const float o = tmax[j];
+            rank += (o > m || (o == m && j < tid)) ? 1 : 0;
+        }
+        if (rank == k - 1) s_T = m;
+    }
+    __syncthreads();
+    const float T = s_T;
+#pragma unroll
+    for (int u = 0; u < NF4; ++u) {
+        const int v4 = lo + (u * 256 + tid) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (q[u][e] >= T && v4 + e < hi) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < TS_CAP) { lv[pos] = q[u][e]; li[pos] = v4 + e; }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_cnt;
+    if (n > TS_CAP) {  // (workgroup-uniform) ties / bans: the exact scan
+        topk_scan_body<KR>(scores, ld, vocab, k, parts, cval, cidx, view);
+        return;
+    }
+    block_topk(lv, li, n, k, cval + ((long)blockIdx.y * parts + blockIdx.x) * BEAM_TOPK, cidx + ((long)blockIdx.y * parts + blockIdx.x) * BEAM_TOPK);
 }
 // stage 2 over `parts` lists of k
 __global__ __launch_bounds__(256) void topk_final_parts_kernel(const float* __restrict__ cval, const int* __restrict__ cidx, int k, int parts,
@@ -713,12 +784,7 @@ __global__ __launch_bounds__(256) void topk_final_wave_kernel(const float* __res
     for (int it = 0; it < k; ++it) {
         float bv = mv;
         int bi = mi;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, WAVE);
-            const int oi = __shfl_xor(bi, o, WAVE);
-            if (topk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-        }
+        wave_argmax_all(bv, bi);  // (DPP: common.h)
         if (lane == 0) { out_val[(long)row * BEAM_TOPK + it] = bv; out_idx[(long)row * BEAM_TOPK + it] = bi; }
         if (bi == mi && bi != 0x7fffffff) {  // (token indices of a row's survivors are distinct: exactly one lane owns the winner)
 #pragma unroll
@@ -732,14 +798,26 @@ __global__ __launch_bounds__(256) void topk_final_wave_kernel(const float* __res
     }
 }
 
+static bool g_topk_thresh = true;  // ISST_TOPK_THRESH=0 (read once): the per-thread-list scan for every workgroup (A/B)
 static int launch_topk_rows_view(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows, const TopkView& view,
                                  hipStream_t s) {
     if (rows <= 0) return ISST_OK;
     if (k < 1 || k > BEAM_TOPK || (vocab + LSE_PARTS - 1) / LSE_PARTS > TOPK_SLICE) return ISST_ERR_ARG;
+    static const bool env_read = [] { if (const char* e = getenv("ISST_TOPK_THRESH")) g_topk_thresh = e[0] && e[0] != '0'; return true; }();
+    (void)env_read;
     if (k <= 16 && ld % 16 == 0 && (reinterpret_cast<uintptr_t>(scores) & 63) == 0) {  // one scan per (part, row) with the candidates in registers; enough parts for ~1024 workgroups
         int parts = 1024 / rows;
+        const int parts_min = (vocab + 16 * 1024 - 1) / (16 * 1024);  // a thread of the threshold kernel holds at most 16 pieces of 4 entries
+        parts = parts < parts_min ? parts_min : parts;
         parts = parts < 1 ? 1 : (parts > LSE_PARTS ? LSE_PARTS : parts);
-        if (k <= 8) hipLaunchKernelGGL(topk_scan_kernel<8>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
+        const int per = ((vocab + parts - 1) / parts + 3) & ~3, nf4 = (per + 1023) / 1024;
+        // (by rocprofv3 inside a beam step, round 5, both with the DPP argmax: 256 rows 77.7 us by threshold against 96.5 us; 4 rows 17.5 against 15.6 us --
+        //  the few-row launches are their reduction rounds, not their scan: profiles/r05/beam_tail_kernels.txt)
+        if (g_topk_thresh && nf4 <= 16 && rows >= 16) {
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view); };
+            if (k <= 8) { if (nf4 <= 2) go(topk_thresh_kernel<8, 2>); else if (nf4 <= 4) go(topk_thresh_kernel<8, 4>); else if (nf4 <= 8) go(topk_thresh_kernel<8, 8>); else go(topk_thresh_kernel<8, 16>); }
+            else { if (nf4 <= 2) go(topk_thresh_kernel<16, 2>); else if (nf4 <= 4) go(topk_thresh_kernel<16, 4>); else if (nf4 <= 8) go(topk_thresh_kernel<16, 8>); else go(topk_thresh_kernel<16, 16>); }
+        } else if (k <= 8) hipLaunchKernelGGL(topk_scan_kernel<8>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
         else hipLaunchKernelGGL(topk_scan_kernel<16>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
         if (parts * k <= 64 * TFW_CPL) hipLaunchKernelGGL(topk_final_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, cval, cidx, k, parts, rows, out_val, out_idx);
         else hipLaunchKernelGGL(topk_final_parts_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, parts, out_val, out_idx);

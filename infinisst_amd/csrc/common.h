@@ -49,6 +49,37 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Wave-wide reductions on DPP (row rotations / broadcasts inside the VALU: ~8 cycles a step) with the result in EVERY lane.  __shfl_xor compiles to
+// ds_bpermute_b32, an LDS-crossbar round trip of ~100 cycles per step: a k-round argmax over (value, index) pairs -- 12-18 dependent bpermutes per round --
+// made the beam search's small top-k kernels 11-25 us of pure latency (profiles/r05/beam_tail_kernels.txt).  Sequence as rocPRIM's warp_reduce_dpp:
+// quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8, row_bcast:15, row_bcast:31 -> lane 63 holds the reduction; v_readlane broadcasts it.
+template <int CTRL>
+__device__ __forceinline__ int dpp_take(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }  // (lanes without a source keep their own value)
+__device__ __forceinline__ float wave_max_all(float v) {
+    v = fmaxf(v, __int_as_float(dpp_take<0xb1>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_take<0x4e>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_take<0x124>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_take<0x128>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_take<0x142>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_take<0x143>(__float_as_int(v))));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_all(int v) {
+    v = min(v, dpp_take<0xb1>(v));
+    v = min(v, dpp_take<0x4e>(v));
+    v = min(v, dpp_take<0x124>(v));
+    v = min(v, dpp_take<0x128>(v));
+    v = min(v, dpp_take<0x142>(v));
+    v = min(v, dpp_take<0x143>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// the wave's best (value, index) pair under (value descending, index ascending), in every lane (NaN-free values)
+__device__ __forceinline__ void wave_argmax_all(float& v, int& i) {
+    const float m = wave_max_all(v);
+    i = wave_min_all(v == m ? i : 0x7fffffff);
+    v = m;
+}
+
 // ---- status codes of the C ABI (include/infinisst_hip.h) ----
 #define ISST_OK 0
 #define ISST_ERR_ARG (-1)

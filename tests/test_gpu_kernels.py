@@ -573,17 +573,24 @@ def test_split_kv_merge_fused_into_oproj_equals_combine_then_gemm():
         assert torch.equal(sep, fused), f"M={M}: merge-on-load differs from combine + GEMV"
 
 
+@pytest.mark.parametrize("ties", [True, False])
 @pytest.mark.parametrize("rows,k", [(4, 8), (16, 8), (80, 16), (256, 8), (256, 16)])
-def test_topk_rows_matches_a_sort_with_ties_to_the_lowest_index(rows, k):
-    """csrc/beam.hip: the beam search's candidate selection (reference: torch.topk over the processed scores, patch_hf.py:877-879).  Few rows take the
-    slice-in-LDS kernel, 16+ rows the one-pass scan with the candidates in registers; both must return exactly the k best (value, lowest index first on ties)
-    -- checked on scores quantised so coarsely that ties are everywhere, with -inf entries (suppressed tokens) mixed in."""
+def test_topk_rows_matches_a_sort_with_ties_to_the_lowest_index(rows, k, ties):
+    """csrc/beam.hip: the beam search's candidate selection (reference: torch.topk over the processed scores, patch_hf.py:877-879).  Stage 1 works on
+    (slice, row) workgroups: by threshold (round 5: a thread keeps its share of the slice in registers, the k-th largest of the 256 thread maxima bounds the
+    slice's k-th largest entry from below, the few entries at or above it are collected and sorted) with the exact per-thread-list scan as the fallback when
+    ties or bans make that collection long; stage 2 merges a row's slices in one wave.  Both must return exactly the k best (value, lowest index first on
+    ties): checked on scores quantised so coarsely that ties are everywhere (`ties`: every workgroup takes the fallback) and on continuous scores (the
+    threshold path), with -inf entries (suppressed tokens) mixed in and a row with fewer finite entries than k."""
     from infinisst_amd.engine import load_library, _ptr, _stream_ptr
     lib = load_library()
     V, ld = 128263, 128272
     g = torch.Generator(device="cuda").manual_seed(rows * 31 + k)
     sc = torch.randn(rows, ld, device="cuda", generator=g)
-    sc = torch.round(sc * 3.0) / 3.0  # ~20 distinct values: the top k are all ties
+    if ties:
+        sc = torch.round(sc * 3.0) / 3.0  # ~20 distinct values: the top k are all ties
+    else:
+        sc[0, 1000:1040] = sc[0].max() + 1.0  # ... and one run of equal leaders inside one slice
     sc[:, ::7] = float("-inf")
     sc[rows // 2, :V - 5] = float("-inf")  # a row with five finite entries
     out_val = torch.full((rows, 32), float("nan"), device="cuda")
