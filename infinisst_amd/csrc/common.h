@@ -38,16 +38,6 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
 
 // Wave-wide reductions on DPP (row rotations / broadcasts inside the VALU: ~8 cycles a step) with the result in EVERY lane.  __shfl_xor compiles to
 // ds_bpermute_b32, an LDS-crossbar round trip of ~100 cycles per step: a k-round argmax over (value, index) pairs -- 12-18 dependent bpermutes per round --
@@ -73,6 +63,20 @@ __device__ __forceinline__ int wave_min_all(int v) {
     v = min(v, dpp_take<0x143>(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
+// wave_sum / wave_max of every kernel of the library (norm statistics, softmax, split-KV merge): round 5 moved them from the xor butterfly over ds_bpermute
+// (6 dependent LDS-crossbar round trips, ~0.3 us on a kernel's critical path) onto the same DPP tree.  The sum's association order changed with it -- lanes
+// (0,1), quads, rows of 16 by rotation, then rows -- once, for every consumer alike: each path still adds in ONE fixed order, the bit-identity tests between
+// launch forms compare like with like.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __int_as_float(dpp_take<0xb1>(__float_as_int(v)));
+    v += __int_as_float(dpp_take<0x4e>(__float_as_int(v)));
+    v += __int_as_float(dpp_take<0x124>(__float_as_int(v)));
+    v += __int_as_float(dpp_take<0x128>(__float_as_int(v)));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3 (the other rows add 0)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) { return wave_max_all(v); }
 // the wave's best (value, index) pair under (value descending, index ascending), in every lane (NaN-free values)
 __device__ __forceinline__ void wave_argmax_all(float& v, int& i) {
     const float m = wave_max_all(v);

@@ -65,8 +65,7 @@ __global__ __launch_bounds__(256) void sample_argmax_part_kernel(const float* __
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int v = lo + threadIdx.x; v < hi; v += blockDim.x) argmax_merge(bv, bi, L[v], v);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, WAVE), __shfl_xor(bi, o, WAVE));
+    wave_argmax_all(bv, bi);  // (DPP reductions, common.h: the same total order -- value, then lowest index)
     if ((threadIdx.x & 63) == 0) { sval[threadIdx.x >> 6] = bv; sidx[threadIdx.x >> 6] = bi; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -80,8 +79,7 @@ __global__ __launch_bounds__(64) void sample_argmax_final_kernel(const float* __
                                                                  int* __restrict__ out_tokens) {
     float bv = pval[blockIdx.x * SAMPLE_PARTS + threadIdx.x];
     int bi = pidx[blockIdx.x * SAMPLE_PARTS + threadIdx.x];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, WAVE), __shfl_xor(bi, o, WAVE));
+    wave_argmax_all(bv, bi);  // (DPP reductions, common.h: the same total order -- value, then lowest index)
     if (threadIdx.x == 0) out_tokens[blockIdx.x] = bi;
 }
 
@@ -147,8 +145,7 @@ __global__ __launch_bounds__(256) void sample_fused_kernel(float* __restrict__ l
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int v = lo + tid; v < hi; v += blockDim.x) argmax_merge(bv, bi, L[v], v);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, WAVE), __shfl_xor(bi, o, WAVE));
+    wave_argmax_all(bv, bi);  // (DPP reductions, common.h: the same total order -- value, then lowest index)
     if ((tid & 63) == 0) { sval[tid >> 6] = bv; sidx[tid >> 6] = bi; }
     __syncthreads();
     if (tid == 0) {
@@ -164,8 +161,7 @@ __global__ __launch_bounds__(256) void sample_fused_kernel(float* __restrict__ l
     __threadfence();
     bv = __hip_atomic_load(pval + stream * SAMPLE_PARTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by other CUs: not through this CU's L1)
     bi = __hip_atomic_load(pidx + stream * SAMPLE_PARTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, o, WAVE), __shfl_xor(bi, o, WAVE));
+    wave_argmax_all(bv, bi);  // (DPP reductions, common.h: the same total order -- value, then lowest index)
     // (ONE system-scope fence per launch: a fence per stream costs ~1.2 us each and they serialise in L2 -- 64 streams: +0.8 ms per step, measured.  So a stream's
     //  last block only publishes device-wide; the block that completes the LAST stream copies all tokens to the host, fences once, then publishes the number)
     int all_done = 0;
