@@ -281,12 +281,15 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
     if (lane == 0) a.log_done[i] = st;
     __threadfence_system();  // every lane: its part of the log is in host memory before this stream's ticket is drawn
     if (lane == 0) {
-        const int t = atomicAdd(a.ticket, 1);
-        if (t == a.n - 1) {
-            *a.ticket = 0;  // re-armed (launch boundary = visibility)
-            __threadfence_system();
-            *reinterpret_cast<volatile int*>(a.log_seq) = a.seq_value;
+        bool last = true;  // (one stream: this wave is the launch -- no ticket, no second fence on the step's critical path)
+        if (a.n > 1) {
+            last = atomicAdd(a.ticket, 1) == a.n - 1;
+            if (last) {
+                *a.ticket = 0;  // re-armed (launch boundary = visibility)
+                __threadfence_system();
+            }
         }
+        if (last) *reinterpret_cast<volatile int*>(a.log_seq) = a.seq_value;
     }
 }
 int launch_beam_select(const BeamSelArgs& a, hipStream_t s) {
@@ -739,20 +742,6 @@ __global__ __launch_bounds__(256) void topk_thresh_kernel(const float* __restric
     }
     block_topk(lv, li, n, k, cval + ((long)blockIdx.y * parts + blockIdx.x) * BEAM_TOPK, cidx + ((long)blockIdx.y * parts + blockIdx.x) * BEAM_TOPK);
 }
-// stage 2 over `parts` lists of k
-__global__ __launch_bounds__(256) void topk_final_parts_kernel(const float* __restrict__ cval, const int* __restrict__ cidx, int k, int parts,
-                                                               float* __restrict__ out_val, int* __restrict__ out_idx) {
-    __shared__ float vals[LSE_PARTS * BEAM_TOPK];
-    __shared__ int ids[LSE_PARTS * BEAM_TOPK];
-    for (int e = threadIdx.x; e < parts * k; e += blockDim.x) {
-        const int part = e / k, j = e % k;
-        vals[e] = cval[((long)blockIdx.x * parts + part) * BEAM_TOPK + j];
-        ids[e] = cidx[((long)blockIdx.x * parts + part) * BEAM_TOPK + j];
-    }
-    __syncthreads();
-    block_topk(vals, ids, parts * k, k, out_val + (long)blockIdx.x * BEAM_TOPK, out_idx + (long)blockIdx.x * BEAM_TOPK);
-}
-
 // stage 2, one WAVE per row: the parts x k survivors of a row sit in registers (<= TFW_CPL per lane); a round is one shuffle reduction over the lanes'
 // current bests under the same total order (value desc, index asc) and the winner's owner drops that entry.  The block-wide form above (LDS image, two
 // levels, barriers) took 17.9 us for 4 rows x 512 candidates inside a one-stream beam step (profiles/r05/trace_busy_profb4_b.txt).
@@ -819,8 +808,8 @@ static int launch_topk_rows_view(const float* scores, long ld, int vocab, int k,
             else { if (nf4 <= 2) go(topk_thresh_kernel<16, 2>); else if (nf4 <= 4) go(topk_thresh_kernel<16, 4>); else if (nf4 <= 8) go(topk_thresh_kernel<16, 8>); else go(topk_thresh_kernel<16, 16>); }
         } else if (k <= 8) hipLaunchKernelGGL(topk_scan_kernel<8>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
         else hipLaunchKernelGGL(topk_scan_kernel<16>, dim3(parts, rows), dim3(256), 0, s, scores, ld, vocab, k, parts, cval, cidx, view);
-        if (parts * k <= 64 * TFW_CPL) hipLaunchKernelGGL(topk_final_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, cval, cidx, k, parts, rows, out_val, out_idx);
-        else hipLaunchKernelGGL(topk_final_parts_kernel, dim3(rows), dim3(256), 0, s, cval, cidx, k, parts, out_val, out_idx);
+        static_assert(LSE_PARTS * 16 <= 64 * TFW_CPL, "a wave holds every survivor of a row (parts <= LSE_PARTS, k <= 16)");
+        hipLaunchKernelGGL(topk_final_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, cval, cidx, k, parts, rows, out_val, out_idx);
         return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
     }
     hipLaunchKernelGGL(topk_part_kernel, dim3(LSE_PARTS, rows), dim3(256), 0, s, scores, ld, vocab, k, cval, cidx, view);

@@ -168,13 +168,17 @@ __global__ __launch_bounds__(256) void sample_fused_kernel(float* __restrict__ l
     if (tid == 0) {
         out_tokens[stream] = bi;
         tickets[2 + stream] = 0;  // re-armed for the next launch (launch boundary = visibility)
-        __threadfence();
-        all_done = atomicAdd(&tickets[0], 1) == n_streams - 1;
+        if (n_streams > 1) {
+            __threadfence();
+            all_done = atomicAdd(&tickets[0], 1) == n_streams - 1;
+        } else {
+            all_done = 1;  // (one stream: its last block is the launch's last -- no second ticket, no fences around it: ~4 us of the per-token critical path)
+        }
     }
     all_done = __shfl(all_done, 0, WAVE);
     if (!all_done) return;
-    __threadfence();
-    for (int i = tid; i < n_streams; i += 64) host_tokens[i] = __hip_atomic_load(out_tokens + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_streams > 1) __threadfence();
+    for (int i = tid; i < n_streams; i += 64) host_tokens[i] = n_streams > 1 ? __hip_atomic_load(out_tokens + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bi;
     if (adv.enabled) {  // one stream: the next pass's inputs, on the device (the launch boundary makes them visible to it)
         const int tok = bi;  // (this wave merged stream 0 itself: the reduction left the argmax in every lane)
         if (tid == 0) {
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void sample_fused_kernel(float* __restrict__ l
     }
     __threadfence_system();  // every lane: its tokens are in host memory before the call's sequence number can be
     if (tid == 0) {
-        tickets[0] = 0;
+        if (n_streams > 1) tickets[0] = 0;
         const int seq = atomicAdd(&tickets[1], 1) + 1;
         *reinterpret_cast<volatile int*>(host_seq) = seq;
     }
