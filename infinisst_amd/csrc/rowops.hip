@@ -223,23 +223,31 @@ int launch_conv0(const bf16_t* audio, long audio_batch, const bf16_t* w, const b
 // Up to 8 slices: every load is issued before the first add (the runtime-bounded loop below waits for each slice's round trip in turn: at 256 rows one
 // workgroup per row then sits through 4-8 serial round trips); slices past n_slabs re-read slice 0 and are dropped by a select AFTER the add, so the
 // arithmetic is exactly the loop's.  rmsnorm_reduce_kernel: 7.08 -> 6.05 us per launch over a 128-stream step (A/B of library builds, same box).
+template <int NMAX>
+__device__ __forceinline__ void slab_sum_upto(const float* __restrict__ slabs, long slab_stride, int n_slabs, long off, float (&acc)[8]) {
+    f32x4_t a[NMAX], b[NMAX];
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        const float* sp = slabs + (long)(k < n_slabs ? k : 0) * slab_stride + off;
+        a[k] = *reinterpret_cast<const f32x4_t*>(sp);
+        b[k] = *reinterpret_cast<const f32x4_t*>(sp + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        const bool on = k < n_slabs;
+        acc[0] = on ? acc[0] + a[k].x : acc[0]; acc[1] = on ? acc[1] + a[k].y : acc[1]; acc[2] = on ? acc[2] + a[k].z : acc[2]; acc[3] = on ? acc[3] + a[k].w : acc[3];
+        acc[4] = on ? acc[4] + b[k].x : acc[4]; acc[5] = on ? acc[5] + b[k].y : acc[5]; acc[6] = on ? acc[6] + b[k].z : acc[6]; acc[7] = on ? acc[7] + b[k].w : acc[7];
+    }
+}
 __device__ __forceinline__ void slab_sum8(const float* __restrict__ slabs, long slab_stride, int n_slabs, long off, float (&acc)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (n_slabs <= 4) {  // (o_proj's 4 slices at 65..256 rows: half the load instructions of the 8-wide form)
+        slab_sum_upto<4>(slabs, slab_stride, n_slabs, off, acc);
+        return;
+    }
     if (n_slabs <= 8) {
-        f32x4_t a[8], b[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float* sp = slabs + (long)(k < n_slabs ? k : 0) * slab_stride + off;
-            a[k] = *reinterpret_cast<const f32x4_t*>(sp);
-            b[k] = *reinterpret_cast<const f32x4_t*>(sp + 4);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool on = k < n_slabs;
-            acc[0] = on ? acc[0] + a[k].x : acc[0]; acc[1] = on ? acc[1] + a[k].y : acc[1]; acc[2] = on ? acc[2] + a[k].z : acc[2]; acc[3] = on ? acc[3] + a[k].w : acc[3];
-            acc[4] = on ? acc[4] + b[k].x : acc[4]; acc[5] = on ? acc[5] + b[k].y : acc[5]; acc[6] = on ? acc[6] + b[k].z : acc[6]; acc[7] = on ? acc[7] + b[k].w : acc[7];
-        }
+        slab_sum_upto<8>(slabs, slab_stride, n_slabs, off, acc);
         return;
     }
     for (int k = 0; k < n_slabs; ++k) {
