@@ -270,6 +270,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
     bf16_t* xr = x + row * ldx;
     float v[STEPS][8];
     float sum = 0.f;
+    // weight and bias are asked for with the row (the encoder's widths, STEPS <= 2): read after the two wave reductions they were a dependent round trip
+    // at the end of a 6 us launch
+    constexpr bool PRE = STEPS <= 2;
+    u32x4_t wraw[PRE ? STEPS : 1], braw[PRE ? STEPS : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int c = (lane + 64 * s) * 8;
+            const bool on = w && c < C;
+            wraw[s] = on ? *reinterpret_cast<const u32x4_t*>(w + c) : (u32x4_t){0u, 0u, 0u, 0u};
+            braw[s] = on ? *reinterpret_cast<const u32x4_t*>(b + c) : (u32x4_t){0u, 0u, 0u, 0u};
+        }
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         const int c = (lane + 64 * s) * 8;
@@ -314,8 +327,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
         const int c = (lane + 64 * s) * 8;
         if (c < C) {
             float wv[8], bv[8], y[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(w + c), wv);
-            unpack8(*reinterpret_cast<const u32x4_t*>(b + c), bv);
+            if constexpr (PRE) {
+                unpack8(wraw[s], wv);
+                unpack8(braw[s], bv);
+            } else {
+                unpack8(*reinterpret_cast<const u32x4_t*>(w + c), wv);
+                unpack8(*reinterpret_cast<const u32x4_t*>(b + c), bv);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 y[j] = (v[s][j] - mean) * rstd * wv[j] + bv[j];
@@ -367,6 +385,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     const bf16_t* xr = x + row * ldx;
     float v[STEPS][8];
     float sq = 0.f;
+    u32x4_t wraw[STEPS];  // (asked for with the row, not after the barrier)
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8;
+        wraw[s] = c < D ? *reinterpret_cast<const u32x4_t*>(w + c) : (u32x4_t){0u, 0u, 0u, 0u};
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         const int c = (threadIdx.x + 256 * s) * 8;
@@ -387,7 +411,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
         const int c = (threadIdx.x + 256 * s) * 8;
         if (c < D) {
             float wv[8], y[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(w + c), wv);
+            unpack8(wraw[s], wv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = wv[j] * bfr(v[s][j] * r);
             *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
@@ -419,6 +443,13 @@ __global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(const float* __rest
     bf16_t* xr = x + row * ldx;
     float v[STEPS][8];
     float sq = 0.f;
+    // (the norm weight is asked for FIRST: read after the row's barrier it was one more dependent round trip at the end of a 8 us launch)
+    u32x4_t wraw[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8;
+        wraw[s] = (w && c < D) ? *reinterpret_cast<const u32x4_t*>(w + c) : (u32x4_t){0u, 0u, 0u, 0u};
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
         const int c = (threadIdx.x + 256 * s) * 8;
@@ -445,7 +476,7 @@ __global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(const float* __rest
         const int c = (threadIdx.x + 256 * s) * 8;
         if (c < D) {
             float wv[8], y[8];
-            unpack8(*reinterpret_cast<const u32x4_t*>(w + c), wv);
+            unpack8(wraw[s], wv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = wv[j] * bfr(v[s][j] * r);
             *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
