@@ -79,7 +79,8 @@ extern "C" int isst_debug_enc_trace_read(void* dst, long bytes) {
 
 template <int QT, bool RND>  // QT: m-tiles of 16 query rows per workgroup; RND: every product of the rotation rounds to bf16 (enc_rope_mode "bf16": as a compile-time
                               // constant -- as a runtime flag every rotated pair carried a branch, 160 of them per key tile in a phase that is bound by instruction issue)
-__global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
+__global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  // (48-row blocks run two workgroups per CU: 4 waves per SIMD, 128 registers -- stated, not left to luck)
+    const bf16_t* __restrict__ qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                                                             const EncStreamView* __restrict__ sv,
                                                             const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                                             int /*round_each: RND*/, bf16_t* __restrict__ out, int Q, int heads, int cap,
@@ -133,6 +134,8 @@ __global__ __launch_bounds__(512) void enc_attention_kernel(const bf16_t* __rest
     // One stream (QT == 1: 48 workgroups on 256 CUs, nothing else to hide a round trip behind) walks its 5 key tiles per wave with ALL their loads -- key rows and
     // rotary table entries -- in flight before the first rotation: the phase was a chain of 5 dependent round trips, 9.0 of the launch's 18.4 us
     // (profiles/r05/enc_attention_trace_1_stream.txt).  Many streams (QT == 3, two workgroups per CU, VALU-bound) keep one tile at a time and their registers.
+    // (16 waves x 3 tiles instead of 8 x 5 for the lone stream: the phase took 10.9 us instead of 9.0 -- it is bound by the instructions a SIMD has to issue at the clock
+    //  the chip holds, not by latency: profiles/r05/enc_attention_trace_1_stream_16_waves_SLOWER.txt)
     constexpr int TCH = QT == 1 ? 5 : 1;
     const int n_tiles = cap >> 4;
     for (int nt0 = wave; nt0 < n_tiles; nt0 += ENC_WAVES * TCH) {
