@@ -42,4 +42,5 @@ for n in 1 4 8 16 32 64 128; do
 done
 cat $O/streams_sweep_beam4.txt
 timeout 600 $B --no-roofline --steps 1875 --warmup 8 > $O/bench_30min_stream.log 2>&1; tail -1 $O/bench_30min_stream.log | cut -c1-400
+timeout 600 $B --no-roofline --streams 64 --beam 4 --steps 200 --warmup 4 > $O/soak_64x4_beams_200_steps.log 2>&1; tail -1 $O/soak_64x4_beams_200_steps.log | cut -c1-400
 ls -la $O
