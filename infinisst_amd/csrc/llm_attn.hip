@@ -369,6 +369,8 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
                 sc[r] = ok ? st[r] * scale : -INFINITY;
                 mx = fmaxf(mx, sc[r]);
             }
+            // (the two column reductions of a tile as v_permlane16_swap / v_permlane32_swap instead of ds_bpermute: measured, no gain at 1 / 64 streams, greedy
+            //  or beam 4 -- profiles/r05/ab_attention_column_reductions_permlane_swap_no_gain.txt; the walk waits for memory, not for these)
             mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
             mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
             const float m_new = fmaxf(m_run[ct], mx);
