@@ -436,6 +436,8 @@ static int launch_wide_cfg(const GemmArgs& g, hipStream_t stream) {
 // ring depths (profiles/gemm_wide_probe.py, r04/wide_probe_v4*): W ring 4 K-steps / A ring 6 stages up to 128 rows (deeper rings measured equal or slower);
 // 256 rows: the 128 accumulator registers of a consumer leave room for a W ring of 2 steps, and the 32 KB stages for 4 of them (a 4-step W ring with
 // fragment groups of 4 instead of 8 fits too -- 234 VGPRs, no spill -- and measures the same: gate/up 63.6 / 65.1 us, profiles/r04/wide_probe_row_blocks.txt)
+// (round 5: a FIFTH 32 KB stage -- all 160 KB of LDS, one more K-step of activations in flight -- measures the same too: gate/up 63.5 / 63.5 us, 64 x 4 beams
+//  101.1 / 100.9 ms per step: profiles/r05/wide_256_rows_5_stage_ring_no_gain.txt)
 template <int EPI>
 static int launch_wide_epi(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 64) return launch_wide_cfg<4, 4, 6, EPI>(g, stream);
