@@ -52,3 +52,10 @@ def test_hand_scheduled_kernels_use_no_scratch(tmp_path, built_library):
     assert max(v[2] for v in wide.values()) <= 256  # two 8-wave workgroups per CU (launch_bounds(512, 2))
     fused = {n: v for n, v in ks.items() if "llm_attn_oproj_kernel" in n}
     assert max(v[2] for v in fused.values()) <= 256  # one 8-wave workgroup per CU
+    # the many-stream encoder attention (48-row query blocks, QT = 3) runs two 8-wave workgroups per CU: 4 waves per SIMD = 128 registers (enc_attn.hip's launch bounds)
+    enc3 = {n: v for n, v in ks.items() if "enc_attention_kernelILi3" in n}
+    assert enc3 and max(v[2] for v in enc3.values()) <= 128
+    # the prefill attention is written for two 8-wave workgroups per CU (128 registers); it is KNOWN to spill a few registers around its rotation at that budget
+    # (24-28 since round 4) -- a jump means its loop changed shape
+    pf = {n: v for n, v in ks.items() if "llm_attn_prefill_kernel" in n}
+    assert pf and max(v[2] for v in pf.values()) <= 128 and max(v[1] for v in pf.values()) <= 32, {n: v for n, v in pf.items()}
