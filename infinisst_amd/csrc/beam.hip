@@ -101,6 +101,72 @@ int launch_kv_positions_copy_list(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool,
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
+// ---- every copy of a beam step in ONE launch (kernels.h BeamReorder).  grid (kv heads, layers, streams) ----
+template <int NB>
+__global__ __launch_bounds__(128) void kv_beam_reorder_kernel(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf,
+                                                             const BeamReorder* __restrict__ recs, int B, long stream_stride, long tbuf_stride, LlmAttnDims d, int tcap) {
+    const BeamReorder& rec = recs[blockIdx.z];
+    const int n_move = rec.n_move, n_save = rec.n_save;
+    if (n_move == 0 && n_save == 0) return;
+    const int kvh = blockIdx.x, layer = blockIdx.y;
+    const int slots = d.sys_cap + d.ring_cap;
+    const long abase = rec.arena0 + (long)layer * d.layer_stride + (long)kvh * slots * HD;
+    const long bbase = rec.buf0 + ((long)layer * d.kv_heads + kvh) * tcap * HD;
+    int par[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) par[b] = b < B ? rec.par[b] : b;
+    for (int e = threadIdx.x; e < rec.count * (HD / 8); e += 128) {
+        const int t = e / (HD / 8), ch = e % (HD / 8);
+        const int p = rec.p0 + t;
+        long slot;
+        if (p < rec.sys_len) slot = p;
+        else { int x = rec.ring_start + (p - rec.sys_len); x %= d.ring_cap; slot = (long)d.sys_cap + x; }
+        const long ai = abase + slot * HD + ch * 8, bi = bbase + (long)t * HD + ch * 8;
+        // hypothesis tails: (old) beam -> buffer.  Their loads are issued before any arena is written below
+        for (int k = 0; k < n_save; ++k) {
+            const long src = ai + (long)rec.save_beam[k] * stream_stride, dst = bi + (long)rec.save_buf[k] * tbuf_stride;
+            const u32x4_t kk = *reinterpret_cast<const u32x4_t*>(kpool + src), vv = *reinterpret_cast<const u32x4_t*>(vtpool + src);
+            u32x4_t rr = {0u, 0u, 0u, 0u};
+            if (krpool) rr = *reinterpret_cast<const u32x4_t*>(krpool + src);
+            *reinterpret_cast<u32x4_t*>(kbuf + dst) = kk;
+            *reinterpret_cast<u32x4_t*>(vbuf + dst) = vv;
+            if (krpool) *reinterpret_cast<u32x4_t*>(krbuf + dst) = rr;
+        }
+        // the reorder: every moving beam's chunk comes from its parent's arena ...
+        u32x4_t mk[NB], mv[NB], mr[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            mk[b] = mv[b] = mr[b] = (u32x4_t){0u, 0u, 0u, 0u};
+            if (par[b] != b) {  // (wave-uniform)
+                const long src = ai + (long)par[b] * stream_stride;
+                mk[b] = *reinterpret_cast<const u32x4_t*>(kpool + src);
+                mv[b] = *reinterpret_cast<const u32x4_t*>(vtpool + src);
+                if (krpool) mr[b] = *reinterpret_cast<const u32x4_t*>(krpool + src);
+            }
+        }
+        // ... and no arena is written before every load above -- of this thread, the only one that touches this chunk -- has returned
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (par[b] != b) {
+                const long dst = ai + (long)b * stream_stride;
+                *reinterpret_cast<u32x4_t*>(kpool + dst) = mk[b];
+                *reinterpret_cast<u32x4_t*>(vtpool + dst) = mv[b];
+                if (krpool) *reinterpret_cast<u32x4_t*>(krpool + dst) = mr[b];
+            }
+        }
+    }
+}
+int launch_kv_beam_reorder(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf, const BeamReorder* recs, int n_streams, int B,
+                           long stream_stride, long tbuf_stride, LlmAttnDims d, int layers, int tcap, hipStream_t s) {
+    if (n_streams <= 0) return ISST_OK;
+    if (B < 1 || B > BEAM_MAX_B) return ISST_ERR_ARG;
+    const dim3 grid(d.kv_heads, layers, n_streams);
+    if (B <= 4) hipLaunchKernelGGL(kv_beam_reorder_kernel<4>, grid, dim3(128), 0, s, kpool, vtpool, krpool, kbuf, vbuf, krbuf, recs, B, stream_stride, tbuf_stride, d, tcap);
+    else hipLaunchKernelGGL(kv_beam_reorder_kernel<BEAM_MAX_B>, grid, dim3(128), 0, s, kpool, vtpool, krpool, kbuf, vbuf, krbuf, recs, B, stream_stride, tbuf_stride, d, tcap);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
 __device__ __forceinline__ float beam_score_of(float x, int v, float lz, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side);  // (below, with beam_process_kernel)
 __device__ __noinline__ float beam_score_side(int v, const int* __restrict__ side_tok, const float* __restrict__ side_val, int n_side);
 
@@ -120,11 +186,12 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
     __shared__ int ntok[BEAM_MAX_B], npar[BEAM_MAX_B];
     __shared__ float nscore[BEAM_MAX_B], nflp[BEAM_MAX_B];
     __shared__ KvCopyOp l1[2 * BEAM_MAX_B], l2[BEAM_MAX_B];
+    __shared__ BeamReorder R;
     __shared__ int n1, n2, base1, base2, status;
     const int i = blockIdx.x, lane = threadIdx.x, B = a.B;
     BeamDevStream* gS = a.st + i;
     for (int w = lane; w < (int)(sizeof(BeamDevStream) / 4); w += 64) reinterpret_cast<int*>(&S)[w] = reinterpret_cast<const int*>(gS)[w];
-    if (lane == 0) { n1 = 0; n2 = 0; status = 0; }
+    if (lane == 0) { n1 = 0; n2 = 0; status = 0; R.n_save = 0; R.n_move = 0; R.count = 0; }
     __syncthreads();
     const bool upstream_failed = a.err_word && *reinterpret_cast<const volatile int*>(a.err_word) != 0;
     const int len = S.prompt_len + a.step;  // tokens of every beam's sequence before this step
@@ -183,7 +250,8 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
                     if (a.step > 0) {  // the hypothesis keeps a copy of that beam's tail (the reference clones the whole KV cache, :113-120)
                         if (S.n_free == 0) { st = -2; break; }
                         buf = S.free_bufs[--S.n_free];
-                        l1[n1++] = op(b, buf, a.step, 0);
+                        if (a.reorder) { R.save_beam[R.n_save] = b; R.save_buf[R.n_save] = buf; ++R.n_save; }
+                        else l1[n1++] = op(b, buf, a.step, 0);
                     }
                     // BeamHypotheses.add (:278-302)
                     const double hs = (double)sval[rank] / a.powtab[gen_len];
@@ -227,13 +295,19 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
                     ntok[b] = tok; npar[b] = par; nscore[b] = S.score[par] + lp; nflp[b] = lp;
                 }
             }
-            if (st == 0 && a.step > 0) {  // reorder the tails (:910-913): new beam b continues parent npar[b] -- parents staged through temporaries 0..B-1
+            if (st == 0 && a.step > 0 && a.reorder) {  // reorder the tails (:910-913) as one record: kv_beam_reorder_kernel moves them in one launch
+                for (int b = 0; b < B; ++b) { R.par[b] = npar[b]; R.n_move += npar[b] != b ? 1 : 0; }
+                for (int b = B; b < BEAM_MAX_B; ++b) R.par[b] = b;
+                R.arena0 = (long)S.sid * a.max_beams * a.stream_stride;
+                R.buf0 = (long)S.sid * a.nbuf * a.tbuf_stride;
+                R.p0 = S.P0; R.count = a.step; R.sys_len = S.sys_len; R.ring_start = S.ring_start;
+            } else if (st == 0 && a.step > 0) {  // ... or as two op lists: new beam b continues parent npar[b] -- parents staged through temporaries 0..B-1
                 unsigned need = 0;
                 for (int b = 0; b < B; ++b) if (npar[b] != b) need |= 1u << npar[b];
                 for (int src = 0; src < B; ++src) if (need >> src & 1u) l1[n1++] = op(src, src, a.step, 0);
                 for (int b = 0; b < B; ++b) if (npar[b] != b) l2[n2++] = op(b, npar[b], a.step, 1);
             }
-            if (st != 0) { n1 = 0; n2 = 0; }
+            if (st != 0) { n1 = 0; n2 = 0; R.n_save = 0; R.n_move = 0; }
             status = st != 0 ? st : (S.done ? 1 : 0);
             if (st == 0) for (int b = 0; b < B; ++b) S.score[b] = nscore[b];
         }
@@ -267,6 +341,9 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
         // ---- state back to memory ----
         for (int w = lane; w < (int)(sizeof(BeamDevStream) / 4); w += 64) reinterpret_cast<int*>(gS)[w] = reinterpret_cast<const int*>(&S)[w];
     }
+    // ---- the step's copy record: ALWAYS written (a failed or finished stream's says "move nothing": the copy launch must not find the previous step's) ----
+    if (a.reorder)
+        for (int w = lane; w < (int)(sizeof(BeamReorder) / 4); w += 64) reinterpret_cast<int*>(a.reorder + i)[w] = reinterpret_cast<const int*>(&R)[w];
     // ---- log to the host: candidates as the top-k left them, the choices, the stream's status ----
     for (int e = lane; e < a.rows_per * BEAM_TOPK; e += 64) {
         const int b = e / BEAM_TOPK, j = e - b * BEAM_TOPK;

@@ -290,6 +290,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         h->bops_dev[0] = h->dalloc<KvCopyOp>(NB * 2);
         h->bops_dev[1] = h->dalloc<KvCopyOp>(NB);
         h->bop_counts_dev = h->dalloc<int>(((size_t)c.max_new_tokens + 1) * 2, true);
+        h->breorder_dev = h->dalloc<BeamReorder>(ns, true);
         h->bticket_dev = h->dalloc<int>(4, true);
         h->bforce_dev = h->dalloc<int>((size_t)2 * c.max_new_tokens * h->max_beams);
         h->bview.side_cap = h->max_ids;
@@ -298,7 +299,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         h->bview.side_val = h->dalloc<float>(NB * h->max_ids);
         h->bview.side_n = h->dalloc<int>(NB, true);
         if (!h->tbuf_k || !h->tbuf_v || !h->tbuf_kr || !h->lse_max || !h->lse_sum || !h->cand_val || !h->cand_idx || !h->top_val || !h->top_idx || !h->bseq[0] || !h->bseq[1] ||
-            !h->bst_dev || !h->bpow_dev || !h->bops_dev[0] || !h->bops_dev[1] || !h->bop_counts_dev || !h->bticket_dev || !h->bforce_dev || !h->bview.logz || !h->bview.side_tok ||
+            !h->bst_dev || !h->bpow_dev || !h->bops_dev[0] || !h->bops_dev[1] || !h->bop_counts_dev || !h->breorder_dev || !h->bticket_dev || !h->bforce_dev || !h->bview.logz || !h->bview.side_tok ||
             !h->bview.side_val || !h->bview.side_n) {
             h->fail(ISST_ERR_NOMEM, "beam search allocation failed"); return die(ISST_ERR_NOMEM);
         }
@@ -337,6 +338,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         std::memset(h->blog, 0, h->blog_slot_bytes * h->blog_steps + 64);
     }
     if (const char* e = getenv("ISST_BEAM_DEVICE")) h->beam_device = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_BEAM_ONE_COPY")) h->beam_one_copy = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_BEAM_LEAN_TAIL")) h->beam_lean_tail = e[0] && e[0] != '0';
     std::memset(h->tok_host, 0, sizeof(int) * (NB + 16));  // the published sequence number starts at 0 = "no fused tail yet" (samp_seq_expected counts from 1)
     if (hipDeviceSynchronize() != hipSuccess) { h->fail(ISST_ERR_HIP, "device sync after allocation failed"); return die(ISST_ERR_HIP); }

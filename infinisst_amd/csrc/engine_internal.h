@@ -239,6 +239,8 @@ struct isst_handle {
     double* bpow_host = nullptr;             // pinned
     KvCopyOp* bops_dev[2] = {nullptr, nullptr};  // [2 NB], [NB]
     int* bop_counts_dev = nullptr;           // [max_new_tokens + 1][2]
+    BeamReorder* breorder_dev = nullptr;     // [max_streams]: the step's copies as one record per stream (beam_one_copy)
+    bool beam_one_copy = true;               // ISST_BEAM_ONE_COPY=0: the two op-list launches per step instead (A/B aid)
     int* bticket_dev = nullptr;
     int* bforce_dev = nullptr;               // forced (token, parent) choices of stream 0 (test aid): [2][max_new_tokens * max_beams]
     int* bforce_host = nullptr;              // pinned

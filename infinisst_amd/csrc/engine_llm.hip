@@ -955,6 +955,7 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
         a.seq_in = ids_pool; a.seq_in_rows_per = step == 0 ? 1 : B; a.seq_out = h->bseq[(step + 1) & 1];
         a.ids = bd.ids; a.row_pos = bd.row_pos; a.views = bd.views; a.samp = bd.samp;
         a.ops1 = h->bops_dev[0]; a.ops2 = h->bops_dev[1]; a.op_counts = h->bop_counts_dev + 2 * step;
+        a.reorder = h->beam_one_copy ? h->breorder_dev : nullptr;
         a.stream_stride = h->llm_stream_stride; a.tbuf_stride = h->tbuf_stride; a.max_beams = h->max_beams; a.nbuf = h->nbuf;
         a.log_val = slot_val(step); a.log_idx = slot_idx(step); a.log_dec = slot_dec(step); a.log_done = slot_done(step);
         a.log_seq = const_cast<int*>(seq_word); a.seq_value = ++h->bsel_seq; a.ticket = h->bticket_dev;
@@ -965,8 +966,12 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
         CHK(launch_beam_select(a, st));
         if (step > 0) {  // (step 0: every beam descends from beam 0 and no tail exists yet -- nothing to copy)
             bf16_t* kr = h->rot_keys ? h->llm_kr : nullptr;
-            CHK(launch_kv_positions_copy_list(h->llm_k, h->llm_v, kr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, a.ops1, a.op_counts, 2 * nr, h->adims, c.llm_layers, h->tcap, st));
-            CHK(launch_kv_positions_copy_list(h->llm_k, h->llm_v, kr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, a.ops2, a.op_counts + 1, nr, h->adims, c.llm_layers, h->tcap, st));
+            if (a.reorder) {  // hypothesis tails + the reorder in ONE launch, no temporaries (beam.hip kv_beam_reorder_kernel)
+                CHK(launch_kv_beam_reorder(h->llm_k, h->llm_v, kr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, a.reorder, n, B, h->llm_stream_stride, h->tbuf_stride, h->adims, c.llm_layers, h->tcap, st));
+            } else {
+                CHK(launch_kv_positions_copy_list(h->llm_k, h->llm_v, kr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, a.ops1, a.op_counts, 2 * nr, h->adims, c.llm_layers, h->tcap, st));
+                CHK(launch_kv_positions_copy_list(h->llm_k, h->llm_v, kr, h->tbuf_k, h->tbuf_v, h->tbuf_kr, a.ops2, a.op_counts + 1, nr, h->adims, c.llm_layers, h->tcap, st));
+            }
         }
         bt_lap(bt_tail);
         // ---- the step's sequence number (published by the scorer while the copies still run) ----

@@ -169,6 +169,23 @@ struct BeamDecision {            // per (stream, beam) and step, in the pinned h
     float score;
     float forced_lp;
 };
+// What the device scorer decided about one stream's tails at one step (kv_beam_reorder_kernel): new beam b continues par[b]; the hypotheses the step closed keep a
+// copy of their (old) beam's tail in a buffer.  A record with n_move == n_save == 0 moves nothing (a finished stream, a step that only extended every beam).
+struct BeamReorder {
+    long arena0;              // element offset of the stream's arena 0 inside the pools (beam b: + b * stream_stride)
+    long buf0;                // element offset of the stream's buffer 0 (buffer k: + k * tbuf_stride)
+    int p0, count;            // the tail: logical positions p0 .. p0 + count - 1
+    int sys_len, ring_start;
+    int par[BEAM_MAX_B];
+    int save_beam[BEAM_MAX_B], save_buf[BEAM_MAX_B];
+    int n_save, n_move;
+};
+// ONE launch per beam step for every copy the step asks for (the op-list form stages parents through temporaries: two launches of 57 us and twice the bytes at 64
+// streams x 4 beams).  Thread = one 16-byte chunk of one tail position of one (kv head, layer, stream): it loads that chunk from every arena it needs -- hypothesis
+// saves first, then each moving beam's parent --, waits for all of them, and only then stores; chunks are disjoint between threads, so no copy can read what another
+// has already overwritten.
+int launch_kv_beam_reorder(bf16_t* kpool, bf16_t* vtpool, bf16_t* krpool, bf16_t* kbuf, bf16_t* vbuf, bf16_t* krbuf, const BeamReorder* recs, int n_streams, int B,
+                           long stream_stride, long tbuf_stride, LlmAttnDims d, int layers, int tcap, hipStream_t s);
 struct BeamSelArgs {
     int n, B, n_keep, V, step, rows_per, max_ids, max_enc_ids;
     int n_eos, pad_tok;
@@ -185,6 +202,7 @@ struct BeamSelArgs {
     SampleStream* samp;
     KvCopyOp *ops1, *ops2;       // position copies of this step: arena -> buffer (hypothesis tails, parents staged), then buffer -> arena
     int* op_counts;              // [2], zero before the launch
+    BeamReorder* reorder;        // [n] non-null: the step's copies as one record per stream (kv_beam_reorder_kernel) instead of the two op lists
     long stream_stride, tbuf_stride;
     int max_beams, nbuf;
     float* log_val;              // pinned host log of this step: the candidates ...
