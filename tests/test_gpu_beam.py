@@ -528,7 +528,7 @@ def test_beam_sample_is_seeded_reproducible_and_refuses_what_torch_refuses():
     eng.close()
 
 
-@pytest.mark.parametrize("B,n_streams", [(4, 1), (3, 3), (4, 6)])
+@pytest.mark.parametrize("B,n_streams", [(4, 1), (3, 3), (4, 6), (6, 2)])  # (6 beams: the 8-beam form of the one-launch reorder kernel)
 def test_beam_device_scorer_is_bit_identical_to_the_host_scorer(monkeypatch, B, n_streams):
     """The scorer of a beam step runs on the device (csrc/beam.hip beam_select_kernel: merge of the rows' candidates, EOS hypotheses with their tail
     copies, BeamHypotheses.add / is_done, the reorder of tails and token sequences, the next pass's rows) and the stream never waits for the host; the
