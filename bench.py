@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--streams64-beam4-steps", type=int, default=8)
     ap.add_argument("--host-audio-steps", type=int, default=16, help="steps of the PCIe-inclusive leg (chunks handed over as host arrays) after the timed region")
     ap.add_argument("--cold-start", action="store_true", help="do NOT import the steady state: streams start empty (first-chunk behaviour; then use --warmup >= 40)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores, capped at 64)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = the fastest of 64 / 128 / all logical cores on a one-second GEMV probe)")
     ap.add_argument("--cpu-chunks", type=int, default=4, help="steady-state chunks the CPU baseline runs")
     ap.add_argument("--attn-target-wgs", type=int, default=0, help="profiling aid: isst_op_set_attn_tuning (0 = library default)")
     ap.add_argument("--gemm-tuning", type=int, default=0, help="profiling aid: isst_op_set_gemm_tuning(w, 0) (0 = library default; e.g. 900010 + variant: gemm_wide.hip's A/B variants)")
@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="LAUNCHER SELF-TEST, no compute and no GPU: every rank sleeps instead of stepping the engine and the ranks meet over gloo; "
                          "the JSON line is marked dry_run and is not a measurement (tests/test_streams_gloo.py)")
+    ap.add_argument("--dry-fail-step-rank", type=int, default=-1, help="--dry-run only: this rank raises inside the TIMED steps of the 64-streams-per-GPU leg (after the barrier): "
+                    "every rank must leave the leg together and the job must end non-zero")
     ap.add_argument("--dry-fail-rank", type=int, default=-1, help="--dry-run only: this rank reports a failed set-up of the 64-streams-per-GPU leg (every rank must then skip it)")
     return ap.parse_args()
 
@@ -315,6 +317,8 @@ def first_step_record(loop, eng, gen):
 # bf16 paths with different summation orders may differ by twice that at their worst element: the check bounds the MEAN tightly and the maximum loosely.
 SELF_CHECK_TOL = 1.0
 SELF_CHECK_MEAN_TOL = 0.15
+SELF_CHECK_MIN_SHARED = 0.5   # many-stream beams against a one-stream beam engine: share of the listed candidate ids both engines must name
+SELF_CHECK_ID_TOL = 0.5       # ... and |log-prob difference| of a token both engines list (measured on the plain init: 0.13 at worst, 0.06 on average)
 
 
 def leg_self_check(cfg, gen, weights, device, n_streams, first):
@@ -325,7 +329,7 @@ def leg_self_check(cfg, gen, weights, device, n_streams, first):
       * beam search, one stream: the same search with the scorer on the HOST and attention / combine / o_proj as three launches
         (ISST_BEAM_DEVICE=0, ISST_FUSE_ATTN_OPROJ=0): winner and every candidate list must be bit-identical;
       * beam search, many streams: a one-stream beam engine: the candidates of the step behind the prefill (independent of later choices) within
-        SELF_CHECK_TOL, and whether the winners agree (a near-tie may part them: reported, not required)."""
+        SELF_CHECK_TOL BY TOKEN ID (beam_candidates_by_id), and whether the winners agree (a near-tie may part them: reported, not required)."""
     import dataclasses
     env = {"ISST_BEAM_DEVICE": "0", "ISST_FUSE_ATTN_OPROJ": "0"} if (gen.beam > 1 and n_streams == 1) else {}
     saved = {k: os.environ.get(k) for k in env}
@@ -358,13 +362,47 @@ def leg_self_check(cfg, gen, weights, device, n_streams, first):
             ok = same and again["tokens"] == first["tokens"]
             return {"what": "first step recomputed with the scorer on the host and attention / combine / o_proj as three launches: bit-identical candidates and winner required",
                     "scorer_steps": len(t0), "candidates_bit_identical": bool(same), "winner_equal": again["tokens"] == first["tokens"], "ok": bool(ok)}
-        diff = float(np.abs(t0[0][0] - t1[0][0]).max())
-        ids_equal = float(np.mean(t0[0][1] == t1[0][1]))
-        return {"what": "stream 0, first step recomputed by a one-stream beam engine: the candidates of the step behind the prefill",
-                "max_abs_logprob_diff": round(diff, 4), "candidate_ids_equal_fraction": round(ids_equal, 3), "tolerance_max": SELF_CHECK_TOL,
-                "winner_equal": again["tokens"] == first["tokens"], "ok": bool(diff <= SELF_CHECK_TOL)}
+        return beam_candidates_by_id(t0[0], t1[0], again["tokens"] == first["tokens"])
     finally:
         eng.close()
+
+
+def beam_candidates_by_id(c0, c1, winner_equal):
+    """Two engines' candidate lists of ONE scorer step (top log-probs [rows][k], token ids [rows][k]) compared BY TOKEN ID: the log-prob engine B gives a
+    token engine A also lists must agree within the bf16 tolerance, and a token only one engine lists must not sit further above the other engine's k-th
+    candidate than that tolerance allows (the other engine's value for it is at most its k-th).  With the plain random init the top candidates are near-ties
+    (their ORDER legitimately differs between two summation orders), but a wrong kernel moves the values: then either the shared ids disagree or hardly any id
+    is shared, and both fail the check.  (Comparing the sorted values alone passes any two rows of near-uniform log-probs: VERDICT r05.)"""
+    v0, i0, v1, i1 = np.asarray(c0[0], np.float32), np.asarray(c0[1]), np.asarray(c1[0], np.float32), np.asarray(c1[1])
+    rows = min(len(i0), len(i1))
+    worst, diffs, shared, listed, worst_excess = 0.0, [], 0, 0, 0.0
+    for r in range(rows):
+        if not np.isfinite(v0[r]).any() or not np.isfinite(v1[r]).any():
+            continue  # (a beam row that does not take part in this step: HF starts beams 1.. at -1e9)
+        a = {int(t): float(v) for t, v in zip(i0[r], v0[r]) if np.isfinite(v)}
+        b = {int(t): float(v) for t, v in zip(i1[r], v1[r]) if np.isfinite(v)}
+        if not a or not b:
+            continue
+        ka, kb = min(a.values()), min(b.values())
+        listed += len(a)
+        for t, v in a.items():
+            if t in b:
+                shared += 1
+                diffs.append(abs(v - b[t]))
+            else:
+                worst_excess = max(worst_excess, v - kb)
+        for t, v in b.items():
+            if t not in a:
+                worst_excess = max(worst_excess, v - ka)
+    worst = max(diffs) if diffs else float("inf")
+    mean = float(np.mean(diffs)) if diffs else float("inf")
+    frac = shared / max(1, listed)
+    ok = bool(diffs) and frac >= SELF_CHECK_MIN_SHARED and worst <= SELF_CHECK_ID_TOL and mean <= SELF_CHECK_MEAN_TOL and worst_excess <= SELF_CHECK_ID_TOL
+    return {"what": "stream 0, first step recomputed by a one-stream beam engine: the candidates of the step behind the prefill, compared BY TOKEN ID",
+            "candidate_ids_shared_fraction": round(frac, 3), "shared_ids": shared, "max_abs_logprob_diff_same_id": round(worst, 4) if diffs else None,
+            "mean_abs_logprob_diff_same_id": round(mean, 4) if diffs else None, "max_excess_of_unshared_id_over_other_kth": round(worst_excess, 4),
+            "tolerance_max": SELF_CHECK_ID_TOL, "tolerance_mean": SELF_CHECK_MEAN_TOL, "min_shared_fraction": SELF_CHECK_MIN_SHARED,
+            "winner_equal": bool(winner_equal), "ok": ok}
 
 
 def run_streams64(cfg, gen, weights, device, args):
@@ -479,8 +517,21 @@ def run_streams64_all_ranks(cfg, gen, weights, device, args, tg, world, rank):
     tg.barrier()
     torch.cuda.synchronize()
     steps = args.streams64_steps
-    dt_local, lat, host_s = timed_steps(loop, steps)
-    torch.cuda.synchronize()
+    # ... and so can the timed part (a GPU step that raises AFTER the barrier): the healthy ranks would sit in the closing barrier / reductions while the
+    # failing one has left the leg.  Every rank therefore catches, and the ranks agree on the host BEFORE the next collective; a failure anywhere fails
+    # the leg on every rank and main() ends the job non-zero once the line is printed (tests/test_streams_gloo.py, --dry-fail-step-rank)
+    dt_local, lat, host_s = 0.0, [], 0.0
+    try:
+        dt_local, lat, host_s = timed_steps(loop, steps)
+        torch.cuda.synchronize()
+    except Exception as e:  # report, never hide
+        err = f"{type(e).__name__}: {e}"
+    if not tg.all_ok(err is None):
+        try:
+            eng.close()
+        except Exception:
+            pass
+        return {"failed": err or "another rank failed inside the timed steps of the leg", "failed_in": "timed steps", "fatal": True}
     tg.barrier()
     dt = tg.max(dt_local)
     audio = tg.sum(0.96 * steps * len(mine))
@@ -620,7 +671,28 @@ def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=32, n_c
     from oracle import llm as ollm
     from oracle import speech_encoder as oenc
     cores = os.cpu_count() or 1
-    nthreads = threads if threads > 0 else min(cores, 64)
+    if threads > 0:
+        nthreads, thread_note = threads, "--cpu-threads"
+    else:
+        # BASELINE.md's recipe is set_num_threads(os.cpu_count()); on a many-socket host that is not always the fastest setting for one stream's
+        # memory-bound GEMVs, so the thread count is the fastest of {64, 128, all logical cores} on a one-second probe of the layer stack's widest
+        # GEMV (bf16 F.linear, 1 x 4096 -> 28672): the baseline is reported at its best, and the line says what was tried
+        cands = sorted({c for c in (64, 128, cores) if c <= cores}) or [cores]
+        xw = torch.randn(28672, 4096).bfloat16()
+        xv = torch.randn(1, 4096).bfloat16()
+        probe = {}
+        for c in cands:
+            torch.set_num_threads(c)
+            for _ in range(3):
+                torch.nn.functional.linear(xv, xw)
+            t0 = time.perf_counter()
+            for _ in range(12):
+                torch.nn.functional.linear(xv, xw)
+            probe[c] = (time.perf_counter() - t0) / 12
+        del xw, xv
+        nthreads = min(probe, key=probe.get)
+        thread_note = ("fastest of " + ", ".join(f"{c} threads: {1e3 * t:.2f} ms" for c, t in probe.items()) +
+                       f" on a bf16 F.linear 1 x 4096 -> 28672 probe; host has {cores} logical cores (BASELINE.md: set_num_threads(os.cpu_count()))")
     torch.set_num_threads(nthreads)
     run_layers = min(llm_layers_run, cfg.llm_layers)
     keep = lambda k: not k.startswith("model.layers.") or int(k.split(".")[2]) < run_layers
@@ -686,7 +758,8 @@ def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=32, n_c
             measured += t_enc + t_stack + t_head
             log(f"cpu baseline: chunk {c}: encoder {t_enc:.2f} s, layer stack {t_stack:.2f} s, head {t_head:.2f} s")
     dt = float(np.mean(per_chunk_s))
-    return {"value": round(0.96 / dt, 4), "unit": "xRT (audio-s/wall-s), 1 stream", "cores": nthreads, "kind": "port",
+    return {"value": round(0.96 / dt, 4), "unit": "xRT (audio-s/wall-s), 1 stream", "cores": nthreads, "host_cores": cores, "kind": "port",
+            "threads_reason": thread_note,
             "sample": f"{n_chunks} consecutive steady-state chunks ({0.96 * n_chunks:.2f} s audio) of one stream: full speech encoder + {len(prompt)}-token "
                       f"prefill + {gen.max_new_tokens - 1} decode passes per chunk through {run_layers} of {cfg.llm_layers} Llama layers (+ norm, lm_head, "
                       f"processors), eviction between chunks; measured {measured:.1f} s"
@@ -759,9 +832,19 @@ def dry_run(args, world, rank, cores=None):
     elif world > 1 and not args.no_streams64:
         tg.barrier()
         t1 = time.perf_counter()
-        for _ in range(4):
-            b64.step([seg] * len(idx64))
+        step_err = None
+        try:
+            for k in range(4):
+                if rank == args.dry_fail_step_rank and k == 1:
+                    raise RuntimeError("simulated failure of a GPU step inside the timed leg (--dry-fail-step-rank)")
+                b64.step([seg] * len(idx64))
+        except Exception as e:  # (run_streams64_all_ranks: caught, then agreed on before the next collective)
+            step_err = f"{type(e).__name__}: {e}"
         dt64_local = time.perf_counter() - t1
+        leg_ok = tg.all_ok(step_err is None)
+    if s64 is None and world > 1 and not args.no_streams64 and not leg_ok:
+        s64 = {"failed": step_err or "another rank failed inside the timed steps of the leg", "failed_in": "timed steps", "fatal": True, "ranks_seen": dist.get_world_size()}
+    elif s64 is None and world > 1 and not args.no_streams64:
         tg.barrier()
         dt64 = tg.max(dt64_local)
         audio64 = tg.sum(0.96 * 4 * len(mine64))
@@ -778,6 +861,8 @@ def dry_run(args, world, rank, cores=None):
                           "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3), "higher_is_better": True, "scaling": "weak"}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if isinstance(s64, dict) and s64.get("fatal"):
+        sys.exit(3)  # (every rank: the launcher, and bench.py as its parent, then exit non-zero)
 
 
 def main():
@@ -853,8 +938,10 @@ def main():
         # N > 1: configs[3] -- the 64-stream leg on EVERY rank (the N = 1 headline above stays what BENCH measures, so N = 1 SCALE agrees with it)
         try:
             s64 = run_streams64_all_ranks(cfg, gen, weights, device, args, tg, world, rank)
-            if rank == 0:
+            if rank == 0 and s64 is not None and "xrt" in s64:
                 log(f"64-streams-per-GPU leg done on {world} ranks: {s64['xrt']} xRT aggregate, {s64['ms_per_step']} ms per step")
+            elif rank == 0 and s64 is not None:
+                log(f"64-streams-per-GPU leg skipped on every rank: {s64.get('failed')}")
         except Exception as e:  # report, never hide (set-up failures are agreed on and skipped by all ranks inside; what lands here failed in the timed part)
             s64 = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0:
@@ -905,6 +992,8 @@ def main():
             except Exception as e:  # report, never hide
                 base = {"value": None, "unit": "xRT (audio-s/wall-s), 1 stream", "cores": os.cpu_count(), "kind": "port",
                         "sample": f"failed: {type(e).__name__}: {e}"}
+    # (every rank knows: run_streams64_all_ranks returns the agreed failure on all of them)
+    fatal = not tg.all_ok(not (isinstance(s64, dict) and s64.get("fatal")))
     tg.barrier()
     if rank == 0:
         value = audio_s / elapsed
@@ -932,6 +1021,10 @@ def main():
                         "(BASELINE.json configs[2] shape)"),
                        "streams_per_gpu": args.streams, "streams_total": args.streams * world, "chunk_ms": 960, "prompt_tokens": 22,
                        "forward_passes_per_chunk": args.gen_tokens,
+                       "latency_definition": ("ms_per_step / value / p50: one isst_generate call per chunk, audio ALREADY RESIDENT in HBM when the step starts "
+                                              "(the bench contract: inputs resident before the timed region) -> last token id on the host; SURVEY 8(d)'s form -- H2D of "
+                                              "the chunk inside the step -- is the `host_audio` object beside it (never `value`)") if not args.host_audio else
+                                             "SURVEY 8(d): H2D of the chunk -> last token id on the host (--host-audio)",
                        "llm_kv_entries": info["llm_cache_len"], "llm_kv_entries_at_timed_start": kv_min, "encoder_window": info["enc_cache_len"],
                        "steady_state": "cold start (--cold-start)" if args.cold_start else
                                        "imported before the first step (KV, checkpoints, encoder window, audio history)",
@@ -954,6 +1047,8 @@ def main():
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if fatal:
+        sys.exit(3)  # a rank failed inside the timed steps of a multi-rank leg: the line says so, and the job does not end as a success
 
 
 if __name__ == "__main__":

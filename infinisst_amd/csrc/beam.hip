@@ -357,6 +357,7 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
     }
     if (lane == 0) a.log_done[i] = st;
     __threadfence_system();  // every lane: its part of the log is in host memory before this stream's ticket is drawn
+    __syncthreads();         // (the workgroup IS one wave -- launch_beam_select, static_assert above -- so this costs nothing; it states that lane 0's ticket follows every lane's fence)
     if (lane == 0) {
         bool last = true;  // (one stream: this wave is the launch -- no ticket, no second fence on the step's critical path)
         if (a.n > 1) {
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
         if (last) *reinterpret_cast<volatile int*>(a.log_seq) = a.seq_value;
     }
 }
+static_assert(WAVE == 64, "beam_select_kernel is ONE 64-lane wave per stream: wave_sum / wave_argmax_all are its block reductions and its log writes precede lane 0's ticket in program order");
 int launch_beam_select(const BeamSelArgs& a, hipStream_t s) {
     if (a.n <= 0) return ISST_OK;
     if (a.B < 1 || a.B > BEAM_MAX_B || a.n_keep < 1 || a.n_keep > BEAM_TOPK || a.rows_per < 1 || a.rows_per > a.B || a.n_eos < 0 || a.n_eos > 8) return ISST_ERR_ARG;

@@ -43,6 +43,10 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 // ds_bpermute_b32, an LDS-crossbar round trip of ~100 cycles per step: a k-round argmax over (value, index) pairs -- 12-18 dependent bpermutes per round --
 // made the beam search's small top-k kernels 11-25 us of pure latency (profiles/r05/beam_tail_kernels.txt).  Sequence as rocPRIM's warp_reduce_dpp:
 // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8, row_bcast:15, row_bcast:31 -> lane 63 holds the reduction; v_readlane broadcasts it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "the DPP reductions below use row_bcast:15 / row_bcast:31 (wave64, gfx9 family only): this library is written for gfx950"
+#endif
+static_assert(WAVE == 64, "row_bcast:31 and v_readlane 63 assume 64-lane waves");
 template <int CTRL>
 __device__ __forceinline__ int dpp_take(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }  // (lanes without a source keep their own value)
 __device__ __forceinline__ float wave_max_all(float v) {

@@ -181,6 +181,24 @@ def test_bench_skips_the_64_stream_leg_on_every_rank_when_one_rank_fails_to_set_
     assert j["ranks_seen"] == 2 and j["latencies_gathered"] == 8  # the headline leg ran to the end on both ranks
 
 
+def test_bench_ends_non_zero_when_a_rank_fails_inside_the_timed_64_stream_leg():
+    """the set-up failure above is agreed on before the timed barrier; a GPU step that raises AFTER that barrier -- inside the timed steps of
+    the configs[3] leg -- must not strand the healthy ranks in the closing barrier / reductions either.  Every rank catches, the ranks agree on the host
+    before the next collective (TimingGroup.all_ok), rank 0 still prints the line (headline intact, the leg marked failed) and the job exits non-zero
+    well inside the launcher's timeout."""
+    import json
+    import time
+    t0 = time.monotonic()
+    r = _run_bench("--dry-run", "--gpus", "2", "--steps", "4", "--streams", "1", "--dry-fail-step-rank", "1", timeout=300)
+    assert time.monotonic() - t0 < 240, "the healthy rank waited for the failed one"
+    assert r.returncode != 0, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["ranks_seen"] == 2 and j["latencies_gathered"] == 8          # the headline leg ran to the end on both ranks
+    assert "failed" in j["streams64"] and j["streams64"]["failed_in"] == "timed steps" and j["streams64"]["fatal"] is True
+
+
 def test_bench_parent_reports_a_failing_rank():
     """Without --dry-run on a box without GPUs every rank fails loudly (no CPU fallback); the parent must exit non-zero and print no JSON line."""
     import torch
