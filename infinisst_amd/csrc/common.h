@@ -195,6 +195,7 @@ bool gemm_dense_supported(const GemmArgs& g);                     // gemm_dense.
 bool gemm_dense_preferred(const GemmArgs& g);
 bool gemm_dense_would_run(int M, int N, int K);                   // ... as a function of the shape alone (the engine picks its K slices by it)
 int launch_gemm_dense(const GemmArgs& g, hipStream_t stream);
+double gemm_dense_pick_mix(int M, int N, int ks, int* n_full, int* n_half);  // the launch's tile mix (row blocks of 256, then of 128) and its modelled length in 256-row tiles over all of K
 void gemm_dense_set(int mode);                                     // profiling aid: 0 never, 1 heuristic, 2 wherever supported
 bool gemm_wide_supported(const GemmArgs& g);                       // gemm_wide.hip: 65..256 rows, weights read once (8 waves: 4 consumers with the W ring in registers + 4 LDS-DMA loaders for the A ring)
 bool gemm_wide_preferred(const GemmArgs& g);

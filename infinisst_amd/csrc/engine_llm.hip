@@ -49,15 +49,18 @@ int pick_ksplit(int K, int N, int rows, long slab_cap) {
         return s;
     }
     if (gemm_dense_would_run(rows, N, K)) {
-        // 256 x 256 tiles, one workgroup per CU (gemm_dense.hip): rounds of 1/s-length tiles + the slab traffic each further slice adds (write + read of
-        // rows x N fp32: about 4 % of a round per slice at these shapes).  profiles/dense_split_probe.py, GEMM + reducing norm, us:
-        //   1408 rows  o_proj 82.7 / 62.4 / 79.9 / 102.0 for 1 / 2 / 4 / 8 slices, down_proj 241 / 161 / 178 / 183;   704 rows  o_proj 79 / 52 / 43 / 59, down 248 / 139 / 94 / 116
-        const long tiles = (long)((N + 255) / 256) * ((rows + 255) / 256);
+        // gemm_dense.hip, one workgroup per CU: the launcher's own list-scheduling model (gemm_dense_pick_mix: 256- and 128-row tiles dealt longest first to
+        // the 32 CUs of an XCD) gives the GEMM's length in units of one 256-row tile over all of K; on top, in units of such a tile at K = 4096 (~75 us): no
+        // slices = the residual goes through the GEMM's epilogue and a plain norm launch follows (0.11); slices = slab writes + the reducing norm (0.20 + 0.04
+        // per slice).  Round 6, profiles/r06/dense_mix_probe_1408.txt (GEMM + norm, us, 1408 rows): o_proj 57 unsplit on 128-row tiles / 67 in 2 slices of
+        // 256-row tiles / 77 in 4; down_proj 184 unsplit / 153 in 2 / 159 in 4 (mixed) / 163 in 5.  (Rounds 3-5 chose among powers of two by rounds of 256-row
+        // tiles only: o_proj 2, down_proj 2 at 1408 rows.)
         int best = 1;
         double best_cost = 1e30;
-        for (int s = 1; s <= LLM_KSPLIT_MAX; s *= 2) {
-            if (K % (64 * s) != 0 || K / (64 * s) < 4 || (s > 1 && (long)s * rows * N > slab_cap)) break;
-            const double cost = (double)((tiles * s + 255) / 256) / s + 0.04 * s;
+        for (int s = 1; s <= LLM_KSPLIT_MAX; ++s) {
+            if ((K / 64) / s < 4 || (s > 1 && (long)s * rows * N > slab_cap)) break;
+            int nf = 0, nh = 0;
+            const double cost = gemm_dense_pick_mix(rows, N, s, &nf, &nh) * (K / 4096.0) + (s == 1 ? 0.11 : 0.20 + 0.04 * s);
             if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
         }
         return best;

@@ -26,7 +26,27 @@
 //   * K order per accumulator: ascending, two k-steps per K-tile -- the same order as gemm_tiled.hip, so results are bit-identical to it.
 // Scheduling: one workgroup per tile in an XCD-aware order (as gemm_tiled.hip); narrow outputs split K over blockIdx.z into fp32 slabs
 // (EPI_PARTIAL) that the residual + RMSNorm kernel sums.
+//
+// Round 6: HALF TILES (MH = 1).  1408 rows are 5.5 row blocks of 256: the sixth block computes on 128 repeated rows, and 6 x 112 = 672 gate/up tiles are 2.625
+// rounds of the 256 CUs -- three in practice (profiles/r05/trace_busy_prof64.txt: 277 us = 3 x 92).  The same body therefore also exists for a 128-row x 256-column
+// tile: each wave owns 64 rows x 64 columns = the two quadrants (0, 0) (0, 1), a K-tile is two phases, and its three half-tile slots A | B0 | B1 (48 KiB) form a
+// ring of THREE K-tile buffers (144 KiB), so that a DMA still has three phases to land although a K-tile now lasts two: phase 1 of K-tile t issues A(t+2) and the
+// first half of B0(t+2), phase 2 the rest of B0(t+2) and B1(t+2) (three instructions per wave and phase), waits vmcnt(9) / vmcnt(8).  Same K order per
+// accumulator: bit-identical to the 256-row form and to gemm_tiled.hip.  The launcher mixes the two sizes in ONE launch -- row blocks of 256 first, then row blocks
+// of 128, longest first inside every XCD's share of the columns -- wherever its list-scheduling model says the last round gets shorter (dense_pick_mix).
 #include "common.h"
+
+// diagnostic builds only (make ablate; profiles/dense_ablate_probe.py): DENSE_ABLATE bit 0 = no MFMAs (fragments kept live), bit 1 = no DMAs inside the K loop
+// (the prologue's stay), bit 2 = no fragment reads inside the K loop -- what each of the three streams of the loop costs alone.  Results are garbage.
+#ifndef DENSE_ABLATE
+#define DENSE_ABLATE 0
+#endif
+#ifndef DENSE_RING10
+#define DENSE_RING10 1   // 256-row tiles: one half-tile per phase over a ring of slots instead of two K-tile buffers (A/B aid: -DDENSE_RING10=0)
+#endif
+#ifndef DENSE_SLOTS
+#define DENSE_SLOTS 10   // half-tile slots of that ring (10 = all 160 KiB of the CU)
+#endif
 
 #define DT_M 256
 #define DT_NT 16          // n-tiles per tile (256 columns)
@@ -36,40 +56,35 @@
 
 typedef __attribute__((address_space(3))) void* dlds_ptr;
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int raster) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x DT_BUF (all LDS of the kernel: a second object would make hipcc drain the DMAs)
+// tile mix of a launch (dense_pick_mix): row blocks 0 .. n_full-1 are 256 rows, then n_half blocks of 128 rows; mixed launches are 1-D grids that also fold the K
+// slices in (blockIdx.x -> XCD share, tile, slice), so that every XCD walks ITS tiles longest first
+struct DenseSched {
+    int n_full, n_half;
+    int X;               // column blocks
+    int ks;              // K slices folded into the grid (folded launches)
+    int folded;          // 0: the plain grid of rounds 1-5 (256-row tiles, raster flag, blockIdx.y / .z); 1: the 1-D grid below
+};
+
+template <int EPI, int MH>
+__device__ __forceinline__ void dense_tile(const GemmArgs& g, unsigned char* smem, const int m0, const int nt0, const int slice, const int T, const long k0) {
+    constexpr int NBUF = MH == 2 ? 2 : 3;            // K-tile buffers
+    constexpr int BUFSZ = (MH + 2) * DT_HALF;        // A0 (| A1) | B0 | B1
+    constexpr int WROWS = 64 * MH;                   // rows of a wave row
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int KT = g.K >> 5, NTILES = g.N >> 4;
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (raster) {  // XCD-aware tile order: the workgroups an XCD runs at a time form a patch of 8 column blocks x all row blocks (gemm_tiled.hip)
-        const int X = (NTILES + DT_NT - 1) / DT_NT, Y = (g.M + DT_M - 1) / DT_M;
-        const int n_per = gridDim.x >> 3;
-        const int S = (blockIdx.x & 7) * n_per + (blockIdx.x >> 3);
-        if (S >= X * Y) return;
-        const int patch = S / (8 * Y), r = S - patch * (8 * Y);
-        const int pw = min(8, X - patch * 8);
-        by = r / pw;
-        bx = patch * 8 + r % pw;
-    }
-    const int m0 = by * DT_M, nt0 = bx * DT_NT;
-    const int ks = (EPI == EPI_PARTIAL && g.ksplit > 1) ? g.ksplit : 1;
-    const int slice = (EPI == EPI_PARTIAL) ? blockIdx.z : 0;
-    const int T = (g.K / DT_K) / ks;          // K-tiles of this workgroup
-    const long k0 = (long)slice * T * DT_K;   // first K element
 
     // ---- DMA sources of this wave.  A half mh: units 2*wave, 2*wave + 1 of the slot = m-tile (wave & 3) of wave row (wave >> 2);
     //      lane -> (row of the 8-row unit = lane >> 3, destination chunk = lane & 7), source chunk = destination chunk ^ ((row in m-tile >> 1) & 7) ----
-    const bf16_t* asrc[2][2];  // [mh][unit]
+    const bf16_t* asrc[MH][2];  // [mh][unit]
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
+    for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int rim = u * 8 + (lane >> 3);                                   // row inside the 16-row m-tile
-            const int row = min(m0 + (wave >> 2) * 128 + mh * 64 + (wave & 3) * 16 + rim, g.M - 1);  // rows past M repeat the last row (never stored)
+            const int row = min(m0 + (wave >> 2) * WROWS + mh * 64 + (wave & 3) * 16 + rim, g.M - 1);  // rows past M repeat the last row (never stored)
             const int chunk = (lane & 7) ^ ((rim >> 1) & 7);
             asrc[mh][u] = g.A + (long)row * g.lda + k0 + chunk * 8;
         }
@@ -82,17 +97,28 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
     }
     // (past the last K-tile the DMAs re-read K-tile T - 1 into the slot the running index names -- a slot nobody reads any more: the issue
     //  and wait counts then stay the same in every phase)
-    auto dma_a = [&](int t, int mh) {  // A half mh of K-tile t -> buffer t & 1
-        unsigned char* dst = smem + (t & 1) * DT_BUF + mh * DT_HALF + (2 * wave) * 1024;
+    // one DMA instruction: unit u (0 / 1) of this wave's share of a half-tile of K-tile t, into the 16 KiB slot at byte offset `soff`
+    auto dmaA = [&](int soff, int t, int mh, int u) {
+        unsigned char* dst = smem + soff + (2 * wave + u) * 1024;
         const long ko = (long)(t < T ? t : T - 1) * DT_K;
-        __builtin_amdgcn_global_load_lds((const void*)(asrc[mh][0] + ko), (dlds_ptr)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)(asrc[mh][1] + ko), (dlds_ptr)(dst + 1024), 16, 0, 0);
+        if ((DENSE_ABLATE & 2) && t >= 2) return;
+        __builtin_amdgcn_global_load_lds((const void*)(asrc[mh][u] + ko), (dlds_ptr)dst, 16, 0, 0);
+    };
+    auto dmaB = [&](int soff, int t, int nh, int u) {
+        unsigned char* dst = smem + soff + (2 * wave + u) * 1024;
+        const long ko = (long)(t < T ? t : T - 1) * 1024;
+        if ((DENSE_ABLATE & 2) && t >= 2) return;
+        __builtin_amdgcn_global_load_lds((const void*)(bsrc[nh] + ko + u * 512), (dlds_ptr)dst, 16, 0, 0);
+    };
+    auto dma_a1 = [&](int boff, int t, int mh, int u) { dmaA(boff + mh * DT_HALF, t, mh, u); };          // buffer-relative forms (K-tile buffers A0 (| A1) | B0 | B1)
+    auto dma_b1 = [&](int boff, int t, int nh, int u) { dmaB(boff + (MH + nh) * DT_HALF, t, nh, u); };
+    auto dma_a = [&](int t, int mh) {  // (MH == 2) A half mh of K-tile t -> buffer t & 1
+        dma_a1((t & 1) * BUFSZ, t, mh, 0);
+        dma_a1((t & 1) * BUFSZ, t, mh, 1);
     };
     auto dma_b = [&](int t, int nh) {
-        unsigned char* dst = smem + (t & 1) * DT_BUF + (2 + nh) * DT_HALF + (2 * wave) * 1024;
-        const long ko = (long)(t < T ? t : T - 1) * 1024;
-        __builtin_amdgcn_global_load_lds((const void*)(bsrc[nh] + ko), (dlds_ptr)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)(bsrc[nh] + ko + 512), (dlds_ptr)(dst + 1024), 16, 0, 0);
+        dma_b1((t & 1) * BUFSZ, t, nh, 0);
+        dma_b1((t & 1) * BUFSZ, t, nh, 1);
     };
 
     // ---- fragment reads ----
@@ -100,24 +126,29 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
     const int a_sw = (fr >> 1) & 7;
     const int b_rd = wc * 4096 + lane * 16;                              // + (nb * 2 + ks) * 1024
     u32x4_t fa[4][2], fb0[2][2], fb1[2][2];                              // [m-tile][k-step], [n-tile][k-step]
-    auto read_a = [&](int t, int mh) {
-        const unsigned char* base = smem + (t & 1) * DT_BUF + mh * DT_HALF + a_rd;
+    bool first_reads = true;
+    auto rdA = [&](int soff) {  // the A half-tile in the slot at byte offset soff -> fa
+        if ((DENSE_ABLATE & 4) && !first_reads) return;
+        const unsigned char* base = smem + soff + a_rd;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int k = 0; k < 2; ++k) fa[mt][k] = *reinterpret_cast<const u32x4_t*>(base + mt * 2048 + (((k * 4 + fq) ^ a_sw) << 4));
     };
-    auto read_b = [&](int t, int nh, u32x4_t (&fb)[2][2]) {
-        const unsigned char* base = smem + (t & 1) * DT_BUF + (2 + nh) * DT_HALF + b_rd;
+    auto rdB = [&](int soff, u32x4_t (&fb)[2][2]) {
+        if ((DENSE_ABLATE & 4) && !first_reads) return;
+        const unsigned char* base = smem + soff + b_rd;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int k = 0; k < 2; ++k) fb[nb][k] = *reinterpret_cast<const u32x4_t*>(base + (nb * 2 + k) * 1024);
     };
+    auto read_a = [&](int boff, int mh) { rdA(boff + mh * DT_HALF); };
+    auto read_b = [&](int boff, int nh, u32x4_t (&fb)[2][2]) { rdB(boff + (MH + nh) * DT_HALF, fb); };
 
-    f32x4_t acc[2][2][4][2];  // [mh][nh][m-tile][n-tile]
+    f32x4_t acc[MH][2][4][2];  // [mh][nh][m-tile][n-tile]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MH; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -131,59 +162,170 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    c[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[mt][k]), __builtin_bit_cast(bf16x8_t, fb[nb][k]), c[mt][nb], 0, 0, 0);
+                for (int nb = 0; nb < 2; ++nb) {
+                    if constexpr (DENSE_ABLATE & 1) asm volatile("" ::"v"(fa[mt][k]), "v"(fb[nb][k]));
+                    else c[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[mt][k]), __builtin_bit_cast(bf16x8_t, fb[nb][k]), c[mt][nb], 0, 0, 0);
+                }
         __builtin_amdgcn_s_setprio(0);
     };
-#define DT_WAIT_BARRIER()                                   \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
+#define DT_WAIT_BARRIER_N(N)                                \
+    asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");   \
     __builtin_amdgcn_sched_barrier(0);                      \
     __builtin_amdgcn_s_barrier();                           \
     __builtin_amdgcn_sched_barrier(0)
+#define DT_WAIT_BARRIER() DT_WAIT_BARRIER_N(8)
 #define DT_END_PHASE()                                      \
     __builtin_amdgcn_sched_barrier(0);                      \
     __builtin_amdgcn_s_barrier();                           \
     __builtin_amdgcn_sched_barrier(0)
 
-    // ---- prologue: K-tile 0 whole, then A0 / B0 of K-tile 1 (the order the phases below continue: B1(t+1), A1(t+1), A0(t+2), B0(t+2)) ----
-    dma_a(0, 0); dma_b(0, 0); dma_b(0, 1); dma_a(0, 1);
-    dma_a(1, 0); dma_b(1, 0);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-tile 0 has landed (the two youngest half-tiles may fly)
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs half a phase behind
+    if constexpr (MH == 2 && DENSE_RING10) {
+        // ---- ONE HALF-TILE PER PHASE over a ring of DENSE_SLOTS half-tile slots (round 6; ten slots = all 160 KiB of the CU).  The two-buffer form below reads
+        //      12 / 4 / 8 / 0 fragments in the phases of a K-tile: in phase 1 the four waves of a wave row put 4 x 12 x 4 = 192 LDS cycles of reads beside the
+        //      phase's 64 cycles of DMA writes -- the whole 256-cycle MFMA cluster of their partners -- and the matrix pipe waits for them.  Here B0 of K-tile
+        //      t + 1 is read in phase 4 of K-tile t, into the registers B1(t) has just left (the two B register sets swap roles every K-tile: the loop is
+        //      unrolled by two), so the phases read 8 / 4 / 8 / 4 fragments, and every phase consumes exactly one half-tile of the sequence
+        //          B0(0) | A0(t) B1(t) A1(t) B0(t+1) | ...        (sequence index j: phase p = 4 t + k, k = 0 .. 3, reads j = p + 1)
+        //      and issues exactly one (j = p + 1 + LOOK, LOOK = DENSE_SLOTS - 2) into slot j mod DENSE_SLOTS, whose last occupant was read two phases back.
+        //      A wait leaves the LOOK - 1 youngest half-tiles flying; the half-tile a phase reads was retired by the wait of the phase before. ----
+        constexpr int LOOK = DENSE_SLOTS - 2;
+        constexpr int RING = DENSE_SLOTS * DT_HALF;
+        auto adv = [](int off, int n) { const int x = off + n * DT_HALF; return x >= RING ? x - RING : x; };
+        // sequence index j >= 1 -> (kind, K-tile): (j - 1) % 4 = 0: A0, 1: B1, 2: A1, 3: B0 of the NEXT K-tile
+        auto issue = [&](int soff, int tt, int kind) {  // both instructions of this wave's share
+            if (kind == 0) { dmaA(soff, tt, 0, 0); dmaA(soff, tt, 0, 1); }
+            else if (kind == 1) { dmaB(soff, tt, 1, 0); dmaB(soff, tt, 1, 1); }
+            else if (kind == 2) { dmaA(soff, tt, 1, 0); dmaA(soff, tt, 1, 1); }
+            else { dmaB(soff, tt + 1, 0, 0); dmaB(soff, tt + 1, 0, 1); }
+        };
+        dmaB(0, 0, 0, 0); dmaB(0, 0, 0, 1);  // j = 0: B0(0)
+#pragma unroll
+        for (int j = 1; j <= LOOK; ++j) issue((j % DENSE_SLOTS) * DT_HALF, (j - 1) / 4, (j - 1) % 4);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOOK) : "memory");  // B0(0) has landed
+        __builtin_amdgcn_s_barrier();
+        u32x4_t fbx[2][2], fby[2][2];
+        rdB(0, fbx);                                      // "phase -1": B0 of K-tile 0
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LOOK - 1)) : "memory");  // A0(0) has landed
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs half a phase behind
+        int rs = DT_HALF, ws = adv(DT_HALF, LOOK);        // slots of the half-tile this phase reads (j = p + 1) / issues (j = p + 1 + LOOK)
+#define DT_WAIT_RING()                                                              \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LOOK - 1)) : "memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    __builtin_amdgcn_s_barrier();                                                   \
+    __builtin_amdgcn_sched_barrier(0)
+        auto ktile = [&](int t, u32x4_t (&b0)[2][2], u32x4_t (&bo)[2][2]) {  // b0 = B0(t) in registers; bo receives B1(t), then B0(t + 1)
+            const int tl = t + LOOK / 4;  // K-tile of the half-tiles issued below (LOOK = 8: t + 2; kinds follow the phase)
+            // phase 1: quadrant (0, 0)
+            rdA(rs);
+            issue(ws, tl, (0 + LOOK) % 4);
+            DT_WAIT_RING();
+            quadrant(acc[0][0], b0);
+            DT_END_PHASE();
+            // phase 2: quadrant (0, 1)
+            rdB(adv(rs, 1), bo);
+            issue(adv(ws, 1), tl, (1 + LOOK) % 4);
+            DT_WAIT_RING();
+            quadrant(acc[0][1], bo);
+            DT_END_PHASE();
+            // phase 3: quadrant (1, 1)
+            rdA(adv(rs, 2));
+            issue(adv(ws, 2), tl, (2 + LOOK) % 4);
+            DT_WAIT_RING();
+            quadrant(acc[MH - 1][1], bo);
+            DT_END_PHASE();
+            // phase 4: quadrant (1, 0) -- B0(t) is still in registers; B0 of the next K-tile takes B1's place
+            rdB(adv(rs, 3), bo);
+            issue(adv(ws, 3), tl, (3 + LOOK) % 4);
+            DT_WAIT_RING();
+            quadrant(acc[MH - 1][0], b0);
+            DT_END_PHASE();
+            first_reads = false;
+            rs = adv(rs, 4);
+            ws = adv(ws, 4);
+        };
+        static_assert(LOOK % 4 == 0, "the kinds issued by the four phases follow the phase only when the look-ahead is a whole number of K-tiles");
+        int t = 0;
+        for (; t + 1 < T; t += 2) {
+            ktile(t, fbx, fby);
+            ktile(t + 1, fby, fbx);
+        }
+        if (t < T) ktile(t, fbx, fby);
+#undef DT_WAIT_RING
+    } else if constexpr (MH == 2) {
+        // ---- prologue: K-tile 0 whole, then A0 / B0 of K-tile 1 (the order the phases below continue: B1(t+1), A1(t+1), A0(t+2), B0(t+2)) ----
+        dma_a(0, 0); dma_b(0, 0); dma_b(0, 1); dma_a(0, 1);
+        dma_a(1, 0); dma_b(1, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-tile 0 has landed (the two youngest half-tiles may fly)
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs half a phase behind
 
-    for (int t = 0; t < T; ++t) {
-        // phase 1: quadrant (0, 0)
-        read_a(t, 0);
-        read_b(t, 0, fb0);
-        dma_b(t + 1, 1);
-        DT_WAIT_BARRIER();
-        quadrant(acc[0][0], fb0);
-        DT_END_PHASE();
-        // phase 2: quadrant (0, 1)
-        read_b(t, 1, fb1);
-        dma_a(t + 1, 1);
-        DT_WAIT_BARRIER();
-        quadrant(acc[0][1], fb1);
-        DT_END_PHASE();
-        // phase 3: quadrant (1, 1)
-        read_a(t, 1);
-        dma_a(t + 2, 0);
-        DT_WAIT_BARRIER();
-        quadrant(acc[1][1], fb1);
-        DT_END_PHASE();
-        // phase 4: quadrant (1, 0) -- B0 is still in registers
-        dma_b(t + 2, 0);
-        DT_WAIT_BARRIER();
-        quadrant(acc[1][0], fb0);
-        DT_END_PHASE();
+        for (int t = 0; t < T; ++t) {
+            const int bo = (t & 1) * BUFSZ;
+            // phase 1: quadrant (0, 0)
+            read_a(bo, 0);
+            read_b(bo, 0, fb0);
+            dma_b(t + 1, 1);
+            DT_WAIT_BARRIER();
+            quadrant(acc[0][0], fb0);
+            DT_END_PHASE();
+            // phase 2: quadrant (0, 1)
+            read_b(bo, 1, fb1);
+            dma_a(t + 1, 1);
+            DT_WAIT_BARRIER();
+            quadrant(acc[0][1], fb1);
+            DT_END_PHASE();
+            // phase 3: quadrant (1, 1)
+            read_a(bo, 1);
+            dma_a(t + 2, 0);
+            DT_WAIT_BARRIER();
+            quadrant(acc[MH - 1][1], fb1);
+            DT_END_PHASE();
+            // phase 4: quadrant (1, 0) -- B0 is still in registers
+            dma_b(t + 2, 0);
+            DT_WAIT_BARRIER();
+            quadrant(acc[MH - 1][0], fb0);
+            DT_END_PHASE();
+            first_reads = false;
+        }
+    } else {
+        // ---- 128-row tile: two phases per K-tile, ring of three K-tile buffers.  Issue order (per wave): A.0 A.1 B0.0 | B0.1 B1.0 B1.1 of K-tile t + 2 in the
+        //      phases 1 | 2 of K-tile t; the prologue issues K-tiles 0 and 1 in that same order.  A slot is refilled one phase or more after its last read
+        //      (A, B0 of K-tile t - 1: phase 1; B1: phase 2 -- both behind the barrier that ends phase 2 of t - 1) and read one phase after the wait that
+        //      retired it: phase 1 reads A, B0 of t (retired by phase 2 of t - 1: everything up to B0.1(t), i.e. all but B1(t) + the six of t + 1 = vmcnt(8))
+        //      and phase 2 reads B1(t) (retired by phase 1 of t: all but the six of t + 1 and the three just issued = vmcnt(9)) ----
+        dma_a1(0, 0, 0, 0); dma_a1(0, 0, 0, 1); dma_b1(0, 0, 0, 0); dma_b1(0, 0, 0, 1); dma_b1(0, 0, 1, 0); dma_b1(0, 0, 1, 1);
+        dma_a1(BUFSZ, 1, 0, 0); dma_a1(BUFSZ, 1, 0, 1); dma_b1(BUFSZ, 1, 0, 0); dma_b1(BUFSZ, 1, 0, 1); dma_b1(BUFSZ, 1, 1, 0); dma_b1(BUFSZ, 1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A, B0 of K-tile 0 have landed
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs half a phase behind
+        int bo = 0, bn = 2 * BUFSZ;                       // byte offsets of the buffers of K-tiles t and t + 2
+        for (int t = 0; t < T; ++t) {
+            // phase 1: quadrant (0, 0)
+            read_a(bo, 0);
+            read_b(bo, 0, fb0);
+            dma_a1(bn, t + 2, 0, 0); dma_a1(bn, t + 2, 0, 1); dma_b1(bn, t + 2, 0, 0);
+            DT_WAIT_BARRIER_N(9);
+            quadrant(acc[0][0], fb0);
+            DT_END_PHASE();
+            // phase 2: quadrant (0, 1) -- A is still in registers
+            read_b(bo, 1, fb1);
+            dma_b1(bn, t + 2, 0, 1); dma_b1(bn, t + 2, 1, 0); dma_b1(bn, t + 2, 1, 1);
+            DT_WAIT_BARRIER_N(8);
+            quadrant(acc[0][1], fb1);
+            DT_END_PHASE();
+            first_reads = false;
+            bo = bo == (NBUF - 1) * BUFSZ ? 0 : bo + BUFSZ;
+            bn = bn == (NBUF - 1) * BUFSZ ? 0 : bn + BUFSZ;
+        }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();        // balances wave row 1's extra barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued DMAs must not land in LDS after the workgroup has gone
+#undef DT_WAIT_BARRIER_N
 #undef DT_WAIT_BARRIER
 #undef DT_END_PHASE
 
-    // ---- epilogue.  acc[mh][nh][mt][nb][r] = C[m0 + wr*128 + mh*64 + mt*16 + 4 fq + r][(nt0 + wc*4 + nh*2 + nb)*16 + fr] ----
+    // ---- epilogue.  acc[mh][nh][mt][nb][r] = C[m0 + wr*WROWS + mh*64 + mt*16 + 4 fq + r][(nt0 + wc*4 + nh*2 + nb)*16 + fr] ----
     // bf16 outputs go through the wave's own 16 KiB of the (now idle) LDS: each value is written once as bf16 -- after the bias / GELU / SwiGLU
     // arithmetic, i.e. at the reference's rounding point in front of the residual add -- and read back as 16 bytes per lane, so that a store
     // instruction covers 8 rows x 128 contiguous bytes instead of 4 rows x 32 (the accumulator layout) and the residual is read the same way.
@@ -200,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
             __builtin_amdgcn_s_barrier();  // every wave has finished its last fragment reads (and all DMAs have landed): LDS is free
             unsigned char* mine = smem + wave * 16384;
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
+            for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     float bv[2] = {0.f, 0.f};
@@ -239,9 +381,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
             const int gcol = col0 + lc * 8;
             const bool cvalid = gcol < g.n_valid;
 #pragma unroll
-            for (int it = 0; it < 128 / RPI; ++it) {
+            for (int it = 0; it < WROWS / RPI; ++it) {
                 const int lrow = it * RPI + lr;
-                const int row = m0 + wr * 128 + lrow;
+                const int row = m0 + wr * WROWS + lrow;
                 u32x4_t v = *reinterpret_cast<const u32x4_t*>(mine + lrow * RSTRIDE + ((lc ^ (((lrow >> 2) & 3) << SWS)) << 4));
                 if (row < g.M && cvalid) {
                     if constexpr (EPI == EPI_RES || EPI == EPI_BIAS_RES) {
@@ -259,12 +401,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
     }
     // general form (fp32 outputs, ragged n_valid / unaligned rows): straight from the accumulators
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
+    for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wr * 128 + mh * 64 + mt * 16 + fq * 4 + r;
+                const int row = m0 + wr * WROWS + mh * 64 + mt * 16 + fq * 4 + r;
                 if (row >= g.M) continue;
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
@@ -298,12 +440,109 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
             }
 }
 
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int raster, DenseSched sc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x 64 KiB (256-row tiles) or 3 x 48 KiB (launches with 128-row tiles): all LDS of the kernel (a second object would make hipcc drain the DMAs)
+    const int NTILES = g.N >> 4;
+    const int KTILES = g.K / DT_K;
+    if (!sc.folded) {  // ---- the plain grid: 256-row tiles only ----
+        int bx = blockIdx.x, by = blockIdx.y;
+        if (raster) {  // XCD-aware tile order: the workgroups an XCD runs at a time form a patch of 8 column blocks x all row blocks (gemm_tiled.hip)
+            const int X = (NTILES + DT_NT - 1) / DT_NT, Y = (g.M + DT_M - 1) / DT_M;
+            const int n_per = gridDim.x >> 3;
+            const int S = (blockIdx.x & 7) * n_per + (blockIdx.x >> 3);
+            if (S >= X * Y) return;
+            const int patch = S / (8 * Y), r = S - patch * (8 * Y);
+            const int pw = min(8, X - patch * 8);
+            by = r / pw;
+            bx = patch * 8 + r % pw;
+        }
+        const int ks = (EPI == EPI_PARTIAL && g.ksplit > 1) ? g.ksplit : 1;
+        const int slice = (EPI == EPI_PARTIAL) ? blockIdx.z : 0;
+        const int T = KTILES / ks;                  // K-tiles of this workgroup
+        dense_tile<EPI, 2>(g, smem, by * DT_M, bx * DT_NT, slice, T, (long)slice * T * DT_K);
+        return;
+    }
+    // ---- mixed launch: XCD c (= blockIdx.x & 7: the workgroups that share an L2) owns the column blocks [c X / 8, (c + 1) X / 8) and walks, in dispatch order,
+    //      its 256-row tiles (all K slices), then its 128-row tiles: the longest work first, so that the short tiles fill the last round.  Inside a class the
+    //      order is (slice, patch of 8 column blocks x all row blocks of the class, column fastest) as above ----
+    const int xcd = blockIdx.x & 7;
+    int local = blockIdx.x >> 3;
+    const int c0 = xcd * sc.X / 8, cx = (xcd + 1) * sc.X / 8 - c0;
+    const int ks = sc.ks;
+    const int nf = sc.n_full * cx * ks;
+    const bool half = local >= nf;
+    if (half) local -= nf;
+    const int Y = half ? sc.n_half : sc.n_full;
+    if (local >= Y * cx * ks) return;
+    const int slice = local / (Y * cx);
+    const int S = local - slice * (Y * cx);
+    const int patch = S / (8 * Y), r = S - patch * (8 * Y);
+    const int pw = min(8, cx - patch * 8);
+    const int by = r / pw, bx = c0 + patch * 8 + r % pw;
+    // K-tiles of slice s: KTILES / ks, the first KTILES % ks slices one more (slab s holds the partial sum over exactly these K-tiles)
+    const int tq = KTILES / ks, trem = KTILES - tq * ks;
+    const int T = tq + (slice < trem ? 1 : 0);
+    const long k0 = ((long)slice * tq + min(slice, trem)) * DT_K;
+    if (half) dense_tile<EPI, 1>(g, smem, sc.n_full * DT_M + by * (DT_M / 2), bx * DT_NT, slice, T, k0);
+    else dense_tile<EPI, 2>(g, smem, by * DT_M, bx * DT_NT, slice, T, k0);
+}
+
 static int g_dense_mode = 1;  // tuning hook (gemm_dense_set): 0 = never, 1 = heuristic, 2 = wherever supported
-void gemm_dense_set(int mode) { g_dense_mode = mode; }
+static int g_dense_mix = 0;   // ... / 10: 0 = the model below picks the tile mix, 1 = 256-row tiles only (rounds 1-5), 2 = 128-row tiles only, 100 + h = exactly h row blocks of 128
+void gemm_dense_set(int mode) { g_dense_mode = mode % 10; g_dense_mix = mode / 10; }
+
+// ---- tile mix.  List-scheduling model of ONE XCD (32 CUs, its share of the column blocks, tiles dealt in dispatch order to the CU that frees up first): a
+//      256-row tile over all of K costs 1, a 128-row tile DENSE_HALF_COST (measured: profiles/r06/dense_half_tiles_probe.txt -- more than 0.5, the half tile
+//      streams the same weight bytes for half the MFMAs), every workgroup DENSE_WG_COST on top (DMA ring fill + epilogue). ----
+#ifndef DENSE_HALF_COST
+#define DENSE_HALF_COST 0.62
+#endif
+#define DENSE_WG_COST 0.03
+static double dense_makespan(int n_full, int n_half, int cx, int ks) {
+    double cu[32];
+    for (int i = 0; i < 32; ++i) cu[i] = 0.0;
+    auto run = [&](int count, double cost) {
+        for (int k = 0; k < count; ++k) {
+            int best = 0;
+            for (int i = 1; i < 32; ++i)
+                if (cu[i] < cu[best]) best = i;
+            cu[best] += cost;
+        }
+    };
+    run(n_full * cx * ks, 1.0 / ks + DENSE_WG_COST);
+    run(n_half * cx * ks, DENSE_HALF_COST / ks + DENSE_WG_COST);
+    double m = 0.0;
+    for (int i = 0; i < 32; ++i) m = cu[i] > m ? cu[i] : m;
+    return m;
+}
+// row blocks of a launch: n_full of 256 rows, then n_half of 128 (n_half == 0: the plain grid).  Returns the model's makespan in units of one 256-row tile over all of K.
+double gemm_dense_pick_mix(int M, int N, int ks, int* n_full, int* n_half) {
+    const int X = (N / 16 + DT_NT - 1) / DT_NT, cx = (X + 7) / 8;
+    const int blocks128 = (M + 127) / 128;
+    int bf = (M + 255) / 256, bh = 0;
+    double best = dense_makespan(bf, 0, cx, ks);
+    if (g_dense_mix == 1) { *n_full = bf; *n_half = 0; return best; }
+    if (g_dense_mix == 2 || g_dense_mix >= 100) {
+        const int h = g_dense_mix == 2 ? blocks128 : (g_dense_mix - 100 < blocks128 ? g_dense_mix - 100 : blocks128);
+        *n_half = h;
+        *n_full = (M - 128 * h + 255) / 256 > 0 ? (M - 128 * h + 255) / 256 : 0;
+        return dense_makespan(*n_full, h, cx, ks);
+    }
+    for (int h = 1; h <= blocks128; ++h) {
+        const int f = M - 128 * h > 0 ? (M - 128 * h + 255) / 256 : 0;
+        if (f * 256 + h * 128 >= M + 128) continue;  // (a mix that covers a whole spare 128-row block)
+        const double c = dense_makespan(f, h, cx, ks);
+        if (c < best - 0.02) { best = c; bf = f; bh = h; }  // (a mixed launch has to win by more than its own uncertainty)
+    }
+    *n_full = bf; *n_half = bh;
+    return best;
+}
 
 bool gemm_dense_supported(const GemmArgs& g) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
-    return g.batch == 1 && g.K % (DT_K * ks) == 0 && g.K / (DT_K * ks) >= 2 && g.lda % 8 == 0 && !g.norm_w && !g.attn_partial && g.M > 64 &&
+    return g.batch == 1 && g.K % DT_K == 0 && (g.K / DT_K) / ks >= 2 && g.lda % 8 == 0 && !g.norm_w && !g.attn_partial && g.M > 64 &&
            (g.epi != EPI_SWIGLU || g.N % 32 == 0);
 }
 // where the 256-row tiles pay (profiles/dense_probe.py, dense_split_probe.py; gemm_tiled's 128 x 128 tiles keep the rest): from 640 rows on everything
@@ -319,22 +558,36 @@ bool gemm_dense_preferred(const GemmArgs& g) { return gemm_dense_would_run(g.M, 
 int launch_gemm_dense(const GemmArgs& g, hipStream_t stream) {
     const int NTILES = g.N / 16;
     const int ks = g.epi == EPI_PARTIAL ? (g.ksplit > 1 ? g.ksplit : 1) : 1;
-    dim3 grid((NTILES + DT_NT - 1) / DT_NT, (g.M + DT_M - 1) / DT_M, ks), block(512);
-    const int raster = (grid.x * grid.y > 256 && grid.y > 1) ? 1 : 0;
-    if (raster) {
+    DenseSched sc{};
+    sc.X = (NTILES + DT_NT - 1) / DT_NT;
+    sc.ks = ks;
+    gemm_dense_pick_mix(g.M, g.N, ks, &sc.n_full, &sc.n_half);
+    sc.folded = (sc.n_half > 0 || (g.K / DT_K) % ks != 0) ? 1 : 0;  // (K slices of unequal length exist in the folded grid only)
+    dim3 grid(sc.X, (g.M + DT_M - 1) / DT_M, ks), block(512);
+    int raster = (grid.x * grid.y > 256 && grid.y > 1) ? 1 : 0;
+    size_t lds = DENSE_RING10 ? 10 * DT_HALF : 2 * DT_BUF;
+    if (sc.folded) {
+        int n_per = 0;
+        for (int c = 0; c < 8; ++c) {
+            const int cx = (c + 1) * sc.X / 8 - c * sc.X / 8;
+            n_per = cx * (sc.n_full + sc.n_half) * ks > n_per ? cx * (sc.n_full + sc.n_half) * ks : n_per;
+        }
+        grid = dim3(8 * n_per, 1, 1);
+        raster = 0;
+        if (sc.n_half > 0 && !DENSE_RING10) lds = 3 * 3 * DT_HALF;
+    } else if (raster) {
         const unsigned tiles = grid.x * grid.y;
         grid.x = ((tiles + 7) / 8) * 8;
         grid.y = 1;
     }
-    const size_t lds = 2 * DT_BUF;
 #define LAUNCH_D(E)                                                                                                                                  \
     do {                                                                                                                                             \
         static bool attr = false;                                                                                                                    \
         if (!attr) {                                                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dense_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP; \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dense_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, 10 * DT_HALF) != hipSuccess) return ISST_ERR_HIP; \
             attr = true;                                                                                                                             \
         }                                                                                                                                            \
-        hipLaunchKernelGGL(gemm_dense_kernel<E>, grid, block, lds, stream, g, raster);                                                               \
+        hipLaunchKernelGGL(gemm_dense_kernel<E>, grid, block, lds, stream, g, raster, sc);                                                           \
     } while (0)
     switch (g.epi) {
         case EPI_NONE: LAUNCH_D(EPI_NONE); break;

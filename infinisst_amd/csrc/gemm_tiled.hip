@@ -51,16 +51,20 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs g, int raster)
     const int ks = (EPI == EPI_PARTIAL && g.ksplit > 1) ? g.ksplit : 1;
     const long b = (EPI == EPI_PARTIAL) ? 0 : blockIdx.z;
     const int slice = (EPI == EPI_PARTIAL) ? blockIdx.z : 0;
-    const int steps = g.K / TK / ks;
-    const bf16_t* A = g.A + b * g.a_batch + (long)slice * steps * TK;
+    // K steps of slice s: (K / TK) / ks, the first (K / TK) % ks slices one more (the same partition as gemm_dense.hip's folded grid: slab s is the partial sum over
+    // exactly these steps in both kernels)
+    const int ksteps = g.K / TK, sq = ksteps / ks, srem = ksteps - sq * ks;
+    const int steps = sq + (slice < srem ? 1 : 0);
+    const long kstart = (long)slice * sq + min(slice, srem);  // first K step of the slice
+    const bf16_t* A = g.A + b * g.a_batch + kstart * TK;
 
     // staging role: thread t moves 4 x 16 bytes of row (t >> 1): chunks 4*(t & 1) .. +3
     const int srow = tid >> 1, sc0 = (tid & 1) * 4;
     const int grow = min(m0 + srow, g.M - 1);
     const bf16_t* aptr = A + (long)grow * g.lda + sc0 * 8;
     const bool nv0 = nt0 < NTILES, nv1 = nt0 + 1 < NTILES;
-    const u32x4_t* w0 = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(nv0 ? nt0 : 0) * KT + (long)slice * steps * 2) * 64 + lane;
-    const u32x4_t* w1 = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(nv1 ? nt0 + 1 : 0) * KT + (long)slice * steps * 2) * 64 + lane;
+    const u32x4_t* w0 = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(nv0 ? nt0 : 0) * KT + kstart * 2) * 64 + lane;
+    const u32x4_t* w1 = reinterpret_cast<const u32x4_t*>(g.Wp) + ((long)(nv1 ? nt0 + 1 : 0) * KT + kstart * 2) * 64 + lane;
 
     f32x4_t acc[8][2];
 #pragma unroll
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(GemmArgs g, int raster)
 bool gemm_tiled_supported(const GemmArgs& g) {
     const int ks = g.ksplit > 1 ? g.ksplit : 1;
     if (g.epi == EPI_PARTIAL && g.batch != 1) return false;
-    return g.K % (TK * ks) == 0 && g.lda % 8 == 0 && !g.norm_w && (g.M > 64 || g.batch > 1);
+    return g.K % TK == 0 && (g.K / TK) / ks >= 1 && g.lda % 8 == 0 && !g.norm_w && (g.M > 64 || g.batch > 1);
 }
 
 static int g_tiled_raster = 1;  // tuning hook (gemm_tiled_set_raster): 0 = plain 2-D grid always, 1 = heuristic, 2 = rasterised always

@@ -488,6 +488,59 @@ def test_gemm_dense_split_k_slabs(M, N, K, ks):
     close_bf16(n1, ollm.rmsnorm(x1.cpu(), nw, 1e-5), "norm of the updated rows", ulps=2.0, atol=1e-3)
 
 
+def _dense_mix(mix):
+    E.load_library().isst_op_set_gemm_tuning(800000 + 2 + 10 * mix, 0)  # gemm_dense.hip wherever it can run; tile mix: 0 = the model, 1 = 256-row tiles only, 2 = 128-row only, 100 + h
+
+
+@pytest.mark.parametrize("M,N,K", [(1408, 1024, 1024), (700, 2304, 512), (129, 256, 256), (1000, 272, 192)])
+def test_gemm_dense_tile_mixes_are_bit_identical(M, N, K):
+    """Round 6: one launch may hold row blocks of 256 rows (8-wave ping-pong over four quadrants) AND of 128 rows (two quadrants per wave, three K-tile buffers),
+    dealt to the XCDs longest first through a folded 1-D grid.  Every mix -- the launcher's own choice, 128-row tiles only, h blocks of 128 behind blocks of
+    256, ragged last blocks, column counts that do not divide by the 8 XCD shares -- must give the bits of the 256-row-tiles-only form (and so of gemm_tiled)."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf(torch.randn(N, generator=g)).to(DEV)
+    res = bf(torch.randn(M, N, generator=g)).to(DEV)
+    Wp = E.op_pack_weight(W.to(DEV))
+    nb = (M + 127) // 128
+    try:
+        for epi in ("none", "bias_gelu", "bias_res", "f32") + (("swiglu",) if N % 32 == 0 else ()):
+            kw = dict(bias=bias if "bias" in epi else None, res=res if "res" in epi else None)
+            _dense_mode(0)
+            want = E.op_gemm(A, Wp, N, epi, **kw)
+            for mix in [1, 0, 2] + [100 + h for h in sorted({1, 2, 3, nb - 1, nb}) if 1 <= h <= nb]:
+                _dense_mix(mix)
+                got = E.op_gemm(A, Wp, N, epi, **kw)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), f"mix {mix} {epi} M{M} N{N} K{K}: {int((got != want).sum())} elements differ from gemm_tiled"
+    finally:
+        _dense_mode(1)
+
+
+@pytest.mark.parametrize("M,N,K,ks", [(1408, 512, 4096, 3), (700, 256, 1536, 5), (384, 1024, 2048, 7), (1408, 512, 1024, 2)])
+def test_gemm_dense_uneven_k_slices_and_mixes(M, N, K, ks):
+    """K slices of unequal length (K / 64 not a multiple of the slice count: the first (K / 64) % ks slices take one K-tile more) in the dense kernel's folded
+    grid, for every tile mix, against gemm_tiled.hip cutting K at the same places: slabs summed in slice order by the reducing RMSNorm -> identical bits."""
+    g = torch.Generator().manual_seed(M + N + K + ks)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    x = bf(torch.randn(M, N, generator=g)).to(DEV)
+    nw = bf(1 + 0.2 * torch.randn(N, generator=g)).to(DEV)
+    Wp = E.op_pack_weight(W.to(DEV))
+    try:
+        _dense_mode(0)
+        x0, n0 = E.op_gemm_splitk_rmsnorm(A, Wp, x, ks, nw)
+        for mix in (1, 0, 2, 101):
+            _dense_mix(mix)
+            x1, n1 = E.op_gemm_splitk_rmsnorm(A, Wp, x, ks, nw)
+            assert torch.equal(x0, x1) and torch.equal(n0, n1), f"mix {mix}"
+    finally:
+        _dense_mode(1)
+    want = bf(x.cpu().float() + bf(A.cpu().float() @ W.float().t()).float())
+    close_bf16(x1.cpu(), want, f"dense split-K M{M} N{N} K{K} ks{ks}", ulps=2.5, atol=3.2e-2)
+
+
 def test_in_launch_reduction_under_uneven_load():
     """The cross-workgroup hand-off of the in-launch reduction (sc1 slabs, drained, one agent-scope ticket per workgroup, the last arriver reads every
     slice with sc1 loads) checked the way MI355X_MICROARCH.md asks for hand-offs: under UNEVEN load, every word, many times.  A second stream keeps the
