@@ -128,6 +128,9 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     if (const char* e = getenv("ISST_ROT_KEYS")) h->rot_keys = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_COMBINE")) h->fuse_combine = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSE_REDUCE")) h->fuse_reduce = e[0] && e[0] != '0';
+    if (const char* e = getenv("ISST_GEMM_TUNING")) {  // A/B aid: comma-separated gemm_set_tuning codes (e.g. 800011 = gemm_dense with 256-row tiles only)
+        for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr) gemm_set_tuning(atoi(q), 0);
+    }
     if (const char* e = getenv("ISST_ROPE_SIDE")) h->rope_side = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_ROPE_FUSE")) h->rope_fuse = e[0] && e[0] != '0';
     if (const char* e = getenv("ISST_FUSED_SAMPLE")) h->fused_sample = e[0] && e[0] != '0';

@@ -27,6 +27,13 @@ int gemm(isst_handle* h, const bf16_t* A, long lda, const PackedLinear& L, int e
 // (the dense kernel keeps 3 workgroups per CU resident, 768 chip-wide: slicing up to that count instead of 384 and up to 2048 rows instead of
 //  1024 gave, same box, 64 / 32 / 16 / 8 streams 100.6 -> 99.7 / 71.5 -> 70.0 / 53.8 -> 53.4 / 45.9 -> 45.3 ms per chunk; 1152 was worse again at 16-32)
 int pick_ksplit(int K, int N, int rows, long slab_cap) {
+    if (rows > 64) {  // A/B aid: ISST_KSPLIT="K:N:s,..." forces s slices for the projection K -> N at many rows (in-situ comparisons of slice counts)
+        if (const char* e = getenv("ISST_KSPLIT")) {
+            int k = 0, n = 0, sv = 0;
+            for (const char* q = e; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr)
+                if (sscanf(q, "%d:%d:%d", &k, &n, &sv) == 3 && k == K && n == N && sv >= 1 && (long)sv * rows * N <= slab_cap) return sv;
+        }
+    }
     if (rows <= 64) {
         // (N <= 2048 = the encoder's out_proj / fc2, 16..32 column blocks: fc2 20.1 us as GEMM + LayerNorm, 16.6 / 14.7 / 16.5 us with 2 / 4 / 8 slices
         //  + the reducing LayerNorm; out_proj 14.2 -> 11.5 us with 2: profiles/enc_probe.py)
@@ -49,18 +56,20 @@ int pick_ksplit(int K, int N, int rows, long slab_cap) {
         return s;
     }
     if (gemm_dense_would_run(rows, N, K)) {
-        // gemm_dense.hip, one workgroup per CU: the launcher's own list-scheduling model (gemm_dense_pick_mix: 256- and 128-row tiles dealt longest first to
-        // the 32 CUs of an XCD) gives the GEMM's length in units of one 256-row tile over all of K; on top, in units of such a tile at K = 4096 (~75 us): no
-        // slices = the residual goes through the GEMM's epilogue and a plain norm launch follows (0.11); slices = slab writes + the reducing norm (0.20 + 0.04
-        // per slice).  Round 6, profiles/r06/dense_mix_probe_1408.txt (GEMM + norm, us, 1408 rows): o_proj 57 unsplit on 128-row tiles / 67 in 2 slices of
-        // 256-row tiles / 77 in 4; down_proj 184 unsplit / 153 in 2 / 159 in 4 (mixed) / 163 in 5.  (Rounds 3-5 chose among powers of two by rounds of 256-row
-        // tiles only: o_proj 2, down_proj 2 at 1408 rows.)
+        // 256 x 256 tiles, one workgroup per CU (gemm_dense.hip): rounds of 1/s-length tiles + the slab traffic each further slice adds (write + read of
+        // rows x N fp32: about 4 % of a round per slice at these shapes).  profiles/dense_split_probe.py, GEMM + reducing norm, us:
+        //   1408 rows  o_proj 82.7 / 62.4 / 79.9 / 102.0 for 1 / 2 / 4 / 8 slices, down_proj 241 / 161 / 178 / 183;   704 rows  o_proj 79 / 52 / 43 / 59, down 248 / 139 / 94 / 116
+        // (Round 6 tried the unsplit launch on 128-row tiles instead -- 176 workgroups that walk all of K, the residual in the GEMM's epilogue and a plain norm
+        //  launch behind it.  A probe with the weights resident in the Infinity Cache liked it (o_proj 49.5 + 8 us against 67 in two slices); INSIDE a step,
+        //  weights from HBM, the half tiles -- which stream the same weight bytes for half the MFMAs and are bound by the L2 -> LDS path -- took 63.7 + 6.0 us
+        //  against ~50 + 16.5, and the encoder's out_proj / fc2 at 3072 rows lost the same way: +0.44 ms per 64-stream step, same box, kernel traces of both
+        //  libraries (profiles/r06/trace_same_box_*.txt).  The slices stay.)
+        const long tiles = (long)((N + 255) / 256) * ((rows + 255) / 256);
         int best = 1;
         double best_cost = 1e30;
-        for (int s = 1; s <= LLM_KSPLIT_MAX; ++s) {
-            if ((K / 64) / s < 4 || (s > 1 && (long)s * rows * N > slab_cap)) break;
-            int nf = 0, nh = 0;
-            const double cost = gemm_dense_pick_mix(rows, N, s, &nf, &nh) * (K / 4096.0) + (s == 1 ? 0.11 : 0.20 + 0.04 * s);
+        for (int s = 1; s <= LLM_KSPLIT_MAX; s *= 2) {
+            if (K % (64 * s) != 0 || K / (64 * s) < 4 || (s > 1 && (long)s * rows * N > slab_cap)) break;
+            const double cost = (double)((tiles * s + 255) / 256) / s + 0.04 * s;
             if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
         }
         return best;
@@ -1137,9 +1146,9 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
             mh.groups[n_groups].y = std::min(gmax, elen - t);
             ++n_groups;
         }
-        for (int g0 = g_first; g0 < n_groups; g0 += 8) {  // units: runs of <= 8 groups of this stream share their key tiles
+        for (int g0 = g_first; g0 < n_groups; g0 += LLM_PREFILL_UNIT_GROUPS) {  // units: runs of <= 6 groups of this stream share their key tiles (llm_attn_prefill_kernel's consumer waves)
             mh.units[n_units].x = g0;
-            mh.units[n_units].y = std::min(8, n_groups - g0);
+            mh.units[n_units].y = std::min(LLM_PREFILL_UNIT_GROUPS, n_groups - g0);
             max_unit_groups = std::max(max_unit_groups, mh.units[n_units].y);
             ++n_units;
         }

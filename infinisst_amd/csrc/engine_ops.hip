@@ -186,8 +186,8 @@ extern "C" int isst_op_llm_attention(const uint16_t* qkv, int rows, int pos0, ui
     std::vector<int2> groups, units;
     for (int t = 0; t < rows; t += gmax) groups.push_back(make_int2(t, std::min(gmax, rows - t)));
     int max_unit_groups = 0;
-    for (int g0 = 0; g0 < (int)groups.size(); g0 += 8) {
-        units.push_back(make_int2(g0, std::min(8, (int)groups.size() - g0)));
+    for (int g0 = 0; g0 < (int)groups.size(); g0 += LLM_PREFILL_UNIT_GROUPS) {
+        units.push_back(make_int2(g0, std::min(LLM_PREFILL_UNIT_GROUPS, (int)groups.size() - g0)));
         max_unit_groups = std::max(max_unit_groups, units.back().y);
     }
     const size_t off_pos = sizeof(int) * rows, off_view = off_pos + sizeof(int) * rows, off_groups = (off_view + sizeof v + 15) / 16 * 16,

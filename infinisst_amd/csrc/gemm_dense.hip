@@ -464,23 +464,25 @@ __global__ __launch_bounds__(512, 2) void gemm_dense_kernel(GemmArgs g, int rast
         dense_tile<EPI, 2>(g, smem, by * DT_M, bx * DT_NT, slice, T, (long)slice * T * DT_K);
         return;
     }
-    // ---- mixed launch: XCD c (= blockIdx.x & 7: the workgroups that share an L2) owns the column blocks [c X / 8, (c + 1) X / 8) and walks, in dispatch order,
-    //      its 256-row tiles (all K slices), then its 128-row tiles: the longest work first, so that the short tiles fill the last round.  Inside a class the
-    //      order is (slice, patch of 8 column blocks x all row blocks of the class, column fastest) as above ----
+    // ---- folded launch: the tiles of a class (256-row, then 128-row) form ONE sequence -- (slice, patch of 8 column blocks x all row blocks of the class, column
+    //      fastest), the plain grid's order -- and XCD c (= blockIdx.x & 7: the workgroups that share an L2) takes the c-th eighth of each sequence: it walks, in
+    //      dispatch order, its 256-row tiles and then its 128-row tiles, the longest work first, so that the short tiles fill the last round.  (A first form
+    //      dealt whole COLUMN blocks to the XCDs: with 4 column blocks -- the encoder's out_proj / fc2 -- half the chip had no work.) ----
     const int xcd = blockIdx.x & 7;
-    int local = blockIdx.x >> 3;
-    const int c0 = xcd * sc.X / 8, cx = (xcd + 1) * sc.X / 8 - c0;
+    const int local = blockIdx.x >> 3;
     const int ks = sc.ks;
-    const int nf = sc.n_full * cx * ks;
-    const bool half = local >= nf;
-    if (half) local -= nf;
+    const int NF = sc.n_full * sc.X * ks, NH = sc.n_half * sc.X * ks;
+    const int f0 = (int)((long)xcd * NF / 8), f1 = (int)((long)(xcd + 1) * NF / 8);
+    const int h0 = (int)((long)xcd * NH / 8), h1 = (int)((long)(xcd + 1) * NH / 8);
+    const bool half = local >= f1 - f0;
+    const int idx = half ? h0 + local - (f1 - f0) : f0 + local;
+    if (half && idx >= h1) return;
     const int Y = half ? sc.n_half : sc.n_full;
-    if (local >= Y * cx * ks) return;
-    const int slice = local / (Y * cx);
-    const int S = local - slice * (Y * cx);
+    const int slice = idx / (Y * sc.X);
+    const int S = idx - slice * (Y * sc.X);
     const int patch = S / (8 * Y), r = S - patch * (8 * Y);
-    const int pw = min(8, cx - patch * 8);
-    const int by = r / pw, bx = c0 + patch * 8 + r % pw;
+    const int pw = min(8, sc.X - patch * 8);
+    const int by = r / pw, bx = patch * 8 + r % pw;
     // K-tiles of slice s: KTILES / ks, the first KTILES % ks slices one more (slab s holds the partial sum over exactly these K-tiles)
     const int tq = KTILES / ks, trem = KTILES - tq * ks;
     const int T = tq + (slice < trem ? 1 : 0);
@@ -500,7 +502,7 @@ void gemm_dense_set(int mode) { g_dense_mode = mode % 10; g_dense_mix = mode / 1
 #define DENSE_HALF_COST 0.62
 #endif
 #define DENSE_WG_COST 0.03
-static double dense_makespan(int n_full, int n_half, int cx, int ks) {
+static double dense_makespan(int n_full, int n_half, int X, int ks) {
     double cu[32];
     for (int i = 0; i < 32; ++i) cu[i] = 0.0;
     auto run = [&](int count, double cost) {
@@ -511,15 +513,15 @@ static double dense_makespan(int n_full, int n_half, int cx, int ks) {
             cu[best] += cost;
         }
     };
-    run(n_full * cx * ks, 1.0 / ks + DENSE_WG_COST);
-    run(n_half * cx * ks, DENSE_HALF_COST / ks + DENSE_WG_COST);
+    run((n_full * X * ks + 7) / 8, 1.0 / ks + DENSE_WG_COST);   // (the XCD with the largest eighth)
+    run((n_half * X * ks + 7) / 8, DENSE_HALF_COST / ks + DENSE_WG_COST);
     double m = 0.0;
     for (int i = 0; i < 32; ++i) m = cu[i] > m ? cu[i] : m;
     return m;
 }
 // row blocks of a launch: n_full of 256 rows, then n_half of 128 (n_half == 0: the plain grid).  Returns the model's makespan in units of one 256-row tile over all of K.
 double gemm_dense_pick_mix(int M, int N, int ks, int* n_full, int* n_half) {
-    const int X = (N / 16 + DT_NT - 1) / DT_NT, cx = (X + 7) / 8;
+    const int X = (N / 16 + DT_NT - 1) / DT_NT, cx = X;  // (dense_makespan takes the column blocks of the launch)
     const int blocks128 = (M + 127) / 128;
     int bf = (M + 255) / 256, bh = 0;
     double best = dense_makespan(bf, 0, cx, ks);
@@ -530,6 +532,11 @@ double gemm_dense_pick_mix(int M, int N, int ks, int* n_full, int* n_half) {
         *n_full = (M - 128 * h + 255) / 256 > 0 ? (M - 128 * h + 255) / 256 : 0;
         return dense_makespan(*n_full, h, cx, ks);
     }
+    // Mixes only where the 256-row tiles alone make MORE THAN TWO rounds of the chip: a 128-row tile streams the same weight bytes for half the MFMAs, and inside a
+    // step (weights from HBM, not from the Infinity Cache as in a back-to-back probe) it is bound by the L2 -> LDS path -- measured in situ, same box, kernel traces
+    // (profiles/r06/trace_same_box_80001*.txt): gate/up at 1408 rows 279.4 -> 264.7 us with 4 x 256 + 3 x 128 rows, but every one-round launch that took half
+    // tiles lost (o_proj unsplit 63.7 + 6.0 us against ~50 + 16.5 in two slices; the encoder's out_proj / fc2 likewise)
+    if ((long)bf * X * ks <= 2 * 256) { *n_full = bf; *n_half = 0; return best; }
     for (int h = 1; h <= blocks128; ++h) {
         const int f = M - 128 * h > 0 ? (M - 128 * h + 255) / 256 : 0;
         if (f * 256 + h * 128 >= M + 128) continue;  // (a mix that covers a whole spare 128-row block)
@@ -568,9 +575,10 @@ int launch_gemm_dense(const GemmArgs& g, hipStream_t stream) {
     size_t lds = DENSE_RING10 ? 10 * DT_HALF : 2 * DT_BUF;
     if (sc.folded) {
         int n_per = 0;
+        const int NF = sc.n_full * sc.X * ks, NH = sc.n_half * sc.X * ks;
         for (int c = 0; c < 8; ++c) {
-            const int cx = (c + 1) * sc.X / 8 - c * sc.X / 8;
-            n_per = cx * (sc.n_full + sc.n_half) * ks > n_per ? cx * (sc.n_full + sc.n_half) * ks : n_per;
+            const int cnt = (int)((long)(c + 1) * NF / 8 - (long)c * NF / 8) + (int)((long)(c + 1) * NH / 8 - (long)c * NH / 8);
+            n_per = cnt > n_per ? cnt : n_per;
         }
         grid = dim3(8 * n_per, 1, 1);
         raster = 0;

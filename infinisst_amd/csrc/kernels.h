@@ -69,6 +69,7 @@ struct LlmAttnDims {
 // row count): runs of consecutive rows of ONE stream, at most LLM_ATTN_GROUP_ROWS(G) rows each.
 // partial: [rows][heads][slots/64][2 + 128] fp32.
 #define LLM_ATTN_GROUP_ROWS(G) (16 / (G))
+#define LLM_PREFILL_UNIT_GROUPS 6  // row groups of one stream a prefill workgroup serves (llm_attn.hip PREFILL_MAX_GROUPS: six consumer waves + two key loader waves)
 void llm_attn_set_tuning(int target_wgs);  // workgroups wanted before slot spans grow beyond 64 (0 = default)
 // Launch metadata of a ONE-group launch (one stream's decode step or short prefill) passed by value in the kernel arguments:
 // the workgroups then start their key loads at once instead of after three dependent loads (groups -> row_stream/row_pos ->

@@ -707,6 +707,7 @@ __global__ __launch_bounds__(FUSED_WAVES * 64, 1) void llm_attn_oproj_kernel(con
 // no cross-wave merge; with a single split it writes the attention output itself.
 // ------------------------------------------------------------------------------------------------------------------------
 #define PREFILL_MAX_WAVES 8
+#define PREFILL_MAX_GROUPS 6  // row groups of a unit = consumer waves (the other two waves stage the keys)
 #define PF_ST 4  // key / value tiles per staged step (2 loader waves each)
 #define LLM_ATTN_PREFILL_TARGET_WGS 512
 template <int G>
@@ -766,6 +767,90 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) vr_off[nt] = v_off(4 * fq + tq, 2 * nt + (tp >> 1)) + 8 * (tp & 1);
 
+    // ---- roles (round 6; the launch always has 8 waves).  Waves 0 .. 5 are the CONSUMERS, one per row group of the unit (a unit holds at most
+    //      PREFILL_MAX_GROUPS = 6 groups); waves 0 .. 3 also stage the VALUE tile `wave` of every stage (four 16-byte loads and four LDS writes per lane: nothing).
+    //      Waves 6 and 7 are the KEY loaders, two tiles of every stage each: they rotate (rotate-on-read, or the fill of the rotated-key arena), append the
+    //      unit's own keys and write the key images.  Rounds 2-5 made every wave a loader (even waves keys, odd waves values): the three consumers on even
+    //      waves then carried a rotation of 32 dims per lane and stage on top of their four score / softmax / P.V tiles -- waves 0 and 4 share SIMD 0, which
+    //      had 2800 issue slots per stage where SIMD 3 had 1000 (profiles/r06/prefill_attention_roles.txt) -- and the rotation's temporaries met the
+    //      accumulators in ONE register budget (128 at two workgroups per CU): 25 spilled registers in the loop.  With the roles apart the kernel does not spill. ----
+    struct Fetch { u32x4_t raw[4]; int t0, jk; bool is_new, valid; };
+    auto fetch = [&](int stage_first, int slot, bool is_k, Fetch& f) {  // tile `slot` of the stage that starts at compact index stage_first
+        const int tc = stage_first + slot;
+        f.valid = tc < tile_end;
+        f.t0 = phys(f.valid ? tc : tile_begin) * 16;
+        f.jk = llm_logical(v, d, f.t0 + fr, total_u);
+        f.is_new = f.jk >= 0 && f.jk >= v.new_start;
+        const int krow = v.row0 + (f.jk - v.new_start);
+        const bf16_t* src;
+        if (is_k) src = f.is_new ? qkv + (long)krow * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(f.t0 + fr) * HD;
+        else src = f.is_new ? qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD : vb + (long)(f.t0 + fr) * HD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f.raw[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+    };
+    auto commit_k = [&](int buf, int slot, const Fetch& f) {
+        if (!f.valid) return;  // (wave-uniform)
+        const int krow = v.row0 + (f.jk - v.new_start);
+        const bool mine = f.is_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;  // a key of this unit's own rows: append it
+        u32x4_t kf[4];
+        if (!rot || __any(f.is_new)) {
+            rope_row_chunks(f.raw, f.jk >= 0 ? f.jk : 0, fq, rope_cos, rope_sin, kf);
+            if (rot && !f.is_new) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) kf[s] = f.raw[s];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kf[s] = f.raw[s];
+        }
+        if (mine) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                *reinterpret_cast<u32x4_t*>(kb + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = f.raw[s];
+                if (rot || fill) *reinterpret_cast<u32x4_t*>(kr + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
+            }
+        } else if (fill && !f.is_new && f.jk >= 0) {  // a cached key: its rotation of this chunk goes to the arena for the decode passes
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kr + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&kimg[buf][slot][rw_off[s]]) = kf[s];
+    };
+    auto commit_v = [&](int buf, int slot, const Fetch& f) {
+        if (!f.valid) return;
+        const int krow = v.row0 + (f.jk - v.new_start);
+        const bool mine = f.is_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;
+        if (mine) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(vb + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = f.raw[s];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&vimg[buf][slot][rw_off[s]]) = f.raw[s];
+    };
+    int st0 = tile_begin;  // compact index of the current stage's first tile
+    if (wave >= PREFILL_MAX_GROUPS) {
+        // ---- key loader waves: tiles 2 (wave - 6), + 1 of every stage; both tiles' loads stay in flight for a whole stage (these waves hold no accumulators) ----
+        const int sa = (wave - PREFILL_MAX_GROUPS) * 2, sb = sa + 1;
+        Fetch FA, FB;
+        FA.valid = FB.valid = false; FA.t0 = FB.t0 = 0; FA.jk = FB.jk = -1; FA.is_new = FB.is_new = false;
+        if (st0 < tile_end) {
+            fetch(st0, sa, true, FA); fetch(st0, sb, true, FB);
+            commit_k(0, sa, FA); commit_k(0, sb, FB);
+            if (st0 + PF_ST < tile_end) { fetch(st0 + PF_ST, sa, true, FA); fetch(st0 + PF_ST, sb, true, FB); }
+            else FA.valid = FB.valid = false;
+        }
+        __syncthreads();
+        for (int b = 0; st0 < tile_end; st0 += PF_ST, b ^= 1) {
+            if (st0 + PF_ST < tile_end) {
+                commit_k(b ^ 1, sa, FA); commit_k(b ^ 1, sb, FB);
+                if (st0 + 2 * PF_ST < tile_end) { fetch(st0 + 2 * PF_ST, sa, true, FA); fetch(st0 + 2 * PF_ST, sb, true, FB); }
+                else FA.valid = FB.valid = false;
+            }
+            __syncthreads();  // (the consumers' barrier at the end of the stage)
+        }
+        return;
+    }
+    // ---- consumer waves ----
     // rotated queries of this wave's group
     u32x4_t qf[4];
     const int c = fr;
@@ -788,71 +873,16 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) cpos_min = min(cpos_min, __shfl_xor(cpos_min, off, WAVE));
     cpos_min = __builtin_amdgcn_readfirstlane(cpos_min);
-
-    // ---- loader roles (the launch always has 8 waves): wave w stages keys (even) or values (odd) of the stage's tile w >> 1 ----
-    const bool load_k = (wave & 1) == 0;
-    const int my_slot = wave >> 1;
+    const bool vload = wave < PF_ST;  // waves 0 .. 3: the value tile `wave` of every stage
     // staging is split in two so that a tile's global loads are in flight for a whole stage: fetch issues them into registers, commit -- one
-    // stage later -- rotates / appends / writes the LDS images.  (A second register set, two stages in flight, needs 162 VGPRs: one workgroup
-    // per CU instead of two, 170 us against 137 us per launch at 64 streams; squeezed into 128 VGPRs it spills 72.)
-    struct Fetch { u32x4_t raw[4]; int t0, jk; bool is_new, valid; };
+    // stage later -- writes the LDS image (and appends the unit's own values).
     Fetch F0;
     F0.valid = false; F0.t0 = 0; F0.jk = -1; F0.is_new = false;
-    auto fetch = [&](int stage_first, Fetch& f) {  // this wave's tile of the stage that starts at compact index stage_first
-        const int tc = stage_first + my_slot;
-        f.valid = tc < tile_end;
-        f.t0 = phys(f.valid ? tc : tile_begin) * 16;
-        f.jk = llm_logical(v, d, f.t0 + fr, total_u);
-        f.is_new = f.jk >= 0 && f.jk >= v.new_start;
-        const int krow = v.row0 + (f.jk - v.new_start);
-        const bf16_t* src;
-        if (load_k) src = f.is_new ? qkv + (long)krow * ldq + (long)(H + kvh) * HD : (rot ? kr : kb) + (long)(f.t0 + fr) * HD;
-        else src = f.is_new ? qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD : vb + (long)(f.t0 + fr) * HD;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) f.raw[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
-    };
-    auto commit = [&](int buf, const Fetch& f) {
-        if (!f.valid) return;  // (wave-uniform)
-        const int krow = v.row0 + (f.jk - v.new_start);
-        const bool mine = f.is_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;  // a key of this unit's own rows: append it
-        if (load_k) {
-            u32x4_t kf[4];
-            if (!rot || __any(f.is_new)) {
-                rope_row_chunks(f.raw, f.jk >= 0 ? f.jk : 0, fq, rope_cos, rope_sin, kf);
-                if (rot && !f.is_new) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) kf[s] = f.raw[s];
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) kf[s] = f.raw[s];
-            }
-            if (mine) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    *reinterpret_cast<u32x4_t*>(kb + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = f.raw[s];
-                    if (rot || fill) *reinterpret_cast<u32x4_t*>(kr + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
-                }
-            } else if (fill && !f.is_new && f.jk >= 0) {  // a cached key: its rotation of this chunk goes to the arena for the decode passes
-#pragma unroll
-                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(kr + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = kf[s];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&kimg[buf][my_slot][rw_off[s]]) = kf[s];
-        } else {
-            if (mine) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(vb + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = f.raw[s];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&vimg[buf][my_slot][rw_off[s]]) = f.raw[s];
-        }
-    };
     // one stage: commit the NEXT stage (fetched one step ago into `f`) to the other buffer, re-arm `f` with the stage after it, consume this one
     auto step = [&](int s0, int b, Fetch& f) {
-        if (s0 + PF_ST < tile_end) {
-            commit(b ^ 1, f);
-            if (s0 + 2 * PF_ST < tile_end) fetch(s0 + 2 * PF_ST, f);
+        if (vload && s0 + PF_ST < tile_end) {
+            commit_v(b ^ 1, wave, f);
+            if (s0 + 2 * PF_ST < tile_end) fetch(s0 + 2 * PF_ST, wave, false, f);
             else f.valid = false;
         }
         if (active) {
@@ -941,11 +971,10 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
         __syncthreads();  // the other buffer is staged, this one is free again
     };
     // ---- software pipeline over stages: stage s+1 is committed to the other buffer and stage s+2 requested while stage s is consumed ----
-    int st0 = tile_begin;  // compact index of the current stage's first tile
-    if (st0 < tile_end) {
-        fetch(st0, F0);
-        commit(0, F0);
-        if (st0 + PF_ST < tile_end) fetch(st0 + PF_ST, F0); else F0.valid = false;
+    if (vload && st0 < tile_end) {
+        fetch(st0, wave, false, F0);
+        commit_v(0, wave, F0);
+        if (st0 + PF_ST < tile_end) fetch(st0 + PF_ST, wave, false, F0); else F0.valid = false;
     }
     __syncthreads();
     for (; st0 < tile_end; st0 += 2 * PF_ST) {
@@ -1075,7 +1104,7 @@ int launch_llm_attention(const bf16_t* qkv, const int* row_stream, const int* ro
     bool inline_combine = false;
     if (units && n_units > 0 && max_group_rows > 1) {
         // prefill: a unit (<= 8 row groups of one stream) shares every key tile through LDS (llm_attn_prefill_kernel)
-        if (max_unit_groups < 1 || max_unit_groups > PREFILL_MAX_WAVES || max_group_rows * G > 16) return ISST_ERR_ARG;
+        if (max_unit_groups < 1 || max_unit_groups > PREFILL_MAX_GROUPS || max_group_rows * G > 16) return ISST_ERR_ARG;
         const int ptarget = g_attn_prefill_target_wgs > 0 ? g_attn_prefill_target_wgs : LLM_ATTN_PREFILL_TARGET_WGS;
         n_splits = (ptarget + d.kv_heads * n_units - 1) / (d.kv_heads * n_units);
         n_splits = n_splits < 1 ? 1 : (n_splits > slots / 64 ? slots / 64 : n_splits);
