@@ -768,8 +768,8 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
     for (int nt = 0; nt < 8; ++nt) vr_off[nt] = v_off(4 * fq + tq, 2 * nt + (tp >> 1)) + 8 * (tp & 1);
 
     // ---- roles (round 6; the launch always has 8 waves).  Waves 0 .. 5 are the CONSUMERS, one per row group of the unit (a unit holds at most
-    //      PREFILL_MAX_GROUPS = 6 groups); waves 0 .. 3 also stage the VALUE tile `wave` of every stage (four 16-byte loads and four LDS writes per lane: nothing).
-    //      Waves 6 and 7 are the KEY loaders, two tiles of every stage each: they rotate (rotate-on-read, or the fill of the rotated-key arena), append the
+    //      PREFILL_MAX_GROUPS = 6 groups): they issue no global load inside the loop.
+    //      Waves 6 and 7 are the LOADERS, two tiles of every stage each, keys and values: they rotate (rotate-on-read, or the fill of the rotated-key arena), append the
     //      unit's own keys and write the key images.  Rounds 2-5 made every wave a loader (even waves keys, odd waves values): the three consumers on even
     //      waves then carried a rotation of 32 dims per lane and stage on top of their four score / softmax / P.V tiles -- waves 0 and 4 share SIMD 0, which
     //      had 2800 issue slots per stage where SIMD 3 had 1000 (profiles/r06/prefill_attention_roles.txt) -- and the rotation's temporaries met the
@@ -816,26 +816,37 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
 #pragma unroll
         for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&kimg[buf][slot][rw_off[s]]) = kf[s];
     };
-    auto commit_v = [&](int buf, int slot, const Fetch& f) {
-        if (!f.valid) return;
-        const int krow = v.row0 + (f.jk - v.new_start);
-        const bool mine = f.is_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;
-        if (mine) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(vb + (long)(f.t0 + fr) * HD + 32 * s + 8 * fq) = f.raw[s];
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(&vimg[buf][slot][rw_off[s]]) = f.raw[s];
-    };
     int st0 = tile_begin;  // compact index of the current stage's first tile
     if (wave >= PREFILL_MAX_GROUPS) {
         // ---- key loader waves: tiles 2 (wave - 6), + 1 of every stage; both tiles' loads stay in flight for a whole stage (these waves hold no accumulators) ----
         const int sa = (wave - PREFILL_MAX_GROUPS) * 2, sb = sa + 1;
+        // Keys: fetched into registers a whole stage ahead, rotated / appended on their way to LDS.  (The value tiles are staged by the consumer waves, by
+        // LDS-DMA: below.)  These waves also append the unit's own new value rows to the arena (a register copy, last stages only).
         Fetch FA, FB;
         FA.valid = FB.valid = false; FA.t0 = FB.t0 = 0; FA.jk = FB.jk = -1; FA.is_new = FB.is_new = false;
+        auto append_v = [&](int sf, int slot) {
+            const int tc = sf + slot;
+            if (tc >= tile_end) return;  // (wave-uniform)
+            const int t0 = phys(tc) * 16;
+            const int jk = llm_logical(v, d, t0 + fr, total_u);
+            const bool is_new = jk >= 0 && jk >= v.new_start;
+            const int krow = v.row0 + (jk - v.new_start);
+            const bool mine = is_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;
+            if (__any(mine)) {
+                const bf16_t* src = qkv + (long)(mine ? krow : unit_r0) * ldq + (long)(H + KV + kvh) * HD;
+                u32x4_t raw[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) raw[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+                if (mine) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4_t*>(vb + (long)(t0 + fr) * HD + 32 * s + 8 * fq) = raw[s];
+                }
+            }
+        };
         if (st0 < tile_end) {
             fetch(st0, sa, true, FA); fetch(st0, sb, true, FB);
             commit_k(0, sa, FA); commit_k(0, sb, FB);
+            append_v(st0, sa); append_v(st0, sb);
             if (st0 + PF_ST < tile_end) { fetch(st0 + PF_ST, sa, true, FA); fetch(st0 + PF_ST, sb, true, FB); }
             else FA.valid = FB.valid = false;
         }
@@ -843,10 +854,11 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
         for (int b = 0; st0 < tile_end; st0 += PF_ST, b ^= 1) {
             if (st0 + PF_ST < tile_end) {
                 commit_k(b ^ 1, sa, FA); commit_k(b ^ 1, sb, FB);
+                append_v(st0 + PF_ST, sa); append_v(st0 + PF_ST, sb);
                 if (st0 + 2 * PF_ST < tile_end) { fetch(st0 + 2 * PF_ST, sa, true, FA); fetch(st0 + 2 * PF_ST, sb, true, FB); }
                 else FA.valid = FB.valid = false;
             }
-            __syncthreads();  // (the consumers' barrier at the end of the stage)
+            __syncthreads();  // (the consumers' barrier at the end of the stage; no DMA is issued by these waves, so this is a bare s_barrier behind the LDS writes)
         }
         return;
     }
@@ -873,80 +885,115 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) cpos_min = min(cpos_min, __shfl_xor(cpos_min, off, WAVE));
     cpos_min = __builtin_amdgcn_readfirstlane(cpos_min);
-    const bool vload = wave < PF_ST;  // waves 0 .. 3: the value tile `wave` of every stage
-    // staging is split in two so that a tile's global loads are in flight for a whole stage: fetch issues them into registers, commit -- one
-    // stage later -- writes the LDS image (and appends the unit's own values).
-    Fetch F0;
-    F0.valid = false; F0.t0 = 0; F0.jk = -1; F0.is_new = false;
-    // one stage: commit the NEXT stage (fetched one step ago into `f`) to the other buffer, re-arm `f` with the stage after it, consume this one
-    auto step = [&](int s0, int b, Fetch& f) {
-        if (vload && s0 + PF_ST < tile_end) {
-            commit_v(b ^ 1, wave, f);
-            if (s0 + 2 * PF_ST < tile_end) fetch(s0 + 2 * PF_ST, wave, false, f);
-            else f.valid = false;
+    // Value tiles never touch a register: waves 0 .. 3 send tile `wave` of the NEXT stage straight into its LDS image by LDS-DMA (global_load_lds_dwordx4).  The
+    // destination of one instruction is 64 consecutive 16-byte slots = rows 4 q .. 4 q + 3 of the tile, so lane (row, slot) fetches the chunk that the image's XOR
+    // swizzle puts into that slot.  Issued at the top of a step, the DMA has the whole step to land; the step's closing __syncthreads (vmcnt(0) + barrier while a DMA
+    // is in flight) makes it visible.  These waves issue no other vector memory instruction inside the loop.
+    auto dma_v = [&](int sf, int buf) {
+        const int tc = sf + wave;
+        if (wave >= PF_ST || tc >= tile_end) return;  // (wave-uniform)
+        const int t0 = phys(tc) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 4 * q + (lane >> 4), chs = lane & 15;
+            const int ch = chs ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            const int jk = llm_logical(v, d, t0 + row, total_u);
+            const bool is_new = jk >= 0 && jk >= v.new_start;
+            const int krow = v.row0 + (jk - v.new_start);
+            const bf16_t* src = (is_new ? qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD : vb + (long)(t0 + row) * HD) + ch * 8;
+            __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(&vimg[buf][wave][q * 1024]), 16, 0, 0);
         }
+    };
+    // one stage: keys staged by the loader waves, values by the DMAs issued one step ago
+    auto step = [&](int s0, int b) {
+        if (s0 + PF_ST < tile_end) dma_v(s0 + PF_ST, b ^ 1);
         if (active) {
+            // Round 6: ONE running-softmax update per PAIR of tiles (32 keys) instead of one per 16-key tile.  Per tile the update cost two cross-lane maxima, two
+            // cross-lane sums (ds_bpermute round trips on the dependency chain between the two MFMA groups), the exponential of the old maximum, the wave-uniform
+            // "did any maximum move" test and its branch -- ~150 issued instructions per tile of which the MFMAs are 12; three consumer waves per SIMD made the
+            // launch issue-bound at ~2800 cycles per tile step.  Now the two score tiles of a pair are produced back to back, the statistics are reduced once,
+            // and P.V runs on v_mfma_f32_16x16x32_bf16 over PAIRS of tiles: k-slot (fq, j) of the pair is key 4 fq + j of the first tile for j < 4 and of the
+            // second for j >= 4 -- exactly the keys this lane holds of each tile in the C layout of the scores, and exactly what two transposed value reads
+            // deliver -- so neither P nor V moves between lanes.  (Same arithmetic per key; the running maximum advances in steps of 32 keys, so results
+            // differ from the per-tile form in the last bits of a different rounding order -- the parity tests compare against the oracle, not against it.)
+            const int n_t = min(PF_ST, tile_end - s0);  // live tiles of this stage (wave-uniform)
 #pragma unroll
-            for (int sl = 0; sl < PF_ST; ++sl) {
-                if (s0 + sl >= tile_end) break;  // (uniform)
-                const int t0 = phys(s0 + sl) * 16;
-                u32x4_t kf[4];
+            for (int pr = 0; pr < PF_ST / 2; ++pr) {  // pairs of tiles: 32 keys per update (all four tiles' scores at once need 16 more registers than the budget of two workgroups per CU has)
+                const int n_p = min(2, n_t - 2 * pr);  // live tiles of the pair
+                if (n_p <= 0) break;                    // (uniform)
+                float sc[2][4];
+                float mx = -INFINITY;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const u32x4_t*>(&kimg[b][sl][rw_off[s]]);
-                f32x4_t st = {0.f, 0.f, 0.f, 0.f};
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int sl = 2 * pr + h2;
+                    if (h2 >= n_p) {  // (uniform)
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[s]), __builtin_bit_cast(bf16x8_t, qf[s]), st, 0, 0, 0);
-                // logical positions of the lane's four keys (slots t0 + 4 fq + r): the tile's base is wave-uniform, so the ring arithmetic is scalar and a
-                // lane only adds its offset and wraps (llm_logical's arithmetic, once per tile instead of once per key; this loop is VALU-issue-bound:
-                // three waves per SIMD x 65 tiles x ~1000 issue cycles)
-                float sc[4], mx = -INFINITY;
-                const bool sys_tile = t0 < d.sys_cap;
-                int xb = t0 - d.sys_cap - v.ring_start;
-                if (xb < 0) xb += d.ring_cap;
-                // a tile whose 16 slots are all live and all at or before every column's own position needs no mask at all (every cached tile of a
-                // steady-state chunk but the last two or three): the scalar test below replaces 4 x (ring arithmetic + two compares + select) per lane
-                const int j_last = sys_tile ? t0 + 15 : v.sys_len + xb + 15;
-                const bool plain = (sys_tile ? t0 + 15 < v.sys_len : xb + 15 < d.ring_cap) && j_last < total_u && j_last <= cpos_min;
-                if (plain) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sc[r] = st[r] * scale;
-                        mx = fmaxf(mx, sc[r]);
+                        for (int r = 0; r < 4; ++r) sc[h2][r] = -INFINITY;
+                        continue;
                     }
-                } else {
+                    const int t0 = phys(s0 + sl) * 16;
+                    u32x4_t kf[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int jc;
-                        if (sys_tile) {
-                            jc = t0 + 4 * fq + r;
-                            if (jc >= v.sys_len) jc = 0x7fffffff;
-                        } else {
-                            int x = xb + 4 * fq + r;
-                            if (x >= d.ring_cap) x -= d.ring_cap;
-                            jc = v.sys_len + x;
+                    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const u32x4_t*>(&kimg[b][sl][rw_off[s]]);
+                    f32x4_t st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[s]), __builtin_bit_cast(bf16x8_t, qf[s]), st, 0, 0, 0);
+                    // logical positions of the lane's four keys (slots t0 + 4 fq + r): the tile's base is wave-uniform, so the ring arithmetic is scalar and a
+                    // lane only adds its offset and wraps (llm_logical's arithmetic, once per tile instead of once per key)
+                    const bool sys_tile = t0 < d.sys_cap;
+                    int xb = t0 - d.sys_cap - v.ring_start;
+                    if (xb < 0) xb += d.ring_cap;
+                    // a tile whose 16 slots are all live and all at or before every column's own position needs no mask at all (every cached tile of a
+                    // steady-state chunk but the last two or three): the scalar test below replaces 4 x (ring arithmetic + two compares + select) per lane
+                    const int j_last = sys_tile ? t0 + 15 : v.sys_len + xb + 15;
+                    const bool plain = (sys_tile ? t0 + 15 < v.sys_len : xb + 15 < d.ring_cap) && j_last < total_u && j_last <= cpos_min;
+                    if (plain) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            sc[h2][r] = st[r] * scale;
+                            mx = fmaxf(mx, sc[h2][r]);
                         }
-                        const bool ok = jc < total_u && jc <= cpos;
-                        sc[r] = ok ? st[r] * scale : -INFINITY;
-                        mx = fmaxf(mx, sc[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int jc;
+                            if (sys_tile) {
+                                jc = t0 + 4 * fq + r;
+                                if (jc >= v.sys_len) jc = 0x7fffffff;
+                            } else {
+                                int x = xb + 4 * fq + r;
+                                if (x >= d.ring_cap) x -= d.ring_cap;
+                                jc = v.sys_len + x;
+                            }
+                            const bool ok = jc < total_u && jc <= cpos;
+                            sc[h2][r] = ok ? st[r] * scale : -INFINITY;
+                            mx = fmaxf(mx, sc[h2][r]);
+                        }
                     }
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
                 const float m_new = fmaxf(m_run, mx);
                 const float resc = (m_run == -INFINITY) ? 0.f : PF_EXP(m_run - m_new);
-                float p[4], ls = 0.f;
+                float ls = 0.f;
+                u32x2_t pk[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[r] = (sc[r] == -INFINITY) ? 0.f : PF_EXP(sc[r] - m_new);
-                    ls += p[r];
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    float pe[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pe[r] = (sc[h2][r] == -INFINITY) ? 0.f : PF_EXP(sc[h2][r] - m_new);
+                        ls += pe[r];
+                    }
+                    pk[h2].x = pack_bf(pe[0], pe[1]);
+                    pk[h2].y = pack_bf(pe[2], pe[3]);
                 }
                 ls += __shfl_xor(ls, 16, WAVE);
                 ls += __shfl_xor(ls, 32, WAVE);
                 l_run = l_run * resc + ls;
                 m_run = m_new;
-                // rescale of O only when some column's running max moved (wave-uniform test; x * 1.0f is exact, so skipping changes no bit):
-                // after the first few tiles of a span the maxima rarely move and the 32 multiplies + 4 shuffles per tile drop out
+                // rescale of O only when some column's running max moved (wave-uniform test; x * 1.0f is exact, so skipping changes no bit)
                 if (__any(resc != 1.0f)) {
                     float rs[4];
 #pragma unroll
@@ -956,30 +1003,39 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[nt][r] *= rs[r];
                 }
-                u32x2_t pp;
-                pp.x = pack_bf(p[0], p[1]);
-                pp.y = pack_bf(p[2], p[3]);
-                const s16x4_t pa = __builtin_bit_cast(s16x4_t, pp);
+                const int s1 = 2 * pr, s2 = 2 * pr + 1;
+                if (n_p == 2) {  // 32 keys in one v_mfma_f32_16x16x32_bf16 per 16 output dims
+                    u32x4_t pa;
+                    pa.x = pk[0].x; pa.y = pk[0].y; pa.z = pk[1].x; pa.w = pk[1].y;
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    const u32x2_t vf = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                                                       (__attribute__((address_space(3))) s16x4_t*)(&vimg[b][sl][vr_off[nt]])));
-                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf), o[nt], 0, 0, 0);
+                    for (int nt = 0; nt < 8; ++nt) {
+                        const u32x2_t v1 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                           (__attribute__((address_space(3))) s16x4_t*)(&vimg[b][s1][vr_off[nt]])));
+                        const u32x2_t v2 = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                           (__attribute__((address_space(3))) s16x4_t*)(&vimg[b][s2][vr_off[nt]])));
+                        u32x4_t vf;
+                        vf.x = v1.x; vf.y = v1.y; vf.z = v2.x; vf.w = v2.y;
+                        o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pa), __builtin_bit_cast(bf16x8_t, vf), o[nt], 0, 0, 0);
+                    }
+                } else {         // the odd tile of a span's last stage
+                    const s16x4_t pa = __builtin_bit_cast(s16x4_t, pk[0]);
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt) {
+                        const u32x2_t vf = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                                           (__attribute__((address_space(3))) s16x4_t*)(&vimg[b][s1][vr_off[nt]])));
+                        o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, __builtin_bit_cast(s16x4_t, vf), o[nt], 0, 0, 0);
+                    }
                 }
             }
         }
         __syncthreads();  // the other buffer is staged, this one is free again
     };
-    // ---- software pipeline over stages: stage s+1 is committed to the other buffer and stage s+2 requested while stage s is consumed ----
-    if (vload && st0 < tile_end) {
-        fetch(st0, wave, false, F0);
-        commit_v(0, wave, F0);
-        if (st0 + PF_ST < tile_end) fetch(st0 + PF_ST, wave, false, F0); else F0.valid = false;
-    }
+    // ---- stage s + 1 is committed to the other buffer and stage s + 2 requested by the loader waves while stage s is consumed ----
+    if (st0 < tile_end) dma_v(st0, 0);
     __syncthreads();
     for (; st0 < tile_end; st0 += 2 * PF_ST) {
-        step(st0, 0, F0);
-        if (st0 + PF_ST < tile_end) step(st0 + PF_ST, 1, F0);
+        step(st0, 0);
+        if (st0 + PF_ST < tile_end) step(st0 + PF_ST, 1);
     }
     if (!active) return;
     // ---- output: o[nt][r] = O[column 4fq + r][dim 16nt + fr]; the column's statistics sit in the lanes fr == column ----
