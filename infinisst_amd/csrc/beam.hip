@@ -355,7 +355,10 @@ __global__ __launch_bounds__(64) void beam_select_kernel(BeamSelArgs a) {
         dcs.tok = ntok[lane]; dcs.par = npar[lane]; dcs.score = nscore[lane]; dcs.forced_lp = nflp[lane];
         a.log_dec[i * B + lane] = dcs;
     }
-    if (lane == 0) a.log_done[i] = st;
+    // the status word also carries a digest of the hypothesis bookkeeping: the host follower re-derives the step with its own scorer and compares
+    // tokens / parents / scores, but a divergence in WHICH BUFFER a closed hypothesis's tail was saved to -- or in the free list's order -- would only show
+    // when finalize copies a winner's tail out of the wrong buffer.  st >= 0: bit 0 = done, bits 1.. = beam_book_digest (kernels.h) of hyp_n, hyp_buf[], n_free, free_bufs[]
+    if (lane == 0) a.log_done[i] = st < 0 ? st : (st | (int)(beam_book_digest(S.hyp_n, S.hyp_buf, S.n_free, S.free_bufs) << 1));
     __threadfence_system();  // every lane: its part of the log is in host memory before this stream's ticket is drawn
     __syncthreads();         // (the workgroup IS one wave -- launch_beam_select, static_assert above -- so this costs nothing; it states that lane 0's ticket follows every lane's fence)
     if (lane == 0) {

@@ -860,7 +860,10 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
         for (int b = 1; b < B; ++b) push_copy(h, ops, stream_ids[i], b, 0, total0[i], rows_len[i], true);
     CHK(flush_copies(h, ops, mh, md, st));
 
-    // ---- the device's copy of the search state (the stream was idle when this call began: the pinned staging blocks are free) ----
+    // ---- the device's copy of the search state.  The pinned staging blocks written below (bpow_host, bst_host, bforce_host, meta_host2) are free: calls no longer end
+    //      with the stream drained, but every upload out of these blocks is enqueued BEFORE the first beam step of its call, and a call only returns after the
+    //      host has seen the sequence number of its LAST step (published by beam_select_kernel, which runs behind every one of those uploads on the stream).
+    //      Invariant for future edits: no upload from one of these blocks may be enqueued after the last published step of a call. ----
     const bool shared = h->beam_shared && B * (c.llm_heads / c.llm_kv_heads) <= 16 && (p->max_new_tokens + 15) / 16 + 1 <= 4;  // (isst_generate's `beams_share_prefix`: the pre-pass relies on it)
     const int nr = n * B;
     std::memcpy(h->bpow_host, powtab.data(), sizeof(double) * powtab.size());
@@ -924,11 +927,19 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
                                            slot_idx(s) + (size_t)i * B * BEAM_TOPK, f_tok, f_par, nullptr, forced_lp))
                 return rc;
             if (dn[i] < 0) return h->fail(ISST_ERR_STATE, "beam search: the device scorer failed at step %d of stream %d (status %d) where the host scorer did not", s, stream_ids[i], dn[i]);
+            {   // the hypothesis bookkeeping, which both sides keep independently: kept hypotheses' tail buffers in insertion order + the free list
+                int hb[BEAM_MAX_B + 1], nh = 0;
+                for (const BeamHyp& hp : bs[i].hyps.beams) hb[nh++] = hp.buf >= 0 ? hp.buf : -1;
+                const unsigned want = beam_book_digest(nh, hb, (int)bs[i].free_bufs.size(), bs[i].free_bufs.data());
+                if ((unsigned)(dn[i] >> 1) != want)
+                    return h->fail(ISST_ERR_STATE, "beam search: device and host scorers keep different hypothesis buffers at step %d of stream %d (digest %x against %x: %d hypotheses, %d free buffers on the host)",
+                                   s, stream_ids[i], (unsigned)(dn[i] >> 1), want, nh, (int)bs[i].free_bufs.size());
+            }
             for (int b = 0; b < B; ++b) {
                 const BeamDecision& d = dec[i * B + b];
-                if (d.tok != f_tok[b] || d.par != f_par[b] || std::memcmp(&d.score, &bs[i].score[b], sizeof(float)) != 0 || (dn[i] != 0) != bs[i].done)
+                if (d.tok != f_tok[b] || d.par != f_par[b] || std::memcmp(&d.score, &bs[i].score[b], sizeof(float)) != 0 || ((dn[i] & 1) != 0) != bs[i].done)
                     return h->fail(ISST_ERR_STATE, "beam search: device and host scorers disagree at step %d, stream %d, beam %d (device token %d parent %d score %.9g done %d, host token %d parent %d score %.9g done %d)",
-                                   s, stream_ids[i], b, d.tok, d.par, (double)d.score, dn[i], f_tok[b], f_par[b], (double)bs[i].score[b], (int)bs[i].done);
+                                   s, stream_ids[i], b, d.tok, d.par, (double)d.score, dn[i] & 1, f_tok[b], f_par[b], (double)bs[i].score[b], (int)bs[i].done);
             }
         }
         return ISST_OK;
@@ -1003,7 +1014,7 @@ int beam_decode_device(isst_handle* h, const isst_gen_params* p, int n, const in
         h->kv_ops_used = 0;  // (every copy batch enqueued before this step's scorer has run)
         bool all_done = true, upstream_failed = false;
         const int* dn = slot_done(step);
-        for (int i = 0; i < n; ++i) { all_done = all_done && dn[i] == 1; upstream_failed = upstream_failed || dn[i] == -1; }
+        for (int i = 0; i < n; ++i) { all_done = all_done && dn[i] >= 0 && (dn[i] & 1); upstream_failed = upstream_failed || dn[i] == -1; }  // (status >= 0: bit 0 = done, above it the bookkeeping digest)
         if (upstream_failed || *ferr != 0) {
             // a fused attention + o_proj launch of the pass behind these logits gave up waiting: the scorer left its state alone.  Latch the three-launch
             // path and run the same pass and the same step again (the KV appends and the hidden state are rewritten from the token ids)
@@ -1190,8 +1201,8 @@ extern "C" int isst_generate(isst_handle* h, const isst_gen_params* p, int n, co
         HIPCHK(hipMemcpyAsync(h->meta_dev + 4096, h->meta_host + 4096, mh.step_bytes - 4096, hipMemcpyHostToDevice, st));
     } else if (h->rot_keys && any_cached && h->rope_side && st != nullptr) {
         // The host is far ahead of the GPU here (the encoder above is milliseconds of queued work), so the metadata upload and the pre-pass, issued on
-        // the side stream now, run BESIDE the encoder; the prefill waits for both.  (The caller's stream was idle when this call began -- every call ends
-        // with a synchronisation -- so the pre-pass cannot overtake an earlier writer of the caches.)
+        // the side stream now, run BESIDE the encoder; the prefill waits for both.  (Calls no longer end with the caller's stream drained: the event recorded on it
+        // below orders the side stream behind everything the previous call left there, so the pre-pass cannot overtake an earlier writer of the caches.)
         if (!h->side) {
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));

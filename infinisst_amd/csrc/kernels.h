@@ -222,6 +222,17 @@ struct BeamSelArgs {
     BeamScoreView view;
 };
 int launch_beam_select(const BeamSelArgs& a, hipStream_t s);
+// 30-bit digest of a stream's hypothesis bookkeeping, the same arithmetic on the device (beam_select_kernel, in the step's status word) and on the host
+// (the follower of engine_llm.hip): number of kept hypotheses, the tail buffer each one holds in insertion order, the free list in order
+__host__ __device__ inline unsigned beam_book_digest(int hyp_n, const int* hyp_buf, int n_free, const int* free_bufs) {
+    unsigned d = 2166136261u;
+    auto mix = [&](int v) { d = (d ^ (unsigned)(v + 0x40)) * 16777619u; };
+    mix(hyp_n);
+    for (int q = 0; q < hyp_n; ++q) mix(hyp_buf[q]);
+    mix(n_free);
+    for (int q = 0; q < n_free; ++q) mix(free_bufs[q]);
+    return (d ^ (d >> 15)) & 0x3FFFFFFFu;
+}
 int launch_topk_rows(const float* scores, long ld, int vocab, int k, float* cval, int* cidx, float* out_val, int* out_idx, int rows,
                      hipStream_t s);
 // the same in ONE launch; the tokens also go to the pinned array `host_tokens`, and `*host_seq` receives the launch's sequence number (tickets[1], kept on

@@ -58,21 +58,28 @@ __device__ __forceinline__ int llm_logical(const LlmStreamView& v, const LlmAttn
 // rotate the four 8-dim chunks a lane holds of one 128-dim row (dims 8fq + 32s, s = 0..3) at position pos
 __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int fq, const bf16_t* __restrict__ rope_cos,
                                                 const bf16_t* __restrict__ rope_sin, u32x4_t* out) {
-    float x[4][8];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) unpack8(raw[s], x[s]);
+    // y[d] = bf16(bf16(x[d] c) - bf16(x[d + 64] s)),  y[d + 64] = bf16(bf16(x[d + 64] c) + bf16(x[d] s))  (HF apply_rotary_pos_emb in bf16: every torch op rounds).
+    // Word by word (two dims per 32-bit word): the four products of a dim are rounded by TWO v_cvt_pk_bf16_f32 (one instruction rounds two floats) and the two results
+    // of a word are rounded and packed by one -- the element-wise form (a cast per value, then a second cast in pack8) issued ~1.6 x the instructions for the same
+    // bits; this function is the key loaders' whole job in llm_attn_prefill_kernel's arena fill (round 6).
+#pragma clang fp contract(off)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // chunk pairs (s = h, s = h + 2): dims d and d + 64
-        float c[8], sn[8], r1[8], r2[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(rope_cos + (long)pos * 64 + 32 * h + 8 * fq), c);
-        unpack8(*reinterpret_cast<const u32x4_t*>(rope_sin + (long)pos * 64 + 32 * h + 8 * fq), sn);
+        const u32x4_t cw = *reinterpret_cast<const u32x4_t*>(rope_cos + (long)pos * 64 + 32 * h + 8 * fq);
+        const u32x4_t sw = *reinterpret_cast<const u32x4_t*>(rope_sin + (long)pos * 64 + 32 * h + 8 * fq);
+        u32x4_t o1, o2;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            r1[i] = bfr(bfr(x[h][i] * c[i]) - bfr(x[h + 2][i] * sn[i]));
-            r2[i] = bfr(bfr(x[h + 2][i] * c[i]) + bfr(x[h][i] * sn[i]));
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t x1 = raw[h][w], x2 = raw[h + 2][w], c = cw[w], sn = sw[w];
+            const uint32_t lo_a = pack_bf(lo_bf(x1) * lo_bf(c), lo_bf(x2) * lo_bf(sn));   // (bf16(x1 c), bf16(x2 s)) of the word's low dim
+            const uint32_t lo_b = pack_bf(lo_bf(x2) * lo_bf(c), lo_bf(x1) * lo_bf(sn));   // (bf16(x2 c), bf16(x1 s))
+            const uint32_t hi_a = pack_bf(hi_bf(x1) * hi_bf(c), hi_bf(x2) * hi_bf(sn));
+            const uint32_t hi_b = pack_bf(hi_bf(x2) * hi_bf(c), hi_bf(x1) * hi_bf(sn));
+            o1[w] = pack_bf(lo_bf(lo_a) - hi_bf(lo_a), lo_bf(hi_a) - hi_bf(hi_a));
+            o2[w] = pack_bf(lo_bf(lo_b) + hi_bf(lo_b), lo_bf(hi_b) + hi_bf(hi_b));
         }
-        out[h] = pack8(r1);
-        out[h + 2] = pack8(r2);
+        out[h] = o1;
+        out[h + 2] = o2;
     }
 }
 

@@ -50,6 +50,9 @@ line(s, "decode attention", r"llm_attn_partial_kernel<4, 1, true", 64 * KV1)
 line(s, "lm_head (gemm_wide)", r"gemm_wide_kernel<4, 4, 6, 6, true", W["lm_head"])
 line(s, "prefill gate/up (gemm_dense)", r"gemm_dense_kernel<5>", flops=2.0 * 1408 * 28672 * 4096)
 line(s, "prefill q/k/v (gemm_dense)", r"gemm_dense_kernel<0>", flops=2.0 * 1408 * 6144 * 4096)
+line(s, "prefill o_proj + down + encoder out/fc2 avg (gemm_dense, K slices)", r"gemm_dense_kernel<7>", flops=2.0 * (160 * 1408 * 4096 * (4096 + 14336) + 120 * 3072 * 1024 * (1024 + 4096)) / 560)
+line(s, "encoder fc1 at 3072 rows (gemm_dense)", r"gemm_dense_kernel<2>", flops=2.0 * 3072 * 4096 * 1024)
+line(s, "encoder attention, 64 streams", r"enc_attention_kernel<3", 64 * 16 * 624 * 64 * 2 * 2)
 line(s, "prefill attention", r"llm_attn_prefill_kernel", 64 * KV1)
 s = stats("128")
 print("128 streams, decode pass (128 rows):")

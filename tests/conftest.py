@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: extra-coverage cases kept out of the driver's time-limited run; ISST_RUN_SLOW=1 runs them")
 
 
 @pytest.fixture(scope="session")
@@ -22,6 +23,11 @@ def golden_dir():
 def pytest_collection_modifyitems(config, items):
     """`gpu` tests need a device: on a box without one they are skipped (the driver selects them with -m gpu on the GPU box)."""
     import torch
+    if os.environ.get("ISST_RUN_SLOW", "0") in ("", "0"):
+        slow = pytest.mark.skip(reason="slow extra-coverage case (ISST_RUN_SLOW=1 runs it)")
+        for item in items:
+            if "slow" in item.keywords:
+                item.add_marker(slow)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible (the hot path has no CPU implementation)")
