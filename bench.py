@@ -600,7 +600,7 @@ def mfma_probe(cfg, device, rows, in_situ=None, iters=20):
             "in_situ_launches": in_situ[1] if have else 0, "back_to_back_launch_us": round(b2b, 2),
             "back_to_back_tflops": round(flop / (b2b * 1e-6) / 1e12, 1), "flop_per_launch": flop, "achieved": round(tf, 1),
             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-            "source": "HIP events in this run; rocprofv3 per-kernel durations and the MFMA-busy counters of the same kernel: profiles/r03/"}
+            "source": "HIP events in this run; rocprofv3 per-kernel durations, the MFMA-busy / fabric-read counters (dense_pmc.json) and the three-stream ablation of the same kernel: profiles/r06/"}
 
 
 def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
@@ -671,28 +671,7 @@ def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=32, n_c
     from oracle import llm as ollm
     from oracle import speech_encoder as oenc
     cores = os.cpu_count() or 1
-    if threads > 0:
-        nthreads, thread_note = threads, "--cpu-threads"
-    else:
-        # BASELINE.md's recipe is set_num_threads(os.cpu_count()); on a many-socket host that is not always the fastest setting for one stream's
-        # memory-bound GEMVs, so the thread count is the fastest of {64, 128, all logical cores} on a one-second probe of the layer stack's widest
-        # GEMV (bf16 F.linear, 1 x 4096 -> 28672): the baseline is reported at its best, and the line says what was tried
-        cands = sorted({c for c in (64, 128, cores) if c <= cores}) or [cores]
-        xw = torch.randn(28672, 4096).bfloat16()
-        xv = torch.randn(1, 4096).bfloat16()
-        probe = {}
-        for c in cands:
-            torch.set_num_threads(c)
-            for _ in range(3):
-                torch.nn.functional.linear(xv, xw)
-            t0 = time.perf_counter()
-            for _ in range(12):
-                torch.nn.functional.linear(xv, xw)
-            probe[c] = (time.perf_counter() - t0) / 12
-        del xw, xv
-        nthreads = min(probe, key=probe.get)
-        thread_note = ("fastest of " + ", ".join(f"{c} threads: {1e3 * t:.2f} ms" for c, t in probe.items()) +
-                       f" on a bf16 F.linear 1 x 4096 -> 28672 probe; host has {cores} logical cores (BASELINE.md: set_num_threads(os.cpu_count()))")
+    nthreads, thread_note = (threads, "--cpu-threads") if threads > 0 else (min(cores, 64), None)
     torch.set_num_threads(nthreads)
     run_layers = min(llm_layers_run, cfg.llm_layers)
     keep = lambda k: not k.startswith("model.layers.") or int(k.split(".")[2]) < run_layers
@@ -714,6 +693,32 @@ def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=32, n_c
         lc.v = (0.5 * torch.randn(cfg.enc_heads, cfg.max_cache_size, cfg.enc_head_dim, generator=g)).bfloat16()
     rope_l = ollm.llm_rope_tables(cfg, L + 256, torch.bfloat16)
     rope_e = oenc.make_rope(cfg)
+    if threads <= 0:
+        # BASELINE.md's recipe is set_num_threads(os.cpu_count()); on a many-socket host that is far from the fastest setting for one stream (a probe of a
+        # lone GEMV liked 128 threads on one box where the whole chunk then ran 2.8 x slower than with 64), so the thread count is the fastest of
+        # {64, 128, all logical cores} on what the baseline actually spends its time in: ONE decode pass of ONE real Llama layer of this oracle
+        # (RMSNorm, attention over the steady-state cache, SwiGLU MLP), three repetitions each, on a copy of the layer's KV -- a fraction of a second
+        cands = sorted({c for c in (64, 128, cores) if c <= cores}) or [cores]
+        probe = {}
+        xq = torch.randn(1, 1, cfg.llm_dim, generator=g).bfloat16()
+        with torch.inference_mode():
+            for c_ in cands:
+                torch.set_num_threads(c_)
+                best = 1e9
+                for _ in range(4):
+                    kv_p = [[kv[0][0].clone(), kv[0][1].clone()]]
+                    t0 = time.perf_counter()
+                    h_ = ollm.rmsnorm(xq, w["model.layers.0.input_layernorm.weight"], cfg.rms_eps)
+                    y_ = xq + ollm.attention(w, sub, 0, h_, kv_p, rope_l)
+                    h_ = ollm.rmsnorm(y_, w["model.layers.0.post_attention_layernorm.weight"], cfg.rms_eps)
+                    y_ = y_ + ollm.mlp(w, 0, h_)
+                    best = min(best, time.perf_counter() - t0)
+                probe[c_] = best
+        nthreads = min(probe, key=probe.get)
+        thread_note = ("fastest of " + ", ".join(f"{c_} threads: {1e3 * t_:.1f} ms" for c_, t_ in probe.items()) +
+                       f" for one decode pass of one Llama layer of the oracle; host has {cores} logical cores (BASELINE.md: set_num_threads(os.cpu_count()))")
+        torch.set_num_threads(nthreads)
+        log(f"cpu baseline: {thread_note}")
     audio_all = synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=99)
     scale = cfg.llm_layers / run_layers
     per_chunk_s, measured = [], 0.0
