@@ -750,6 +750,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
     // live cached tile of the stream is staged by exactly one loader wave per unit of the stream (same bits from every unit); the decode passes then read 1.
     const bool rot = v.rot_keys == 1, fill = v.rot_keys == 2;
     const float scale = 0.08838834764831845f;
+    const float c2 = scale * 1.44269504088896340736f;  // 1/sqrt(128) x log2(e): the exponentials below are exp2(s c2 - m c2)
     // tiles are walked in the compact index space of the tiles that hold a live slot (see llm_attn_partial_kernel)
     const int sys_tiles = (v.sys_len + 15) >> 4, ring_tiles = d.ring_cap >> 4, ring_tile0 = v.ring_start >> 4;
     const int ring_len = total_u - v.sys_len;
@@ -827,6 +828,10 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
     if (wave >= PREFILL_MAX_GROUPS) {
         // ---- key loader waves: tiles 2 (wave - 6), + 1 of every stage; both tiles' loads stay in flight for a whole stage (these waves hold no accumulators) ----
         const int sa = (wave - PREFILL_MAX_GROUPS) * 2, sb = sa + 1;
+#ifndef PF_LOADER_PRIO
+#define PF_LOADER_PRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(PF_LOADER_PRIO);  // with the arena fill a stage lasts as long as its loaders' two rotations: they go first on their SIMDs (the consumers have the slack)
         // Keys: fetched into registers a whole stage ahead, rotated / appended on their way to LDS.  (The value tiles are staged by the consumer waves, by
         // LDS-DMA: below.)  These waves also append the unit's own new value rows to the arena (a register copy, last stages only).
         Fetch FA, FB;
@@ -955,10 +960,12 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
                     // steady-state chunk but the last two or three): the scalar test below replaces 4 x (ring arithmetic + two compares + select) per lane
                     const int j_last = sys_tile ? t0 + 15 : v.sys_len + xb + 15;
                     const bool plain = (sys_tile ? t0 + 15 < v.sys_len : xb + 15 < d.ring_cap) && j_last < total_u && j_last <= cpos_min;
+                    // (scores stay RAW q.k here: the 1/sqrt(d) scale and the change of base ride in ONE fma in front of v_exp_f32 below -- exp2(s c - m c), c = scale log2(e) --
+                    //  where the per-tile form spent mul (scale), sub (max), mul (log2 e) per element; the running maximum is kept in raw units)
                     if (plain) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            sc[h2][r] = st[r] * scale;
+                            sc[h2][r] = st[r];
                             mx = fmaxf(mx, sc[h2][r]);
                         }
                     } else {
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
                                 jc = v.sys_len + x;
                             }
                             const bool ok = jc < total_u && jc <= cpos;
-                            sc[h2][r] = ok ? st[r] * scale : -INFINITY;
+                            sc[h2][r] = ok ? st[r] : -INFINITY;
                             mx = fmaxf(mx, sc[h2][r]);
                         }
                     }
@@ -982,7 +989,8 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
                 mx = fmaxf(mx, __shfl_xor(mx, 16, WAVE));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, WAVE));
                 const float m_new = fmaxf(m_run, mx);
-                const float resc = (m_run == -INFINITY) ? 0.f : PF_EXP(m_run - m_new);
+                const float resc = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+                const float mneg = (m_new == -INFINITY) ? 0.f : -m_new * c2;  // (a column without a visible key so far: exp2(-inf c + 0) = 0, not exp2(-inf + inf))
                 float ls = 0.f;
                 u32x2_t pk[2];
 #pragma unroll
@@ -990,7 +998,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
                     float pe[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        pe[r] = (sc[h2][r] == -INFINITY) ? 0.f : PF_EXP(sc[h2][r] - m_new);
+                        pe[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[h2][r], c2, mneg));  // masked keys: exp2(-inf) = 0
                         ls += pe[r];
                     }
                     pk[h2].x = pack_bf(pe[0], pe[1]);
@@ -1059,7 +1067,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
             for (int nt = 0; nt < 8; ++nt) out_direct[((long)row * H + head) * HD + 16 * nt + fr] = f2bf(o[nt][r] / Lr[r]);
         } else {
             float* dst = partial + (((long)row * H + head) * n_splits + sp) * ATTN_SLAB;
-            if (fr == 0) { dst[HD] = Mr[r]; dst[HD + 1] = Lr[r]; }
+            if (fr == 0) { dst[HD] = Mr[r] * scale; dst[HD + 1] = Lr[r]; }  // (the running maximum is kept in raw q.k units: the combine pass expects scaled scores)
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) dst[16 * nt + fr] = o[nt][r];
         }
