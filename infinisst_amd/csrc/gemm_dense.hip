@@ -44,6 +44,12 @@
 #ifndef DENSE_RING10
 #define DENSE_RING10 1   // 256-row tiles: one half-tile per phase over a ring of slots instead of two K-tile buffers (A/B aid: -DDENSE_RING10=0)
 #endif
+#ifndef DENSE_MFMA_PRIO
+#define DENSE_MFMA_PRIO 1   // s_setprio inside the MFMA cluster of a phase / in the load segment (reads, DMA issue, wait) around it (A/B aids)
+#endif
+#ifndef DENSE_LOAD_PRIO
+#define DENSE_LOAD_PRIO 0
+#endif
 #ifndef DENSE_SLOTS
 #define DENSE_SLOTS 10   // half-tile slots of that ring (10 = all 160 KiB of the CU)
 #endif
@@ -156,7 +162,7 @@ __device__ __forceinline__ void dense_tile(const GemmArgs& g, unsigned char* sme
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) acc[a][b][mt][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     auto quadrant = [&](f32x4_t (&c)[4][2], const u32x4_t (&fb)[2][2]) {
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(DENSE_MFMA_PRIO);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -166,7 +172,7 @@ __device__ __forceinline__ void dense_tile(const GemmArgs& g, unsigned char* sme
                     if constexpr (DENSE_ABLATE & 1) asm volatile("" ::"v"(fa[mt][k]), "v"(fb[nb][k]));
                     else c[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[mt][k]), __builtin_bit_cast(bf16x8_t, fb[nb][k]), c[mt][nb], 0, 0, 0);
                 }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(DENSE_LOAD_PRIO);
     };
 #define DT_WAIT_BARRIER_N(N)                                \
     asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");   \

@@ -96,6 +96,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
         // FETCHES is its destination chunk XOR ((row in m-tile >> 1) & 7): the DMA writes lane-linear, so the swizzle that makes the consumers'
         // ds_read_b128 conflict-free sits on the source side (gemm_dense.hip's image; rule 21).  Rows past M repeat row M-1 (never stored).
         const int lw = wave - 4;
+#ifndef WIDE_LOADER_PRIO
+#define WIDE_LOADER_PRIO 0   // s_setprio of the loader waves / of the consumer waves (A/B aids; round 6: see below)
+#endif
+#ifndef WIDE_CONSUMER_PRIO
+#define WIDE_CONSUMER_PRIO 0
+#endif
+        if (WIDE_LOADER_PRIO) __builtin_amdgcn_s_setprio(WIDE_LOADER_PRIO);
         const bf16_t* asrc[AU];
 #pragma unroll
         for (int a = 0; a < AU; ++a) {
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(GemmArgs g, int steps
 
     // ================= consumer waves: the W ring in registers, fragments from LDS, MFMA =================
     WIDE_STAMP_RT(240); WIDE_STAMP(241);
+    if (WIDE_CONSUMER_PRIO) __builtin_amdgcn_s_setprio(WIDE_CONSUMER_PRIO);
     const int nt0 = blockIdx.x * WIDE_NT + wave * 2;
     f32x4_t acc[MT][2];
 #pragma unroll
