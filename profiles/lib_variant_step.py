@@ -9,6 +9,8 @@ NS = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 if os.environ.get("AB_ATTN_WGS"):  # decode attention: target number of workgroups (splits per (stream, kv head) follow from it)
     lib.isst_op_set_attn_tuning(int(os.environ["AB_ATTN_WGS"]))
+if os.environ.get("AB_GEMM_TUNE"):  # "a,b" -> isst_op_set_gemm_tuning(a, b) (gemm.hip gemm_set_tuning: e.g. "0,128" = gemm_mid's four-chunk ring)
+    lib.isst_op_set_gemm_tuning(*[int(v) for v in os.environ["AB_GEMM_TUNE"].split(",")])
 import bench
 from infinisst_amd.config import GenConfig, full_config
 cfg = full_config().replace(eos_ids=())
