@@ -25,6 +25,7 @@
 // The mask needs no tensor: row i may see logical columns [lo_i, hi_i) (closed form of :30-77).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 #define ENC_HD 64
 #define ENC_SPAD 8  // bf16 elements of padding per S row (keeps rows 16-byte aligned, shifts banks by 4 per row)
@@ -44,25 +45,71 @@ __device__ __forceinline__ void rot8(const float* x, const float* c, const float
         }
     }
 }
-// 8 dims starting at `dim0` of a row, rotated at position `pos`, as an MFMA operand fragment
-__device__ __forceinline__ u32x4_t rot_frag(const bf16_t* p, int pos, int dim0, const float* __restrict__ rope_cos,
-                                            const float* __restrict__ rope_sin, int round_each) {
-    float x[8], y[8];
-    unpack8(*reinterpret_cast<const u32x4_t*>(p), x);
-    const f32x4_t c = *reinterpret_cast<const f32x4_t*>(rope_cos + (long)pos * 32 + (dim0 >> 1));
-    const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(rope_sin + (long)pos * 32 + (dim0 >> 1));
-    const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+// The rotary table entries of one (position, 8-dim group) as they travel in registers.
+//   TB = false: fp32 tables [pos][32] cos and sin, as handed to isst_set_rope_tables: 2 x 16 B per group.
+//   TB = true:  ONE packed bf16 table [pos][k-step 2][fq 4][cos x 4 | sin x 4] (16 B per group) -- built by the library when every table value IS a bf16 number,
+//               which is the reference's production setting (the encoder is cast to bf16, so its rotary module computes cos / sin in bf16: rope.py "bf16" mode).
+//               Same values, half the bytes and a third fewer load instructions per key tile, 8 instead of 16 registers per tile in flight.
+template <bool TB> struct EncTab;
+template <> struct EncTab<false> { f32x4_t c, s; };
+template <> struct EncTab<true> { u32x4_t cs; };
+template <bool TB>
+__device__ __forceinline__ void enc_tab_load(EncTab<TB>& t, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const bf16_t* __restrict__ rope_cs,
+                                             int pos, int ks, int fq) {
+    if constexpr (TB) {
+        t.cs = *reinterpret_cast<const u32x4_t*>(rope_cs + ((long)pos * 8 + ks * 4 + fq) * 8);
+    } else {
+        t.c = *reinterpret_cast<const f32x4_t*>(rope_cos + (long)pos * 32 + ks * 16 + fq * 4);
+        t.s = *reinterpret_cast<const f32x4_t*>(rope_sin + (long)pos * 32 + ks * 16 + fq * 4);
+    }
+}
+// raw 8 dims (the lane's 16 bytes of a q or k row) rotated with the table entries `t`, as an MFMA operand fragment
+template <bool TB>
+__device__ __forceinline__ u32x4_t rot_frag_regs(const u32x4_t& raw, const EncTab<TB>& t, int round_each) {
+    float x[8], y[8], cc[4], ss[4];
+    unpack8(raw, x);
+    if constexpr (TB) {
+        cc[0] = lo_bf(t.cs.x); cc[1] = hi_bf(t.cs.x); cc[2] = lo_bf(t.cs.y); cc[3] = hi_bf(t.cs.y);
+        ss[0] = lo_bf(t.cs.z); ss[1] = hi_bf(t.cs.z); ss[2] = lo_bf(t.cs.w); ss[3] = hi_bf(t.cs.w);
+    } else {
+        cc[0] = t.c.x; cc[1] = t.c.y; cc[2] = t.c.z; cc[3] = t.c.w;
+        ss[0] = t.s.x; ss[1] = t.s.y; ss[2] = t.s.z; ss[3] = t.s.w;
+    }
     rot8(x, cc, ss, round_each, y);
     return pack8(y);
 }
+// 8 dims (k-step ks, group fq) of the row at `p`, rotated at position `pos`
+template <bool TB>
+__device__ __forceinline__ u32x4_t rot_frag(const bf16_t* p, int pos, int ks, int fq, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                            const bf16_t* __restrict__ rope_cs, int round_each) {
+    EncTab<TB> t;
+    enc_tab_load<TB>(t, rope_cos, rope_sin, rope_cs, pos, ks, fq);
+    return rot_frag_regs<TB>(*reinterpret_cast<const u32x4_t*>(p + ks * 32 + fq * 8), t, round_each);
+}
 
-// the same from registers: the raw 8 dims and the table entries were loaded earlier (several key tiles' loads in flight before the first rotation)
-__device__ __forceinline__ u32x4_t rot_frag_regs(const u32x4_t& raw, const f32x4_t& c, const f32x4_t& sn, int round_each) {
-    float x[8], y[8];
-    unpack8(raw, x);
-    const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
-    rot8(x, cc, ss, round_each, y);
-    return pack8(y);
+// Scores of ONE key tile (16 keys: this lane's key is column fr) against the workgroup's QT m-tiles of queries: rotation of the lane's 2 x 8 key dims, two MFMAs per
+// m-tile, then  bf16(acc / 8)  or -inf by the mask  into S[row][cphys].  `ok(mt, r)`: may row 4 fq + r of m-tile mt see this lane's key?
+// `qfrag(mt, ks)`: the rotated query fragment (registers at one stream, LDS at many: see the kernel).
+template <int QT, bool RND, bool TB, typename QFrag, typename Mask>
+__device__ __forceinline__ void enc_score_tile(const u32x4_t (&kraw)[2], const EncTab<TB> (&kt)[2], QFrag qfrag,
+                                               bf16_t* S, int ldS, int cphys, int fq, Mask ok) {
+    u32x4_t kf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) kf[ks] = rot_frag_regs<TB>(kraw[ks], kt[ks], RND ? 1 : 0);
+#pragma unroll
+    for (int mt = 0; mt < QT; ++mt) {
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qfrag(mt, ks)), __builtin_bit_cast(bf16x8_t, kf[ks]), acc, 0, 0, 0);
+        // C layout: this lane holds column fr (its own key), rows 4 fq + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // q * head_dim^-0.5 (:768) is an exact power-of-two scaling, applied to the accumulated dot product
+            const bf16_t v = ok(mt, r) ? f2bf(0.125f * acc[r]) : (bf16_t)0xFF80;  // -inf
+            S[(long)(mt * 16 + fq * 4 + r) * ldS + cphys] = v;
+        }
+    }
 }
 
 // -DISST_ENC_TRACE (make trace): wave 0 of every workgroup stamps the 100 MHz wall clock at entry / queries rotated / scores written / softmax done /
@@ -77,14 +124,14 @@ extern "C" int isst_debug_enc_trace_read(void* dst, long bytes) {
 #define ENC_STAMP(i) do {} while (0)
 #endif
 
-template <int QT, bool RND>  // QT: m-tiles of 16 query rows per workgroup; RND: every product of the rotation rounds to bf16 (enc_rope_mode "bf16": as a compile-time
+template <int QT, bool RND, bool TB>  // TB: the packed bf16 rotary table (EncTab); QT: m-tiles of 16 query rows per workgroup; RND: every product of the rotation rounds to bf16 (enc_rope_mode "bf16": as a compile-time
                               // constant -- as a runtime flag every rotated pair carried a branch, 160 of them per key tile in a phase that is bound by instruction issue)
 __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  // (48-row blocks run two workgroups per CU: 4 waves per SIMD, 128 registers -- stated, not left to luck)
     const bf16_t* __restrict__ qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                                                             const EncStreamView* __restrict__ sv,
-                                                            const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                                            const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, const bf16_t* __restrict__ rope_cs,
                                                             int /*round_each: RND*/, bf16_t* __restrict__ out, int Q, int heads, int cap,
-                                                            int C, int bs) {
+                                                            int C, int bs, int vn_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ENC_STAMP(0);
     bf16_t* S = reinterpret_cast<bf16_t*>(smem);  // [QT*16][cap + ENC_SPAD]
@@ -104,132 +151,192 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
     const bf16_t* vnew = qkv + (long)s * Q * 3 * D + 2 * D + h * ENC_HD;  // V of new frame i at vnew + i*3D
     const int fr = lane & 15, fq = lane >> 4;
 
-    // ---- rotated query fragments: A[row = fr][k = 8 fq + j] for both 32-dim k-steps ----
-    u32x4_t qf[QT][2];
-#pragma unroll
-    for (int mt = 0; mt < QT; ++mt) {
-        const int qi = q0 + mt * 16 + fr;
-        const bf16_t* qrow = qkv + ((long)s * Q + qi) * 3 * D + h * ENC_HD;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[mt][ks] = rot_frag(qrow + ks * 32 + fq * 8, K - Q + qi, ks * 32 + fq * 8, rope_cos, rope_sin, RND ? 1 : 0);
-    }
-    // visible logical column range of the rows this lane holds in the C layout (rows 4 fq + r of each m-tile)
-    // (patch_speech_encoder.py:30-77; P == 0 is the training mask)
-    int lo[QT][4], hi[QT][4];
-#pragma unroll
-    for (int mt = 0; mt < QT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + mt * 16 + fq * 4 + r;
-            const int a = qi + P;
-            hi[mt][r] = min((a / bs + 1) * bs, P + Q) - off;
-            lo[mt][r] = max(0, qi + P - C) - off;
-        }
+    // ---- the chunk's own V rows [Q][64] into LDS (vn_off >= 0: the launcher found room): 16-byte loads of whole rows, issued before anything else.  Phase 3 needs
+    //      them TRANSPOSED (8 keys of one dim) wherever a fragment of the V^T ring touches slots this chunk is only now filling, and so does the append to the ring:
+    //      both were 2-byte global loads (8 per lane and mixed fragment, each fragment a round trip of its own behind a divergent branch) ----
+    const bool use_vn = QT == 1 && vn_off >= 0;  // (48-row blocks never stage: the launcher says why)
+    bf16_t* Vn = reinterpret_cast<bf16_t*>(smem + (use_vn ? vn_off : 0));
+    if (use_vn)
+        for (int e = tid; e < Q * 8; e += ENC_WAVES * 64)
+            *reinterpret_cast<u32x4_t*>(Vn + (e >> 3) * ENC_HD + (e & 7) * 8) = *reinterpret_cast<const u32x4_t*>(vnew + (long)(e >> 3) * 3 * D + (e & 7) * 8);
 
+    // ---- rotated query fragments: A[row = fr][k = 8 fq + j] for both 32-dim k-steps ----
+    // One stream (QT == 1): both fragments in every wave's registers, no barrier.  Many streams (QT == 3): six fragments -- 24 registers in each of 8 waves, rotated
+    // eight times over -- are rotated ONCE (wave w < 2 QT takes fragment w) into LDS (the bytes Ohalf uses after phase 1) and re-read per key tile: the registers
+    // are what the second key tile in flight needs (phase 1 below) at two workgroups per CU.
+    constexpr bool QLDS = QT > 1;
+    u32x4_t* Qs = reinterpret_cast<u32x4_t*>(Ohalf);  // [QT * 2][64 lanes] x 16 B
+    static_assert(QT * 2 * 64 * 16 <= QT * 16 * ENC_HD * 4, "the query fragments fit the bytes of Ohalf");
+    u32x4_t qf[QLDS ? 1 : QT][2];
+    if constexpr (QLDS) {
+        if (wave < QT * 2) {
+            const int mt = wave >> 1, ks = wave & 1;
+            const int qi = q0 + mt * 16 + fr;
+            const bf16_t* qrow = qkv + ((long)s * Q + qi) * 3 * D + h * ENC_HD;
+            Qs[wave * 64 + lane] = rot_frag<TB>(qrow, K - Q + qi, ks, fq, rope_cos, rope_sin, rope_cs, RND ? 1 : 0);
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < QT; ++mt) {
+            const int qi = q0 + mt * 16 + fr;
+            const bf16_t* qrow = qkv + ((long)s * Q + qi) * 3 * D + h * ENC_HD;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[mt][ks] = rot_frag<TB>(qrow, K - Q + qi, ks, fq, rope_cos, rope_sin, rope_cs, RND ? 1 : 0);
+        }
+    }
+    auto qfrag = [&](int mt, int ks) -> u32x4_t {
+        if constexpr (QLDS) return Qs[(mt * 2 + ks) * 64 + lane];
+        else return qf[mt][ks];
+    };
 #ifdef ISST_ENC_TRACE
-    asm volatile("s_nop 0" :: "v"(qf[0][0].x), "v"(qf[0][1].x));
+    if constexpr (!QLDS) asm volatile("s_nop 0" :: "v"(qf[0][0].x), "v"(qf[0][1].x));
 #endif
     ENC_STAMP(1);
     // ---- 1. scores ----
-    // One stream (QT == 1: 48 workgroups on 256 CUs, nothing else to hide a round trip behind) walks its 5 key tiles per wave with ALL their loads -- key rows and
-    // rotary table entries -- in flight before the first rotation: the phase was a chain of 5 dependent round trips, 9.0 of the launch's 18.4 us
-    // (profiles/r05/enc_attention_trace_1_stream.txt).  Many streams (QT == 3, two workgroups per CU, VALU-bound) keep one tile at a time and their registers.
-    // (16 waves x 3 tiles instead of 8 x 5 for the lone stream: the phase took 10.9 us instead of 9.0 -- it is bound by the instructions a SIMD has to issue at the clock
-    //  the chip holds, not by latency: profiles/r05/enc_attention_trace_1_stream_16_waves_SLOWER.txt)
-    constexpr int TCH = QT == 1 ? 5 : 1;
+    // The mask needs no tensor: row qi may see logical columns [lo, hi) (patch_speech_encoder.py:30-77; P == 0 is the training mask):
+    //   hi = min(end of the block of frame qi + P, P + Q) - off,   lo = max(0, qi + P - C) - off,   off = max(0, P - C).
+    // lo in one form for both signs of P - C:  j >= lo  <=>  j - min(P - C, 0) - qi >= 0  (j >= 0 always).
     const int n_tiles = cap >> 4;
-    for (int nt0 = wave; nt0 < n_tiles; nt0 += ENC_WAVES * TCH) {
-        u32x4_t kraw[TCH][2];
-        f32x4_t kc[TCH][2], ksn[TCH][2];
-        int jj[TCH], cph[TCH];
-        bool lv[TCH];
+    // one key tile's loads: the lane's key row (2 x 16 B) and its rotary table entries (4 x 16 B); returns the key's logical index (>= K: outside the window)
+    auto issue = [&](int nt, u32x4_t (&kraw)[2], EncTab<TB> (&kt)[2]) -> int {
+        const int cphys = nt * 16 + fr;       // physical slot of this lane's key
+        int j = cphys - start;                // logical index
+        if (j < 0) j += cap;
+        const bool live = j < K;
+        const int jpos = live ? j : 0;
+        const bool is_new = live && j >= len;  // written by this chunk: still only in the qkv rows
+        const bf16_t* krow = is_new ? knew + (long)(j - len) * 3 * D : kr + (long)cphys * ENC_HD;
 #pragma unroll
-        for (int t = 0; t < TCH; ++t) {
-            const int nt = min(nt0 + t * ENC_WAVES, n_tiles - 1);  // (a tile past the end re-reads the last one; it is not used)
-            const int cphys = nt * 16 + fr;       // physical slot of this lane's key
-            int j = cphys - start;                // logical index
-            if (j < 0) j += cap;
-            const bool live = j < K;
-            const int jpos = live ? j : 0;
-            const bool is_new = live && j >= len;  // written by this chunk: still only in the qkv rows
-            const bf16_t* krow = is_new ? knew + (long)(j - len) * 3 * D : kr + (long)cphys * ENC_HD;
-            jj[t] = j; cph[t] = cphys; lv[t] = live;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                kraw[t][ks] = *reinterpret_cast<const u32x4_t*>(krow + ks * 32 + fq * 8);
-                kc[t][ks] = *reinterpret_cast<const f32x4_t*>(rope_cos + (long)jpos * 32 + ((ks * 32 + fq * 8) >> 1));
-                ksn[t][ks] = *reinterpret_cast<const f32x4_t*>(rope_sin + (long)jpos * 32 + ((ks * 32 + fq * 8) >> 1));
-            }
+        for (int ks = 0; ks < 2; ++ks) {
+            kraw[ks] = *reinterpret_cast<const u32x4_t*>(krow + ks * 32 + fq * 8);
+            enc_tab_load<TB>(kt[ks], rope_cos, rope_sin, rope_cs, jpos, ks, fq);
         }
+        return j;
+    };
+    // the chunk's own keys go to the ring unrotated (query block 0 owns the append)
+    auto append_key = [&](int nt, int j, const u32x4_t (&kraw)[2]) {
+        if (j < K && j >= len && qb == 0) {
 #pragma unroll
-        for (int t = 0; t < TCH; ++t) {
-            if (nt0 + t * ENC_WAVES >= n_tiles) break;  // (wave-uniform)
-            const int j = jj[t], cphys = cph[t];
-            const bool live = lv[t];
-            if (live && j >= len && qb == 0) {  // append the unrotated key to the ring (query block 0 owns the append)
+            for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<u32x4_t*>(kr + (long)(nt * 16 + fr) * ENC_HD + ks * 32 + fq * 8) = kraw[ks];
+        }
+    };
+    const int a0 = q0 + P;
+    const int blk0 = a0 / bs;
+    // every row of the workgroup in ONE block of the mask (always, unless the block size changed mid-stream or a query block straddles two blocks): hi is one
+    // number and lo a comparison against a constant -- no per-row bounds in registers, which is what pays for the second tile in flight below
+    const bool one_block = QT > 1 && (a0 + QT * 16 - 1) / bs == blk0;
+    if (one_block) {
+        // Many streams (QT == 3, two workgroups per CU): a wave's tiles were a chain of [6 loads -> rotation -> MFMAs -> 12 stores], ~2.5 us each with nothing of its
+        // own in flight behind the loads (13 of a workgroup's 37 us, profiles/r03/enc_attention_trace_64_streams.txt).  Two register sets: tile i + 1 is requested
+        // before tile i is rotated.
+        const int hi_s = min((blk0 + 1) * bs, P + Q) - off;      // (<= K: a key below hi is live)
+        const int jb = min(P - C, 0) + q0 + fq * 4;              // row 4 fq + r of m-tile mt sees key j  <=>  j - jb >= 16 mt + r
+        u32x4_t rawA[2], rawB[2];
+        EncTab<TB> tA[2], tB[2];
+        int jA = 0, jB = 0;
+        int nt = wave;
+        if (nt < n_tiles) jA = issue(nt, rawA, tA);
+        for (; nt < n_tiles; nt += 2 * ENC_WAVES) {
+            const bool more = nt + ENC_WAVES < n_tiles;  // (wave-uniform)
+            if (more) jB = issue(nt + ENC_WAVES, rawB, tB);
+            append_key(nt, jA, rawA);
+            { const int j = jA, jl = jA - jb; enc_score_tile<QT, RND, TB>(rawA, tA, qfrag, S, ldS, nt * 16 + fr, fq, [&](int mt, int r) { return j < hi_s && jl >= mt * 16 + r; }); }
+            if (!more) break;
+            if (nt + 2 * ENC_WAVES < n_tiles) jA = issue(nt + 2 * ENC_WAVES, rawA, tA);
+            append_key(nt + ENC_WAVES, jB, rawB);
+            { const int j = jB, jl = jB - jb; enc_score_tile<QT, RND, TB>(rawB, tB, qfrag, S, ldS, (nt + ENC_WAVES) * 16 + fr, fq, [&](int mt, int r) { return j < hi_s && jl >= mt * 16 + r; }); }
+        }
+    } else {
+        // visible logical column range of the rows this lane holds in the C layout (rows 4 fq + r of each m-tile)
+        int lo[QT][4], hi[QT][4];
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<u32x4_t*>(kr + (long)cphys * ENC_HD + ks * 32 + fq * 8) = kraw[t][ks];
+        for (int mt = 0; mt < QT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = q0 + mt * 16 + fq * 4 + r;
+                const int a = qi + P;
+                hi[mt][r] = min((a / bs + 1) * bs, P + Q) - off;
+                lo[mt][r] = max(0, qi + P - C) - off;
             }
-            u32x4_t kf[2];
+        // One stream (QT == 1: 48 workgroups on 256 CUs, nothing else to hide a round trip behind) walks its 5 key tiles per wave with ALL their loads -- key rows and
+        // rotary table entries -- in flight before the first rotation: the phase was a chain of 5 dependent round trips, 9.0 of the launch's 18.4 us
+        // (profiles/r05/enc_attention_trace_1_stream.txt).
+        // (16 waves x 3 tiles instead of 8 x 5 for the lone stream: the phase took 10.9 us instead of 9.0 -- it is bound by the instructions a SIMD has to issue at the clock
+        //  the chip holds, not by latency: profiles/r05/enc_attention_trace_1_stream_16_waves_SLOWER.txt)
+        constexpr int TCH = QT == 1 ? 5 : 1;
+        for (int nt0 = wave; nt0 < n_tiles; nt0 += ENC_WAVES * TCH) {
+            u32x4_t kraw[TCH][2];
+            EncTab<TB> kt[TCH][2];
+            int jj[TCH];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kf[ks] = rot_frag_regs(kraw[t][ks], kc[t][ks], ksn[t][ks], RND ? 1 : 0);
+            for (int t = 0; t < TCH; ++t) jj[t] = issue(min(nt0 + t * ENC_WAVES, n_tiles - 1), kraw[t], kt[t]);  // (a tile past the end re-reads the last one; it is not used)
 #pragma unroll
-            for (int mt = 0; mt < QT; ++mt) {
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qf[mt][ks]), __builtin_bit_cast(bf16x8_t, kf[ks]), acc, 0, 0, 0);
-                // C layout: this lane holds column fr (its own key), rows 4 fq + r
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = live && j >= lo[mt][r] && j < hi[mt][r];
-                    // q * head_dim^-0.5 (:768) is an exact power-of-two scaling, applied to the accumulated dot product
-                    const bf16_t v = ok ? f2bf(0.125f * acc[r]) : (bf16_t)0xFF80;  // -inf
-                    S[(long)(mt * 16 + fq * 4 + r) * ldS + cphys] = v;
-                }
+            for (int t = 0; t < TCH; ++t) {
+                const int nt = nt0 + t * ENC_WAVES;
+                if (nt >= n_tiles) break;  // (wave-uniform)
+                const int j = jj[t];
+                append_key(nt, j, kraw[t]);
+                enc_score_tile<QT, RND, TB>(kraw[t], kt[t], qfrag, S, ldS, nt * 16 + fr, fq, [&](int mt, int r) { return j < K && j >= lo[mt][r] && j < hi[mt][r]; });
             }
         }
     }
     __syncthreads();
     ENC_STAMP(2);
+    // physical slot range of the new keys: [nlo, nlo + Q) mod cap
+    int nlo = start + len;
+    if (nlo >= cap) nlo -= cap;
+    // ---- append V^T of the chunk's own keys (query block 0): [dim][slot] <- V[new frame][dim], from the staged rows; the stores drain under phases 2 and 3
+    //      (phase 3 patches every fragment that touches these slots from LDS, so it does not matter to anyone when they land) ----
+    if (qb == 0 && use_vn) {
+        for (int e = tid; e < Q * ENC_HD; e += ENC_WAVES * 64) {
+            int slot = nlo + e / ENC_HD;
+            if (slot >= cap) slot -= cap;
+            vt[(long)(e % ENC_HD) * cap + slot] = Vn[e];
+        }
+    }
 
     // ---- 2. softmax per row (fp32), probabilities rounded to bf16 in place ----
+    // A lane takes 8 consecutive columns of the first 512 (one 16-byte access) and `te` = (cap - 512) / 64 consecutive columns of the rest: a 640-slot ring is 10
+    // elements per lane.  (Rounds 1-5 ran a second 8-column pass for the columns past 512 with 16 of 64 lanes active: 16 element-slots of exp / compare / multiply
+    // per row for 10 elements of work, in a phase that is VALU-bound at many streams.)
+    const int n8 = min(cap, 512) >> 3;               // lanes of the 16-byte pass
+    const int te = cap > 512 ? (cap - 512) >> 6 : 0;  // 0..8 tail columns per lane, from column 512 + lane * te
     for (int row = wave; row < QT * 16; row += ENC_WAVES) {
         bf16_t* srow = S + (long)row * ldS;
-        float v[2][8];
+        bf16_t* trow = srow + 512 + lane * te;
+        float v[8], tv[8];
         float mx = -INFINITY;
+        if (lane < n8) {
+            unpack8(*reinterpret_cast<const u32x4_t*>(srow + lane * 8), v);
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int c = (lane + 64 * pass) * 8;
-            if (c < cap) {
-                unpack8(*reinterpret_cast<const u32x4_t*>(srow + c), v[pass]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[pass][e]);
-            }
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[e]);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < te) { tv[e] = bf2f(trow[e]); mx = fmaxf(mx, tv[e]); }
         mx = wave_max(mx);
         float sum = 0.f;
+        if (lane < n8) {
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            if ((lane + 64 * pass) * 8 < cap) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[pass][e] = (v[pass][e] == -INFINITY) ? 0.f : __expf(v[pass][e] - mx);  // v_exp_f32(x log2 e): the launch is VALU-bound at many streams (-8 %)
-                    sum += v[pass][e];
-                }
+            for (int e = 0; e < 8; ++e) {
+                v[e] = (v[e] == -INFINITY) ? 0.f : __expf(v[e] - mx);  // v_exp_f32(x log2 e): the launch is VALU-bound at many streams (-8 %)
+                sum += v[e];
             }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < te) { tv[e] = (tv[e] == -INFINITY) ? 0.f : __expf(tv[e] - mx); sum += tv[e]; }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
+        if (lane < n8) {
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int c = (lane + 64 * pass) * 8;
-            if (c < cap) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[pass][e] *= inv;
-                *reinterpret_cast<u32x4_t*>(srow + c) = pack8(v[pass]);
-            }
+            for (int e = 0; e < 8; ++e) v[e] *= inv;
+            *reinterpret_cast<u32x4_t*>(srow + lane * 8) = pack8(v);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < te) trow[e] = f2bf(tv[e] * inv);
     }
     __syncthreads();
     ENC_STAMP(3);
@@ -243,10 +350,7 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
     const bf16_t* vrow = vt + (long)dim * cap + fq * 8;  // B[k = 8 fq + j][col = fr] = V^T[dim][slot]
     const int k_steps = cap >> 5, k_half = (k_steps + 1) >> 1;
     const int ks_lo = half * k_half, ks_hi = min(ks_lo + k_half, k_steps);
-    // physical slot range of the new keys: [nlo, nlo + Q) mod cap
-    int nlo = start + len;
-    if (nlo >= cap) nlo -= cap;
-    constexpr int VB = QT == 1 ? 10 : 4;  // V^T fragments in flight before the first use (one stream: the whole half of a full window in ONE round trip instead of three)
+    constexpr int VB = 10;  // V^T fragments in flight before the first use: the whole half of a full 640-slot window in ONE round trip instead of three (the registers of phase 1 are free by now)
     for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += VB) {
         u32x4_t vf[VB];
 #pragma unroll
@@ -256,8 +360,8 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
             int rel = t0 - nlo;
             if (rel < 0) rel += cap;
             const bool any_new = rel < Q || rel + 7 >= cap;  // the 8 slots touch [nlo, nlo+Q) (possibly wrapping)
-            if (!any_new) {
-                vf[u] = *reinterpret_cast<const u32x4_t*>(vrow + ks * 32);
+            if (!any_new || use_vn) {
+                vf[u] = *reinterpret_cast<const u32x4_t*>(vrow + ks * 32);  // (staged rows: the new slots' stale bytes are replaced below)
             } else {  // mixed fragment: new keys come from the qkv rows
                 bf16_t e[8];
 #pragma unroll
@@ -270,6 +374,27 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
                 vf[u].y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
                 vf[u].z = (uint32_t)e[4] | ((uint32_t)e[5] << 16);
                 vf[u].w = (uint32_t)e[6] | ((uint32_t)e[7] << 16);
+            }
+        }
+        if (use_vn) {  // fragments that touch the slots this chunk is filling take those keys from the staged rows
+#pragma unroll
+            for (int u = 0; u < VB; ++u) {
+                const int t0 = (ks0 + u < ks_hi ? ks0 + u : ks_hi - 1) * 32 + fq * 8;
+                int rel = t0 - nlo;
+                if (rel < 0) rel += cap;
+                if (rel < Q || rel + 7 >= cap) {
+                    uint32_t w[4] = {vf[u].x, vf[u].y, vf[u].z, vf[u].w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        int r2 = rel + q;
+                        if (r2 >= cap) r2 -= cap;
+                        if (r2 < Q) {
+                            const uint32_t nv = Vn[r2 * ENC_HD + dim];
+                            w[q >> 1] = (q & 1) ? ((w[q >> 1] & 0x0000ffffu) | (nv << 16)) : ((w[q >> 1] & 0xffff0000u) | nv);
+                        }
+                    }
+                    vf[u] = (u32x4_t){w[0], w[1], w[2], w[3]};
+                }
             }
         }
 #pragma unroll
@@ -304,13 +429,25 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
             }
     }
     ENC_STAMP(5);
-    // ---- append V^T of the chunk's own keys (query block 0): [dim][slot] <- V[new frame][dim] ----
-    if (qb == 0) {
-        for (int e = tid; e < Q * ENC_HD; e += ENC_WAVES * 64) {
-            const int i = e / ENC_HD, dd = e % ENC_HD;
-            int slot = nlo + i;
-            if (slot >= cap) slot -= cap;
-            vt[(long)dd * cap + slot] = vnew[(long)i * 3 * D + dd];
+    // ---- append V^T of the chunk's own keys (query block 0): [dim][slot] <- V[new frame][dim]; a thread's 2-byte loads all in flight before its first store ----
+    if (qb == 0 && !use_vn) {
+        constexpr int AB = 6;  // (Q = 48: one batch)
+        for (int e0 = tid; e0 < Q * ENC_HD; e0 += ENC_WAVES * 64 * AB) {
+            bf16_t val[AB];
+#pragma unroll
+            for (int u = 0; u < AB; ++u) {
+                const int e = e0 + u * (ENC_WAVES * 64);
+                val[u] = e < Q * ENC_HD ? vnew[(long)(e / ENC_HD) * 3 * D + (e % ENC_HD)] : (bf16_t)0;
+            }
+#pragma unroll
+            for (int u = 0; u < AB; ++u) {
+                const int e = e0 + u * (ENC_WAVES * 64);
+                if (e < Q * ENC_HD) {
+                    int slot = nlo + e / ENC_HD;
+                    if (slot >= cap) slot -= cap;
+                    vt[(long)(e % ENC_HD) * cap + slot] = val[u];
+                }
+            }
         }
     }
     ENC_STAMP(6);
@@ -318,24 +455,35 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
 
 int launch_enc_attention(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                          const EncStreamView* sv, const float* rope_cos, const float* rope_sin, int rope_round_each,
-                         bf16_t* out, int n_streams, int Q, int heads, int cap, int max_cache, int blocksize, hipStream_t s) {
+                         bf16_t* out, int n_streams, int Q, int heads, int cap, int max_cache, int blocksize, hipStream_t s, const bf16_t* rope_cs) {
     if (Q <= 0 || n_streams <= 0) return ISST_OK;
     if (Q % 16 != 0 || cap % 64 != 0 || cap > 1024 || max_cache + Q > cap) return ISST_ERR_ARG;
     const int QT = (Q % 48 == 0 && n_streams * (Q / 16) * heads >= 1024) ? 3 : 1;  // few streams: 16-row query blocks give 3x the workgroups (the K rotation is redone per block)
-    const size_t lds = (size_t)QT * 16 * (cap + ENC_SPAD) * 2 + (size_t)QT * 16 * ENC_HD * sizeof(float);
+    size_t lds = (size_t)QT * 16 * (cap + ENC_SPAD) * 2 + (size_t)QT * 16 * ENC_HD * sizeof(float);
+    // the chunk's own V rows staged in LDS (Q x 128 B): few streams only (16-row query blocks).  Measured on one box (profiles/r06/enc_attention_rework_ab.txt):
+    // one stream 20.9 -> 19.7 us per launch with the rows staged; 64 streams (48-row blocks, two workgroups per CU, bound by what the SIMDs issue, not by round
+    // trips) 81.1 -> 85.8 us -- there the patching of the fragments costs more than the few lanes of 2-byte loads it replaces, so those launches keep the global path
+    int vn_off = -1;
+    static const bool vn_on = !(getenv("ISST_ENC_VN") && atoi(getenv("ISST_ENC_VN")) == 0);  // A/B knob: 0 = the rows stay in global memory (rounds 1-5)
+    if (vn_on && QT == 1 && lds + (size_t)Q * 128 <= 160 * 1024) { vn_off = (int)lds; lds += (size_t)Q * 128; }
     dim3 grid(heads, Q / (QT * 16), n_streams), block(ENC_WAVES * 64);
     auto go = [&](auto kern, size_t& lds_set) -> int {
         if (lds > 64 * 1024 && lds > lds_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISST_ERR_HIP;
             lds_set = lds;
         }
-        hipLaunchKernelGGL(kern, grid, block, lds, s, qkv, kring, vring, stream_stride, sv, rope_cos, rope_sin, rope_round_each, out, Q, heads, cap, max_cache, blocksize);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, qkv, kring, vring, stream_stride, sv, rope_cos, rope_sin, rope_cs, rope_round_each, out, Q, heads, cap, max_cache, blocksize, vn_off);
         return ISST_OK;
     };
-    static size_t lds_set[4] = {0, 0, 0, 0};
+    static size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rc;
-    if (QT == 3) rc = rope_round_each ? go(enc_attention_kernel<3, true>, lds_set[0]) : go(enc_attention_kernel<3, false>, lds_set[1]);
-    else rc = rope_round_each ? go(enc_attention_kernel<1, true>, lds_set[2]) : go(enc_attention_kernel<1, false>, lds_set[3]);
+    if (rope_cs) {
+        if (QT == 3) rc = rope_round_each ? go(enc_attention_kernel<3, true, true>, lds_set[4]) : go(enc_attention_kernel<3, false, true>, lds_set[5]);
+        else rc = rope_round_each ? go(enc_attention_kernel<1, true, true>, lds_set[6]) : go(enc_attention_kernel<1, false, true>, lds_set[7]);
+    } else {
+        if (QT == 3) rc = rope_round_each ? go(enc_attention_kernel<3, true, false>, lds_set[0]) : go(enc_attention_kernel<3, false, false>, lds_set[1]);
+        else rc = rope_round_each ? go(enc_attention_kernel<1, true, false>, lds_set[2]) : go(enc_attention_kernel<1, false, false>, lds_set[3]);
+    }
     if (rc != ISST_OK) return rc;
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }

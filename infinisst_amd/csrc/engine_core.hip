@@ -237,6 +237,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
     h->llm_rope_rows = h->sys_cap + h->ring_cap;
     h->enc_cos = h->dalloc<float>((size_t)h->enc_rope_rows * 32, true);
     h->enc_sin = h->dalloc<float>((size_t)h->enc_rope_rows * 32, true);
+    h->enc_cs = h->dalloc<bf16_t>((size_t)h->enc_rope_rows * 64, true);
     h->llm_cos = h->dalloc<bf16_t>((size_t)h->llm_rope_rows * 64, true);
     h->llm_sin = h->dalloc<bf16_t>((size_t)h->llm_rope_rows * 64, true);
 
@@ -314,7 +315,7 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         h->meta_dev2 = h->dalloc<unsigned char>(h->meta_bytes);
         if (!h->meta_dev2) { h->fail(ISST_ERR_NOMEM, "beam search allocation failed"); return die(ISST_ERR_NOMEM); }
     }
-    const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->llm_kr, h->enc_cos, h->enc_sin, h->llm_cos, h->llm_sin, h->pcm_f32,
+    const void* must[] = {h->audio_hist, h->enc_k, h->enc_v, h->llm_k, h->llm_v, h->llm_kr, h->enc_cos, h->enc_sin, h->enc_cs, h->llm_cos, h->llm_sin, h->pcm_f32,
                           h->window, h->act_a, h->act_b, h->ex, h->exn, h->eqkv, h->eattn, h->effn, h->speech, h->lx, h->lxn, h->lqkv, h->lqrot,
                           h->lattn, h->lact, h->llast, h->lpartial, h->lslab, h->logits, h->out_tok, h->samp_val, h->samp_idx, h->meta_dev};
     for (const void* p : must)
@@ -491,6 +492,28 @@ extern "C" int isst_set_rope_tables(isst_handle* h, const float* enc_cos, const 
         return h->fail(ISST_ERR_ARG, "rope tables too short: need %d encoder rows and %d llm rows", h->enc_rope_rows, h->llm_rope_rows);
     HIPCHK(hipMemcpy(h->enc_cos, enc_cos, (size_t)h->enc_rope_rows * 32 * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->enc_sin, enc_sin, (size_t)h->enc_rope_rows * 32 * sizeof(float), hipMemcpyHostToDevice));
+    // The reference's production setting casts the encoder to bf16 (agents/infinisst.py:173), so its rotary module's cos / sin ARE bf16 numbers (rope.py "bf16" mode).
+    // Then the attention kernel reads them from one packed bf16 table [position][k-step][8-dim group][cos x 4 | sin x 4] -- same values, half the bytes, one 16-byte
+    // load per group instead of two (enc_attn.hip EncTab); tables with any other fp32 value (rope.py "fp32" mode) are read as handed over.  ISST_ENC_TAB_BF16=0: always fp32.
+    {
+        const size_t n = (size_t)h->enc_rope_rows * 32;
+        auto is_bf16 = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return (u & 0xffffu) == 0; };
+        bool exact = !(getenv("ISST_ENC_TAB_BF16") && atoi(getenv("ISST_ENC_TAB_BF16")) == 0);
+        for (size_t i = 0; exact && i < n; ++i) exact = is_bf16(enc_cos[i]) && is_bf16(enc_sin[i]);
+        h->enc_cs_valid = false;
+        if (exact) {
+            auto top = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return (uint16_t)(u >> 16); };
+            std::vector<uint16_t> cs((size_t)h->enc_rope_rows * 64);
+            for (int pos = 0; pos < h->enc_rope_rows; ++pos)
+                for (int g = 0; g < 8; ++g)  // g = k-step * 4 + group: pairs 4 g .. 4 g + 3
+                    for (int i = 0; i < 4; ++i) {
+                        cs[((size_t)pos * 8 + g) * 8 + i] = top(enc_cos[(size_t)pos * 32 + g * 4 + i]);
+                        cs[((size_t)pos * 8 + g) * 8 + 4 + i] = top(enc_sin[(size_t)pos * 32 + g * 4 + i]);
+                    }
+            HIPCHK(hipMemcpy(h->enc_cs, cs.data(), cs.size() * 2, hipMemcpyHostToDevice));
+            h->enc_cs_valid = true;
+        }
+    }
     HIPCHK(hipMemcpy(h->llm_cos, llm_cos, (size_t)h->llm_rope_rows * 64 * 2, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->llm_sin, llm_sin, (size_t)h->llm_rope_rows * 64 * 2, hipMemcpyHostToDevice));
     h->rope_set = true;

@@ -105,13 +105,13 @@ int run_encoder(isst_handle* h, int n, const int* sids, const float* const* pcm,
             bf16_t* kb = h->enc_k + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
             bf16_t* vb = h->enc_v + (size_t)sids[0] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
             CHK(launch_enc_attention(h->eqkv, kb, vb, h->enc_stream_stride, ev, h->enc_cos, h->enc_sin, c.enc_rope_round_each, h->eattn, n, Q,
-                                     c.enc_heads, h->enc_cap, c.max_cache_size, bs, st));
+                                     c.enc_heads, h->enc_cap, c.max_cache_size, bs, st, h->enc_cs_valid ? h->enc_cs : nullptr));
         } else {
             for (int i = 0; i < n; ++i) {
                 bf16_t* kb = h->enc_k + (size_t)sids[i] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
                 bf16_t* vb = h->enc_v + (size_t)sids[i] * h->enc_stream_stride + (size_t)l * h->enc_layer_stride;
                 CHK(launch_enc_attention(h->eqkv + (size_t)i * Q * 3 * D, kb, vb, 0, ev + i, h->enc_cos, h->enc_sin, c.enc_rope_round_each,
-                                         h->eattn + (size_t)i * Q * D, 1, Q, c.enc_heads, h->enc_cap, c.max_cache_size, bs, st));
+                                         h->eattn + (size_t)i * Q * D, 1, Q, c.enc_heads, h->enc_cap, c.max_cache_size, bs, st, h->enc_cs_valid ? h->enc_cs : nullptr));
             }
         }
         if (s_out > 1) {

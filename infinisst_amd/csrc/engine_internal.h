@@ -175,6 +175,8 @@ struct isst_handle {
     bf16_t* final_norm = nullptr;
     PackedLinear lm_head;
     float *enc_cos = nullptr, *enc_sin = nullptr;
+    bf16_t* enc_cs = nullptr;   // both encoder tables as ONE packed bf16 table (enc_attn.hip EncTab), valid when every value handed to isst_set_rope_tables is a bf16 number
+    bool enc_cs_valid = false;
     bf16_t *llm_cos = nullptr, *llm_sin = nullptr;
     int enc_rope_rows = 0, llm_rope_rows = 0;
     bf16_t* enc_pos = nullptr;  // cfg.enc_abs_pos (--rope 0): sinusoid rows [enc_pos_rows][enc_dim], one per bf16 integer position (isst_set_enc_position_table)

@@ -55,7 +55,8 @@ int launch_embed_splice(const int* ids, const int* speech_row, const bf16_t* tab
 // also appends the chunk's own k / v (from the qkv rows) to the rings: no separate append launch is needed
 int launch_enc_attention(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long stream_stride,
                          const EncStreamView* sv, const float* rope_cos, const float* rope_sin, int rope_round_each,
-                         bf16_t* out, int n_streams, int Q, int heads, int cap, int max_cache, int blocksize, hipStream_t s);
+                         bf16_t* out, int n_streams, int Q, int heads, int cap, int max_cache, int blocksize, hipStream_t s,
+                         const bf16_t* rope_cs = nullptr);  // rope_cs: the packed bf16 form of both tables (enc_attn.hip EncTab; null: the fp32 tables are read)
 
 // ---- LLM attention (llm_attn.hip) ----
 struct LlmAttnDims {
