@@ -26,24 +26,29 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define ENC_HD 64
 #define ENC_SPAD 8  // bf16 elements of padding per S row (keeps rows 16-byte aligned, shifts banks by 4 per row)
 #define ENC_WAVES 8
 
-// interleaved-pair rotation of 8 consecutive dims (4 pairs) [3P rotary_embedding_torch semantics, see oracle]
-__device__ __forceinline__ void rot8(const float* x, const float* c, const float* sn, int round_each, float* y) {
+// interleaved-pair rotation of 8 consecutive dims (4 pairs) [3P rotary_embedding_torch semantics, see oracle]; returns the four rotated pairs packed as bf16.
+// round_each ("bf16" mode, the reference's production numerics): every product and every sum is a bf16 number.  Written word by word: the two products of an output
+// element are rounded by ONE v_cvt_pk_bf16_f32 and come back as fp32 by a shift and a mask, and the sums of a pair are rounded by the conversion that packs them
+// -- rounding twice (bfr, then pack8) gave the same bits for ~16 instead of ~10 instructions per pair in a phase that is bound by instruction issue.
+__device__ __forceinline__ u32x4_t rot8(const float* x, const float* c, const float* sn, int round_each) {
+    uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float a = x[2 * i], b = x[2 * i + 1];
         if (round_each) {
-            y[2 * i] = bfr(bfr(a * c[i]) + bfr(-b * sn[i]));
-            y[2 * i + 1] = bfr(bfr(b * c[i]) + bfr(a * sn[i]));
+            const uint32_t t = pack_bf(a * c[i], -b * sn[i]), u = pack_bf(b * c[i], a * sn[i]);
+            w[i] = pack_bf(lo_bf(t) + hi_bf(t), lo_bf(u) + hi_bf(u));
         } else {
-            y[2 * i] = bfr(a * c[i] - b * sn[i]);
-            y[2 * i + 1] = bfr(b * c[i] + a * sn[i]);
+            w[i] = pack_bf(a * c[i] - b * sn[i], b * c[i] + a * sn[i]);
         }
     }
+    return (u32x4_t){w[0], w[1], w[2], w[3]};
 }
 // The rotary table entries of one (position, 8-dim group) as they travel in registers.
 //   TB = false: fp32 tables [pos][32] cos and sin, as handed to isst_set_rope_tables: 2 x 16 B per group.
@@ -66,7 +71,7 @@ __device__ __forceinline__ void enc_tab_load(EncTab<TB>& t, const float* __restr
 // raw 8 dims (the lane's 16 bytes of a q or k row) rotated with the table entries `t`, as an MFMA operand fragment
 template <bool TB>
 __device__ __forceinline__ u32x4_t rot_frag_regs(const u32x4_t& raw, const EncTab<TB>& t, int round_each) {
-    float x[8], y[8], cc[4], ss[4];
+    float x[8], cc[4], ss[4];
     unpack8(raw, x);
     if constexpr (TB) {
         cc[0] = lo_bf(t.cs.x); cc[1] = hi_bf(t.cs.x); cc[2] = lo_bf(t.cs.y); cc[3] = hi_bf(t.cs.y);
@@ -75,16 +80,23 @@ __device__ __forceinline__ u32x4_t rot_frag_regs(const u32x4_t& raw, const EncTa
         cc[0] = t.c.x; cc[1] = t.c.y; cc[2] = t.c.z; cc[3] = t.c.w;
         ss[0] = t.s.x; ss[1] = t.s.y; ss[2] = t.s.z; ss[3] = t.s.w;
     }
-    rot8(x, cc, ss, round_each, y);
-    return pack8(y);
+    return rot8(x, cc, ss, round_each);
 }
-// 8 dims (k-step ks, group fq) of the row at `p`, rotated at position `pos`
+// 8 dims (k-step ks, group fq) of the QUERY row at `p`, rotated at position `pos` and scaled by head_dim^-0.5 = 1/8.  The reference scales q before the
+// product (patch_speech_encoder.py:768); a power of two commutes with every rounding on the way (bf16 and fp32 share their exponent range), so whether the
+// rotated query, the products or the accumulated score is scaled gives the same bits -- scaled here, once per query, the 12 scores a lane holds per key tile
+// need no multiplication
 template <bool TB>
 __device__ __forceinline__ u32x4_t rot_frag(const bf16_t* p, int pos, int ks, int fq, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                             const bf16_t* __restrict__ rope_cs, int round_each) {
     EncTab<TB> t;
     enc_tab_load<TB>(t, rope_cos, rope_sin, rope_cs, pos, ks, fq);
-    return rot_frag_regs<TB>(*reinterpret_cast<const u32x4_t*>(p + ks * 32 + fq * 8), t, round_each);
+    const u32x4_t r = rot_frag_regs<TB>(*reinterpret_cast<const u32x4_t*>(p + ks * 32 + fq * 8), t, round_each);
+    float y[8];
+    unpack8(r, y);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] *= 0.125f;
+    return pack8(y);
 }
 
 // Scores of ONE key tile (16 keys: this lane's key is column fr) against the workgroup's QT m-tiles of queries: rotation of the lane's 2 x 8 key dims, two MFMAs per
@@ -102,12 +114,13 @@ __device__ __forceinline__ void enc_score_tile(const u32x4_t (&kraw)[2], const E
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qfrag(mt, ks)), __builtin_bit_cast(bf16x8_t, kf[ks]), acc, 0, 0, 0);
-        // C layout: this lane holds column fr (its own key), rows 4 fq + r
+        // C layout: this lane holds column fr (its own key), rows 4 fq + r.  Masked scores become -inf BEFORE the conversion, two scores per v_cvt_pk_bf16_f32
+        // (bf16(-inf) = 0xFF80); the query carries the 1/8 (rot_frag)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // q * head_dim^-0.5 (:768) is an exact power-of-two scaling, applied to the accumulated dot product
-            const bf16_t v = ok(mt, r) ? f2bf(0.125f * acc[r]) : (bf16_t)0xFF80;  // -inf
-            S[(long)(mt * 16 + fq * 4 + r) * ldS + cphys] = v;
+        for (int r = 0; r < 4; r += 2) {
+            const uint32_t w = pack_bf(ok(mt, r) ? acc[r] : -INFINITY, ok(mt, r + 1) ? acc[r + 1] : -INFINITY);
+            S[(long)(mt * 16 + fq * 4 + r) * ldS + cphys] = (bf16_t)(w & 0xffffu);
+            S[(long)(mt * 16 + fq * 4 + r + 1) * ldS + cphys] = (bf16_t)(w >> 16);
         }
     }
 }
@@ -123,6 +136,35 @@ extern "C" int isst_debug_enc_trace_read(void* dst, long bytes) {
 #else
 #define ENC_STAMP(i) do {} while (0)
 #endif
+
+// Softmax of one row of S in place (phase 2) for rings of 512 + 128 TD slots: lane l owns columns 8 l .. 8 l + 7 and 512 + 2 TD l .. + 2 TD - 1 -- one 16-byte access and
+// TD dwords, no lane predicate, no branch (the general form below tests `lane < n8` and `e < te` per element: ~350 instructions per row against ~130 here, in a phase
+// that is bound by what the SIMDs issue).  Same arithmetic and the same summation order as the general form.
+template <int TD>
+__device__ __forceinline__ void enc_softmax_row(bf16_t* srow, int lane) {
+    float v[8 + 2 * TD];
+    unpack8(*reinterpret_cast<const u32x4_t*>(srow + lane * 8), v);
+    uint32_t* tw = reinterpret_cast<uint32_t*>(srow + 512) + lane * TD;
+#pragma unroll
+    for (int d = 0; d < TD; ++d) { const uint32_t w = tw[d]; v[8 + 2 * d] = lo_bf(w); v[9 + 2 * d] = hi_bf(w); }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8 + 2 * TD; ++e) mx = fmaxf(mx, v[e]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8 + 2 * TD; ++e) {
+        v[e] = __expf(v[e] - mx);  // v_exp_f32(x log2 e); a masked score is -inf and gives exactly 0 (every row sees its own key: mx is finite)
+        sum += v[e];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int e = 0; e < 8 + 2 * TD; ++e) v[e] *= inv;
+    *reinterpret_cast<u32x4_t*>(srow + lane * 8) = pack8(v);
+#pragma unroll
+    for (int d = 0; d < TD; ++d) tw[d] = pack_bf(v[8 + 2 * d], v[9 + 2 * d]);
+}
 
 template <int QT, bool RND, bool TB>  // TB: the packed bf16 rotary table (EncTab); QT: m-tiles of 16 query rows per workgroup; RND: every product of the rotation rounds to bf16 (enc_rope_mode "bf16": as a compile-time
                               // constant -- as a runtime flag every rotated pair carried a branch, 160 of them per key tile in a phase that is bound by instruction issue)
@@ -160,6 +202,81 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
         for (int e = tid; e < Q * 8; e += ENC_WAVES * 64)
             *reinterpret_cast<u32x4_t*>(Vn + (e >> 3) * ENC_HD + (e & 7) * 8) = *reinterpret_cast<const u32x4_t*>(vnew + (long)(e >> 3) * 3 * D + (e & 7) * 8);
 
+    // ---- append the chunk's own keys, unrotated, to the ring (query block 0): one 16-byte load + store per thread, before anything else.  Nobody reads these
+    //      slots in this launch (every workgroup takes the chunk's keys from the qkv rows), so it does not matter when the stores land; inside the tile loop of
+    //      phase 1 a conditional store made hipcc drain vmcnt(0) at every tile, which took the tile in flight down with it ----
+    // physical slot range of the chunk's own keys: [nlo, nlo + Q) mod cap
+    int nlo = start + len;
+    if (nlo >= cap) nlo -= cap;
+    // (Q <= 64: one 16-byte piece per thread, LOADED here and stored behind the query rotation -- a store right here would make its wave wait a whole round trip
+    //  before it even asks for its query rows)
+    const bool k_split = Q * 8 <= ENC_WAVES * 64;
+    const bool k_mine = qb == 0 && k_split && tid < Q * 8;
+    u32x4_t k_val = {0u, 0u, 0u, 0u};
+    bf16_t* k_dst = kr;
+    if (k_mine) {
+        int slot = nlo + (tid >> 3);
+        if (slot >= cap) slot -= cap;
+        k_dst = kr + (long)slot * ENC_HD + (tid & 7) * 8;
+        k_val = *reinterpret_cast<const u32x4_t*>(knew + (long)(tid >> 3) * 3 * D + (tid & 7) * 8);
+    }
+    if (qb == 0 && !k_split) {
+        for (int e = tid; e < Q * 8; e += ENC_WAVES * 64) {
+            int slot = nlo + (e >> 3);
+            if (slot >= cap) slot -= cap;
+            *reinterpret_cast<u32x4_t*>(kr + (long)slot * ENC_HD + (e & 7) * 8) = *reinterpret_cast<const u32x4_t*>(knew + (long)(e >> 3) * 3 * D + (e & 7) * 8);
+        }
+    }
+    // ---- ... and V^T [dim][slot] <- V[new frame][dim].  A thread owns (dim, one ALIGNED group of 8 ring slots that the chunk's keys touch): it reads the group
+    //      (16 B), replaces the slots of the new keys -- eight 2-byte loads at most; a wave's lanes are 64 consecutive dims of one frame: one line per load -- and
+    //      stores the group back (slots of older keys get their own bytes again: this workgroup is the ring's only writer in the launch).  Rounds 1-5 stored element
+    //      by element: 3072 two-byte stores per workgroup, every lane of a wave into a line of its own.
+    //      Many streams (48-row blocks) whose workgroup is the only one of its (head, stream) do it HERE: phase 3, three barriers on, then reads every fragment of
+    //      V^T from the ring -- no fragment mixed from ring and qkv rows (8 two-byte loads per lane behind a divergent branch) -- and nobody else reads these slots.
+    const bool v_first = QT > 1 && gridDim.y == 1 && vn_off != -2;  // (-2: A/B knob ISST_ENC_VFIRST=0)
+    auto append_vt8 = [&]() {
+        const int a0 = nlo & ~7, ng = ((nlo & 7) + Q + 7) >> 3;
+        for (int e = tid; e < ng * ENC_HD; e += ENC_WAVES * 64) {
+            const int dd = e % ENC_HD;
+            int base = a0 + (e / ENC_HD) * 8;
+            if (base >= cap) base -= cap;  // (cap is a multiple of 8: an aligned group does not wrap)
+            bf16_t* gp = vt + (long)dd * cap + base;
+            const u32x4_t old = *reinterpret_cast<const u32x4_t*>(gp);
+            uint32_t w[4] = {old.x, old.y, old.z, old.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                int rel = base + q - nlo;
+                if (rel < 0) rel += cap;
+                if (rel < Q) {
+                    const uint32_t nv = vnew[(long)rel * 3 * D + dd];
+                    w[q >> 1] = (q & 1) ? ((w[q >> 1] & 0x0000ffffu) | (nv << 16)) : ((w[q >> 1] & 0xffff0000u) | nv);
+                }
+            }
+            *reinterpret_cast<u32x4_t*>(gp) = (u32x4_t){w[0], w[1], w[2], w[3]};
+        }
+    };
+    // (the common shape -- at most 512 (dim, group) pairs: Q = 48 -- in two halves: the loads here, the patched group's store behind the query rotation, so that
+    //  no wave sits waiting for these loads; the barrier that follows the rotation does not wait for the stores)
+    const int v_ng = ((nlo & 7) + Q + 7) >> 3;
+    const bool v_split = v_first && v_ng * ENC_HD <= ENC_WAVES * 64;
+    if (v_first && !v_split) append_vt8();
+    u32x4_t v_old = {0u, 0u, 0u, 0u};
+    uint32_t v_nv[8];
+    int v_rel0 = 0;
+    bf16_t* v_gp = vt;
+    const bool v_mine = v_split && tid < v_ng * ENC_HD;
+    if (v_mine) {
+        const int dd = tid % ENC_HD;
+        int base = (nlo & ~7) + (tid / ENC_HD) * 8;
+        if (base >= cap) base -= cap;
+        v_gp = vt + (long)dd * cap + base;
+        v_old = *reinterpret_cast<const u32x4_t*>(v_gp);
+        v_rel0 = base - nlo;
+        if (v_rel0 < -7) v_rel0 += cap;  // slot q of the group is new key v_rel0 + q where that lies in [0, Q) (v_rel0 in -7 .. Q - 1)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v_nv[q] = vnew[(long)min(max(v_rel0 + q, 0), Q - 1) * 3 * D + dd];  // (unconditional loads; the unused ones are dropped below)
+    }
+
     // ---- rotated query fragments: A[row = fr][k = 8 fq + j] for both 32-dim k-steps ----
     // One stream (QT == 1): both fragments in every wave's registers, no barrier.  Many streams (QT == 3): six fragments -- 24 registers in each of 8 waves, rotated
     // eight times over -- are rotated ONCE (wave w < 2 QT takes fragment w) into LDS (the bytes Ohalf uses after phase 1) and re-read per key tile: the registers
@@ -175,7 +292,18 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
             const bf16_t* qrow = qkv + ((long)s * Q + qi) * 3 * D + h * ENC_HD;
             Qs[wave * 64 + lane] = rot_frag<TB>(qrow, K - Q + qi, ks, fq, rope_cos, rope_sin, rope_cs, RND ? 1 : 0);
         }
-        __syncthreads();
+        if (k_mine) *reinterpret_cast<u32x4_t*>(k_dst) = k_val;
+        if (v_mine) {
+            uint32_t w[4] = {v_old.x, v_old.y, v_old.z, v_old.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if ((unsigned)(v_rel0 + q) < (unsigned)Q) w[q >> 1] = (q & 1) ? ((w[q >> 1] & 0x0000ffffu) | (v_nv[q] << 16)) : ((w[q >> 1] & 0xffff0000u) | v_nv[q]);
+            *reinterpret_cast<u32x4_t*>(v_gp) = (u32x4_t){w[0], w[1], w[2], w[3]};
+        }
+        // LDS-only barrier: the query fragments are in LDS for every wave.  (__syncthreads would also wait for the ring stores above -- the keys and V^T groups of
+        // the chunk -- to be acknowledged: ~4 us at the head of every workgroup; nobody reads them before the barrier that ends phase 1, a full fence)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     } else {
 #pragma unroll
         for (int mt = 0; mt < QT; ++mt) {
@@ -184,6 +312,7 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) qf[mt][ks] = rot_frag<TB>(qrow, K - Q + qi, ks, fq, rope_cos, rope_sin, rope_cs, RND ? 1 : 0);
         }
+        if (k_mine) *reinterpret_cast<u32x4_t*>(k_dst) = k_val;
     }
     auto qfrag = [&](int mt, int ks) -> u32x4_t {
         if constexpr (QLDS) return Qs[(mt * 2 + ks) * 64 + lane];
@@ -205,21 +334,19 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
         if (j < 0) j += cap;
         const bool live = j < K;
         const int jpos = live ? j : 0;
-        const bool is_new = live && j >= len;  // written by this chunk: still only in the qkv rows
-        const bf16_t* krow = is_new ? knew + (long)(j - len) * 3 * D : kr + (long)cphys * ENC_HD;
+        // written by this chunk: still only in the qkv rows for all this launch knows
+        const bool is_new = live && j >= len;
+        // (one base + one 32-bit element offset, both chosen by selects: written as two pointer expressions hipcc put a divergent branch with two 64-bit
+        //  multiplications into every tile)
+        const bf16_t* kbase = is_new ? knew : kr;
+        const int koff = is_new ? (j - len) * 3 * D : cphys * ENC_HD;
+        const bf16_t* krow = kbase + koff;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             kraw[ks] = *reinterpret_cast<const u32x4_t*>(krow + ks * 32 + fq * 8);
             enc_tab_load<TB>(kt[ks], rope_cos, rope_sin, rope_cs, jpos, ks, fq);
         }
         return j;
-    };
-    // the chunk's own keys go to the ring unrotated (query block 0 owns the append)
-    auto append_key = [&](int nt, int j, const u32x4_t (&kraw)[2]) {
-        if (j < K && j >= len && qb == 0) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<u32x4_t*>(kr + (long)(nt * 16 + fr) * ENC_HD + ks * 32 + fq * 8) = kraw[ks];
-        }
     };
     const int a0 = q0 + P;
     const int blk0 = a0 / bs;
@@ -235,17 +362,25 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
         u32x4_t rawA[2], rawB[2];
         EncTab<TB> tA[2], tB[2];
         int jA = 0, jB = 0;
-        int nt = wave;
-        if (nt < n_tiles) jA = issue(nt, rawA, tA);
-        for (; nt < n_tiles; nt += 2 * ENC_WAVES) {
-            const bool more = nt + ENC_WAVES < n_tiles;  // (wave-uniform)
-            if (more) jB = issue(nt + ENC_WAVES, rawB, tB);
-            append_key(nt, jA, rawA);
-            { const int j = jA, jl = jA - jb; enc_score_tile<QT, RND, TB>(rawA, tA, qfrag, S, ldS, nt * 16 + fr, fq, [&](int mt, int r) { return j < hi_s && jl >= mt * 16 + r; }); }
-            if (!more) break;
-            if (nt + 2 * ENC_WAVES < n_tiles) jA = issue(nt + 2 * ENC_WAVES, rawA, tA);
-            append_key(nt + ENC_WAVES, jB, rawB);
-            { const int j = jB, jl = jB - jb; enc_score_tile<QT, RND, TB>(rawB, tB, qfrag, S, ldS, (nt + ENC_WAVES) * 16 + fr, fq, [&](int mt, int r) { return j < hi_s && jl >= mt * 16 + r; }); }
+        // (every issue inside the loop is unconditional -- past the end the wave's last tile is re-read and not used --: a branch around loads makes hipcc wait
+        //  with vmcnt(0), i.e. for the tile in flight too)
+        // row 4 fq + r of m-tile mt sees key j  <=>  j < hi_s  and  j - jb >= 16 mt + r: ONE comparison per score against  jm = j < hi_s ? j - jb : INT_MIN
+        // Loop shape: tiles in PAIRS with no branch between a tile's loads and its use, the odd last tile behind the loop.  (With an early exit between the issue of
+        // tile i + 1 and its use hipcc sinks those loads below the exit test -- they are only needed on one side of it -- i.e. behind the rotation of tile i.)
+        const int cnt = wave < n_tiles ? (n_tiles - wave + ENC_WAVES - 1) / ENC_WAVES : 0;  // this wave's tiles: wave, wave + 8, ..
+        if (cnt > 0) {
+            const int last = wave + (cnt - 1) * ENC_WAVES;
+            jA = issue(wave, rawA, tA);
+            int nt = wave;
+            for (int i = 0; i + 1 < cnt; i += 2, nt += 2 * ENC_WAVES) {
+                jB = issue(nt + ENC_WAVES, rawB, tB);
+                __builtin_amdgcn_sched_barrier(0);  // (program order pinned: left alone the scheduler moves these loads behind the rotation below, to shorten their live ranges)
+                { const int jm = jA < hi_s ? jA - jb : (int)0x80000000; enc_score_tile<QT, RND, TB>(rawA, tA, qfrag, S, ldS, nt * 16 + fr, fq, [&](int mt, int r) { return jm >= mt * 16 + r; }); }
+                jA = issue(min(nt + 2 * ENC_WAVES, last), rawA, tA);
+                __builtin_amdgcn_sched_barrier(0);
+                { const int jm = jB < hi_s ? jB - jb : (int)0x80000000; enc_score_tile<QT, RND, TB>(rawB, tB, qfrag, S, ldS, (nt + ENC_WAVES) * 16 + fr, fq, [&](int mt, int r) { return jm >= mt * 16 + r; }); }
+            }
+            if (cnt & 1) { const int jm = jA < hi_s ? jA - jb : (int)0x80000000; enc_score_tile<QT, RND, TB>(rawA, tA, qfrag, S, ldS, last * 16 + fr, fq, [&](int mt, int r) { return jm >= mt * 16 + r; }); }
         }
     } else {
         // visible logical column range of the rows this lane holds in the C layout (rows 4 fq + r of each m-tile)
@@ -276,16 +411,12 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
                 const int nt = nt0 + t * ENC_WAVES;
                 if (nt >= n_tiles) break;  // (wave-uniform)
                 const int j = jj[t];
-                append_key(nt, j, kraw[t]);
-                enc_score_tile<QT, RND, TB>(kraw[t], kt[t], qfrag, S, ldS, nt * 16 + fr, fq, [&](int mt, int r) { return j < K && j >= lo[mt][r] && j < hi[mt][r]; });
+                enc_score_tile<QT, RND, TB>(kraw[t], kt[t], qfrag, S, ldS, nt * 16 + fr, fq, [&](int mt, int r) { return (j >= lo[mt][r]) & (j < hi[mt][r]); });  // (hi <= K: a key below hi is live; & not &&: no branches)
             }
         }
     }
     __syncthreads();
     ENC_STAMP(2);
-    // physical slot range of the new keys: [nlo, nlo + Q) mod cap
-    int nlo = start + len;
-    if (nlo >= cap) nlo -= cap;
     // ---- append V^T of the chunk's own keys (query block 0): [dim][slot] <- V[new frame][dim], from the staged rows; the stores drain under phases 2 and 3
     //      (phase 3 patches every fragment that touches these slots from LDS, so it does not matter to anyone when they land) ----
     if (qb == 0 && use_vn) {
@@ -302,6 +433,18 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
     // per row for 10 elements of work, in a phase that is VALU-bound at many streams.)
     const int n8 = min(cap, 512) >> 3;               // lanes of the 16-byte pass
     const int te = cap > 512 ? (cap - 512) >> 6 : 0;  // 0..8 tail columns per lane, from column 512 + lane * te
+    if (cap >= 512 && (te & 1) == 0) {  // (ldS = cap + 8: rows and their column 512 are 16-byte aligned)
+        auto rows = [&](auto td) {
+            for (int row = wave; row < QT * 16; row += ENC_WAVES) enc_softmax_row<decltype(td)::value>(S + (long)row * ldS, lane);
+        };
+        switch (te >> 1) {
+            case 0: rows(std::integral_constant<int, 0>{}); break;
+            case 1: rows(std::integral_constant<int, 1>{}); break;  // 640 slots: max_cache_size 576 + one block of 48
+            case 2: rows(std::integral_constant<int, 2>{}); break;
+            case 3: rows(std::integral_constant<int, 3>{}); break;
+            default: rows(std::integral_constant<int, 4>{}); break;
+        }
+    } else
     for (int row = wave; row < QT * 16; row += ENC_WAVES) {
         bf16_t* srow = S + (long)row * ldS;
         bf16_t* trow = srow + 512 + lane * te;
@@ -320,13 +463,13 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
         if (lane < n8) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v[e] = (v[e] == -INFINITY) ? 0.f : __expf(v[e] - mx);  // v_exp_f32(x log2 e): the launch is VALU-bound at many streams (-8 %)
+                v[e] = __expf(v[e] - mx);  // v_exp_f32(x log2 e); a masked score is -inf and gives exactly 0 (every row sees its own key: mx is finite)
                 sum += v[e];
             }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            if (e < te) { tv[e] = (tv[e] == -INFINITY) ? 0.f : __expf(tv[e] - mx); sum += tv[e]; }
+            if (e < te) { tv[e] = __expf(tv[e] - mx); sum += tv[e]; }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
         if (lane < n8) {
@@ -360,7 +503,7 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
             int rel = t0 - nlo;
             if (rel < 0) rel += cap;
             const bool any_new = rel < Q || rel + 7 >= cap;  // the 8 slots touch [nlo, nlo+Q) (possibly wrapping)
-            if (!any_new || use_vn) {
+            if (!any_new || use_vn || v_first) {
                 vf[u] = *reinterpret_cast<const u32x4_t*>(vrow + ks * 32);  // (staged rows: the new slots' stale bytes are replaced below)
             } else {  // mixed fragment: new keys come from the qkv rows
                 bf16_t e[8];
@@ -429,27 +572,8 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
             }
     }
     ENC_STAMP(5);
-    // ---- append V^T of the chunk's own keys (query block 0): [dim][slot] <- V[new frame][dim]; a thread's 2-byte loads all in flight before its first store ----
-    if (qb == 0 && !use_vn) {
-        constexpr int AB = 6;  // (Q = 48: one batch)
-        for (int e0 = tid; e0 < Q * ENC_HD; e0 += ENC_WAVES * 64 * AB) {
-            bf16_t val[AB];
-#pragma unroll
-            for (int u = 0; u < AB; ++u) {
-                const int e = e0 + u * (ENC_WAVES * 64);
-                val[u] = e < Q * ENC_HD ? vnew[(long)(e / ENC_HD) * 3 * D + (e % ENC_HD)] : (bf16_t)0;
-            }
-#pragma unroll
-            for (int u = 0; u < AB; ++u) {
-                const int e = e0 + u * (ENC_WAVES * 64);
-                if (e < Q * ENC_HD) {
-                    int slot = nlo + e / ENC_HD;
-                    if (slot >= cap) slot -= cap;
-                    vt[(long)(e % ENC_HD) * cap + slot] = val[u];
-                }
-            }
-        }
-    }
+    // ---- append V^T of the chunk's own keys (query block 0) where it has not happened yet ----
+    if (qb == 0 && !use_vn && !v_first) append_vt8();
     ENC_STAMP(6);
 }
 
@@ -466,6 +590,8 @@ int launch_enc_attention(const bf16_t* qkv, bf16_t* kring, bf16_t* vring, long s
     int vn_off = -1;
     static const bool vn_on = !(getenv("ISST_ENC_VN") && atoi(getenv("ISST_ENC_VN")) == 0);  // A/B knob: 0 = the rows stay in global memory (rounds 1-5)
     if (vn_on && QT == 1 && lds + (size_t)Q * 128 <= 160 * 1024) { vn_off = (int)lds; lds += (size_t)Q * 128; }
+    static const bool vfirst_on = !(getenv("ISST_ENC_VFIRST") && atoi(getenv("ISST_ENC_VFIRST")) == 0);  // A/B knob: 0 = 48-row blocks append V^T at the end and mix fragments
+    if (QT == 3 && !vfirst_on) vn_off = -2;
     dim3 grid(heads, Q / (QT * 16), n_streams), block(ENC_WAVES * 64);
     auto go = [&](auto kern, size_t& lds_set) -> int {
         if (lds > 64 * 1024 && lds > lds_set) {
