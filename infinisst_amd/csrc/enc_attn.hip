@@ -370,17 +370,49 @@ __global__ __launch_bounds__(512, QT == 1 ? 2 : 4) void enc_attention_kernel(  /
         const int cnt = wave < n_tiles ? (n_tiles - wave + ENC_WAVES - 1) / ENC_WAVES : 0;  // this wave's tiles: wave, wave + 8, ..
         if (cnt > 0) {
             const int last = wave + (cnt - 1) * ENC_WAVES;
-            jA = issue(wave, rawA, tA);
-            int nt = wave;
-            for (int i = 0; i + 1 < cnt; i += 2, nt += 2 * ENC_WAVES) {
-                jB = issue(nt + ENC_WAVES, rawB, tB);
-                __builtin_amdgcn_sched_barrier(0);  // (program order pinned: left alone the scheduler moves these loads behind the rotation below, to shorten their live ranges)
-                { const int jm = jA < hi_s ? jA - jb : (int)0x80000000; enc_score_tile<QT, RND, TB>(rawA, tA, qfrag, S, ldS, nt * 16 + fr, fq, [&](int mt, int r) { return jm >= mt * 16 + r; }); }
-                jA = issue(min(nt + 2 * ENC_WAVES, last), rawA, tA);
+            auto score = [&](const u32x4_t (&raw)[2], const EncTab<TB> (&t)[2], int j, int nt) {
+                const int jm = j < hi_s ? j - jb : (int)0x80000000;
+                enc_score_tile<QT, RND, TB>(raw, t, qfrag, S, ldS, nt * 16 + fr, fq, [&](int mt, int r) { return jm >= mt * 16 + r; });
+            };
+#ifndef ENC_SCORE_DEPTH
+#define ENC_SCORE_DEPTH 2   // register sets of key tiles: 2 = one tile in flight behind the one being rotated, 3 = two.  Measured equal (61.3 / 62.5 against
+                            // 61.7 / 62.4 us per launch at 64 streams, same box, profiles/r06/enc_attention_rework_ab4_depth.txt): with one tile in flight
+                            // the phase is no longer waiting for loads
+#endif
+            if constexpr (ENC_SCORE_DEPTH == 3 && TB) {
+                u32x4_t rawC[2];
+                EncTab<TB> tC[2];
+                int jC = 0;
+                jA = issue(wave, rawA, tA);
+                jB = issue(min(wave + ENC_WAVES, last), rawB, tB);
                 __builtin_amdgcn_sched_barrier(0);
-                { const int jm = jB < hi_s ? jB - jb : (int)0x80000000; enc_score_tile<QT, RND, TB>(rawB, tB, qfrag, S, ldS, (nt + ENC_WAVES) * 16 + fr, fq, [&](int mt, int r) { return jm >= mt * 16 + r; }); }
+                int nt = wave, i = 0;
+                for (; i + 2 < cnt; i += 3, nt += 3 * ENC_WAVES) {  // TRIPLES: no branch between a tile's loads and its use
+                    jC = issue(nt + 2 * ENC_WAVES, rawC, tC);
+                    __builtin_amdgcn_sched_barrier(0);  // (program order pinned: left alone the scheduler moves the loads behind the rotation below, to shorten their live ranges)
+                    score(rawA, tA, jA, nt);
+                    jA = issue(min(nt + 3 * ENC_WAVES, last), rawA, tA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    score(rawB, tB, jB, nt + ENC_WAVES);
+                    jB = issue(min(nt + 4 * ENC_WAVES, last), rawB, tB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    score(rawC, tC, jC, nt + 2 * ENC_WAVES);
+                }
+                if (i < cnt) score(rawA, tA, jA, nt);
+                if (i + 1 < cnt) score(rawB, tB, jB, nt + ENC_WAVES);
+            } else {
+                jA = issue(wave, rawA, tA);
+                int nt = wave;
+                for (int i = 0; i + 1 < cnt; i += 2, nt += 2 * ENC_WAVES) {
+                    jB = issue(nt + ENC_WAVES, rawB, tB);
+                    __builtin_amdgcn_sched_barrier(0);  // (program order pinned: left alone the scheduler moves these loads behind the rotation below, to shorten their live ranges)
+                    score(rawA, tA, jA, nt);
+                    jA = issue(min(nt + 2 * ENC_WAVES, last), rawA, tA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    score(rawB, tB, jB, nt + ENC_WAVES);
+                }
+                if (cnt & 1) score(rawA, tA, jA, last);
             }
-            if (cnt & 1) { const int jm = jA < hi_s ? jA - jb : (int)0x80000000; enc_score_tile<QT, RND, TB>(rawA, tA, qfrag, S, ldS, last * 16 + fr, fq, [&](int mt, int r) { return jm >= mt * 16 + r; }); }
         }
     } else {
         // visible logical column range of the rows this lane holds in the C layout (rows 4 fq + r of each m-tile)
