@@ -695,28 +695,32 @@ def cpu_baseline(cfg, gen, weights_dev, sys_n, threads=0, llm_layers_run=32, n_c
     rope_e = oenc.make_rope(cfg)
     if threads <= 0:
         # BASELINE.md's recipe is set_num_threads(os.cpu_count()); on a many-socket host that is far from the fastest setting for one stream (a probe of a
-        # lone GEMV liked 128 threads on one box where the whole chunk then ran 2.8 x slower than with 64), so the thread count is the fastest of
-        # {64, 128, all logical cores} on what the baseline actually spends its time in: ONE decode pass of ONE real Llama layer of this oracle
-        # (RMSNorm, attention over the steady-state cache, SwiGLU MLP), three repetitions each, on a copy of the layer's KV -- a fraction of a second
+        # lone GEMV liked 128 threads on one box where the whole chunk then ran 2.8 x slower than with 64; a probe of ONE real layer, whose 436 MB of weights
+        # stay in the host's caches, liked 128 threads at 4.1 against 9.9 ms where the chunk then took 19.8 s against 9.3), so the thread count is the fastest of
+        # {64, 128, all logical cores} on what the baseline actually spends its time in: ONE decode pass through EIGHT consecutive real Llama layers of this
+        # oracle (RMSNorm, attention over the steady-state cache, SwiGLU MLP: 3.5 GB of weights, past every cache), two repetitions each, on copies of the layers' KV
         cands = sorted({c for c in (64, 128, cores) if c <= cores}) or [cores]
         probe = {}
+        probe_layers = min(8, run_layers)
         xq = torch.randn(1, 1, cfg.llm_dim, generator=g).bfloat16()
         with torch.inference_mode():
             for c_ in cands:
                 torch.set_num_threads(c_)
                 best = 1e9
-                for _ in range(4):
-                    kv_p = [[kv[0][0].clone(), kv[0][1].clone()]]
+                for _ in range(2):
+                    kv_p = [[kv[l_][0].clone(), kv[l_][1].clone()] for l_ in range(probe_layers)]
                     t0 = time.perf_counter()
-                    h_ = ollm.rmsnorm(xq, w["model.layers.0.input_layernorm.weight"], cfg.rms_eps)
-                    y_ = xq + ollm.attention(w, sub, 0, h_, kv_p, rope_l)
-                    h_ = ollm.rmsnorm(y_, w["model.layers.0.post_attention_layernorm.weight"], cfg.rms_eps)
-                    y_ = y_ + ollm.mlp(w, 0, h_)
+                    y_ = xq
+                    for l_ in range(probe_layers):
+                        h_ = ollm.rmsnorm(y_, w[f"model.layers.{l_}.input_layernorm.weight"], cfg.rms_eps)
+                        y_ = y_ + ollm.attention(w, sub, l_, h_, kv_p, rope_l)
+                        h_ = ollm.rmsnorm(y_, w[f"model.layers.{l_}.post_attention_layernorm.weight"], cfg.rms_eps)
+                        y_ = y_ + ollm.mlp(w, l_, h_)
                     best = min(best, time.perf_counter() - t0)
                 probe[c_] = best
         nthreads = min(probe, key=probe.get)
         thread_note = ("fastest of " + ", ".join(f"{c_} threads: {1e3 * t_:.1f} ms" for c_, t_ in probe.items()) +
-                       f" for one decode pass of one Llama layer of the oracle; host has {cores} logical cores (BASELINE.md: set_num_threads(os.cpu_count()))")
+                       f" for one decode pass of {probe_layers} consecutive Llama layers of the oracle; host has {cores} logical cores (BASELINE.md: set_num_threads(os.cpu_count()))")
         torch.set_num_threads(nthreads)
         log(f"cpu baseline: {thread_note}")
     audio_all = synth.synthetic_audio(cfg.chunk_samples * n_chunks, stream_id=99)
