@@ -258,7 +258,10 @@ __device__ __forceinline__ void slab_sum8(const float* __restrict__ slabs, long 
     }
 }
 
-template <int STEPS>
+// LF: the slabs of a step are summed loads-first (slab_sum8: every slice's loads in flight before the first add).  Few rows (one stream's 48 frames: 12 workgroups,
+// nothing to hide a round trip behind) are a chain of n_slabs dependent round trips otherwise; at many rows (one wave per row, thousands of waves) the plain loop
+// measured faster (16.4 against 20.5 us at 128 streams), so the launcher picks by the row count.
+template <int STEPS, bool LF = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ b, bf16_t* out, long ldo,
                                                         int rows, int C, float eps, int gelu, const float* __restrict__ slabs, long slab_stride,
@@ -290,6 +293,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
             unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
             if (slabs) {
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pb[8];
+                if constexpr (LF) slab_sum8(slabs, slab_stride, n_slabs, row * C + c, acc);
+                else
                 for (int k = 0; k < n_slabs; ++k) {  // (slab_sum8's loads-first form measured SLOWER here at many rows -- 16.4 -> 20.5 us at 128 streams: one wave per row, registers)
                     const float* sp = slabs + (long)k * slab_stride + row * C + c;
                     const f32x4_t a = *reinterpret_cast<const f32x4_t*>(sp), a2 = *reinterpret_cast<const f32x4_t*>(sp + 4);
@@ -352,6 +357,8 @@ static int launch_layernorm_impl(bf16_t* x, long ldx, const bf16_t* w, const bf1
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 512)
         hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias, tin, ldt);
+    else if (C <= 1024 && slabs && rows <= 256)
+        hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias, tin, ldt);
     else if (C <= 1024)
         hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias, tin, ldt);
     else

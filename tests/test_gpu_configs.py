@@ -204,3 +204,44 @@ def test_agent_multiplier_2_with_a_short_last_segment_matches_oracle_agent():
     assert k >= min(first_tie, len(ref))
     if got == ref:
         assert eng.stream_info(st.stream_id)["llm_cache_len"] == ollm.kv_len(so.past_key_values)
+
+
+@pytest.mark.parametrize("m,n,mode,chunks", [(1, 176, "bf16", 15), (1, 176, "fp32", 3), (2, 90, "bf16", 8)])
+def test_encoder_48_row_blocks_at_many_streams_match_the_streams_alone(m, n, mode, chunks):
+    """enc_attn.hip's many-stream form (48-row query blocks, two workgroups per CU, a second key tile in flight, the packed bf16 rotary table) runs from
+    1024 (stream, head, block) workgroups on: 176 toy streams (2 heads) at m = 1 -- ONE block per (head, stream): the workgroup appends the chunk's keys and
+    V^T groups at its start and phase 3 reads them back from the ring -- and 90 streams at m = 2 -- two blocks per (head, stream): the chunk's keys and values
+    come from the qkv rows, fragments of V^T are mixed, block 0 appends at its end.  "fp32" tables are read as handed over (no packed table).
+    Streams 0, n // 2 and n - 1 are held to the SAME streams stepped alone (16-row blocks, few-row GEMMs) chunk by chunk: first chunk, growing window, and at
+    m = 1 the saturated window (from chunk 13) with the ring wrapping (640 slots).  Batched and alone differ by the GEMM kernels' summation orders only."""
+    cfg = toy_config().replace(enc_rope_mode=mode)
+    gen = GenConfig(latency_multiplier=m, max_new_tokens=1, max_llm_cache_size=150)
+    w = synth.random_weights(cfg, dtype=torch.bfloat16, std=0.08, norm_jitter=0.1, seed=35)
+    eng = Engine(cfg, max_streams=n + 1, max_multiplier=m, max_prompt_len=160, max_new_tokens=4, max_llm_cache_size=150, max_system_prompt=64, debug_taps=True)
+    eng.load_weights(w)
+    sids = [eng.open_stream() for _ in range(n)]
+    solo = eng.open_stream()
+    ns = cfg.chunk_samples * m
+    picks = (0, n // 2, n - 1)
+    audio = [synth.synthetic_audio(ns * chunks, stream_id=500 + i) for i in range(n)]
+    ref = {}
+    for i in picks:  # the picked streams alone: the speech features of every chunk
+        eng.reset_stream(solo)
+        ref[i] = [eng.encode_speech(solo, audio[i][c * ns:(c + 1) * ns], multiplier=m).float().cpu() for c in range(chunks)]
+    S = ref[picks[0]][0].shape[0]
+    worst = 0.0
+    for c in range(chunks):
+        p = synth.chunk_prompt_ids(cfg, m, first=(c == 0))
+        eng.generate(gen, sids, [a[c * ns:(c + 1) * ns] for a in audio], [p] * n, [[] for _ in range(n)])
+        got = eng.debug_tap("speech").view(n, S, -1).float().cpu()
+        for i in picks:
+            err = (got[i] - ref[i][c]).abs()
+            worst = max(worst, float(err.max()))
+            bad = err > 0.06 + 0.02 * ref[i][c].abs()
+            assert not bad.any(), f"m={m} {mode} chunk {c} stream {i} of {n}: max |d| {float(err.max()):.4f} (max |ref| {float(ref[i][c].abs().max()):.3f}), {int(bad.sum())} out of tolerance"
+        for sid in sids:  # keep the LLM cache inside its ring (what it holds does not reach the speech features)
+            if eng.stream_info(sid)["llm_cache_len"] > 100:
+                eng.kv_evict(sid, 40, 0)
+    info = eng.stream_info(sids[0])
+    assert info["enc_n_steps"] == 48 * m * chunks and info["enc_cache_len"] == min(576 + 48 * m, 48 * m * chunks)  # (the window is trimmed at the next chunk's start)
+    print(f"m={m} {mode}: {n} streams x {chunks} chunks, worst |d| vs the streams alone {worst:.4f}")
