@@ -55,9 +55,9 @@ __device__ __forceinline__ int llm_logical(const LlmStreamView& v, const LlmAttn
     return (j >= 0 && j < total) ? j : -1;
 }
 
-// rotate the four 8-dim chunks a lane holds of one 128-dim row (dims 8fq + 32s, s = 0..3) at position pos
-__device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int fq, const bf16_t* __restrict__ rope_cos,
-                                                const bf16_t* __restrict__ rope_sin, u32x4_t* out) {
+// rotate the four 8-dim chunks a lane holds of one 128-dim row (dims 8fq + 32s, s = 0..3) with the table entries tab = (cos, sin of dims 8 fq .. + 7, cos, sin of
+// dims 32 + 8 fq .. + 7) of its position
+__device__ __forceinline__ void rope_row_chunks_tab(const u32x4_t* raw, const u32x4_t* tab, u32x4_t* out) {
     // y[d] = bf16(bf16(x[d] c) - bf16(x[d + 64] s)),  y[d + 64] = bf16(bf16(x[d + 64] c) + bf16(x[d] s))  (HF apply_rotary_pos_emb in bf16: every torch op rounds).
     // Word by word (two dims per 32-bit word): the four products of a dim are rounded by TWO v_cvt_pk_bf16_f32 (one instruction rounds two floats) and the two results
     // of a word are rounded and packed by one -- the element-wise form (a cast per value, then a second cast in pack8) issued ~1.6 x the instructions for the same
@@ -65,8 +65,7 @@ __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int
 #pragma clang fp contract(off)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // chunk pairs (s = h, s = h + 2): dims d and d + 64
-        const u32x4_t cw = *reinterpret_cast<const u32x4_t*>(rope_cos + (long)pos * 64 + 32 * h + 8 * fq);
-        const u32x4_t sw = *reinterpret_cast<const u32x4_t*>(rope_sin + (long)pos * 64 + 32 * h + 8 * fq);
+        const u32x4_t cw = tab[2 * h], sw = tab[2 * h + 1];
         u32x4_t o1, o2;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -81,6 +80,20 @@ __device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int
         out[h] = o1;
         out[h + 2] = o2;
     }
+}
+__device__ __forceinline__ void rope_tab_load(int pos, int fq, const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin, u32x4_t* tab) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        tab[2 * h] = *reinterpret_cast<const u32x4_t*>(rope_cos + (long)pos * 64 + 32 * h + 8 * fq);
+        tab[2 * h + 1] = *reinterpret_cast<const u32x4_t*>(rope_sin + (long)pos * 64 + 32 * h + 8 * fq);
+    }
+}
+// ... at position pos (table entries loaded here)
+__device__ __forceinline__ void rope_row_chunks(const u32x4_t* raw, int pos, int fq, const bf16_t* __restrict__ rope_cos,
+                                                const bf16_t* __restrict__ rope_sin, u32x4_t* out) {
+    u32x4_t tab[4];
+    rope_tab_load(pos, fq, rope_cos, rope_sin, tab);
+    rope_row_chunks_tab(raw, tab, out);
 }
 
 // MULTI: a wave may take several tiles (running softmax, next tile's keys prefetched); false: exactly one tile per wave,
@@ -297,6 +310,18 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
     bool nknew = false;
     prep(cur_tp, cur_beam, nks, nvs, jk_n, knew_n);
     if (n_it > 0) fetch(nks, nvs);
+    // One tile per wave (the one-stream forms): the rotary table entries the tile's rotation will need are requested HERE, with its key / value rows.  With the
+    // rotated-key arena only the tile that holds the launch's own key(s) rotates anything; asked for inside the tile body its table loads sat behind the
+    // append stores of that key -- vmcnt counts in order -- and the wave waited ~2.8 us for the stores' acknowledgements: the ONE workgroup per kv head that meets
+    // the step's own key had its tile done at 5.8 us where every other one had at 3.0, and the launch waits for its last workgroup
+    // (profiles/r06/attn_oproj_trace_per_wg.txt).  The lanes whose rotation is dropped (cached keys, already rotated) read the row of the launch's first own
+    // position, which the query rotation has just read.
+    u32x4_t tab0[4];
+    bool tab0_have = false;
+    if constexpr (!MULTI) {
+        tab0_have = n_it > 0 && (!rot || __any(knew_n));
+        if (tab0_have) rope_tab_load((rot && !knew_n) ? v.new_start : (jk_n >= 0 ? jk_n : 0), fq, rope_cos, rope_sin, tab0);
+    }
     after_fetch();
     int nxt_tp = cur_tp, nxt_beam = cur_beam, nxt_idx = cur_idx;
     bool nxt_own = cur_own;
@@ -323,6 +348,12 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
             if (i + 2 < n_it) tile_next(nxt_tp, nxt_beam, nxt_idx, nxt_own, i + 2);
             prep(nxt_tp, nxt_beam, nks, nvs, njk, nknew);
         }
+        // One tile per wave: EVERY load of the wave -- key rows, value rows, table entries -- has landed before anything else happens, on every path.  The appends
+        // below are conditional stores; hipcc counts such a store as "maybe not issued", so a later wait for an OLDER load is written with a count that, when
+        // the stores were issued, also waits for their acknowledgements: ~2.8 us for the one wave per kv head that holds the step's own key, with a one-stream
+        // launch waiting for it (profiles/r06/attn_oproj_trace_per_wg.txt).  (Waiting for the value rows here costs the other tiles nothing measurable: they
+        // land right behind the key rows.)
+        if constexpr (!MULTI) asm volatile("" :: "v"(kraw[3].x), "v"(vraw[0].x), "v"(vraw[1].x), "v"(vraw[2].x), "v"(vraw[3].x), "v"(tab0[0].x), "v"(tab0[1].x), "v"(tab0[2].x), "v"(tab0[3].x));
         const bool tile_live = __any(jk >= 0);
         if (!tile_live) return;
         const bool tile_has_new = __any(k_new);
@@ -332,6 +363,8 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
         for (int r = 0; r < 4; ++r) jc[r] = llm_logical(v, d, t0 + 4 * fq + r, total);
 
         // ---- append this group's own new keys (unrotated K row, V row) ----
+        // (the multi-tile walk keeps its appends where the tile is met: compiled out altogether -- timing only -- the 64-stream launch took 52.65 instead of 53.05 us,
+        //  64 x 4 beams 63.3 instead of 63.9: profiles/r06/attn_walk_without_appends_timing_only.txt)
         if (k_new && (!shared || own)) {  // (shared-prefix beams: whoever walks beam b's own tiles appends beam b's key to arena b)
             const int krow = v.row0 + beam + (jk - v.new_start);
             if (krow >= r0 && krow < r0 + nrows) {
@@ -344,7 +377,11 @@ __device__ __forceinline__ void llm_attn_partial_body(const bf16_t* __restrict__
         }
         u32x4_t kf[4];
         if (!rot || tile_has_new) {
-            rope_row_chunks(kraw, jk >= 0 ? jk : 0, fq, rope_cos, rope_sin, kf);
+            if constexpr (!MULTI) {
+                rope_row_chunks_tab(kraw, tab0, kf);  // (requested with the tile's rows: tab0_have == this condition)
+            } else {
+                rope_row_chunks(kraw, jk >= 0 ? jk : 0, fq, rope_cos, rope_sin, kf);
+            }
             if (rot && !k_new) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) kf[s] = kraw[s];

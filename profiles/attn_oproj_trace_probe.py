@@ -29,3 +29,8 @@ for i, n in enumerate(names):
     if not sel.any(): continue
     a = (t[sel, i] - t0) / 100.0
     print(f"{n:44s} n {int(sel.sum()):3d}  min {a.min():6.2f}  p50 {np.median(a):6.2f}  max {a.max():6.2f} us")
+# per attention workgroup, in workgroup order (the launch maps workgroup w to (kv head, slot split)): when its tiles were done / its slab stored
+sel = np.where(t[:, 3] > t0)[0]
+print("workgroup: tiles done / slab stored (us after the first entry)")
+for k in range(0, len(sel), 8):
+    print("  " + "  ".join(f"{int(w):3d}: {(t[w, 2] - t0) / 100.0:4.1f}/{(t[w, 3] - t0) / 100.0:4.1f}" for w in sel[k:k + 8]))
