@@ -819,7 +819,11 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
     //      waves then carried a rotation of 32 dims per lane and stage on top of their four score / softmax / P.V tiles -- waves 0 and 4 share SIMD 0, which
     //      had 2800 issue slots per stage where SIMD 3 had 1000 (profiles/r06/prefill_attention_roles.txt) -- and the rotation's temporaries met the
     //      accumulators in ONE register budget (128 at two workgroups per CU): 25 spilled registers in the loop.  With the roles apart the kernel does not spill. ----
-    struct Fetch { u32x4_t raw[4]; int t0, jk; bool is_new, valid; };
+    // (tab: the rotary table entries the tile's rotation will use, requested WITH its rows -- a stage ahead.  Asked for inside commit_k they were a dependent
+    //  round trip per tile in front of every rotation, and sat behind the arena stores of the tile before: vmcnt counts in order, and hipcc writes the wait for
+    //  a load that is older than a CONDITIONAL store with a count that also waits for the store's acknowledgement once it was issued -- each loader wave spent
+    //  ~2 x 2 us per stage on acknowledgements of stores nothing was waiting for, and with the arena fill the loaders are what a stage lasts.)
+    struct Fetch { u32x4_t raw[4]; u32x4_t tab[4]; int t0, jk; bool is_new, valid; };
     auto fetch = [&](int stage_first, int slot, bool is_k, Fetch& f) {  // tile `slot` of the stage that starts at compact index stage_first
         const int tc = stage_first + slot;
         f.valid = tc < tile_end;
@@ -832,6 +836,14 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
         else src = f.is_new ? qkv + (long)krow * ldq + (long)(H + KV + kvh) * HD : vb + (long)(f.t0 + fr) * HD;
 #pragma unroll
         for (int s = 0; s < 4; ++s) f.raw[s] = *reinterpret_cast<const u32x4_t*>(src + 32 * s + 8 * fq);
+        // (unconditional: a branch around loads costs the counted waits.  Lanes whose rotation is dropped -- rotated-key arena, cached key -- read the row of the
+        //  launch's first own position, which its query rotations have just read)
+        if (is_k) rope_tab_load((rot && !f.is_new) ? v.new_start : (f.jk >= 0 ? f.jk : 0), fq, rope_cos, rope_sin, f.tab);
+    };
+    // every load of both fetches has landed (they were issued a stage ago): from here to the next fetch the loader issues stores only
+    auto landed = [&](const Fetch& a, const Fetch& b) {
+        asm volatile("" :: "v"(a.raw[0].x), "v"(a.raw[1].x), "v"(a.raw[2].x), "v"(a.raw[3].x), "v"(a.tab[0].x), "v"(a.tab[1].x), "v"(a.tab[2].x), "v"(a.tab[3].x),
+                           "v"(b.raw[0].x), "v"(b.raw[1].x), "v"(b.raw[2].x), "v"(b.raw[3].x), "v"(b.tab[0].x), "v"(b.tab[1].x), "v"(b.tab[2].x), "v"(b.tab[3].x));
     };
     auto commit_k = [&](int buf, int slot, const Fetch& f) {
         if (!f.valid) return;  // (wave-uniform)
@@ -839,7 +851,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
         const bool mine = f.is_new && krow >= unit_r0 && krow < unit_r0 + unit_rows;  // a key of this unit's own rows: append it
         u32x4_t kf[4];
         if (!rot || __any(f.is_new)) {
-            rope_row_chunks(f.raw, f.jk >= 0 ? f.jk : 0, fq, rope_cos, rope_sin, kf);
+            rope_row_chunks_tab(f.raw, f.tab, kf);
             if (rot && !f.is_new) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) kf[s] = f.raw[s];
@@ -894,6 +906,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
         };
         if (st0 < tile_end) {
             fetch(st0, sa, true, FA); fetch(st0, sb, true, FB);
+            landed(FA, FB);
             commit_k(0, sa, FA); commit_k(0, sb, FB);
             append_v(st0, sa); append_v(st0, sb);
             if (st0 + PF_ST < tile_end) { fetch(st0 + PF_ST, sa, true, FA); fetch(st0 + PF_ST, sb, true, FB); }
@@ -902,6 +915,7 @@ __global__ __launch_bounds__(PREFILL_MAX_WAVES * 64, 4) void llm_attn_prefill_ke
         __syncthreads();
         for (int b = 0; st0 < tile_end; st0 += PF_ST, b ^= 1) {
             if (st0 + PF_ST < tile_end) {
+                landed(FA, FB);
                 commit_k(b ^ 1, sa, FA); commit_k(b ^ 1, sb, FB);
                 append_v(st0 + PF_ST, sa); append_v(st0 + PF_ST, sb);
                 if (st0 + 2 * PF_ST < tile_end) { fetch(st0 + 2 * PF_ST, sa, true, FA); fetch(st0 + 2 * PF_ST, sb, true, FB); }
