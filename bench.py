@@ -605,7 +605,7 @@ def mfma_probe(cfg, device, rows, in_situ=None, iters=20):
 
 def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
     """Dominant kernel: gemm_skinny_kernel streaming the gate/up projection of one Llama layer for one token (M=1, N=2*ffn,
-    K=dim, fused RMSNorm prologue, SwiGLU epilogue) -- 235 MB of weights per launch at full size, 32 % of the chunk's kernel
+    K=dim, fused RMSNorm prologue, SwiGLU epilogue on self-paired tiles: the copy of the weights a one-row pass reads) -- 235 MB of weights per launch at full size, 32 % of the chunk's kernel
     time.  Two live measurements with HIP events on the launch stream:
       * `launch_us` (-> achieved): one event pair around `iters` back-to-back launches of exactly that kernel, cycling enough
         distinct weight copies that no launch finds its weights in the 256 MiB Infinity Cache -- launches pipeline, so this is
@@ -621,19 +621,19 @@ def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
     g = torch.Generator(device=device)
     g.manual_seed(1)
     packs = []
-    for _ in range(copies):
+    for _ in range(copies):  # (the form a one-row pass streams: gate / up as self-paired tiles, isst_op_pack_gateup8 + epi swiglu8 -- engine_llm.hip llm_forward)
         w = torch.empty((N, K), device=device, dtype=torch.float32).normal_(0, 0.02, generator=g).bfloat16()
-        packs.append(E.op_pack_weight(w))
+        packs.append(E.op_pack_gateup8(w[: N // 2], w[N // 2:]))
         del w
     x = torch.randn(1, K, device=device, generator=g).bfloat16()
     nw = (1 + 0.1 * torch.randn(K, device=device, generator=g)).bfloat16()  # post_attention_layernorm weight (fused RMSNorm)
     for p in packs:
-        E.op_gemm(x, p, N, "swiglu", norm_w=nw, norm_eps=cfg.rms_eps)
+        E.op_gemm(x, p, N, "swiglu8", norm_w=nw, norm_eps=cfg.rms_eps)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for i in range(iters):
-        E.op_gemm(x, packs[i % copies], N, "swiglu", norm_w=nw, norm_eps=cfg.rms_eps)
+        E.op_gemm(x, packs[i % copies], N, "swiglu8", norm_w=nw, norm_eps=cfg.rms_eps)
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / iters
@@ -656,7 +656,7 @@ def gemm_roofline(cfg, device, loop=None, eng=None, iters=40, chunks=4):
                           f"kernel ({tj.get('collected', 'see profiles/README.md')}); PMC counters cannot be read inside this run")
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "gemm_skinny_kernel<1,2,EPI_SWIGLU,nt,AMODE=2> (gate/up GEMV with fused RMSNorm)",
+            "kernel": "gemm_skinny_kernel<1,1,EPI_SWIGLU8,nt,AMODE=2> (gate/up GEMV of a one-row pass with fused RMSNorm: self-paired gate | up tiles, 1792 one-tile workgroups)",
             "launch_us": round(ms * 1e3, 2), "algorithmic_bytes_per_launch": algo_bytes,
             "in_situ_event_bracket_us": None if in_situ is None else round(in_situ, 2), "in_situ_launches": launches,
             "shape": f"M=1 N={N} K={K} (gate/up of one layer, one token)"}

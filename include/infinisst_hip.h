@@ -212,6 +212,10 @@ int isst_op_llm_attention(const uint16_t* qkv, int rows, int pos0, uint16_t* kpo
 /* W [n_rows][K] row-major bf16 (conv_k > 0: Conv1d weight [n_rows][K/conv_k][conv_k]) -> packed tiles */
 int isst_op_pack_weight(const uint16_t* w, uint16_t* packed, int n_rows, int K, int conv_k, void* hip_stream);
 int64_t isst_op_packed_elems(int n_rows, int K);
+/* gate_proj and up_proj ([ffn][K] each, ffn % 8 == 0) as SELF-PAIRED tiles: tile t = gate rows 8t..8t+7 | up rows 8t..8t+7, 2 * ffn packed rows in all; isst_op_gemm with
+ * epi 8 (SwiGLU8, <= 16 rows) then gives out[8t + c] = silu(gate) * up with HF LlamaMLP's rounding points [3P] -- the bits of epi 5 on tile pairs.  What the library streams for
+ * the one-row decode passes of reference model/llm.py:114-126 -> LlamaMLP (engine_llm.hip llm_forward). */
+int isst_op_pack_gateup8(const uint16_t* gate, const uint16_t* up, uint16_t* packed, int ffn, int K, void* hip_stream);
 /* out = epi(A @ W^T); epi: 0 none, 1 bias, 2 bias+gelu, 3 residual, 4 bias+residual, 5 swiglu (packed rows
  * alternate gate/up tiles), 6 fp32 out.  Replaces torch F.linear / F.conv1d call sites (see gemm.hip).
  * norm_w != NULL (epi 0, 5, 6 only): LlamaRMSNorm(norm_w, norm_eps) is applied to the rows of A on load. */

@@ -112,6 +112,7 @@ enum GemmEpi {
     EPI_SWIGLU = 5,     // tile pairs (gate, up): out = bf16(bf16(silu(bf16 g)) * bf16 u)
     EPI_F32 = 6,        // out(fp32) = bf16-rounded acc
     EPI_PARTIAL = 7,    // split-K slab: out(fp32)[slice][M][N] = raw partial sum (gemm_mid.hip; reduced by rmsnorm_reduce)
+    EPI_SWIGLU8 = 8,    // SwiGLU on SELF-PAIRED tiles (gemm.hip, one-row passes): tile t = gate rows 8t..8t+7 | up rows 8t..8t+7 (launch_pack_weight_half): out[8t + c] as EPI_SWIGLU
 };
 
 // launchers (defined in the kernel .hip files; all asynchronous on `stream`)
@@ -215,3 +216,5 @@ void gemm_mid_set_tuning(int wn);
 void gemm_mid_set_min_rows(int rows);                              // rows above which gemm_mid replaces the skinny kernel (default 16)
 int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int row_offset_tiles, int tile_stride,
                        int tile_phase, int conv_k, hipStream_t stream);
+// rows r of src -> rows (r % 8) + 8 * half of tile r / 8: gate_proj (half 0) and up_proj (half 1) packed this way give tiles that hold BOTH operands of 8 SwiGLU outputs
+int launch_pack_weight_half(const bf16_t* src, bf16_t* dst, int n_rows, int K, int half, hipStream_t stream);

@@ -214,6 +214,12 @@ extern "C" int isst_create(const isst_config* cfg, isst_handle** out) {
         ok = ok && L.in_norm && L.post_norm && alloc_linear(h, L.qkv, (H + 2 * KV) * 128, DL, false) && alloc_linear(h, L.o, DL, H * 128, false) &&
              alloc_linear(h, L.gateup, 2 * c.llm_ffn, DL, false) && alloc_linear(h, L.down, DL, c.llm_ffn, false);
         L.gateup.n_valid = c.llm_ffn;
+        // (+ 2 ffn x dim bf16 per layer -- 7.5 GB at Llama-3.1-8B size, of 288 -- for the copy the one-row passes stream: engine_llm.hip llm_forward)
+        static const bool gateup8_on = !(getenv("ISST_GATEUP8") && atoi(getenv("ISST_GATEUP8")) == 0);
+        if (gateup8_on && c.llm_ffn % 8 == 0) {
+            ok = ok && alloc_linear(h, L.gateup8, 2 * c.llm_ffn, DL, false);
+            L.gateup8.n_valid = c.llm_ffn;
+        }
     }
     h->final_norm = h->dalloc<bf16_t>(DL, true);
     ok = ok && h->final_norm && alloc_linear(h, h->lm_head, c.vocab, DL, false);
@@ -474,8 +480,16 @@ extern "C" int isst_load_weight(isst_handle* h, const char* name, const void* da
         if (!strcmp(suf, "self_attn.k_proj.weight")) { if (!shape_is(ndim, shape, {KV * 128, DL})) return bad_shape(); rc = pack_into(h, L.qkv, src, KV * 128, H * 8, 1, 0, 0); }
         if (!strcmp(suf, "self_attn.v_proj.weight")) { if (!shape_is(ndim, shape, {KV * 128, DL})) return bad_shape(); rc = pack_into(h, L.qkv, src, KV * 128, (H + KV) * 8, 1, 0, 0); }
         if (!strcmp(suf, "self_attn.o_proj.weight")) { if (!shape_is(ndim, shape, {DL, H * 128})) return bad_shape(); rc = pack_into(h, L.o, src, DL, 0, 1, 0, 0); }
-        if (!strcmp(suf, "mlp.gate_proj.weight")) { if (!shape_is(ndim, shape, {c.llm_ffn, DL})) return bad_shape(); rc = pack_into(h, L.gateup, src, c.llm_ffn, 0, 2, 0, 0); }
-        if (!strcmp(suf, "mlp.up_proj.weight")) { if (!shape_is(ndim, shape, {c.llm_ffn, DL})) return bad_shape(); rc = pack_into(h, L.gateup, src, c.llm_ffn, 0, 2, 1, 0); }
+        if (!strcmp(suf, "mlp.gate_proj.weight")) {
+            if (!shape_is(ndim, shape, {c.llm_ffn, DL})) return bad_shape();
+            rc = pack_into(h, L.gateup, src, c.llm_ffn, 0, 2, 0, 0);
+            if (rc == ISST_OK && L.gateup8.wp) rc = launch_pack_weight_half(src, L.gateup8.wp, c.llm_ffn, DL, 0, 0);
+        }
+        if (!strcmp(suf, "mlp.up_proj.weight")) {
+            if (!shape_is(ndim, shape, {c.llm_ffn, DL})) return bad_shape();
+            rc = pack_into(h, L.gateup, src, c.llm_ffn, 0, 2, 1, 0);
+            if (rc == ISST_OK && L.gateup8.wp) rc = launch_pack_weight_half(src, L.gateup8.wp, c.llm_ffn, DL, 1, 0);
+        }
         if (!strcmp(suf, "mlp.down_proj.weight")) { if (!shape_is(ndim, shape, {DL, c.llm_ffn})) return bad_shape(); rc = pack_into(h, L.down, src, DL, 0, 1, 0, 0); }
     }
     if (rc == ISST_ERR_NOTFOUND) return h->fail(rc, "tensor %s is not part of the hot path", name);

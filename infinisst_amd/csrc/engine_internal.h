@@ -66,6 +66,7 @@ struct LlmLayer {
     bf16_t* in_norm = nullptr;
     bf16_t* post_norm = nullptr;
     PackedLinear qkv, o, gateup, down;
+    PackedLinear gateup8;  // gate / up once more, as self-paired tiles (gemm.hip EPI_SWIGLU8): what a ONE-row pass streams -- 1792 one-tile workgroups (7 per CU) instead of 896 tile pairs (3.5 per CU); wp == null: not kept (ISST_GATEUP8=0)
 };
 struct StreamState {
     bool open = false;

@@ -7,6 +7,11 @@ extern "C" int64_t isst_op_packed_elems(int n_rows, int K) { return (int64_t)rou
 extern "C" int isst_op_pack_weight(const uint16_t* w, uint16_t* packed, int n_rows, int K, int conv_k, void* hip_stream) {
     return launch_pack_weight(w, packed, n_rows, K, 0, 1, 0, conv_k, reinterpret_cast<hipStream_t>(hip_stream));
 }
+extern "C" int isst_op_pack_gateup8(const uint16_t* gate, const uint16_t* up, uint16_t* packed, int ffn, int K, void* hip_stream) {
+    if (!gate || !up || !packed) return ISST_ERR_ARG;
+    const int rc = launch_pack_weight_half(gate, packed, ffn, K, 0, reinterpret_cast<hipStream_t>(hip_stream));
+    return rc != ISST_OK ? rc : launch_pack_weight_half(up, packed, ffn, K, 1, reinterpret_cast<hipStream_t>(hip_stream));
+}
 extern "C" int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, const uint16_t* res, int64_t ldres,
                             void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, const uint16_t* norm_w, float norm_eps,
                             void* hip_stream) {

@@ -78,6 +78,25 @@ int launch_pack_weight(const bf16_t* src, bf16_t* dst, int n_rows, int K, int ro
     return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
 }
 
+// Self-paired SwiGLU tiles (EPI_SWIGLU8): source row r of gate_proj (half 0) / up_proj (half 1) becomes row (r % 8) + 8 * half of tile r / 8.
+__global__ void pack_weight_half_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int n_rows, int K, int half) {
+    const int KT = K >> 5;
+    const long tile = blockIdx.x;  // rt * KT + kt, rt over groups of 8 source rows
+    const int rt = (int)(tile / KT), kt = (int)(tile % KT);
+    const int lane = threadIdx.x;
+    if (((lane & 15) >> 3) != half) return;
+    const int n = rt * 8 + (lane & 7);
+    const int k0 = kt * 32 + 8 * (lane >> 4);
+    bf16_t* d = dst + ((long)rt * KT + kt) * 512 + lane * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = n < n_rows ? src[(long)n * K + k0 + j] : (bf16_t)0;
+}
+int launch_pack_weight_half(const bf16_t* src, bf16_t* dst, int n_rows, int K, int half, hipStream_t stream) {
+    if (K % 32 != 0 || n_rows <= 0 || n_rows % 8 != 0 || (half != 0 && half != 1)) return ISST_ERR_ARG;
+    hipLaunchKernelGGL(pack_weight_half_kernel, dim3((unsigned)((long)(n_rows / 8) * (K / 32))), dim3(64), 0, stream, src, dst, n_rows, K, half);
+    return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+}
+
 // -DISST_GEMV_TRACE (make trace -> libinfinisst_hip_trace.so, profiles/gemv_trace_probe.py): wave 0 of every workgroup of the skinny kernel
 // stamps the 100 MHz wall clock at entry / rows staged / first weight batch consumed / k-loop done / output stored, plus its XCC and CU id.
 #ifdef ISST_GEMV_TRACE
@@ -366,15 +385,18 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
         int mt, nb;
         if constexpr (EPI == EPI_SWIGLU) { mt = ot / (NTB / 2); nb = (ot % (NTB / 2)) * 2; }
         else { mt = ot / NTB; nb = ot % NTB; }
+        if constexpr (EPI == EPI_SWIGLU8) { if ((l & 15) >= 8) continue; }  // (column c < 8 of the tile is the gate of output 8 t + c, column c + 8 its up)
         float s = 0.f, s2 = 0.f;
         for (int w = 0; w < W; ++w) {
             const float* p = red + (long)w * (TILES * 256);
             s += p[((mt * NTB + nb) * 4 + r) * 64 + l];
             if constexpr (EPI == EPI_SWIGLU) s2 += p[((mt * NTB + nb + 1) * 4 + r) * 64 + l];
+            if constexpr (EPI == EPI_SWIGLU8) s2 += p[((mt * NTB + nb) * 4 + r) * 64 + l + 8];
         }
         const int row = m0 + mt * 16 + (l >> 4) * 4 + r;
         int col;
         if constexpr (EPI == EPI_SWIGLU) col = ((nt0 + nb) >> 1) * 16 + (l & 15);
+        else if constexpr (EPI == EPI_SWIGLU8) col = (nt0 + nb) * 8 + (l & 15);
         else col = (nt0 + nb) * 16 + (l & 15);
         if (row >= g.M || col >= g.n_valid) continue;
         if constexpr (EPI == EPI_F32) {
@@ -386,7 +408,7 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
             else if constexpr (EPI == EPI_BIAS_GELU) v = gelu_erf(bfr(s + bf2f(g.bias[col])));
             else if constexpr (EPI == EPI_RES) v = bf2f(res[(long)row * g.ldres + col]) + bfr(s);
             else if constexpr (EPI == EPI_BIAS_RES) v = bf2f(res[(long)row * g.ldres + col]) + bfr(s + bf2f(g.bias[col]));
-            else /* EPI_SWIGLU */ v = bfr(silu(bfr(s))) * bfr(s2);
+            else /* EPI_SWIGLU, EPI_SWIGLU8 */ v = bfr(silu(bfr(s))) * bfr(s2);
             reinterpret_cast<bf16_t*>(g.out)[b * g.out_batch + (long)row * g.ldo + col] = f2bf(v);
         }
     }
@@ -457,7 +479,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (g.norm_w) {
         // fused norm: decode shapes only; every block re-normalises its rows, free at M <= 8 and wasteful beyond
         // (callers run the norm kernel first for larger M)
-        if constexpr (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_F32) {
+        if constexpr (EPI == EPI_NONE || EPI == EPI_SWIGLU || EPI == EPI_SWIGLU8 || EPI == EPI_F32) {
             if (gemm_can_stage(g)) return launch_cfg<1, EPI, true, 2>(g, stream);
         }
         return ISST_ERR_ARG;
@@ -495,6 +517,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
         case EPI_BIAS_RES: return (g.res && g.bias) ? launch_epi<EPI_BIAS_RES>(g, stream) : ISST_ERR_ARG;
         case EPI_SWIGLU: return (g.N % 32 == 0) ? launch_epi<EPI_SWIGLU>(g, stream) : ISST_ERR_ARG;
         case EPI_F32: return launch_epi<EPI_F32>(g, stream);
+        case EPI_SWIGLU8: return (g.M <= 16 && g.batch == 1) ? launch_epi<EPI_SWIGLU8>(g, stream) : ISST_ERR_ARG;  // (the register-A GEMV only: the other kernels pair tiles)
     }
     return ISST_ERR_ARG;
 }

@@ -22,7 +22,7 @@ _lib = None
 
 ISST_MAX_CONV, ISST_MAX_SHRINK, ISST_MAX_EOS = 8, 4, 8
 
-EPI = {"none": 0, "bias": 1, "bias_gelu": 2, "res": 3, "bias_res": 4, "swiglu": 5, "f32": 6}
+EPI = {"none": 0, "bias": 1, "bias_gelu": 2, "res": 3, "bias_res": 4, "swiglu": 5, "f32": 6, "swiglu8": 8}
 
 
 class IsstError(RuntimeError):
@@ -71,7 +71,7 @@ EXPORTS = [
     "isst_stream_import_llm_kv", "isst_stream_import_enc_kv", "isst_stream_import_audio_history",
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
     "isst_op_attn_combine", "isst_op_gemm_attn_merge", "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
-    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_begin_rows", "isst_profile_end", "isst_op_pack_weight",
+    "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_begin_rows", "isst_profile_end", "isst_op_pack_weight", "isst_op_pack_gateup8",
     "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_topk_rows", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample", "isst_op_warp", "isst_op_warp_sample", "isst_op_sample_uniform", "isst_op_multinomial_wor",
 ]
 
@@ -127,6 +127,7 @@ def load_library(path: Optional[str] = None):
     lib.isst_profile_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.isst_op_pack_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.isst_op_packed_elems.argtypes = [C.c_int, C.c_int]
+    lib.isst_op_pack_gateup8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.isst_op_gemm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                  C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
     lib.isst_op_gemm_splitk_rmsnorm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -469,6 +470,17 @@ def op_pack_weight(w: torch.Tensor, conv_k: int = 0) -> torch.Tensor:
     return out
 
 
+def op_pack_gateup8(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """gate_proj / up_proj (ffn, K) as self-paired tiles for op_gemm(..., N=2 * ffn, epi="swiglu8")."""
+    lib = load_library()
+    ffn, K = gate.shape
+    out = torch.zeros(2 * ffn * K, dtype=torch.bfloat16, device=gate.device)
+    rc = lib.isst_op_pack_gateup8(_ptr(gate.contiguous()), _ptr(up.contiguous()), _ptr(out), ffn, K, _stream_ptr())
+    if rc:
+        raise IsstError(f"isst_op_pack_gateup8 -> {rc}")
+    return out
+
+
 def op_gemm(A: torch.Tensor, packed: torch.Tensor, N: int, epi: str = "none", bias=None, res=None, n_valid=None,
             lda: Optional[int] = None, M: Optional[int] = None, K: Optional[int] = None, norm_w=None,
             norm_eps: float = 1e-5) -> torch.Tensor:
@@ -476,7 +488,7 @@ def op_gemm(A: torch.Tensor, packed: torch.Tensor, N: int, epi: str = "none", bi
     M = A.shape[0] if M is None else M
     K = A.shape[1] if K is None else K
     lda = A.stride(0) if lda is None else lda
-    n_out = (N // 2 if epi == "swiglu" else N) if n_valid is None else n_valid
+    n_out = (N // 2 if epi in ("swiglu", "swiglu8") else N) if n_valid is None else n_valid
     out = torch.zeros((M, n_out), dtype=torch.float32 if epi == "f32" else torch.bfloat16, device=A.device)
     rc = lib.isst_op_gemm(_ptr(A), lda, _ptr(packed), _ptr(bias), _ptr(res), 0 if res is None else res.stride(0),
                           _ptr(out), out.stride(0), M, N, K, n_out, EPI[epi], _ptr(norm_w), norm_eps, _stream_ptr())

@@ -31,7 +31,7 @@ DF=$(find $O/dpmc_fetch -name "*counter_collection.csv" | head -1); DM=$(find $O
 python3 profiles/dense_pmc_reduce.py $DF $DM $DS $O/dense_pmc.json
 python3 - <<PY
 import csv
-for f, k, o in (("$F", "gemm_skinny_kernel<1, 2, 5", "gemv_pmc_fetch_size.csv"), ("$W", "gemm_skinny_kernel<1, 2, 5", "gemv_pmc_write_size.csv"),
+for f, k, o in (("$F", "gemm_skinny_kernel<1, 1, 8", "gemv_pmc_fetch_size.csv"), ("$W", "gemm_skinny_kernel<1, 1, 8", "gemv_pmc_write_size.csv"),
                 ("$DF", "gemm_dense_kernel<5>", "dense_pmc_fetch_size.csv"), ("$DM", "gemm_dense_kernel<5>", "dense_pmc_mfma.csv")):
     rows = [r for r in csv.DictReader(open(f)) if k in r["Kernel_Name"]]
     if rows:

@@ -36,7 +36,7 @@ def line(st, label, pat, nbytes=None, flops=None):
 
 s = stats("1")
 print("one stream (configs[1]), decode pass:")
-line(s, "gate/up GEMV (fused norm)", r"gemm_skinny_kernel<1, 2, 5", W["gateup"])
+line(s, "gate/up GEMV (fused norm, self-paired tiles)", r"gemm_skinny_kernel<1, 1, 8", W["gateup"])
 line(s, "down_proj GEMV", r"gemm_skinny_kernel<1, 1, 3", W["down"])
 line(s, "q/k/v GEMV (fused norm)", r"gemm_skinny_kernel<1, 1, 0, true, 2", W["qkv"])
 line(s, "attention + combine + o_proj (one launch)", r"llm_attn_oproj_kernel", W["o"] + KV1)

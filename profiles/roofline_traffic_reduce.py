@@ -3,7 +3,7 @@
     python profiles/roofline_traffic_reduce.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [label]
 Counters are in KiB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM section: 128-byte requests are tallied at 64 B); WRITE_SIZE is exact."""
 import csv, json, statistics, sys
-KERNEL = "gemm_skinny_kernel<1, 2, 5, true, 2, 4"
+KERNEL = "gemm_skinny_kernel<1, 1, 8, true, 2, 4"  # (rounds 1-5 and the first half of round 6: <1, 2, 5, ...>, the tile-pair form)
 
 
 def median_of(path, counter):
@@ -21,7 +21,7 @@ fetch, n = median_of(sys.argv[1], "FETCH_SIZE")
 write, _ = median_of(sys.argv[2], "WRITE_SIZE")
 algo = 28672 * 4096 * 2 + 4096 * 2 + 14336 * 2
 hbm = fetch * 1024 * 2 + write * 1024
-out = {"kernel": "gemm_skinny_kernel<1,2,EPI_SWIGLU,nt,AMODE=2,DEPTH=4> (gate/up GEMV with fused RMSNorm, M=1, N=28672, K=4096)",
+out = {"kernel": "gemm_skinny_kernel<1,1,EPI_SWIGLU8,nt,AMODE=2,DEPTH=4> (gate/up GEMV with fused RMSNorm on self-paired tiles, M=1, N=28672, K=4096)",
        "FETCH_SIZE_KiB_raw_median": fetch, "WRITE_SIZE_KiB_raw_median": write, "fetch_bytes_corrected_x2": fetch * 2048, "write_bytes": write * 1024,
        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": round(hbm / algo, 5), "launches_sampled": n,
        "collected": sys.argv[4] if len(sys.argv) > 4 else "",

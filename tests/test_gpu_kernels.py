@@ -128,6 +128,30 @@ def test_gemm_swiglu(M):
     close_bf16(out, ref, f"swiglu M{M}", ulps=3, atol=2e-3)
 
 
+@pytest.mark.parametrize("M", [1, 2, 4, 8])
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("I,K", [(512, 256), (14336, 4096)])
+def test_gemm_swiglu_self_paired_tiles_are_bit_identical_to_tile_pairs(M, norm, I, K):
+    """gate / up as SELF-PAIRED tiles (isst_op_pack_gateup8 + epi swiglu8: tile t = gate rows 8t..8t+7 | up rows 8t..8t+7; the copy a one-row decode pass streams,
+    engine_llm.hip) against the tile-pair form (epi swiglu) on the same weights: the same bits, with and without the fused RMSNorm, toy and Llama-3.1-8B widths --
+    both forms run the register-A GEMV with the same waves per workgroup at one and two rows, i.e. one summation order per output -- and the oracle's HF LlamaMLP value at every row count."""
+    g = torch.Generator().manual_seed(M + I)
+    A = bf(torch.randn(M, K, generator=g))
+    nw = bf(1 + 0.2 * torch.randn(K, generator=g))
+    Wg, Wu = bf(torch.randn(I, K, generator=g) * 0.05), bf(torch.randn(I, K, generator=g) * 0.05)
+    inter = torch.stack([Wg.view(I // 16, 16, K), Wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K)
+    kw = dict(norm_w=nw.to(DEV), norm_eps=1e-5) if norm else {}
+    pairs = E.op_gemm(A.to(DEV), E.op_pack_weight(inter.to(DEV)), 2 * I, "swiglu", **kw)
+    self8 = E.op_gemm(A.to(DEV), E.op_pack_gateup8(Wg.to(DEV), Wu.to(DEV)), 2 * I, "swiglu8", **kw)
+    torch.cuda.synchronize()
+    assert self8.shape == pairs.shape == (M, I)
+    if M <= 2:  # (from 3 rows on the fused-norm launcher gives one-tile workgroups 8 waves and tile pairs 4: another order of the same sum; the engine takes this form at ONE row)
+        assert torch.equal(self8.view(torch.int16), pairs.view(torch.int16)), f"M{M} norm {norm} I{I}: max |d| {float((self8.float() - pairs.float()).abs().max())}"
+    x = ollm.rmsnorm(A, nw, 1e-5) if norm else A
+    ref = torch.nn.functional.silu(bf(x.float() @ Wg.float().t())) * bf(x.float() @ Wu.float().t())
+    close_bf16(self8, bf(ref.float()), f"swiglu8 vs oracle M{M} norm {norm} I{I}", ulps=3, atol=4e-3 if K <= 512 else 2e-2)
+
+
 @pytest.mark.parametrize("M", [1, 2, 5, 8])
 @pytest.mark.parametrize("epi", ["none", "f32", "swiglu"])
 def test_gemm_fused_rmsnorm(M, epi):
