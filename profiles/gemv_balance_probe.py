@@ -32,5 +32,5 @@ for M in (1, 4):
         for label, w in (("plain", None), ("fused norm", nw)):
             if epi == "res" and w is not None: continue
             t = timeit(lambda i: run(A, Wps[i % 4], N, K, epi, res, out, w))
-            line += f"  {label} {t:6.2f} us = {mb / t / 1e3 * 1e3 / 1e3:5.2f} TB/s (stream part at 3 us of ramp: {mb / (t - 3) / 1e3:5.2f})"
+            line += f"  {label} {t:6.2f} us = {mb / t:5.2f} TB/s (stream part at 3 us of ramp: {mb / (t - 3):5.2f})"
         print(line, flush=True)
