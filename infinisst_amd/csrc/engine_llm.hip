@@ -269,10 +269,10 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             }
             if (fuse) {
                 CHK(prof_open(&pe));
-                // ONE row (a greedy stream's decode step): the self-paired copy of gate / up -- 1792 one-tile workgroups, 7 on every CU, where the tile pairs are
-                // 896 = 3.5 per CU: 36.2 against 38.0 us for the same bytes (profiles/r06/gemv_balance_probe.txt); from two rows on the pairs win (every
-                // workgroup normalises the rows it stages: twice the workgroups, twice that work)
-                if (rows == 1 && L.gateup8.wp)
+                // One or two rows (the decode step of one or two greedy streams): the self-paired copy of gate / up -- 1792 one-tile workgroups, 7 on every CU, where
+                // the tile pairs are 896 = 3.5 per CU: 36.2 against 38.0 us for the same bytes at one row, 37.9 against 39.7 at two (profiles/r06/gemv_balance_probe.txt,
+                // gemv_balance_rows_probe.txt); from three rows on the pairs win (every workgroup normalises the rows it stages: twice the workgroups, twice that work)
+                if (rows <= 2 && L.gateup8.wp)
                     CHK(gemm(h, h->lx, DL, L.gateup8, EPI_SWIGLU8, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
                 else
                 CHK(gemm(h, h->lx, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st, 1, 0, 0, 0, L.post_norm, c.rms_eps));
