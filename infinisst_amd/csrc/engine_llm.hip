@@ -280,6 +280,11 @@ int llm_forward(isst_handle* h, const StepMeta& d, int rows, int n_last, int n_g
             } else {
                 CHK(launch_rmsnorm(h->lx, DL, nullptr, L.post_norm, h->lxn, DL, rows, DL, c.rms_eps, st));
                 CHK(prof_open(&pe));
+                // (5 and 6 rows -- the register-A GEMV behind the norm launch -- also stream the self-paired copy: 39.0 / 39.5 against 40.7 / 40.8 us; at 8 rows the
+                //  pairs are level again, every workgroup reads all rows: profiles/r06/gemv_balance_rows_probe.txt)
+                if (rows <= 6 && L.gateup8.wp)
+                    CHK(gemm(h, h->lxn, DL, L.gateup8, EPI_SWIGLU8, nullptr, 0, h->lact, c.llm_ffn, rows, st));
+                else
                 CHK(gemm(h, h->lxn, DL, L.gateup, EPI_SWIGLU, nullptr, 0, h->lact, c.llm_ffn, rows, st));
                 if (pe) HIPCHK(hipEventRecord(pe, st));
             }

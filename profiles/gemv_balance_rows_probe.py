@@ -20,7 +20,7 @@ pairs = [E.op_pack_weight(torch.stack([g.view(I // 16, 16, K), u.view(I // 16, 1
 self8 = [E.op_pack_gateup8(g, u) for g, u in zip(Wg, Wu)]
 del Wg, Wu
 nw = torch.ones(K, device=dev).bfloat16()
-for M in (1, 2, 3, 4, 6, 8):
+for M in (1, 2, 3, 4, 5, 6, 8, 10, 12):
     A = torch.randn(M, K, device=dev).bfloat16()
     line = f"M={M}:"
     for wv in (0, 4, 8):
@@ -29,4 +29,7 @@ for M in (1, 2, 3, 4, 6, 8):
         ts = timeit(lambda i: E.op_gemm(A, self8[i % 3], 2 * I, "swiglu8", norm_w=nw))
         line += f"   waves {wv or 'auto'}: pairs {tp:6.2f} us, self-paired {ts:6.2f} us"
     lib.isst_op_set_gemm_tuning(0, 0)
+    tp = timeit(lambda i: E.op_gemm(A, pairs[i % 3], 2 * I, "swiglu"))
+    ts = timeit(lambda i: E.op_gemm(A, self8[i % 3], 2 * I, "swiglu8"))
+    line += f"   NO fused norm (the engine's form from 5 rows on): pairs {tp:6.2f} us, self-paired {ts:6.2f} us"
     print(line, flush=True)
