@@ -217,7 +217,7 @@ int64_t isst_op_packed_elems(int n_rows, int K);
  * the one-row decode passes of reference model/llm.py:114-126 -> LlamaMLP (engine_llm.hip llm_forward). */
 int isst_op_pack_gateup8(const uint16_t* gate, const uint16_t* up, uint16_t* packed, int ffn, int K, void* hip_stream);
 /* out = epi(A @ W^T); epi: 0 none, 1 bias, 2 bias+gelu, 3 residual, 4 bias+residual, 5 swiglu (packed rows
- * alternate gate/up tiles), 6 fp32 out.  Replaces torch F.linear / F.conv1d call sites (see gemm.hip).
+ * alternate gate/up tiles), 6 fp32 out, 8 swiglu on self-paired tiles (isst_op_pack_gateup8; <= 16 rows).  Replaces torch F.linear / F.conv1d call sites (see gemm.hip).
  * norm_w != NULL (epi 0, 5, 6 only): LlamaRMSNorm(norm_w, norm_eps) is applied to the rows of A on load. */
 int isst_op_gemm(const uint16_t* A, int64_t lda, const uint16_t* packed, const uint16_t* bias, const uint16_t* res,
                  int64_t ldres, void* out, int64_t ldo, int M, int N, int K, int n_valid, int epi, const uint16_t* norm_w,
