@@ -491,11 +491,92 @@ __global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(const float* __rest
     }
 }
 
+// The same pass for the decode launches of 65..256 rows (one workgroup per row on one CU each: nothing hides a round trip), ALL loads first.  The kernel above walks
+// a row in STEPS steps of: slab loads -> wait -> the x chunk (asked for behind the sums) -> wait -> store x; and because vmcnt counts loads and stores in order, the
+// wait for step 1's loads also waits for the acknowledgement of step 0's store: four dependent load round trips and a store round trip per 8 us launch.  Here every
+// load of the row -- norm weight, x, every slice of every step -- is in flight before the first add, and every one has landed before the first store (DESIGN.md
+// section 7, "what a conditional store does to counted waits"); loads of columns past D re-read column 0 and are dropped.  Same arithmetic, same order.
+template <int STEPS, int NMAX>
+__global__ __launch_bounds__(256) void rmsnorm_reduce_lf_kernel(const float* __restrict__ slabs, long slab_stride, int n_slabs, bf16_t* x, long ldx,
+                                                                const bf16_t* __restrict__ w, bf16_t* __restrict__ out, long ldo, int D, float eps) {
+    __shared__ float part[4];
+    const long row = blockIdx.x;
+    bf16_t* xr = x + row * ldx;
+    u32x4_t wraw[STEPS], xraw[STEPS];
+    f32x4_t sa[STEPS][NMAX], sb[STEPS][NMAX];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8, cl = c < D ? c : 0;
+        wraw[s] = *reinterpret_cast<const u32x4_t*>((w ? w : xr) + cl);
+        xraw[s] = *reinterpret_cast<const u32x4_t*>(xr + cl);
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+            const float* sp = slabs + (long)(k < n_slabs ? k : 0) * slab_stride + row * D + cl;
+            sa[s][k] = *reinterpret_cast<const f32x4_t*>(sp);
+            sb[s][k] = *reinterpret_cast<const f32x4_t*>(sp + 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" :: "v"(sa[STEPS - 1][NMAX - 1].x), "v"(sb[STEPS - 1][NMAX - 1].x));  // (returns are counted in order: the last one in is every one in)
+    float v[STEPS][8];
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+            const bool on = k < n_slabs;
+            const f32x4_t a = sa[s][k], b = sb[s][k];
+            acc[0] = on ? acc[0] + a.x : acc[0]; acc[1] = on ? acc[1] + a.y : acc[1]; acc[2] = on ? acc[2] + a.z : acc[2]; acc[3] = on ? acc[3] + a.w : acc[3];
+            acc[4] = on ? acc[4] + b.x : acc[4]; acc[5] = on ? acc[5] + b.y : acc[5]; acc[6] = on ? acc[6] + b.z : acc[6]; acc[7] = on ? acc[7] + b.w : acc[7];
+        }
+        unpack8(xraw[s], v[s]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + bfr(acc[j]));
+        if (c < D) {
+            *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sq += v[s][j] * v[s][j];
+        }
+    }
+    if (!w) return;
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    const float tot = part[0] + part[1] + part[2] + part[3];
+    const float r = rsqrtf(tot / D + eps);
+    bf16_t* orow = out + row * ldo;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (threadIdx.x + 256 * s) * 8;
+        if (c < D) {
+            float wv[8], y[8];
+            unpack8(wraw[s], wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = wv[j] * bfr(v[s][j] * r);
+            *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
+        }
+    }
+}
+
 // slabs: fp32 [n_slabs][rows][D] (dense rows); x: residual stream, updated in place; w == null: no norm output
 int launch_rmsnorm_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* x, long ldx, const bf16_t* w, bf16_t* out, long ldo,
                           int rows, int D, float eps, hipStream_t s) {
     if (rows <= 0) return ISST_OK;
     if (D % 8 != 0 || D > 8192 || ldx % 8 != 0 || ldo % 8 != 0 || n_slabs < 1) return ISST_ERR_ARG;
+    static const int lf_rows = [] { const char* e = getenv("ISST_RMS_LF_ROWS"); return e ? atoi(e) : 256; }();  // (0: the stepwise kernel everywhere)
+    if (rows <= lf_rows && n_slabs <= 8 && D <= 4096) {
+        if (D <= 2048 && n_slabs <= 4)
+            hipLaunchKernelGGL((rmsnorm_reduce_lf_kernel<1, 4>), dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);
+        else if (D <= 2048)
+            hipLaunchKernelGGL((rmsnorm_reduce_lf_kernel<1, 8>), dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);
+        else if (n_slabs <= 4)
+            hipLaunchKernelGGL((rmsnorm_reduce_lf_kernel<2, 4>), dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);
+        else
+            hipLaunchKernelGGL((rmsnorm_reduce_lf_kernel<2, 8>), dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);
+        return hipGetLastError() == hipSuccess ? ISST_OK : ISST_ERR_HIP;
+    }
     if (D <= 2048)
         hipLaunchKernelGGL(rmsnorm_reduce_kernel<1>, dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);
     else if (D <= 4096)

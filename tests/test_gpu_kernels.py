@@ -388,6 +388,29 @@ def test_gemm_splitk_rmsnorm(M, N, K, ks, with_norm):
         assert normed is None
 
 
+@pytest.mark.parametrize("N,K,ks", [(4096, 2048, 4), (4096, 4096, 8), (1024, 2048, 2), (1040, 512, 2), (2048, 1024, 8), (4096, 1024, 1)])
+def test_residual_rmsnorm_reduce_all_loads_first_carries_the_stepwise_kernels_bits(N, K, ks):
+    """The residual + RMSNorm reduce of the 65..256-row decode passes asks for every load of a row before its first add (rowops.hip
+    rmsnorm_reduce_lf_kernel); above 256 rows the stepwise kernel runs.  Same slabs, same arithmetic, same order: the first 256 rows of a 300-row
+    call and a 256-row call on the same data carry the same bits, x and normalised rows; both are held to the oracle."""
+    g = torch.Generator().manual_seed(N + K + ks)
+    A = bf(torch.randn(300, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    x = bf(torch.randn(300, N, generator=g))
+    nw = bf(1 + 0.2 * torch.randn(N, generator=g))
+    Wp = E.op_pack_weight(W.to(DEV))
+    x_big, n_big = E.op_gemm_splitk_rmsnorm(A.to(DEV), Wp, x.to(DEV), ks, nw.to(DEV), 1e-5)
+    for M in ((256, 131, 66) if ks > 1 else (256, 131)):  # (one slice at 66 rows: a GEMM kernel with another summation order inside the slice)
+        x_lf, n_lf = E.op_gemm_splitk_rmsnorm(A[:M].to(DEV), Wp, x[:M].to(DEV), ks, nw.to(DEV), 1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(x_lf.cpu().view(torch.int16), x_big[:M].cpu().view(torch.int16)), f"x bits M{M} N{N} K{K} S{ks}"
+        assert torch.equal(n_lf.cpu().view(torch.int16), n_big[:M].cpu().view(torch.int16)), f"norm bits M{M} N{N} K{K} S{ks}"
+    close_bf16(x_big, ref_linear(A, W, "res", res=x), f"reduce x N{N} K{K} S{ks}", ulps=2.5, atol=3.2e-2)
+    close_bf16(n_big, ollm.rmsnorm(x_big.cpu(), nw, 1e-5), f"reduce norm N{N}", ulps=2.0, atol=1e-3)
+    x_nn, none = E.op_gemm_splitk_rmsnorm(A[:200].to(DEV), Wp, x[:200].to(DEV), ks, None, 1e-5)
+    assert none is None and torch.equal(x_nn.cpu().view(torch.int16), x_big[:200].cpu().view(torch.int16))
+
+
 @pytest.mark.parametrize("M,N,K,ks,N2,epi2", [(13, 256, 1024, 2, 512, "none"), (22, 4096, 4096, 2, 1024, "swiglu"), (64, 4096, 2048, 4, 768, "none"),
                                               (64, 512, 2048, 4, 512, "f32"), (48, 1024, 14336, 4, 2048, "swiglu"), (33, 256, 4096, 8, 256, "none")])
 def test_launch_free_residual_rmsnorm_equals_the_reduce_launch(M, N, K, ks, N2, epi2):
