@@ -253,6 +253,10 @@ int isst_op_set_gemm_tuning(int waves_per_block, int ntiles_per_block);
  * (stream, kv head), which also folds a shared-prefix beam group's per-beam keys into that workgroup (what 16+ streams x beams select by themselves);
  * n < 0 = the target -n - 1 with the beams' per-beam workgroups kept at any stream count (A/B runs).  Bits 16.. : the same target for the prefill form. */
 int isst_op_set_attn_tuning(int target_workgroups);
+/* test aid: row limits of the all-loads-first forms of the two reduce launches (csrc/rowops.hip rmsnorm_reduce_lf_kernel, layernorm_reduce_lf_kernel: the residual +
+ * RMSNorm / LayerNorm passes that sum a projection's K slices); 0 = the stepwise kernels everywhere, -1 = the default (ISST_RMS_LF_ROWS / ISST_LN_LF_ROWS, else by
+ * slice count).  Both forms carry the same bits: the tests run one against the other through this switch. */
+int isst_op_set_reduce_tuning(int rms_lf_rows, int ln_lf_rows);
 /* test entry: the beam search's per-row top-k over the processed log-probs (csrc/beam.hip; replaces torch.topk(next_token_scores, ...) of the reference's
  * _beam_search, patch_hf.py:863-879): scores [rows][ld] fp32 on the device, out_val / out_idx [rows][32]; ties go to the lowest index */
 int isst_op_topk_rows(const float* scores, long ld, int vocab, int k, int rows, float* out_val, int* out_idx, void* hip_stream);

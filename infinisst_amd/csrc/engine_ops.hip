@@ -104,6 +104,10 @@ extern "C" int isst_profile_end(isst_handle* h, void* hip_stream, double* avg_us
     *avg_us = *launches ? sum / *launches : 0.0;
     return ISST_OK;
 }
+extern "C" int isst_op_set_reduce_tuning(int rms_lf_rows, int ln_lf_rows) {
+    reduce_set_tuning(rms_lf_rows, ln_lf_rows);
+    return ISST_OK;
+}
 extern "C" int isst_op_set_attn_tuning(int target_workgroups) {
     llm_attn_set_tuning(target_workgroups);
     return ISST_OK;

@@ -44,6 +44,7 @@ int launch_rmsnorm(const bf16_t* x, long ldx, const int* rows_idx, const bf16_t*
                    float eps, hipStream_t s);
 // split-K slabs (gemm_mid.hip EPI_PARTIAL) -> x += sum, then RMSNorm of the updated rows (w == null: update only)
 // out = bf16(sum of fp32 slabs [n_slabs][rows][N])
+void reduce_set_tuning(int rms_lf_rows, int ln_lf_rows);  // (test aid: isst_op_set_reduce_tuning)
 int launch_slab_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* out, long ldo, int rows, int N, hipStream_t s);
 int launch_rmsnorm_reduce(const float* slabs, long slab_stride, int n_slabs, bf16_t* x, long ldx, const bf16_t* w, bf16_t* out, long ldo,
                           int rows, int D, float eps, hipStream_t s);

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
             unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
             if (slabs) {
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pb[8];
+                const u32x4_t praw = *reinterpret_cast<const u32x4_t*>(proj_bias + c);  // (ahead of the slices, not behind their sums)
                 if constexpr (LF) slab_sum8(slabs, slab_stride, n_slabs, row * C + c, acc);
                 else
                 for (int k = 0; k < n_slabs; ++k) {  // (slab_sum8's loads-first form measured SLOWER here at many rows -- 16.4 -> 20.5 us at 128 streams: one wave per row, registers)
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
                     acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
                     acc[4] += a2.x; acc[5] += a2.y; acc[6] += a2.z; acc[7] += a2.w;
                 }
-                unpack8(*reinterpret_cast<const u32x4_t*>(proj_bias + c), pb);
+                unpack8(praw, pb);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + bfr(acc[j] + pb[j]));
                 *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
@@ -349,6 +350,97 @@ __global__ __launch_bounds__(256) void layernorm_kernel(bf16_t* x, long ldx, con
     }
 }
 
+// Few rows (one stream's 48 frames = 12 workgroups), a projection's K slices to sum, C <= 1024, <= NMAX slices: ALL loads first.  layernorm_kernel<2, true> still walks
+// the row in two steps with the x store of step 0 between them, and vmcnt counts loads and stores in order: the wait for step 1's loads is also a wait for that store's
+// acknowledgement (rmsnorm_reduce_lf_kernel below has the long form of this).  Every load of the row -- x, projection bias, slices, weight, bias --
+// is in flight before the first add here, and nothing is stored before the last one has landed.  Same arithmetic, same order as the stepwise kernel.
+template <int NMAX>
+__global__ __launch_bounds__(256) void layernorm_reduce_lf_kernel(bf16_t* x, long ldx, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b, bf16_t* out, long ldo,
+                                                                  int rows, int C, float eps, int gelu, const float* __restrict__ slabs, long slab_stride,
+                                                                  int n_slabs, const bf16_t* __restrict__ proj_bias) {
+    constexpr int STEPS = 2;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    bf16_t* xr = x + row * ldx;
+    u32x4_t wraw[STEPS], braw[STEPS], xraw[STEPS], praw[STEPS];
+    f32x4_t sa[STEPS][NMAX], sb[STEPS][NMAX];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (lane + 64 * s) * 8, cl = c < C ? c : 0;
+        wraw[s] = *reinterpret_cast<const u32x4_t*>((w ? w : proj_bias) + cl);
+        braw[s] = *reinterpret_cast<const u32x4_t*>((w ? b : proj_bias) + cl);
+        xraw[s] = *reinterpret_cast<const u32x4_t*>(xr + cl);
+        praw[s] = *reinterpret_cast<const u32x4_t*>(proj_bias + cl);
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+            const float* sp = slabs + (long)(k < n_slabs ? k : 0) * slab_stride + row * C + cl;
+            sa[s][k] = *reinterpret_cast<const f32x4_t*>(sp);
+            sb[s][k] = *reinterpret_cast<const f32x4_t*>(sp + 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" :: "v"(sa[STEPS - 1][NMAX - 1].x), "v"(sb[STEPS - 1][NMAX - 1].x));  // (returns are counted in order: the last one in is every one in)
+    float v[STEPS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (lane + 64 * s) * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, pb[8];
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+            const bool on = k < n_slabs;
+            const f32x4_t a = sa[s][k], a2 = sb[s][k];
+            acc[0] = on ? acc[0] + a.x : acc[0]; acc[1] = on ? acc[1] + a.y : acc[1]; acc[2] = on ? acc[2] + a.z : acc[2]; acc[3] = on ? acc[3] + a.w : acc[3];
+            acc[4] = on ? acc[4] + a2.x : acc[4]; acc[5] = on ? acc[5] + a2.y : acc[5]; acc[6] = on ? acc[6] + a2.z : acc[6]; acc[7] = on ? acc[7] + a2.w : acc[7];
+        }
+        unpack8(xraw[s], v[s]);
+        unpack8(praw[s], pb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + bfr(acc[j] + pb[j]));
+        if (c < C) {
+            *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[s][j];
+        }
+    }
+    if (!w) return;
+    const float mean = wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s)
+        if ((lane + 64 * s) * 8 < C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[s][j] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / C + eps);
+    bf16_t* orow = out + row * ldo;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int c = (lane + 64 * s) * 8;
+        if (c < C) {
+            float wv[8], bv[8], y[8];
+            unpack8(wraw[s], wv);
+            unpack8(braw[s], bv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                y[j] = (v[s][j] - mean) * rstd * wv[j] + bv[j];
+                if (gelu) y[j] = gelu_erf(bfr(y[j]));
+            }
+            *reinterpret_cast<u32x4_t*>(orow + c) = pack8(y);
+        }
+    }
+}
+
+// ISST_LN_LF_ROWS=n: the all-loads-first kernel up to n rows (0: the stepwise kernel everywhere).  Default: every row count with <= 4 slices (3072 rows, 64 streams:
+// 13.2 -> 12.3 us per launch), up to 256 rows with 5..8 (170 registers per wave: measured at 192 rows only) -- profiles/r06/reduce_kernels_many_rows_ab.txt
+static int g_rms_lf_rows = -1, g_ln_lf_rows = -1;  // isst_op_set_reduce_tuning (test aid): >= 0 overrides the environment
+void reduce_set_tuning(int rms_lf_rows, int ln_lf_rows) { g_rms_lf_rows = rms_lf_rows; g_ln_lf_rows = ln_lf_rows; }
+static int ln_all_loads_first_rows(int n_slabs) {
+    static const int n = [] { const char* e = getenv("ISST_LN_LF_ROWS"); return e ? atoi(e) : -1; }();
+    if (g_ln_lf_rows >= 0) return g_ln_lf_rows;
+    return n >= 0 ? n : (n_slabs <= 4 ? 1 << 30 : 256);
+}
 static int launch_layernorm_impl(bf16_t* x, long ldx, const bf16_t* w, const bf16_t* b, bf16_t* out, long ldo, int rows, int C, float eps,
                                  int gelu, const float* slabs, long slab_stride, int n_slabs, const bf16_t* proj_bias, hipStream_t s,
                                  const bf16_t* tin = nullptr, long ldt = 0) {
@@ -357,6 +449,10 @@ static int launch_layernorm_impl(bf16_t* x, long ldx, const bf16_t* w, const bf1
     dim3 grid((rows + 3) / 4), block(256);
     if (C <= 512)
         hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias, tin, ldt);
+    else if (C <= 1024 && slabs && rows <= ln_all_loads_first_rows(n_slabs) && n_slabs <= 8 && n_slabs > 4 && proj_bias && !tin)
+        hipLaunchKernelGGL(layernorm_reduce_lf_kernel<8>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias);
+    else if (C <= 1024 && slabs && rows <= ln_all_loads_first_rows(n_slabs) && n_slabs <= 4 && proj_bias && !tin)
+        hipLaunchKernelGGL(layernorm_reduce_lf_kernel<4>, grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias);
     else if (C <= 1024 && slabs && rows <= 256)
         hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, ldx, w, b, out, ldo, rows, C, eps, gelu, slabs, slab_stride, n_slabs, proj_bias, tin, ldt);
     else if (C <= 1024)
@@ -462,8 +558,9 @@ __global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(const float* __rest
         const int c = (threadIdx.x + 256 * s) * 8;
         if (c < D) {
             float acc[8];
+            const u32x4_t xraw = *reinterpret_cast<const u32x4_t*>(xr + c);  // (asked for ahead of the slices: behind slab_sum8's branches it was a round trip of its own)
             slab_sum8(slabs, slab_stride, n_slabs, row * D + c, acc);
-            unpack8(*reinterpret_cast<const u32x4_t*>(xr + c), v[s]);
+            unpack8(xraw, v[s]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[s][j] = bfr(v[s][j] + bfr(acc[j]));
             *reinterpret_cast<u32x4_t*>(xr + c) = pack8(v[s]);
@@ -491,7 +588,8 @@ __global__ __launch_bounds__(256) void rmsnorm_reduce_kernel(const float* __rest
     }
 }
 
-// The same pass for the decode launches of 65..256 rows (one workgroup per row on one CU each: nothing hides a round trip), ALL loads first.  The kernel above walks
+// The same pass with ALL loads first -- written for the decode launches of 65..256 rows (one workgroup per row on one CU each: nothing hides a round trip), and
+// the faster one at the prefill's 1408 rows too.  The kernel above walks
 // a row in STEPS steps of: slab loads -> wait -> the x chunk (asked for behind the sums) -> wait -> store x; and because vmcnt counts loads and stores in order, the
 // wait for step 1's loads also waits for the acknowledgement of step 0's store: four dependent load round trips and a store round trip per 8 us launch.  Here every
 // load of the row -- norm weight, x, every slice of every step -- is in flight before the first add, and every one has landed before the first store (DESIGN.md
@@ -565,7 +663,10 @@ int launch_rmsnorm_reduce(const float* slabs, long slab_stride, int n_slabs, bf1
                           int rows, int D, float eps, hipStream_t s) {
     if (rows <= 0) return ISST_OK;
     if (D % 8 != 0 || D > 8192 || ldx % 8 != 0 || ldo % 8 != 0 || n_slabs < 1) return ISST_ERR_ARG;
-    static const int lf_rows = [] { const char* e = getenv("ISST_RMS_LF_ROWS"); return e ? atoi(e) : 256; }();  // (0: the stepwise kernel everywhere)
+    // (ISST_RMS_LF_ROWS=n: up to n rows, 0: the stepwise kernel everywhere.  Default: every row count with <= 4 slices -- 1408 rows, the prefill of 64 streams:
+    //  16.3 -> 15.0 us per launch, profiles/r06/reduce_kernels_many_rows_ab.txt --, up to 256 rows with 5..8 slices: 150 registers per wave, measured there only)
+    static const int lf_env = [] { const char* e = getenv("ISST_RMS_LF_ROWS"); return e ? atoi(e) : -1; }();
+    const int lf_rows = g_rms_lf_rows >= 0 ? g_rms_lf_rows : lf_env >= 0 ? lf_env : (n_slabs <= 4 ? 1 << 30 : 256);
     if (rows <= lf_rows && n_slabs <= 8 && D <= 4096) {
         if (D <= 2048 && n_slabs <= 4)
             hipLaunchKernelGGL((rmsnorm_reduce_lf_kernel<1, 4>), dim3(rows), dim3(256), 0, s, slabs, slab_stride, n_slabs, x, ldx, w, out, ldo, D, eps);

@@ -72,7 +72,7 @@ EXPORTS = [
     "isst_debug_beam_trace_begin", "isst_debug_beam_trace_step", "isst_debug_beam_trace_end",
     "isst_op_attn_combine", "isst_op_gemm_attn_merge", "isst_op_splice_map", "isst_op_embed_splice", "isst_op_enc_attention", "isst_op_llm_attention",
     "isst_generate", "isst_kv_evict", "isst_encode_speech", "isst_debug_tap", "isst_debug_read_kv", "isst_profile_begin", "isst_profile_begin_rows", "isst_profile_end", "isst_op_pack_weight", "isst_op_pack_gateup8",
-    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_topk_rows", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample", "isst_op_warp", "isst_op_warp_sample", "isst_op_sample_uniform", "isst_op_multinomial_wor",
+    "isst_op_packed_elems", "isst_op_gemm", "isst_op_gemm_splitk_rmsnorm", "isst_op_gemm_splitk_fused", "isst_op_gemm_splitk_plain", "isst_op_gemm_norm_ssq", "isst_op_gemm_splitk_layernorm", "isst_op_set_gemm_tuning", "isst_op_set_attn_tuning", "isst_op_set_reduce_tuning", "isst_op_topk_rows", "isst_op_layernorm", "isst_op_rmsnorm", "isst_op_conv0", "isst_op_sample", "isst_op_warp", "isst_op_warp_sample", "isst_op_sample_uniform", "isst_op_multinomial_wor",
 ]
 
 
@@ -136,6 +136,7 @@ def load_library(path: Optional[str] = None):
                                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
     lib.isst_op_set_gemm_tuning.argtypes = [C.c_int, C.c_int]
     lib.isst_op_set_attn_tuning.argtypes = [C.c_int]
+    lib.isst_op_set_reduce_tuning.argtypes = [C.c_int, C.c_int]
     lib.isst_op_layernorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                       C.c_int, C.c_void_p]
     lib.isst_op_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]

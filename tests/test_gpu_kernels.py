@@ -390,25 +390,33 @@ def test_gemm_splitk_rmsnorm(M, N, K, ks, with_norm):
 
 @pytest.mark.parametrize("N,K,ks", [(4096, 2048, 4), (4096, 4096, 8), (1024, 2048, 2), (1040, 512, 2), (2048, 1024, 8), (4096, 1024, 1)])
 def test_residual_rmsnorm_reduce_all_loads_first_carries_the_stepwise_kernels_bits(N, K, ks):
-    """The residual + RMSNorm reduce of the 65..256-row decode passes asks for every load of a row before its first add (rowops.hip
-    rmsnorm_reduce_lf_kernel); above 256 rows the stepwise kernel runs.  Same slabs, same arithmetic, same order: the first 256 rows of a 300-row
-    call and a 256-row call on the same data carry the same bits, x and normalised rows; both are held to the oracle."""
+    """The residual + RMSNorm reduce asks for every load of a row before its first add and stores nothing before the last one has landed
+    (rowops.hip rmsnorm_reduce_lf_kernel; the stepwise kernel remains for 5..8 slices above 256 rows and for D > 4096).  Same slabs, same
+    arithmetic, same order: both forms (isst_op_set_reduce_tuning) carry the same bits, x and normalised rows, at every row count; held to the oracle."""
     g = torch.Generator().manual_seed(N + K + ks)
     A = bf(torch.randn(300, K, generator=g))
     W = bf(torch.randn(N, K, generator=g) * 0.05)
     x = bf(torch.randn(300, N, generator=g))
     nw = bf(1 + 0.2 * torch.randn(N, generator=g))
     Wp = E.op_pack_weight(W.to(DEV))
-    x_big, n_big = E.op_gemm_splitk_rmsnorm(A.to(DEV), Wp, x.to(DEV), ks, nw.to(DEV), 1e-5)
-    for M in ((256, 131, 66) if ks > 1 else (256, 131)):  # (one slice at 66 rows: a GEMM kernel with another summation order inside the slice)
-        x_lf, n_lf = E.op_gemm_splitk_rmsnorm(A[:M].to(DEV), Wp, x[:M].to(DEV), ks, nw.to(DEV), 1e-5)
-        torch.cuda.synchronize()
-        assert torch.equal(x_lf.cpu().view(torch.int16), x_big[:M].cpu().view(torch.int16)), f"x bits M{M} N{N} K{K} S{ks}"
-        assert torch.equal(n_lf.cpu().view(torch.int16), n_big[:M].cpu().view(torch.int16)), f"norm bits M{M} N{N} K{K} S{ks}"
-    close_bf16(x_big, ref_linear(A, W, "res", res=x), f"reduce x N{N} K{K} S{ks}", ulps=2.5, atol=3.2e-2)
-    close_bf16(n_big, ollm.rmsnorm(x_big.cpu(), nw, 1e-5), f"reduce norm N{N}", ulps=2.0, atol=1e-3)
-    x_nn, none = E.op_gemm_splitk_rmsnorm(A[:200].to(DEV), Wp, x[:200].to(DEV), ks, None, 1e-5)
-    assert none is None and torch.equal(x_nn.cpu().view(torch.int16), x_big[:200].cpu().view(torch.int16))
+    lib = E.load_library()
+    try:
+        for M in (300, 256, 131, 66, 22):
+            lib.isst_op_set_reduce_tuning(0, 0)
+            x_st, n_st = E.op_gemm_splitk_rmsnorm(A[:M].to(DEV), Wp, x[:M].to(DEV), ks, nw.to(DEV), 1e-5)
+            xp_st, none = E.op_gemm_splitk_rmsnorm(A[:M].to(DEV), Wp, x[:M].to(DEV), ks, None, 1e-5)
+            lib.isst_op_set_reduce_tuning(1 << 30, 1 << 30)
+            x_lf, n_lf = E.op_gemm_splitk_rmsnorm(A[:M].to(DEV), Wp, x[:M].to(DEV), ks, nw.to(DEV), 1e-5)
+            xp_lf, none_lf = E.op_gemm_splitk_rmsnorm(A[:M].to(DEV), Wp, x[:M].to(DEV), ks, None, 1e-5)
+            torch.cuda.synchronize()
+            assert none is None and none_lf is None
+            assert torch.equal(x_lf.view(torch.int16), x_st.view(torch.int16)), f"x bits M{M} N{N} K{K} S{ks}"
+            assert torch.equal(n_lf.view(torch.int16), n_st.view(torch.int16)), f"norm bits M{M} N{N} K{K} S{ks}"
+            assert torch.equal(xp_lf.view(torch.int16), x_st.view(torch.int16)) and torch.equal(xp_st.view(torch.int16), x_st.view(torch.int16)), f"no-norm x bits M{M}"
+            close_bf16(x_lf, ref_linear(A[:M], W, "res", res=x[:M]), f"reduce x M{M} N{N} K{K} S{ks}", ulps=2.5, atol=3.2e-2)
+            close_bf16(n_lf, ollm.rmsnorm(x_lf.cpu(), nw, 1e-5), f"reduce norm M{M} N{N}", ulps=2.0, atol=1e-3)
+    finally:
+        lib.isst_op_set_reduce_tuning(-1, -1)
 
 
 @pytest.mark.parametrize("M,N,K,ks,N2,epi2", [(13, 256, 1024, 2, 512, "none"), (22, 4096, 4096, 2, 1024, "swiglu"), (64, 4096, 2048, 4, 768, "none"),
@@ -640,6 +648,34 @@ def test_gemm_splitk_layernorm(M, N, K, ks):
     close_bf16(x_new, ref_linear(A, W, "bias_res", bias, x), f"splitk-ln x M{M}", ulps=2.5, atol=3.2e-2)
     ref_ln = torch.nn.functional.layer_norm(x_new.float().cpu(), (N,), lw.float(), lb.float(), 1e-5)
     close_bf16(normed, bf(ref_ln), f"splitk-ln norm M{M}", ulps=2.0, atol=4e-3)
+
+
+@pytest.mark.parametrize("N,K,ks", [(1024, 1024, 2), (1024, 4096, 4), (768, 2048, 4), (1024, 4096, 8), (1024, 1024, 1)])
+def test_layernorm_reduce_all_loads_first_carries_the_stepwise_kernels_bits(N, K, ks):
+    """The LayerNorm that sums the K slices of the encoder's out_proj / fc2 asks for every load of a row before its first add (rowops.hip
+    layernorm_reduce_lf_kernel, 512 < C <= 1024, <= 8 slices).  Both forms (isst_op_set_reduce_tuning) carry the same bits, x and normalised
+    rows, from one stream's 48 rows to 300; held to the oracle."""
+    g = torch.Generator().manual_seed(N + K + ks)
+    A = bf(torch.randn(300, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    bias = bf(torch.randn(N, generator=g))
+    x = bf(torch.randn(300, N, generator=g))
+    lw, lb = bf(1 + 0.2 * torch.randn(N, generator=g)), bf(0.1 * torch.randn(N, generator=g))
+    Wp = E.op_pack_weight(W.to(DEV))
+    lib = E.load_library()
+    try:
+        for M in (300, 256, 130, 48, 13):
+            lib.isst_op_set_reduce_tuning(0, 0)
+            x_st, n_st = E.op_gemm_splitk_layernorm(A[:M].to(DEV), Wp, bias.to(DEV), x[:M].to(DEV), ks, lw.to(DEV), lb.to(DEV), 1e-5)
+            lib.isst_op_set_reduce_tuning(1 << 30, 1 << 30)
+            x_lf, n_lf = E.op_gemm_splitk_layernorm(A[:M].to(DEV), Wp, bias.to(DEV), x[:M].to(DEV), ks, lw.to(DEV), lb.to(DEV), 1e-5)
+            torch.cuda.synchronize()
+            assert torch.equal(x_lf.view(torch.int16), x_st.view(torch.int16)), f"x bits M{M} N{N} K{K} S{ks}"
+            assert torch.equal(n_lf.view(torch.int16), n_st.view(torch.int16)), f"norm bits M{M} N{N} K{K} S{ks}"
+            close_bf16(x_lf, ref_linear(A[:M], W, "bias_res", bias, x[:M]), f"ln-reduce x M{M} N{N}", ulps=2.5, atol=3.2e-2)
+            close_bf16(n_lf, bf(torch.nn.functional.layer_norm(x_lf.float().cpu(), (N,), lw.float(), lb.float(), 1e-5)), f"ln-reduce norm M{M} N{N}", ulps=2.0, atol=4e-3)
+    finally:
+        lib.isst_op_set_reduce_tuning(-1, -1)
 
 
 def test_split_kv_merge_fused_into_oproj_equals_combine_then_gemm():
