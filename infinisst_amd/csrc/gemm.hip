@@ -195,6 +195,9 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
     const int rpr = W / wpr;                     // rows per round
     const int my_slot = wave / wpr, my_sub = wave % wpr;
     const int cstep = wpr * 512, cfirst = (my_sub * 64 + lane) * 8;
+    // where a lane's chunk lies past K it re-reads a chunk that exists (and drops it): its OWN first chunk -- or, with more waves on a row than the row has
+    // 512-element groups (16 waves on K = 4096: forced through isst_op_set_gemm_tuning it faulted on the norm weight), the row's first
+    const int csafe = cfirst < g.K ? cfirst : 0;
     // the first group of the first round (for one stream: everything) is requested BEFORE the weight ring, so that waiting for it
     // leaves the ring in flight (vmcnt counts in order); the norm weight comes with it instead of after the first barrier
     u32x4_t xv0[4], nw0[4];
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = cfirst + u * cstep;
-            xv0[u] = *reinterpret_cast<const u32x4_t*>(xr + (c < g.K ? c : cfirst));
-            if constexpr (AMODE == 2) nw0[u] = *reinterpret_cast<const u32x4_t*>(g.norm_w + (c < g.K ? c : cfirst));
+            xv0[u] = *reinterpret_cast<const u32x4_t*>(xr + (c < g.K ? c : csafe));
+            if constexpr (AMODE == 2) nw0[u] = *reinterpret_cast<const u32x4_t*>(g.norm_w + (c < g.K ? c : csafe));
         }
         __builtin_amdgcn_sched_barrier(0);
         if (g.tune & 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int c = c0 + u * cstep;
-                        xv[u] = *reinterpret_cast<const u32x4_t*>(xr + (c < g.K ? c : cfirst));
+                        xv[u] = *reinterpret_cast<const u32x4_t*>(xr + (c < g.K ? c : csafe));
                     }
                     stage_group(xv, rr, c0, sq);
                 }
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(AMODE == 3 ? 512 : 1024) void gemm_skinny_kernel(Ge
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int c = c0 + u * cstep;
-                            wv[u] = *reinterpret_cast<const u32x4_t*>(g.norm_w + (c < g.K ? c : cfirst));
+                            wv[u] = *reinterpret_cast<const u32x4_t*>(g.norm_w + (c < g.K ? c : csafe));
                         }
                         norm_group(wv, rr, c0, rs);
                     }

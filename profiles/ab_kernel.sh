@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 for L in "$@"; do
   case $L in *=*) export "$L"; echo "  [env $L]"; continue;; esac
   D=$R/gpurun_out/ab_tmp; rm -rf $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/profiles/lib_variant_step.py $R/$L $NS 12 2>/dev/null | grep "ms per step"
+  timeout ${AB_TIMEOUT:-420} rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/profiles/lib_variant_step.py $R/$L $NS 12 2>/dev/null | grep "ms per step"
   S=$(find $D -name "*kernel_stats.csv" | head -1)
   python3 - "$S" "$PAT" <<'PY'
 import csv, re, sys
